@@ -1,0 +1,124 @@
+/*
+ * oracle/oracle_ops.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * The two test operators, written as reference-shaped callbacks
+ * matvec(n,m,x,ax) / precnd(n,m,fac,x,px) (reference README.md:34-35):
+ *
+ *  - dense:  a_ii = i+1, a_ij = 1/(i+j)   (reference main.f90:311-317), applied
+ *            column by column like main.f90:72-90 (mmult), preconditioned like
+ *            main.f90:146-171 (mprec).
+ *  - synth:  A = diag(d) + sigma W W^T, d_i = i+1, W(i,j) = (2 u01(1,i,j) - 1)/sqrt(i),
+ *            i the 1-based GLOBAL row.  Matrix-free, rank_w columns.
+ *            Preconditioner = mprec semantics on a_ii = d_i + sigma |W_i|^2.
+ *
+ * State is file-global, like the reference harness' module utils (utils.f90:1-9).
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------- dense ---------------- */
+static int     g_dn = 0;
+static double* g_da = NULL;
+
+void orc_dense_setup(int n)
+{
+  free(g_da);
+  g_dn = n;
+  g_da = (double*)malloc(sizeof(double) * (size_t)n * n);
+  for (int i = 1; i <= n; ++i) {
+    g_da[(size_t)(i - 1) * n + (i - 1)] = (double)i + 1.0;
+    for (int j = 1; j < i; ++j) {
+      double v = 1.0 / (double)(i + j);
+      g_da[(size_t)(i - 1) * n + (j - 1)] = v;
+      g_da[(size_t)(j - 1) * n + (i - 1)] = v;
+    }
+  }
+}
+
+void orc_dense_matvec(const int* pn, const int* pm, const double* x, double* ax)
+{
+  int n = *pn, m = *pm;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    const double* row = g_da + (size_t)i * n; /* symmetric: row i == column i */
+    for (int c = 0; c < m; ++c) {
+      const double* xc = x + (size_t)c * n;
+      double s = 0.0;
+      for (int j = 0; j < n; ++j) s += row[j] * xc[j];
+      ax[(size_t)c * n + i] = s;
+    }
+  }
+}
+
+void orc_dense_precnd(const int* pn, const int* pm, const double* fac, const double* x, double* px)
+{
+  int n = *pn, m = *pm;
+  for (int c = 0; c < m; ++c)
+    for (int i = 0; i < n; ++i) {
+      double den = g_da[(size_t)i * n + i] + *fac;
+      size_t p = (size_t)c * n + i;
+      px[p] = (fabs(den) > 1.0e-5) ? x[p] / den : x[p];
+    }
+}
+
+/* ---------------- synthetic matrix-free ---------------- */
+static long long g_row0 = 0;
+static int       g_nl = 0, g_rw = 0;
+static double    g_sigma = 0.0;
+static double*   g_w = NULL;   /* n_local x rank_w */
+static double*   g_diag = NULL;
+
+void orc_synth_setup(long long n_global, long long row0, int n_local, int rank_w, double sigma)
+{
+  (void)n_global;
+  free(g_w); free(g_diag);
+  g_row0 = row0; g_nl = n_local; g_rw = rank_w; g_sigma = sigma;
+  g_w = (double*)malloc(sizeof(double) * (size_t)n_local * rank_w);
+  g_diag = (double*)malloc(sizeof(double) * (size_t)n_local);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n_local; ++i) {
+    unsigned long long gi = (unsigned long long)(row0 + i + 1);
+    double s = 0.0;
+    double inv = 1.0 / sqrt((double)gi);
+    for (int j = 0; j < rank_w; ++j) {
+      double h = 2.0 * orc_u01(1ULL, gi, (unsigned long long)(j + 1)) - 1.0;
+      double w = h * inv;
+      g_w[(size_t)j * n_local + i] = w;
+      s += w * w;
+    }
+    g_diag[i] = ((double)gi + 1.0) + sigma * s;
+  }
+}
+
+const double* orc_synth_w(void) { return g_w; }
+const double* orc_synth_diag(void) { return g_diag; }
+
+void orc_synth_matvec(const int* pn, const int* pm, const double* x, double* ax)
+{
+  int n = *pn, m = *pm;
+  double* t = (double*)malloc(sizeof(double) * (size_t)g_rw * m);
+  orc_gemm_tn(n, g_rw, m, g_w, n, x, n, t, g_rw);   /* t = W^T x */
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < m; ++c)
+    for (int i = 0; i < n; ++i) {
+      double d = (double)(g_row0 + i + 1) + 1.0;
+      double s = 0.0;
+      for (int q = 0; q < g_rw; ++q) s += g_w[(size_t)q * n + i] * t[q + (size_t)c * g_rw];
+      ax[(size_t)c * n + i] = d * x[(size_t)c * n + i] + g_sigma * s;
+    }
+  free(t);
+}
+
+void orc_synth_precnd(const int* pn, const int* pm, const double* fac, const double* x, double* px)
+{
+  int n = *pn, m = *pm;
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < m; ++c)
+    for (int i = 0; i < n; ++i) {
+      double den = g_diag[i] + *fac;
+      size_t p = (size_t)c * n + i;
+      px[p] = (fabs(den) > 1.0e-5) ? x[p] / den : x[p];
+    }
+}

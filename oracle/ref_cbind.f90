@@ -1,0 +1,105 @@
+!
+! oracle/ref_cbind.f90 -- TEST INFRASTRUCTURE, not product code.
+!
+! C-callable doors into the *unmodified* reference library (Molecolab-Pisa/diaglib),
+! which oracle/Makefile compiles from /root/reference/*.f90 where those files lie.
+! Nothing of the reference is restated here: every routine below only converts
+! C scalars/pointers to the F77-style by-reference arguments that the reference's
+! public module procedures expect (reference diaglib.f90:166-167 public list) and
+! forwards the call.  The callbacks are plain C function pointers with the
+! reference's own matvec(n,m,x,ax) / precnd(n,m,shift,x,ax) shape
+! (reference README.md:34-35).
+!
+module ref_cbind
+  use iso_c_binding
+  use diaglib, only : davidson_driver, lobpcg_driver, ortho_cd, ortho_vs_x, &
+                      b_ortho, b_ortho_vs_x
+  implicit none
+!
+  abstract interface
+    subroutine mv_iface(n,m,x,ax) bind(C)
+      import :: c_int, c_double
+      integer(c_int) :: n, m
+      real(c_double) :: x(*), ax(*)
+    end subroutine mv_iface
+    subroutine pc_iface(n,m,fac,x,px) bind(C)
+      import :: c_int, c_double
+      integer(c_int) :: n, m
+      real(c_double) :: fac
+      real(c_double) :: x(*), px(*)
+    end subroutine pc_iface
+  end interface
+!
+contains
+!
+  subroutine ref_davidson(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift, &
+                          matvec,precnd,eig,evec,ok) bind(C,name='ref_davidson')
+    integer(c_int), value :: verbose, n, n_targ, n_max, max_iter, max_dav
+    real(c_double), value :: tol, shift
+    type(c_funptr), value :: matvec, precnd
+    real(c_double)        :: eig(n_max), evec(n,n_max)
+    integer(c_int)        :: ok
+    procedure(mv_iface), pointer :: mv
+    procedure(pc_iface), pointer :: pc
+    logical :: lok, lverb
+    call c_f_procpointer(matvec, mv)
+    call c_f_procpointer(precnd, pc)
+    lok = .false.
+    lverb = verbose .ne. 0
+    call davidson_driver(lverb,n,n_targ,n_max,max_iter,tol,max_dav,shift,mv,pc,eig,evec,lok)
+    ok = 0
+    if (lok) ok = 1
+  end subroutine ref_davidson
+!
+  subroutine ref_lobpcg(verbose,gen_eig,n,n_targ,n_max,max_iter,tol,shift, &
+                        matvec,precnd,bvec,eig,evec,ok) bind(C,name='ref_lobpcg')
+    integer(c_int), value :: verbose, gen_eig, n, n_targ, n_max, max_iter
+    real(c_double), value :: tol, shift
+    type(c_funptr), value :: matvec, precnd, bvec
+    real(c_double)        :: eig(n_max), evec(n,n_max)
+    integer(c_int)        :: ok
+    procedure(mv_iface), pointer :: mv, bv
+    procedure(pc_iface), pointer :: pc
+    logical :: lok, lverb, lgen
+    call c_f_procpointer(matvec, mv)
+    call c_f_procpointer(precnd, pc)
+    call c_f_procpointer(bvec, bv)
+    lok = .false.
+    lverb = verbose .ne. 0
+    lgen  = gen_eig .ne. 0
+    call lobpcg_driver(lverb,lgen,n,n_targ,n_max,max_iter,tol,shift,mv,pc,bv,eig,evec,lok)
+    ok = 0
+    if (lok) ok = 1
+  end subroutine ref_lobpcg
+!
+  subroutine ref_ortho_cd(n,m,u,growth,ok) bind(C,name='ref_ortho_cd')
+    integer(c_int), value :: n, m
+    real(c_double)        :: u(n,m), growth
+    integer(c_int)        :: ok
+    logical :: lok
+    lok = .false.
+    call ortho_cd(n,m,u,growth,lok)
+    ok = 0
+    if (lok) ok = 1
+  end subroutine ref_ortho_cd
+!
+  subroutine ref_ortho_vs_x(n,m,k,x,u) bind(C,name='ref_ortho_vs_x')
+    integer(c_int), value :: n, m, k
+    real(c_double)        :: x(n,m), u(n,k)
+    real(c_double)        :: xx(1)
+    call ortho_vs_x(n,m,k,x,u,xx,xx)
+  end subroutine ref_ortho_vs_x
+!
+  subroutine ref_b_ortho(n,m,u,bu) bind(C,name='ref_b_ortho')
+    integer(c_int), value :: n, m
+    real(c_double)        :: u(n,m), bu(n,m)
+    call b_ortho(n,m,u,bu)
+  end subroutine ref_b_ortho
+!
+  subroutine ref_b_ortho_vs_x(n,m,k,x,bx,u) bind(C,name='ref_b_ortho_vs_x')
+    integer(c_int), value :: n, m, k
+    real(c_double)        :: x(n,m), bx(n,m), u(n,k)
+    call b_ortho_vs_x(n,m,k,x,bx,u)
+  end subroutine ref_b_ortho_vs_x
+!
+end module ref_cbind
