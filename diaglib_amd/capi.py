@@ -1,0 +1,401 @@
+"""ctypes binding of the C-ABI in ``include/diaglib_amd.h``.
+
+This is plumbing for tests and ``bench.py``: it loads ``diaglib_amd/lib/libdiaglib_amd.so`` (HIP
+engine + Fortran drivers) and mirrors the reference's interface -- ``davidson_driver`` /
+``lobpcg_driver`` with ``matvec(n,m,x,ax)`` / ``precnd(n,m,fac,x,px)`` callbacks (reference
+diaglib.f90:1483-1539, 171-228, README.md:34-35).  There is no CPU path: if the library or a
+GPU is missing, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Callable, Optional, Union
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libdiaglib_amd.so")
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+MATVEC_T = C.CFUNCTYPE(None, c_ip, c_ip, c_dp, c_dp)
+PRECND_T = C.CFUNCTYPE(None, c_ip, c_ip, c_dp, c_dp, c_dp)
+ALLREDUCE_T = C.CFUNCTYPE(None, C.c_void_p, c_dp, C.c_int, C.c_int)
+
+OPT_CALLBACKS_ON_DEVICE, OPT_EVEC_ON_DEVICE, OPT_PROFILE, OPT_VERBOSE_ORTHO = 1, 2, 3, 4
+OP_NAMES = ["gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd"]
+
+# every symbol include/diaglib_amd.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "dla_create", "dla_destroy", "dla_default_ctx", "dla_set_option", "dla_get_option", "dla_last_error",
+    "dla_backend_name", "dla_get_stats", "dla_reset_stats", "dla_stream",
+    "dla_comm_unique_id", "dla_comm_init", "dla_comm_info", "dla_set_allreduce_hook", "dla_set_shard",
+    "dla_alloc", "dla_free", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
+    "dla_gram", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_ritz_residual", "dla_axpy",
+    "dla_nrm2", "dla_random_fill",
+    "dla_ortho_cd", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
+    "dla_call_matvec", "dla_call_precnd",
+    "dla_syev", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
+    "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd",
+    "dla_davidson_driver", "dla_lobpcg_driver", "dla_last_solve_info", "dla_set_solve_info",
+]
+
+
+class Stats(C.Structure):
+    _fields_ = [("launches", C.c_longlong * 7), ("alg_bytes", C.c_double * 7), ("flops", C.c_double * 7),
+                ("ms", C.c_double * 7), ("allreduces", C.c_longlong), ("host_syncs", C.c_longlong)]
+
+    def as_dict(self) -> dict:
+        d = {"allreduces": int(self.allreduces), "host_syncs": int(self.host_syncs)}
+        for i, nm in enumerate(OP_NAMES):
+            d[nm] = {"launches": int(self.launches[i]), "alg_bytes": float(self.alg_bytes[i]),
+                     "flops": float(self.flops[i]), "ms": float(self.ms[i])}
+        return d
+
+
+class DlaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+    """Load the native library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise DlaError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+    sig = {
+        "dla_create": (i, [C.POINTER(vp), i]), "dla_destroy": (i, [vp]), "dla_default_ctx": (vp, []),
+        "dla_set_option": (i, [vp, i, i]), "dla_get_option": (i, [vp, i]),
+        "dla_last_error": (C.c_char_p, [vp]), "dla_backend_name": (C.c_char_p, [vp]),
+        "dla_get_stats": (i, [vp, C.POINTER(Stats)]), "dla_reset_stats": (i, [vp]), "dla_stream": (vp, [vp]),
+        "dla_comm_unique_id": (i, [C.c_char_p]), "dla_comm_init": (i, [vp, i, i, C.c_char_p]),
+        "dla_comm_info": (i, [vp, c_ip, c_ip]),
+        "dla_set_allreduce_hook": (i, [vp, vp, vp, i, i]), "dla_set_shard": (i, [vp, C.c_longlong, C.c_longlong]),
+        "dla_alloc": (i, [vp, sz, C.POINTER(vp)]), "dla_free": (i, [vp, vp]), "dla_zero": (i, [vp, vp, sz]),
+        "dla_upload": (i, [vp, vp, vp, sz]), "dla_download": (i, [vp, vp, vp, sz]), "dla_copy": (i, [vp, vp, vp, sz]),
+        "dla_sync": (i, [vp]),
+        "dla_gram": (i, [vp, i, i, vp, i, vp, c_dp, i]),
+        "dla_panel_gemm": (i, [vp, i, i, vp, i, c_dp, i, vp]),
+        "dla_panel_update": (i, [vp, i, i, vp, i, c_dp, i, vp]),
+        "dla_trmm_linvt": (i, [vp, i, i, vp, c_dp, i]),
+        "dla_ritz_residual": (i, [vp, i, i, i, vp, vp, c_dp, i, c_dp, i, c_ip, vp, vp, vp, c_dp]),
+        "dla_axpy": (i, [vp, sz, d, vp, vp]), "dla_nrm2": (i, [vp, sz, vp, c_dp]),
+        "dla_random_fill": (i, [vp, i, i, vp]),
+        "dla_ortho_cd": (i, [vp, i, i, vp, c_dp, c_ip]), "dla_ortho_vs_x": (i, [vp, i, i, i, vp, vp]),
+        "dla_b_ortho": (i, [vp, i, i, vp, vp]), "dla_b_ortho_vs_x": (i, [vp, i, i, i, vp, vp, vp]),
+        "dla_check_guess": (i, [vp, i, i, vp]),
+        "dla_get_coeffs": (i, [vp, i, i, i, i, c_dp, c_dp, c_dp]),
+        "dla_call_matvec": (i, [vp, vp, i, i, vp, vp]), "dla_call_precnd": (i, [vp, vp, i, i, d, vp, vp]),
+        "dla_syev": (i, [C.c_char, i, c_dp, i, c_dp]), "dla_potrf_lower": (i, [i, c_dp, i]),
+        "dla_trtri_lower": (i, [i, c_dp, i]), "dla_norm_est": (d, [i, c_dp, i]),
+        "dla_synth_setup": (i, [vp, C.c_longlong, C.c_longlong, i, i, d]),
+        "dla_davidson_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, c_ip]),
+        "dla_lobpcg_driver": (None, [i, i, i, i, i, i, d, d, vp, vp, vp, vp, vp, c_ip]),
+        "dla_last_solve_info": (None, [c_ip, c_ip, c_ip]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def fn_address(name: str) -> int:
+    """Address of an exported function (e.g. the built-in ``dla_synth_matvec`` callback)."""
+    return C.cast(getattr(load(), name), C.c_void_p).value
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(c_dp)
+
+
+class DevPanel:
+    """A column-major float64 n x m panel in HBM (ld = n)."""
+
+    def __init__(self, ctx: "Context", n: int, m: int, ptr: Optional[int] = None, owner: bool = True):
+        self.ctx, self.n, self.m, self.owner = ctx, int(n), int(m), owner
+        if ptr is None:
+            p = C.c_void_p()
+            ctx._chk(ctx.lib.dla_alloc(ctx.h, max(8, 8 * self.n * self.m), C.byref(p)))
+            ptr = p.value
+        self.ptr = ptr
+
+    def col(self, j: int, m: Optional[int] = None) -> "DevPanel":
+        """View of columns j .. j+m-1 (0-based)."""
+        m = self.m - j if m is None else m
+        return DevPanel(self.ctx, self.n, m, self.ptr + 8 * self.n * j, owner=False)
+
+    def upload(self, a: np.ndarray) -> "DevPanel":
+        a = np.asfortranarray(a, dtype=np.float64)
+        assert a.size == self.n * self.m, (a.shape, self.n, self.m)
+        self.ctx._chk(self.ctx.lib.dla_upload(self.ctx.h, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.n, self.m), dtype=np.float64, order="F")
+        self.ctx._chk(self.ctx.lib.dla_download(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def zero(self) -> "DevPanel":
+        self.ctx._chk(self.ctx.lib.dla_zero(self.ctx.h, self.ptr, 8 * self.n * self.m))
+        return self
+
+    def free(self) -> None:
+        if self.owner and self.ptr:
+            self.ctx.lib.dla_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+Callback = Union[int, Callable]
+
+
+class Context:
+    """The library's default context (the one the Fortran drivers use)."""
+
+    def __init__(self):
+        self.lib = load()
+        self.h = self.lib.dla_default_ctx()
+        if not self.h:
+            raise DlaError("no HIP device")
+        self._keep = []
+
+    # ---- plumbing
+    def _chk(self, st: int) -> None:
+        if st != 0:
+            raise DlaError(f"status {st}: {self.lib.dla_last_error(self.h).decode()}")
+
+    @property
+    def backend(self) -> str:
+        return self.lib.dla_backend_name(self.h).decode()
+
+    def set_option(self, opt: int, val: int) -> None:
+        self._chk(self.lib.dla_set_option(self.h, opt, int(val)))
+
+    def sync(self) -> None:
+        self._chk(self.lib.dla_sync(self.h))
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._chk(self.lib.dla_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self) -> None:
+        self._chk(self.lib.dla_reset_stats(self.h))
+
+    def panel(self, a_or_n, m: Optional[int] = None) -> DevPanel:
+        if isinstance(a_or_n, np.ndarray):
+            a = np.asfortranarray(a_or_n, dtype=np.float64)
+            if a.ndim == 1:
+                a = a.reshape(-1, 1, order="F")
+            return DevPanel(self, a.shape[0], a.shape[1]).upload(a)
+        return DevPanel(self, a_or_n, m)
+
+    # ---- multi-GPU
+    def unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._chk(self.lib.dla_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, uid: bytes) -> None:
+        self._chk(self.lib.dla_comm_init(self.h, nranks, rank, uid))
+
+    def set_shard(self, n_global: int, row0: int) -> None:
+        self._chk(self.lib.dla_set_shard(self.h, n_global, row0))
+
+    def set_allreduce_hook(self, fn: Optional[Callable], nranks: int, rank: int) -> None:
+        """fn(buf: np.ndarray, op: int) reduces buf in place over ranks (op 0 sum, 1 max)."""
+        if fn is None:
+            self._chk(self.lib.dla_set_allreduce_hook(self.h, None, None, 1, 0))
+            return
+
+        def tramp(_user, buf, count, op):
+            fn(np.ctypeslib.as_array(buf, (count,)), op)
+
+        cb = ALLREDUCE_T(tramp)
+        self._keep.append(cb)
+        self._chk(self.lib.dla_set_allreduce_hook(self.h, C.cast(cb, C.c_void_p), None, nranks, rank))
+
+    # ---- block algebra
+    def gram(self, x: DevPanel, u: DevPanel) -> np.ndarray:
+        c = np.zeros((x.m, u.m), order="F")
+        self._chk(self.lib.dla_gram(self.h, x.n, x.m, x.ptr, u.m, u.ptr, _dp(c), max(1, x.m)))
+        return c
+
+    def panel_gemm(self, x: DevPanel, c: np.ndarray, z: DevPanel) -> None:
+        c = np.asfortranarray(c, dtype=np.float64)
+        self._chk(self.lib.dla_panel_gemm(self.h, x.n, x.m, x.ptr, c.shape[1], _dp(c), max(1, c.shape[0]), z.ptr))
+
+    def panel_update(self, x: DevPanel, c: np.ndarray, u: DevPanel) -> None:
+        c = np.asfortranarray(c, dtype=np.float64)
+        self._chk(self.lib.dla_panel_update(self.h, x.n, x.m, x.ptr, c.shape[1], _dp(c), max(1, c.shape[0]), u.ptr))
+
+    def trmm_linvt(self, u: DevPanel, linv: np.ndarray) -> None:
+        linv = np.asfortranarray(linv, dtype=np.float64)
+        self._chk(self.lib.dla_trmm_linvt(self.h, u.n, u.m, u.ptr, _dp(linv), linv.shape[0]))
+
+    def ritz_residual(self, v: DevPanel, av: DevPanel, y: np.ndarray, eig: np.ndarray, n_res: int,
+                      skip: np.ndarray, evec: DevPanel, r: DevPanel, avy: Optional[DevPanel] = None) -> np.ndarray:
+        y = np.asfortranarray(y, dtype=np.float64)
+        eig = np.ascontiguousarray(eig, dtype=np.float64)
+        skip = np.ascontiguousarray(skip, dtype=np.int32)
+        rn = np.zeros((2, max(1, n_res)), order="F")
+        self._chk(self.lib.dla_ritz_residual(self.h, v.n, v.m, evec.m, v.ptr, av.ptr, _dp(y), y.shape[0], _dp(eig),
+                                             n_res, skip.ctypes.data_as(c_ip), evec.ptr, r.ptr,
+                                             avy.ptr if avy is not None else None, _dp(rn)))
+        return rn
+
+    def axpy(self, alpha: float, x: DevPanel, y: DevPanel) -> None:
+        self._chk(self.lib.dla_axpy(self.h, x.n * x.m, alpha, x.ptr, y.ptr))
+
+    def nrm2(self, x: DevPanel) -> float:
+        out = C.c_double(0.0)
+        self._chk(self.lib.dla_nrm2(self.h, x.n * x.m, x.ptr, C.byref(out)))
+        return out.value
+
+    def random_fill(self, x: DevPanel) -> None:
+        self._chk(self.lib.dla_random_fill(self.h, x.n, x.m, x.ptr))
+
+    # ---- orthogonalisation
+    def ortho_cd(self, u: DevPanel):
+        g = C.c_double(0.0); ok = C.c_int(0)
+        self._chk(self.lib.dla_ortho_cd(self.h, u.n, u.m, u.ptr, C.byref(g), C.byref(ok)))
+        return g.value, bool(ok.value)
+
+    def ortho_vs_x(self, x: DevPanel, u: DevPanel, m: Optional[int] = None) -> None:
+        self._chk(self.lib.dla_ortho_vs_x(self.h, x.n, x.m if m is None else m, u.m, x.ptr, u.ptr))
+
+    def b_ortho(self, u: DevPanel, bu: DevPanel) -> None:
+        self._chk(self.lib.dla_b_ortho(self.h, u.n, u.m, u.ptr, bu.ptr))
+
+    def b_ortho_vs_x(self, x: DevPanel, bx: DevPanel, u: DevPanel) -> None:
+        self._chk(self.lib.dla_b_ortho_vs_x(self.h, x.n, x.m, u.m, x.ptr, bx.ptr, u.ptr))
+
+    def check_guess(self, evec: DevPanel) -> None:
+        self._chk(self.lib.dla_check_guess(self.h, evec.n, evec.m, evec.ptr))
+
+    def get_coeffs(self, a_red: np.ndarray, len_u: int, n_max: int, n_act: int):
+        a_red = np.asfortranarray(a_red, dtype=np.float64)
+        u_x = np.zeros((len_u, n_max), order="F"); u_p = np.zeros((len_u, max(1, n_act)), order="F")
+        self._chk(self.lib.dla_get_coeffs(self.h, a_red.shape[0], len_u, n_max, n_act, _dp(a_red), _dp(u_x), _dp(u_p)))
+        return u_x, u_p[:, :n_act]
+
+    # ---- built-in operator
+    def synth_setup(self, n_global: int, row0: int, n_local: int, rank_w: int = 4, sigma: float = 0.5) -> None:
+        self._chk(self.lib.dla_synth_setup(self.h, n_global, row0, n_local, rank_w, sigma))
+
+    def synth_matvec(self, x: DevPanel, ax: DevPanel) -> None:
+        self._chk(self.lib.dla_call_matvec(self.h, fn_address("dla_synth_matvec"), x.n, x.m, x.ptr, ax.ptr))
+
+    # ---- callbacks
+    def _wrap_mv(self, f: Callback) -> int:
+        if isinstance(f, int):
+            return f
+
+        def tramp(pn, pm, px, pax):
+            n, m = pn[0], pm[0]
+            x = np.ctypeslib.as_array(px, (m, n)).T
+            ax = np.ctypeslib.as_array(pax, (m, n)).T
+            ax[:, :] = f(x)
+
+        cb = MATVEC_T(tramp)
+        self._keep.append(cb)
+        return C.cast(cb, C.c_void_p).value
+
+    def _wrap_pc(self, f: Callback) -> int:
+        if isinstance(f, int):
+            return f
+
+        def tramp(pn, pm, pf, px, ppx):
+            n, m = pn[0], pm[0]
+            x = np.ctypeslib.as_array(px, (m, n)).T
+            y = np.ctypeslib.as_array(ppx, (m, n)).T
+            y[:, :] = f(pf[0], x)
+
+        cb = PRECND_T(tramp)
+        self._keep.append(cb)
+        return C.cast(cb, C.c_void_p).value
+
+    # ---- drivers (reference argument order)
+    def davidson_driver(self, n: int, n_targ: int, n_max: int, max_iter: int, tol: float, max_dav: int, shift: float,
+                        matvec: Callback, precnd: Callback, evec, verbose: bool = False):
+        """evec: numpy (n, n_max) guess (host mode) or DevPanel (evec-on-device mode).
+        Returns (eig, evec_out, ok, info)."""
+        mv, pc = self._wrap_mv(matvec), self._wrap_pc(precnd)
+        eig = np.zeros(n_max); ok = C.c_int(0)
+        if isinstance(evec, DevPanel):
+            self.set_option(OPT_EVEC_ON_DEVICE, 1)
+            ev_ptr, out = evec.ptr, evec
+        else:
+            self.set_option(OPT_EVEC_ON_DEVICE, 0)
+            out = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
+            ev_ptr = out.ctypes.data
+        self.lib.dla_davidson_driver(int(verbose), n, n_targ, n_max, max_iter, tol, max_dav, shift, mv, pc,
+                                     eig.ctypes.data, ev_ptr, C.byref(ok))
+        return eig, out, bool(ok.value), self.last_solve_info()
+
+    def lobpcg_driver(self, n: int, n_targ: int, n_max: int, max_iter: int, tol: float, shift: float,
+                      matvec: Callback, precnd: Callback, evec, verbose: bool = False):
+        mv, pc = self._wrap_mv(matvec), self._wrap_pc(precnd)
+        eig = np.zeros(n_max); ok = C.c_int(0)
+        if isinstance(evec, DevPanel):
+            self.set_option(OPT_EVEC_ON_DEVICE, 1)
+            ev_ptr, out = evec.ptr, evec
+        else:
+            self.set_option(OPT_EVEC_ON_DEVICE, 0)
+            out = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
+            ev_ptr = out.ctypes.data
+        self.lib.dla_lobpcg_driver(int(verbose), 0, n, n_targ, n_max, max_iter, tol, shift, mv, pc, mv,
+                                   eig.ctypes.data, ev_ptr, C.byref(ok))
+        return eig, out, bool(ok.value), self.last_solve_info()
+
+    def last_solve_info(self) -> dict:
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.lib.dla_last_solve_info(C.byref(a), C.byref(b), C.byref(c))
+        return {"iters": a.value, "matvec_cols": b.value, "restarts": c.value}
+
+
+# ---- host-size dense helpers (no GPU needed)
+def syev(a: np.ndarray, uplo: str = "l"):
+    L = load()
+    a = np.asfortranarray(a, dtype=np.float64).copy(order="F")
+    n = a.shape[0]
+    w = np.zeros(n)
+    info = L.dla_syev(uplo.encode(), n, _dp(a), n, _dp(w))
+    if info != 0:
+        raise DlaError(f"dla_syev info={info}")
+    return w, a
+
+
+def potrf_lower(a: np.ndarray):
+    L = load()
+    a = np.asfortranarray(a, dtype=np.float64).copy(order="F")
+    info = L.dla_potrf_lower(a.shape[0], _dp(a), a.shape[0])
+    return a, info
+
+
+def trtri_lower(a: np.ndarray):
+    L = load()
+    a = np.asfortranarray(a, dtype=np.float64).copy(order="F")
+    info = L.dla_trtri_lower(a.shape[0], _dp(a), a.shape[0])
+    return a, info
+
+
+def norm_est(a: np.ndarray) -> float:
+    L = load()
+    a = np.asfortranarray(a, dtype=np.float64)
+    return float(L.dla_norm_est(a.shape[0], _dp(a), a.shape[0]))

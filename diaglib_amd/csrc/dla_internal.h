@@ -1,0 +1,80 @@
+// diaglib_amd/csrc/dla_internal.h -- internal seam between the host logic (host_logic.cpp:
+// ortho_cd / ortho_vs_x control flow, callback trampolines, statistics) and the device
+// engine (hip_engine.hip: HIP kernels, streams, RCCL).  The product library links exactly
+// one engine, the HIP one; there is no CPU engine in the product.
+#pragma once
+#include <cstddef>
+#include <string>
+#include "../../include/diaglib_amd.h"
+
+namespace dla {
+
+// What the host logic needs from a device.  All panel pointers are device addresses,
+// column-major, ld = n.  Reductions (gram / residual norms / nrm2) return host-visible,
+// cross-rank-reduced results and imply a stream synchronisation.
+struct Engine {
+  virtual ~Engine() {}
+  virtual const char* name() const = 0;
+  virtual void* stream() = 0;
+
+  virtual int alloc(size_t bytes, void** dev) = 0;
+  virtual int free_(void* dev) = 0;
+  virtual int zero(void* dev, size_t bytes) = 0;
+  virtual int h2d(void* dev, const void* host, size_t bytes) = 0;
+  virtual int d2h(void* host, const void* dev, size_t bytes) = 0;
+  virtual int d2d(void* dst, const void* src, size_t bytes) = 0;
+  virtual int sync() = 0;
+
+  virtual int gram(int n, int l, const double* x, int k, const double* u, double* c_host, int ldc) = 0;
+  // mode 0: Z = X C ; mode 1: Z -= X C (Z read and written)
+  virtual int gemm(int n, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode) = 0;
+  // in place U <- U W, W (k x k, host, general) -- used for the triangular update
+  virtual int trmm(int n, int k, double* u, const double* w_host, int ld) = 0;
+  virtual int ritz_residual(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
+                            const double* eig, int n_res, const int* skip, double* evec, double* r,
+                            double* avy /* optional n x m: uncorrected AV*Y */,
+                            double* sumsq_max /* 2*n_res: sum r^2, max|r| */) = 0;
+  virtual int axpy(size_t len, double alpha, const double* x, double* y) = 0;
+  virtual int sumsq(size_t len, const double* x, double* out) = 0;
+  virtual int random_fill(int n, int m, double* evec, long long row0) = 0;
+
+  virtual int synth_setup(long long n_global, long long row0, int n_local, int rank_w, double sigma) = 0;
+  virtual int synth_matvec(int n, int m, const double* x, double* ax) = 0;
+  virtual int synth_precnd(int n, int m, double fac, const double* x, double* px) = 0;
+
+  // pinned host staging for host-mode callbacks
+  virtual int host_alloc(size_t bytes, void** p) = 0;
+  virtual int host_free(void* p) = 0;
+
+  // collectives
+  virtual int comm_init(int nranks, int rank, const char id[128]) = 0;
+  int nranks = 1, rank = 0;
+  dla_allreduce_fn hook = nullptr;
+  void* hook_user = nullptr;
+
+  // statistics
+  dla_stats stats{};
+  bool profile = false;
+  virtual void collect_times() {}
+  std::string err;
+};
+
+// provided by the engine translation unit linked into the library
+Engine* make_engine(int device, std::string& err);
+int engine_unique_id(char id[128]);
+
+}  // namespace dla
+
+struct dla_ctx {
+  dla::Engine* eng = nullptr;
+  int callbacks_on_device = 0;
+  int evec_on_device = 0;
+  int verbose_ortho = 0;
+  long long n_global = -1;   // -1: single shard, n_global == n
+  long long row0 = 0;
+  std::string err;
+  // pinned staging buffers for host-mode callbacks
+  double* stage_x = nullptr;
+  double* stage_y = nullptr;
+  size_t stage_bytes = 0;
+};

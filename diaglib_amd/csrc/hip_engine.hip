@@ -1,0 +1,1085 @@
+// diaglib_amd/csrc/hip_engine.hip -- the device engine: hand-written HIP kernels for gfx950
+// (CDNA4, wave64, FP64 MFMA 16x16x4), one HIP stream, RCCL for the small cross-rank sums.
+//
+// Data layout: every panel is column-major float64, leading dimension n (local
+// rows), columns contiguous -- the reference layout (diaglib.f90:1607), so column blocks can be
+// handed to matvec/precnd callbacks unchanged.  n even => every column is 16-byte aligned and
+// the kernels use 16-byte (double2) accesses (VEC=2); odd n falls back to 8-byte accesses (VEC=1).
+//
+// Kernels and what bounds them (all HBM-bound; arithmetic intensity k/4 flop/B):
+//   gram_kernel        C = X^T U          reads 8n(l+k) B     -- MFMA contracts over rows
+//   gemm_kernel        Z = XC, Z -= XC    reads 8n(l[+k]) B, writes 8nk B
+//                      (also U <- U W in place for the Cholesky-QR triangular update)
+//   ritz_kernel        evec = V Y, r = AV Y - theta evec, ||r||, max|r| in one sweep over V, AV
+//   elementwise        axpy / sumsq / random fill / built-in operator + preconditioner
+// The FP64 MFMA is used because it is the only way to contract a 16-wide column tile over
+// rows held in different lanes without a shuffle storm; at k=13 it runs at ~1/3 of its peak
+// when the kernel streams at HBM rate.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "dla_internal.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// VEC doubles per lane per access: a scalar for VEC == 1, a 16-byte vector for VEC == 2
+template <int V> struct VecOf;
+template <> struct VecOf<1> { typedef double type; };
+template <> struct VecOf<2> { typedef v2d type; };
+template <int V> __device__ __forceinline__ double vget(const typename VecOf<V>::type& v, int e);
+template <> __device__ __forceinline__ double vget<1>(const double& v, int) { return v; }
+template <> __device__ __forceinline__ double vget<2>(const v2d& v, int e) { return e == 0 ? v.x : v.y; }
+template <int V> __device__ __forceinline__ typename VecOf<V>::type vmake(double a, double b);
+template <> __device__ __forceinline__ double vmake<1>(double a, double) { return a; }
+template <> __device__ __forceinline__ v2d vmake<2>(double a, double b) { return (v2d){a, b}; }
+template <int V> __device__ __forceinline__ typename VecOf<V>::type vzero() { return vmake<V>(0.0, 0.0); }
+
+#define HIPCHK(call)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+      return DLA_ERR_RUNTIME;                                                         \
+    }                                                                                 \
+  } while (0)
+
+namespace {
+
+// ======================================================================================
+// Gram / projection:  C(l x k) = X(n x l)^T U(n x k)
+// ======================================================================================
+// One wave owns a set of rows and ALL column tiles of this pass: TLW tiles (16 columns each)
+// of X times KT tiles of U.  v_mfma_f64_16x16x4 computes D(16x16) += A(16x4) B(4x16) with the
+// contraction index (4) spread over lane>>4; lane (c = lane&15, g = lane>>4) supplies
+// A[c][g] = X[row(g)][col c] and B[g][c] = U[row(g)][col c].  Any row may sit in slot g as long
+// as A and B agree, so each lane reads VEC consecutive rows (one 16-byte load for VEC=2):
+// step s of a chunk covers rows  rbase + 4*VEC*s + VEC*g + e,  e < VEC.
+// D layout (f64): lane holds D[(lane>>4) + 4*reg][lane&15], reg = 0..3.
+struct GramArgs {
+  const double* x;
+  const double* u;
+  double* partial;   // [pass][block][slot][256]
+  long long n;
+  int l, k;
+  int passes_x;
+};
+
+template <int TLW, int KT, int VEC, int RSTEP>
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
+{
+  constexpr int CH = 4 * VEC * RSTEP;  // rows per chunk
+  typedef typename VecOf<VEC>::type vec_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int xg = blockIdx.y % a.passes_x, ug = blockIdx.y / a.passes_x;
+  const long long n = a.n;
+
+  const double* xp[TLW];
+  const double* up[KT];
+#pragma unroll
+  for (int t = 0; t < TLW; ++t) {
+    int col = (xg * TLW + t) * 16 + c;
+    col = col < a.l ? col : a.l - 1;           // clamp: garbage only reaches unused D rows
+    xp[t] = a.x + (size_t)col * (size_t)n + VEC * g;
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    int col = (ug * KT + t) * 16 + c;
+    col = col < a.k ? col : a.k - 1;
+    up[t] = a.u + (size_t)col * (size_t)n + VEC * g;
+  }
+  v4d acc[TLW][KT];
+#pragma unroll
+  for (int t = 0; t < TLW; ++t)
+#pragma unroll
+    for (int q = 0; q < KT; ++q) acc[t][q] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  const long long nchunks = (n + CH - 1) / CH;
+  for (long long ch = (long long)blockIdx.x * 4 + wave; ch < nchunks; ch += (long long)gridDim.x * 4) {
+    const long long rbase = ch * CH;
+    vec_t xv[TLW][RSTEP], uv[KT][RSTEP];
+    if (rbase + CH <= n) {
+#pragma unroll
+      for (int q = 0; q < KT; ++q)
+#pragma unroll
+        for (int s = 0; s < RSTEP; ++s) uv[q][s] = *(const vec_t*)(up[q] + rbase + 4 * VEC * s);
+#pragma unroll
+      for (int t = 0; t < TLW; ++t)
+#pragma unroll
+        for (int s = 0; s < RSTEP; ++s) xv[t][s] = *(const vec_t*)(xp[t] + rbase + 4 * VEC * s);
+    } else {
+      // tail chunk: rows >= n contribute zero (n even when VEC == 2, so pairs are all-in or all-out)
+#pragma unroll
+      for (int s = 0; s < RSTEP; ++s) {
+        const bool ok = rbase + 4 * VEC * s + VEC * g < n;
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+          uv[q][s] = vzero<VEC>();
+          if (ok) uv[q][s] = *(const vec_t*)(up[q] + rbase + 4 * VEC * s);
+        }
+#pragma unroll
+        for (int t = 0; t < TLW; ++t) {
+          xv[t][s] = vzero<VEC>();
+          if (ok) xv[t][s] = *(const vec_t*)(xp[t] + rbase + 4 * VEC * s);
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < RSTEP; ++s)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+#pragma unroll
+        for (int t = 0; t < TLW; ++t)
+#pragma unroll
+          for (int q = 0; q < KT; ++q) {
+            acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vget<VEC>(xv[t][s], e), vget<VEC>(uv[q][s], e),
+                                                             acc[t][q], 0, 0, 0);
+          }
+  }
+
+  // deterministic in-block reduction over the 4 waves, one slot at a time
+  __shared__ double red[4][256];
+  double* pout = a.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(TLW * KT) * 256;
+#pragma unroll
+  for (int t = 0; t < TLW; ++t)
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][r * 64 + lane] = acc[t][q][r];
+      __syncthreads();
+      double s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+      pout[(size_t)(t * KT + q) * 256 + threadIdx.x] = s;
+      __syncthreads();
+    }
+}
+
+// second stage: sum the block partials in a fixed order and scatter into column-major C (ld = l)
+struct GramReduceArgs {
+  const double* partial;
+  double* c;         // l x k, ld = l
+  int nblk, l, k, tlw, kt, passes_x;
+};
+
+__global__ __launch_bounds__(1024) void gram_reduce_kernel(GramReduceArgs a)
+{
+  // blockIdx.x = pass * slots + slot ; 1024 threads = 4 groups x 256 elements
+  const int slots = a.tlw * a.kt;
+  const int pass = blockIdx.x / slots, slot = blockIdx.x % slots;
+  const int e = threadIdx.x & 255, grp = threadIdx.x >> 8;
+  const double* p = a.partial + ((size_t)pass * a.nblk) * (size_t)slots * 256 + (size_t)slot * 256 + e;
+  const int per = (a.nblk + 3) / 4;
+  const int b0 = grp * per, b1 = min(a.nblk, b0 + per);
+  double s = 0.0;
+  for (int b = b0; b < b1; ++b) s += p[(size_t)b * slots * 256];
+  __shared__ double red[4][256];
+  red[grp][e] = s;
+  __syncthreads();
+  if (grp == 0) {
+    double tot = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    const int xg = pass % a.passes_x, ug = pass / a.passes_x;
+    const int t = slot / a.kt, q = slot % a.kt;
+    const int reg = e >> 6, lane = e & 63;
+    const int xcol = (xg * a.tlw + t) * 16 + (lane >> 4) + 4 * reg;
+    const int ucol = (ug * a.kt + q) * 16 + (lane & 15);
+    if (xcol < a.l && ucol < a.k) a.c[(size_t)xcol + (size_t)ucol * a.l] = tot;
+  }
+}
+
+// ======================================================================================
+// Panel products along rows:  Z = X C  |  Z -= X C  |  U <- U W (in place)
+// ======================================================================================
+// Transposed formulation D^T = C^T X^T so that the 16-lane index follows ROWS (coalesced):
+// lane (i = lane&15, g = lane>>4) loads rows r0 + VEC*i + e of column 4*cs + g (B operand,
+// 16 B per lane, 256 B contiguous per 16 lanes); the A operand is C[4cs+g][16q + i] read from
+// the LDS copy of C.  D layout: lane holds Z[row(i)][16q + g + 4*reg]; the VEC row values of
+// one (q,reg) are stored with one 16-byte store.
+struct GemmArgs {
+  const double* x;     // n x l
+  const double* cpk;   // packed C: [KT][l4][16] (zero padded), device
+  double* z;           // n x k
+  long long n;
+  int l, l4, k;
+};
+
+// MODE 0: Z = XC   1: Z -= XC   2: in place U <- U W (x == z)   3: Z += XC
+template <int KT, int VEC, int MODE>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a)
+{
+  constexpr int RT = 2;                    // row groups per wave tile
+  constexpr int RG = 16 * VEC;             // rows per group
+  constexpr int WT = RT * RG;              // rows per wave tile (64 for VEC=2)
+  extern __shared__ __attribute__((aligned(16))) double cs[];  // [KT][l4][16]
+  typedef typename VecOf<VEC>::type vec_t;
+  const long long n = a.n;
+  const int l = a.l, l4 = a.l4;
+  for (int idx = threadIdx.x; idx < KT * l4 * 16; idx += 256) cs[idx] = a.cpk[idx];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const long long ntiles = (n + WT - 1) / WT;
+  const int nsteps = l4 / 4;
+
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    const long long r0 = tile * WT;
+    v4d acc[RT][VEC][KT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+#pragma unroll
+        for (int q = 0; q < KT; ++q) acc[rt][e][q] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    long long row[RT];
+    bool rok[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      row[rt] = r0 + rt * RG + VEC * i;
+      rok[rt] = row[rt] < n;               // n even for VEC == 2: the pair is all-in or all-out
+      if (!rok[rt]) row[rt] = 0;           // clamp to a valid address; result discarded
+    }
+#pragma unroll 4
+    for (int cs4 = 0; cs4 < nsteps; ++cs4) {
+      int col = 4 * cs4 + g;
+      const bool cok = col < l;
+      col = cok ? col : l - 1;
+      const double* xc = a.x + (size_t)col * (size_t)n;
+      vec_t xv[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        vec_t v = *(const vec_t*)(xc + row[rt]);
+        xv[rt] = cok ? v : vzero<VEC>();
+      }
+      double cf[KT];
+#pragma unroll
+      for (int q = 0; q < KT; ++q) cf[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * cs4 + g) * 16 + i];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+#pragma unroll
+          for (int q = 0; q < KT; ++q) {
+            acc[rt][e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[q], vget<VEC>(xv[rt], e), acc[rt][e][q], 0, 0, 0);
+          }
+    }
+    // epilogue
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      if (!rok[rt]) continue;
+#pragma unroll
+      for (int q = 0; q < KT; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int j = 16 * q + g + 4 * reg;
+          if (j >= a.k) continue;
+          double* zp = a.z + (size_t)j * (size_t)n + row[rt];
+          vec_t v = vmake<VEC>(acc[rt][0][q][reg], acc[rt][VEC - 1][q][reg]);
+          if constexpr (MODE == 1) { vec_t old = *(const vec_t*)zp; v = old - v; }
+          if constexpr (MODE == 3) { vec_t old = *(const vec_t*)zp; v = old + v; }
+          *(vec_t*)zp = v;
+        }
+    }
+  }
+}
+
+// ======================================================================================
+// Fused Ritz step: evec = V Y, r = AV Y, r_j -= theta_j evec_j (active j), sum r^2, max |r|
+// (optionally also the uncorrected AV Y, which LOBPCG keeps as ax_new)
+// ======================================================================================
+struct RitzArgs {
+  const double* v;     // n x l
+  const double* av;    // n x l
+  const double* cpk;   // packed Y: [KT][l4][16]
+  double* evec;        // n x k
+  double* r;           // n x k
+  double* avy;         // n x k or nullptr
+  double* red;         // block partials [nblk][16*KT][2]
+  long long n;
+  int l, l4, k;
+  double theta[48];
+  int active[48];
+};
+
+template <int KT, int VEC>
+__global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
+{
+  constexpr int RG = 16 * VEC;             // rows per wave tile (one row group)
+  extern __shared__ __attribute__((aligned(16))) double cs[];  // [KT][l4][16], later reduction scratch
+  typedef typename VecOf<VEC>::type vec_t;
+  const long long n = a.n;
+  const int l = a.l, l4 = a.l4;
+  for (int idx = threadIdx.x; idx < KT * l4 * 16; idx += 256) cs[idx] = a.cpk[idx];
+  __shared__ double s_theta[48];
+  __shared__ int s_active[48];
+  if (threadIdx.x < 48) { s_theta[threadIdx.x] = a.theta[threadIdx.x]; s_active[threadIdx.x] = a.active[threadIdx.x]; }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const long long ntiles = (n + RG - 1) / RG;
+  const int nsteps = l4 / 4;
+
+  double th[KT][4];
+  int act[KT][4];
+  double ssq[KT][4], smx[KT][4];
+#pragma unroll
+  for (int q = 0; q < KT; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = 16 * q + g + 4 * reg;
+      th[q][reg] = s_theta[j];
+      act[q][reg] = s_active[j];
+      ssq[q][reg] = 0.0;
+      smx[q][reg] = 0.0;
+    }
+
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    long long row = tile * RG + VEC * i;
+    const bool rok = row < n;
+    if (!rok) row = 0;
+    v4d av[VEC][KT], aav[VEC][KT];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+      for (int q = 0; q < KT; ++q) { av[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; aav[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll 4
+    for (int cs4 = 0; cs4 < nsteps; ++cs4) {
+      int col = 4 * cs4 + g;
+      const bool cok = col < l;
+      col = cok ? col : l - 1;
+      vec_t xv = *(const vec_t*)(a.v + (size_t)col * (size_t)n + row);
+      vec_t yv = *(const vec_t*)(a.av + (size_t)col * (size_t)n + row);
+      xv = cok ? xv : vzero<VEC>();
+      yv = cok ? yv : vzero<VEC>();
+      double cf[KT];
+#pragma unroll
+      for (int q = 0; q < KT; ++q) cf[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * cs4 + g) * 16 + i];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+          av[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[q], vget<VEC>(xv, e), av[e][q], 0, 0, 0);
+          aav[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[q], vget<VEC>(yv, e), aav[e][q], 0, 0, 0);
+        }
+    }
+    if (rok) {
+#pragma unroll
+      for (int q = 0; q < KT; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int j = 16 * q + g + 4 * reg;
+          if (j >= a.k) continue;
+          const double e0 = av[0][q][reg], e1 = av[VEC - 1][q][reg];
+          double r0 = aav[0][q][reg], r1 = aav[VEC - 1][q][reg];
+          if (a.avy) *(vec_t*)(a.avy + (size_t)j * (size_t)n + row) = vmake<VEC>(r0, r1);
+          if (act[q][reg]) {
+            r0 = r0 - th[q][reg] * e0;   // daxpy(-eig), reference diaglib.f90:1729
+            ssq[q][reg] += r0 * r0;
+            smx[q][reg] = fmax(smx[q][reg], fabs(r0));
+            if constexpr (VEC == 2) {
+              r1 = r1 - th[q][reg] * e1;
+              ssq[q][reg] += r1 * r1;
+              smx[q][reg] = fmax(smx[q][reg], fabs(r1));
+            }
+          }
+          *(vec_t*)(a.evec + (size_t)j * (size_t)n + row) = vmake<VEC>(e0, e1);
+          *(vec_t*)(a.r + (size_t)j * (size_t)n + row) = vmake<VEC>(r0, r1);
+        }
+    }
+  }
+  // reduce over the 16 lanes that share g (xor-shuffles stay inside 16-lane groups), then over waves
+  __syncthreads();   // everyone is done with cs as the copy of Y
+  double* sred = cs; // [4 waves][16*KT][2]
+#pragma unroll
+  for (int q = 0; q < KT; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      double s = ssq[q][reg], m = smx[q][reg];
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        s += __shfl_xor(s, off, 64);
+        m = fmax(m, __shfl_xor(m, off, 64));
+      }
+      if (i == 0) {
+        const int j = 16 * q + g + 4 * reg;
+        sred[(wave * 16 * KT + j) * 2 + 0] = s;
+        sred[(wave * 16 * KT + j) * 2 + 1] = m;
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x < 16 * KT) {
+    const int j = threadIdx.x;
+    double s = 0.0, m = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      s += sred[(w * 16 * KT + j) * 2 + 0];
+      m = fmax(m, sred[(w * 16 * KT + j) * 2 + 1]);
+    }
+    a.red[((size_t)blockIdx.x * 16 * KT + j) * 2 + 0] = s;
+    a.red[((size_t)blockIdx.x * 16 * KT + j) * 2 + 1] = m;
+  }
+}
+
+// out[j] = { sum_b red[b][j][0], max_b red[b][j][1] }, fixed order
+__global__ void ritz_reduce_kernel(const double* red, int nblk, int ncol, double* out)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ncol) return;
+  double s = 0.0, m = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += red[((size_t)b * ncol + j) * 2 + 0];
+    m = fmax(m, red[((size_t)b * ncol + j) * 2 + 1]);
+  }
+  out[j] = s;
+  out[ncol + j] = m;
+}
+
+// ======================================================================================
+// Elementwise
+// ======================================================================================
+__global__ void axpy_kernel(size_t len, double alpha, const double* __restrict__ x, double* __restrict__ y)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < len; i += stride) y[i] += alpha * x[i];
+}
+
+// block partial sums of squares; fixed grid => deterministic
+__global__ __launch_bounds__(256) void sumsq_kernel(size_t len, const double* __restrict__ x, double* partial)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double s = 0.0;
+  for (; i < len; i += stride) s += x[i] * x[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  __shared__ double w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((w[0] + w[1]) + w[2]) + w[3];
+}
+
+__global__ void sum_partials_kernel(const double* partial, int nblk, double* out)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[b];
+    out[0] = s;
+  }
+}
+
+// documented counter-based generator (same as oracle/oracle.c orc_u01)
+__device__ __host__ inline double u01(unsigned long long seed, unsigned long long i, unsigned long long j)
+{
+  unsigned long long z = seed * 0x9E3779B97F4A7C15ULL + i * 0xBF58476D1CE4E5B9ULL + j * 0x94D049BB133111EBULL;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+  z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__global__ void random_fill_kernel(long long n, int m, double* evec, long long row0)
+{
+  const long long total = n * (long long)m;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; idx < total; idx += stride) {
+    const long long i = idx % n, j = idx / n;
+    evec[idx] = u01(7ULL, (unsigned long long)(row0 + i + 1), (unsigned long long)(j + 1));
+  }
+}
+
+// built-in operator A = diag(i+1) + sigma W W^T
+__global__ void synth_build_kernel(long long row0, int n, int rw, double sigma, double* w, double* diag)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long gi = (unsigned long long)(row0 + i + 1);
+  const double inv = 1.0 / sqrt((double)gi);
+  double s = 0.0;
+  for (int j = 0; j < rw; ++j) {
+    const double h = 2.0 * u01(1ULL, gi, (unsigned long long)(j + 1)) - 1.0;
+    const double v = h * inv;
+    w[(size_t)j * n + i] = v;
+    s += v * v;
+  }
+  diag[i] = ((double)gi + 1.0) + sigma * s;
+}
+
+// ax = d x + sigma W t,  t = W^T x (rw x m, column-major, ld rw) already reduced
+template <int RW>
+__global__ __launch_bounds__(256) void synth_apply_kernel(long long row0, int n, int m, double sigma,
+                                                          const double* __restrict__ w, const double* __restrict__ t,
+                                                          const double* __restrict__ x, double* __restrict__ ax)
+{
+  extern __shared__ double ts[];  // RW x m
+  for (int idx = threadIdx.x; idx < RW * m; idx += 256) ts[idx] = t[idx];
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const double d = (double)(row0 + i + 1) + 1.0;
+    double wv[RW];
+#pragma unroll
+    for (int q = 0; q < RW; ++q) wv[q] = w[(size_t)q * n + i];
+    for (int c = 0; c < m; ++c) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < RW; ++q) s += wv[q] * ts[q + c * RW];
+      ax[(size_t)c * n + i] = d * x[(size_t)c * n + i] + sigma * s;
+    }
+  }
+}
+
+__global__ void synth_precnd_kernel(int n, int m, double fac, const double* __restrict__ diag,
+                                    const double* __restrict__ x, double* __restrict__ px)
+{
+  const size_t total = (size_t)n * m;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; idx < total; idx += stride) {
+    const double den = diag[idx % n] + fac;
+    px[idx] = (fabs(den) > 1.0e-5) ? x[idx] / den : x[idx];   // mprec, main.f90:161-169
+  }
+}
+
+// ======================================================================================
+// host side of the engine
+// ======================================================================================
+struct TimedLaunch { hipEvent_t a, b; int cls; };
+
+struct HipEngine : dla::Engine {
+  int device = 0;
+  int ncu = 256;
+  hipStream_t st = nullptr;
+  std::string nm;
+  // workspaces
+  double* d_partial = nullptr; size_t partial_bytes = 0;
+  double* d_small = nullptr;   size_t small_bytes = 0;    // reduced results (device)
+  double* h_small = nullptr;                              // pinned mirror
+  static const int RING = 8;
+  double* h_ring[RING] = {nullptr}; hipEvent_t ring_ev[RING]; size_t ring_bytes = 0; int ring_pos = 0;
+  double* d_cpk = nullptr; size_t cpk_bytes = 0;
+    // built-in operator
+  double* d_w = nullptr; double* d_diag = nullptr; double* d_t = nullptr;
+  long long syn_row0 = 0; int syn_n = 0, syn_rw = 0; double syn_sigma = 0.0;
+  // rccl
+  ncclComm_t comm = nullptr;
+  // timing
+  std::vector<TimedLaunch> timed;
+  std::vector<hipEvent_t> ev_pool;
+
+  const char* name() const override { return nm.c_str(); }
+  void* stream() override { return (void*)st; }
+
+  ~HipEngine() override
+  {
+    if (st) (void)hipStreamSynchronize(st);
+    if (comm) ncclCommDestroy(comm);
+    for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (d_partial) (void)hipFree(d_partial);
+    if (d_small) (void)hipFree(d_small);
+    if (h_small) (void)hipHostFree(h_small);
+    for (int i = 0; i < RING; ++i) if (h_ring[i]) { (void)hipHostFree(h_ring[i]); (void)hipEventDestroy(ring_ev[i]); }
+    if (d_cpk) (void)hipFree(d_cpk);
+    if (d_w) (void)hipFree(d_w);
+    if (d_diag) (void)hipFree(d_diag);
+    if (d_t) (void)hipFree(d_t);
+    if (st) (void)hipStreamDestroy(st);
+  }
+
+  int init(int dev)
+  {
+    int cnt = 0;
+    HIPCHK(hipGetDeviceCount(&cnt));
+    if (cnt <= 0) { err = "no HIP device"; return DLA_ERR_NO_DEVICE; }
+    if (dev >= cnt) dev = dev % cnt;
+    device = dev;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    ncu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    nm = std::string("hip:") + p.gcnArchName;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    small_bytes = sizeof(double) * 512 * 512;
+    HIPCHK(hipMalloc((void**)&d_small, small_bytes));
+    HIPCHK(hipHostMalloc((void**)&h_small, small_bytes, hipHostMallocDefault));
+    return DLA_OK;
+  }
+
+  // ---- timing helpers
+  struct Scope {
+    HipEngine* e; int cls; hipEvent_t a = nullptr, b = nullptr;
+    Scope(HipEngine* e_, int cls_, double bytes, double flops) : e(e_), cls(cls_)
+    {
+      e->stats.launches[cls] += 1;
+      e->stats.alg_bytes[cls] += bytes;
+      e->stats.flops[cls] += flops;
+      if (e->profile) {
+        a = e->get_event(); b = e->get_event();
+        (void)hipEventRecord(a, e->st);
+      }
+    }
+    ~Scope()
+    {
+      if (e->profile) {
+        (void)hipEventRecord(b, e->st);
+        e->timed.push_back({a, b, cls});
+        if (e->timed.size() > 4096) e->collect_times();
+      }
+    }
+  };
+  hipEvent_t get_event()
+  {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+  }
+  void collect_times() override
+  {
+    if (timed.empty()) return;
+    (void)hipStreamSynchronize(st);
+    for (auto& t : timed) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) stats.ms[t.cls] += ms;
+      ev_pool.push_back(t.a); ev_pool.push_back(t.b);
+    }
+    timed.clear();
+  }
+
+  // ---- memory
+  int alloc(size_t bytes, void** dev) override
+  {
+    *dev = nullptr;
+    if (bytes == 0) bytes = 8;
+    hipError_t e = hipMalloc(dev, bytes);
+    if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return DLA_ERR_ALLOC; }
+    return DLA_OK;
+  }
+  int free_(void* dev) override { if (dev) { (void)hipStreamSynchronize(st); HIPCHK(hipFree(dev)); } return DLA_OK; }
+  int zero(void* dev, size_t bytes) override
+  {
+    Scope s(this, DLA_OP_ELEM, (double)bytes, 0.0);
+    HIPCHK(hipMemsetAsync(dev, 0, bytes, st));
+    return DLA_OK;
+  }
+  int h2d(void* dev, const void* host, size_t bytes) override
+  {
+    HIPCHK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return DLA_OK;
+  }
+  int d2h(void* host, const void* dev, size_t bytes) override
+  {
+    HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    stats.host_syncs++;
+    return DLA_OK;
+  }
+  int d2d(void* dst, const void* src, size_t bytes) override
+  {
+    Scope s(this, DLA_OP_ELEM, 2.0 * (double)bytes, 0.0);
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+    return DLA_OK;
+  }
+  int sync() override { HIPCHK(hipStreamSynchronize(st)); return DLA_OK; }
+  int host_alloc(size_t bytes, void** p) override { HIPCHK(hipHostMalloc(p, bytes, hipHostMallocDefault)); return DLA_OK; }
+  int host_free(void* p) override { if (p) HIPCHK(hipHostFree(p)); return DLA_OK; }
+
+  int ensure_partial(size_t bytes)
+  {
+    if (bytes <= partial_bytes) return DLA_OK;
+    if (d_partial) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(d_partial)); d_partial = nullptr; }
+    HIPCHK(hipMalloc((void**)&d_partial, bytes));
+    partial_bytes = bytes;
+    return DLA_OK;
+  }
+  int ensure_small(size_t bytes)
+  {
+    if (bytes <= small_bytes) return DLA_OK;
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipFree(d_small)); HIPCHK(hipHostFree(h_small));
+    small_bytes = bytes;
+    HIPCHK(hipMalloc((void**)&d_small, small_bytes));
+    HIPCHK(hipHostMalloc((void**)&h_small, small_bytes, hipHostMallocDefault));
+    return DLA_OK;
+  }
+
+  // stage a small host matrix to the device through a ring of pinned buffers (no host sync)
+  int stage_to_device(const double* host_packed, size_t bytes, double* dev)
+  {
+    if (bytes > ring_bytes) {
+      HIPCHK(hipStreamSynchronize(st));
+      for (int i = 0; i < RING; ++i) {
+        if (h_ring[i]) { HIPCHK(hipHostFree(h_ring[i])); } else { HIPCHK(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming)); }
+        HIPCHK(hipHostMalloc((void**)&h_ring[i], std::max(bytes, (size_t)1 << 16), hipHostMallocDefault));
+      }
+      ring_bytes = std::max(bytes, (size_t)1 << 16);
+    }
+    const int slot = ring_pos;
+    ring_pos = (ring_pos + 1) % RING;
+    HIPCHK(hipEventSynchronize(ring_ev[slot]));
+    std::memcpy(h_ring[slot], host_packed, bytes);
+    HIPCHK(hipMemcpyAsync(dev, h_ring[slot], bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(ring_ev[slot], st));
+    return DLA_OK;
+  }
+
+  // ---- collectives on small device buffers
+  int allreduce_dev(double* dev, int count, int op /*0 sum, 1 max*/, double* host_mirror)
+  {
+    if (nranks <= 1) return DLA_OK;
+    stats.allreduces++;
+    if (comm) {
+      ncclResult_t r = ncclAllReduce(dev, dev, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax, comm, st);
+      if (r != ncclSuccess) { err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return DLA_ERR_COMM; }
+      return DLA_OK;
+    }
+    if (hook) {
+      HIPCHK(hipMemcpyAsync(host_mirror, dev, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      hook(hook_user, host_mirror, count, op);
+      HIPCHK(hipMemcpyAsync(dev, host_mirror, sizeof(double) * count, hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+      return DLA_OK;
+    }
+    err = "nranks > 1 but neither an RCCL communicator nor a reduction hook is attached";
+    return DLA_ERR_COMM;
+  }
+  int comm_init(int nr, int rk, const char id[128]) override
+  {
+    ncclUniqueId uid;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    std::memcpy(&uid, id, 128);
+    HIPCHK(hipSetDevice(device));
+    ncclResult_t r = ncclCommInitRank(&comm, nr, uid, rk);
+    if (r != ncclSuccess) { err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); comm = nullptr; return DLA_ERR_COMM; }
+    nranks = nr; rank = rk;
+    return DLA_OK;
+  }
+
+  // ---- Gram
+  template <int TLW, int KT>
+  int launch_gram(const GramArgs& a, dim3 grid, bool vec2)
+  {
+    constexpr int RS = (TLW * KT >= 6) ? 2 : 4;
+    if (vec2) hipLaunchKernelGGL((gram_kernel<TLW, KT, 2, RS>), grid, dim3(256), 0, st, a);
+    else      hipLaunchKernelGGL((gram_kernel<TLW, KT, 1, RS>), grid, dim3(256), 0, st, a);
+    return DLA_OK;
+  }
+
+  // result stays on the device in d_small (l x k, ld = l), reduced over ranks
+  int gram_dev(int n, int l, const double* x, int k, const double* u)
+  {
+    const int tx = (l + 15) / 16, tu = (k + 15) / 16;
+    // tile shape of one pass: KT U-tiles x TLW X-tiles, at most 12 accumulators
+    int kt = std::min(tu, 4);
+    const int passes_u = (tu + kt - 1) / kt;
+    kt = (tu + passes_u - 1) / passes_u;
+    static const int maxtl[5] = {0, 12, 6, 4, 3};
+    const int passes_x = (tx + maxtl[kt] - 1) / maxtl[kt];
+    int tlw = (tx + passes_x - 1) / passes_x;
+    // round up to an instantiated width
+    static const int avail1[] = {1, 2, 3, 4, 6, 8, 12};
+    if (kt == 1) { for (int v : avail1) if (v >= tlw) { tlw = v; break; } }
+    else if (kt == 2) { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : tlw <= 4 ? 4 : 6; }
+    else if (kt == 3) { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : 4; }
+    else { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : 3; }
+    const int px = (tx + tlw - 1) / tlw;
+    const int passes = px * passes_u;
+    const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)u) % 16 == 0);
+    const int ch = vec2 ? 32 : 16;
+    long long nchunks = ((long long)n + ch - 1) / ch;
+    long long want = (nchunks + 4 * 4 - 1) / (4 * 4);   // >= 4 chunks per wave
+    int blocks_per_pass = (int)std::max(1LL, std::min((long long)(2 * ncu) / std::max(1, std::min(passes, 2)), want));
+    const int slots = tlw * kt;
+    int stc = ensure_partial(sizeof(double) * (size_t)passes * blocks_per_pass * slots * 256);
+    if (stc) return stc;
+    stc = ensure_small(sizeof(double) * (size_t)l * k);
+    if (stc) return stc;
+    GramArgs a{x, u, d_partial, (long long)n, l, k, px};
+    dim3 grid(blocks_per_pass, passes);
+    {
+      const bool same = (x == u) && (l == k);
+      Scope s(this, DLA_OP_GRAM, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k);
+#define GL(T, K) if (tlw == T && kt == K) launch_gram<T, K>(a, grid, vec2); else
+      GL(1, 1) GL(2, 1) GL(3, 1) GL(4, 1) GL(6, 1) GL(8, 1) GL(12, 1)
+      GL(1, 2) GL(2, 2) GL(4, 2) GL(6, 2)
+      GL(1, 3) GL(2, 3) GL(4, 3)
+      GL(1, 4) GL(2, 4) GL(3, 4)
+      { err = "gram: no kernel instance"; return DLA_ERR_RUNTIME; }
+#undef GL
+      GramReduceArgs ra{d_partial, d_small, blocks_per_pass, l, k, tlw, kt, px};
+      hipLaunchKernelGGL(gram_reduce_kernel, dim3(passes * slots), dim3(1024), 0, st, ra);
+    }
+    HIPCHK(hipGetLastError());
+    return allreduce_dev(d_small, l * k, 0, h_small);
+  }
+
+  int gram(int n, int l, const double* x, int k, const double* u, double* c_host, int ldc) override
+  {
+    int stc = gram_dev(n, l, x, k, u);
+    if (stc) return stc;
+    HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * (size_t)l * k, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    stats.host_syncs++;
+    for (int j = 0; j < k; ++j) std::memcpy(c_host + (size_t)j * ldc, h_small + (size_t)j * l, sizeof(double) * l);
+    return DLA_OK;
+  }
+
+  // ---- packed C upload: [KT][l4][16], zero padded
+  int upload_packed(const double* c_host, int ldc, int l0, int l, int k, int kt, int l4)
+  {
+    const size_t cnt = (size_t)kt * l4 * 16;
+    if (sizeof(double) * cnt > cpk_bytes) {
+      HIPCHK(hipStreamSynchronize(st));
+      if (d_cpk) HIPCHK(hipFree(d_cpk));
+      cpk_bytes = std::max(sizeof(double) * cnt, (size_t)1 << 16);
+      HIPCHK(hipMalloc((void**)&d_cpk, cpk_bytes));
+    }
+    std::vector<double> pk(cnt, 0.0);
+    for (int j = 0; j < k; ++j) {
+      const int q = j / 16, jj = j % 16;
+      for (int p = 0; p < l; ++p) pk[(size_t)q * l4 * 16 + (size_t)p * 16 + jj] = c_host[(size_t)(l0 + p) + (size_t)j * ldc];
+    }
+    return stage_to_device(pk.data(), sizeof(double) * cnt, d_cpk);
+  }
+
+  template <int KT>
+  void launch_gemm(const GemmArgs& a, int blocks, size_t lds, bool vec2, int mode)
+  {
+#define GM(V, M) hipLaunchKernelGGL((gemm_kernel<KT, V, M>), dim3(blocks), dim3(256), lds, st, a)
+    if (vec2) { if (mode == 0) GM(2, 0); else if (mode == 1) GM(2, 1); else if (mode == 2) GM(2, 2); else GM(2, 3); }
+    else      { if (mode == 0) GM(1, 0); else if (mode == 1) GM(1, 1); else if (mode == 2) GM(1, 2); else GM(1, 3); }
+#undef GM
+  }
+
+  int gemm_chunk(int n, int l0, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode, int cls)
+  {
+    const int kt = (k + 15) / 16;
+    const int l4 = ((l + 3) / 4) * 4;
+    int stc = upload_packed(c_host, ldc, l0, l, k, kt, l4);
+    if (stc) return stc;
+    const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)z) % 16 == 0);
+    const int wt = vec2 ? 64 : 32;
+    const long long ntiles = ((long long)n + wt - 1) / wt;
+    const size_t lds = sizeof(double) * (size_t)kt * l4 * 16;
+    const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
+    const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu, (ntiles + 3) / 4));
+    GemmArgs a{};
+    a.x = x + (size_t)l0 * n; a.cpk = d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k;
+    const double rd = (mode == 0) ? 8.0 * n * (double)l : (mode == 2 ? 8.0 * n * (double)k : 8.0 * n * (double)(l + k));
+    Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k);
+    switch (kt) {
+      case 1: launch_gemm<1>(a, blocks, lds, vec2, mode); break;
+      case 2: launch_gemm<2>(a, blocks, lds, vec2, mode); break;
+      case 3: launch_gemm<3>(a, blocks, lds, vec2, mode); break;
+      default: err = "gemm: k > 48 not supported in one call"; return DLA_ERR_ARG;
+    }
+    HIPCHK(hipGetLastError());
+    return DLA_OK;
+  }
+
+  int gemm_cols(int n, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode, int cls)
+  {
+    // split the contraction so that the LDS copy of C stays <= 64 KiB (two blocks per CU)
+    const int kt = (k + 15) / 16;
+    int lmax = (int)((64 * 1024) / (sizeof(double) * 16 * kt));
+    lmax = std::max(4, (lmax / 4) * 4);
+    if (mode == 2 && l > lmax) { err = "trmm: k too large"; return DLA_ERR_ARG; }
+    if (l == 0) {
+      if (mode == 0) return zero(z, sizeof(double) * (size_t)n * k);
+      return DLA_OK;
+    }
+    int l0 = 0, m = mode;
+    while (l0 < l) {
+      const int lc = std::min(lmax, l - l0);
+      int stc = gemm_chunk(n, l0, lc, x, k, c_host, ldc, z, m, cls);
+      if (stc) return stc;
+      l0 += lc;
+      if (m == 0) m = 3;   // later chunks accumulate
+    }
+    return DLA_OK;
+  }
+
+  int gemm(int n, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode) override
+  {
+    // wide outputs are processed 48 columns at a time
+    for (int k0 = 0; k0 < k; k0 += 48) {
+      const int kc = std::min(48, k - k0);
+      int stc = gemm_cols(n, l, x, kc, c_host + (size_t)k0 * ldc, ldc, z + (size_t)k0 * n, mode, DLA_OP_GEMM);
+      if (stc) return stc;
+    }
+    return DLA_OK;
+  }
+
+  int trmm(int n, int k, double* u, const double* w_host, int ld) override
+  {
+    if (k > 48) { err = "trmm: block wider than 48 columns"; return DLA_ERR_ARG; }
+    return gemm_cols(n, k, u, k, w_host, ld, u, 2, DLA_OP_TRMM);
+  }
+
+  int ritz_residual(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
+                    const double* eig, int n_res, const int* skip, double* evec, double* r, double* avy,
+                    double* out) override
+  {
+    if (m > 48) { err = "ritz_residual: m > 48"; return DLA_ERR_ARG; }
+    const int kt = (m + 15) / 16;
+    const int l4 = ((l + 3) / 4) * 4;
+    const size_t lds_c = sizeof(double) * (size_t)kt * l4 * 16;
+    if (lds_c > 150 * 1024) { err = "ritz_residual: subspace too large for the LDS copy of Y"; return DLA_ERR_ARG; }
+    int stc = upload_packed(y_host, ldy, 0, l, m, kt, l4);
+    if (stc) return stc;
+    RitzArgs a{};
+    int nact = 0;
+    for (int j = 0; j < n_res && j < 48; ++j) {
+      if (skip && skip[j]) continue;
+      a.theta[j] = eig[j]; a.active[j] = 1; ++nact;
+    }
+    uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy;
+    const bool vec2 = (n % 2 == 0) && (al % 16 == 0);
+    const int rg = vec2 ? 32 : 16;
+    const long long ntiles = ((long long)n + rg - 1) / rg;
+    const size_t lds = std::max(lds_c, sizeof(double) * 4 * 16 * kt * 2);
+    const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
+    const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu, (ntiles + 7) / 8));
+    stc = ensure_partial(sizeof(double) * (size_t)blocks * 16 * kt * 2);
+    if (stc) return stc;
+    a.v = v; a.av = av; a.cpk = d_cpk; a.evec = evec; a.r = r; a.avy = avy; a.red = d_partial;
+    a.n = n; a.l = l; a.l4 = l4; a.k = m;
+    const int ncol = 16 * kt;
+    {
+      Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact);
+      if (vec2) {
+        if (kt == 1) hipLaunchKernelGGL((ritz_kernel<1, 2>), dim3(blocks), dim3(256), lds, st, a);
+        else if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 2>), dim3(blocks), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((ritz_kernel<3, 2>), dim3(blocks), dim3(256), lds, st, a);
+      } else {
+        if (kt == 1) hipLaunchKernelGGL((ritz_kernel<1, 1>), dim3(blocks), dim3(256), lds, st, a);
+        else if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 1>), dim3(blocks), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((ritz_kernel<3, 1>), dim3(blocks), dim3(256), lds, st, a);
+      }
+      hipLaunchKernelGGL(ritz_reduce_kernel, dim3(1), dim3(64), 0, st, d_partial, blocks, ncol, d_small);
+    }
+    HIPCHK(hipGetLastError());
+    stc = allreduce_dev(d_small, ncol, 0, h_small);
+    if (stc) return stc;
+    stc = allreduce_dev(d_small + ncol, ncol, 1, h_small + ncol);
+    if (stc) return stc;
+    HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * 2 * ncol, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    stats.host_syncs++;
+    for (int j = 0; j < n_res; ++j) { out[2 * j] = h_small[j]; out[2 * j + 1] = h_small[ncol + j]; }
+    return DLA_OK;
+  }
+
+  int axpy(size_t len, double alpha, const double* x, double* y) override
+  {
+    Scope s(this, DLA_OP_ELEM, 24.0 * (double)len, 2.0 * (double)len);
+    const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 8, (len + 255) / 256));
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, st, len, alpha, x, y);
+    HIPCHK(hipGetLastError());
+    return DLA_OK;
+  }
+
+  int sumsq(size_t len, const double* x, double* out) override
+  {
+    const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 4, (len + 1023) / 1024));
+    int stc = ensure_partial(sizeof(double) * blocks);
+    if (stc) return stc;
+    {
+      Scope s(this, DLA_OP_ELEM, 8.0 * (double)len, 2.0 * (double)len);
+      hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, len, x, d_partial);
+      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, d_partial, blocks, d_small);
+    }
+    HIPCHK(hipGetLastError());
+    stc = allreduce_dev(d_small, 1, 0, h_small);
+    if (stc) return stc;
+    HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    stats.host_syncs++;
+    *out = h_small[0];
+    return DLA_OK;
+  }
+
+  int random_fill(int n, int m, double* evec, long long row0) override
+  {
+    Scope s(this, DLA_OP_ELEM, 8.0 * (double)n * m, 0.0);
+    const size_t total = (size_t)n * m;
+    const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 8, (total + 255) / 256));
+    hipLaunchKernelGGL(random_fill_kernel, dim3(blocks), dim3(256), 0, st, (long long)n, m, evec, row0);
+    HIPCHK(hipGetLastError());
+    return DLA_OK;
+  }
+
+  // ---- built-in operator
+  int synth_setup(long long n_global, long long row0, int n_local, int rank_w, double sigma) override
+  {
+    (void)n_global;
+    if (rank_w != 4) { err = "synth operator: rank_w must be 4"; return DLA_ERR_ARG; }
+    HIPCHK(hipStreamSynchronize(st));
+    if (d_w) HIPCHK(hipFree(d_w));
+    if (d_diag) HIPCHK(hipFree(d_diag));
+    if (!d_t) HIPCHK(hipMalloc((void**)&d_t, sizeof(double) * 4 * 64));
+    HIPCHK(hipMalloc((void**)&d_w, sizeof(double) * (size_t)n_local * rank_w));
+    HIPCHK(hipMalloc((void**)&d_diag, sizeof(double) * (size_t)n_local));
+    syn_row0 = row0; syn_n = n_local; syn_rw = rank_w; syn_sigma = sigma;
+    hipLaunchKernelGGL(synth_build_kernel, dim3((n_local + 255) / 256), dim3(256), 0, st, row0, n_local, rank_w, sigma, d_w, d_diag);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return DLA_OK;
+  }
+
+  int synth_matvec(int n, int m, const double* x, double* ax) override
+  {
+    if (n != syn_n) { err = "synth_matvec: n differs from setup"; return DLA_ERR_ARG; }
+    if (m > 64) { err = "synth_matvec: m > 64"; return DLA_ERR_ARG; }
+    int stc = gram_dev(n, syn_rw, d_w, m, x);     // t = W^T x  (4 x m), reduced over ranks, on device
+    if (stc) return stc;
+    Scope s(this, DLA_OP_MATVEC, 8.0 * n * (2.0 * m + syn_rw), 2.0 * (double)n * m * (2 * syn_rw + 1));
+    HIPCHK(hipMemcpyAsync(d_t, d_small, sizeof(double) * syn_rw * m, hipMemcpyDeviceToDevice, st));
+    const int blocks = std::max(1, std::min(ncu * 8, (n + 255) / 256));
+    hipLaunchKernelGGL((synth_apply_kernel<4>), dim3(blocks), dim3(256), sizeof(double) * 4 * m, st,
+                       syn_row0, n, m, syn_sigma, d_w, d_t, x, ax);
+    HIPCHK(hipGetLastError());
+    return DLA_OK;
+  }
+
+  int synth_precnd(int n, int m, double fac, const double* x, double* px) override
+  {
+    if (n != syn_n) { err = "synth_precnd: n differs from setup"; return DLA_ERR_ARG; }
+    Scope s(this, DLA_OP_PRECND, 8.0 * n * (2.0 * m + 1.0), (double)n * m);
+    const size_t total = (size_t)n * m;
+    const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 8, (total + 255) / 256));
+    hipLaunchKernelGGL(synth_precnd_kernel, dim3(blocks), dim3(256), 0, st, n, m, fac, d_diag, x, px);
+    HIPCHK(hipGetLastError());
+    return DLA_OK;
+  }
+};
+
+}  // namespace
+
+namespace dla {
+
+Engine* make_engine(int device, std::string& err)
+{
+  HipEngine* e = new HipEngine();
+  if (e->init(device) != DLA_OK) {
+    err = e->err;
+    delete e;
+    return nullptr;
+  }
+  return e;
+}
+
+int engine_unique_id(char id[128])
+{
+  ncclUniqueId uid;
+  if (ncclGetUniqueId(&uid) != ncclSuccess) return DLA_ERR_COMM;
+  std::memcpy(id, &uid, 128);
+  return DLA_OK;
+}
+
+}  // namespace dla

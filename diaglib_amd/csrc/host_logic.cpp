@@ -1,0 +1,533 @@
+// diaglib_amd/csrc/host_logic.cpp -- host side of the C-ABI (include/diaglib_amd.h):
+// context, callback trampolines, and the control flow of the orthogonalisation kernels
+// (Cholesky-QR with refinement, block Gram-Schmidt).  All O(n) work is delegated to the
+// device engine (dla_internal.h); this file only sees the small k x k / m x k matrices.
+//
+// Behavioural spec: reference diaglib.f90:3185-3341 (ortho_cd), :3481-3574 (ortho_vs_x),
+// :3094-3183 (b_ortho), :3576-3663 (b_ortho_vs_x), :3734-3786 (check_guess),
+// :3686-3732 (get_coeffs) -- see SURVEY.md 8a rows A8, A10, A12, A14, A15.
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "dla_internal.h"
+
+using dla::Engine;
+
+namespace {
+
+const double kEps = DBL_EPSILON;           // epsilon(one)
+const double kTolOrtho = 2.0 * DBL_EPSILON;  // tol_ortho, diaglib.f90:151
+const int kMaxIt = 10;                     // maxit, diaglib.f90:3224,3521
+
+dla_ctx* g_default = nullptr;
+// built-in operator callbacks have the reference's context-free shape; they act on this ctx
+dla_ctx* g_synth_ctx = nullptr;
+
+int fail(dla_ctx* c, int code, const std::string& msg)
+{
+  if (c) c->err = msg;
+  return code;
+}
+
+int engfail(dla_ctx* c, int code)
+{
+  if (code != 0 && c) c->err = c->eng->err;
+  return code;
+}
+
+long long global_rows(dla_ctx* c, int n) { return c->n_global > 0 ? c->n_global : (long long)n; }
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ context
+int dla_create(dla_ctx** out, int device)
+{
+  if (!out) return DLA_ERR_ARG;
+  *out = nullptr;
+  if (device < 0) {
+    const char* lr = std::getenv("LOCAL_RANK");
+    device = lr ? std::atoi(lr) : 0;
+  }
+  std::string err;
+  Engine* e = dla::make_engine(device, err);
+  if (!e) {
+    std::fprintf(stderr, "diaglib_amd: cannot create the HIP engine: %s\n", err.c_str());
+    return DLA_ERR_NO_DEVICE;
+  }
+  dla_ctx* c = new dla_ctx();
+  c->eng = e;
+  *out = c;
+  return DLA_OK;
+}
+
+int dla_destroy(dla_ctx* c)
+{
+  if (!c) return DLA_OK;
+  if (c->stage_x) c->eng->host_free(c->stage_x);
+  if (c->stage_y) c->eng->host_free(c->stage_y);
+  delete c->eng;
+  if (g_default == c) g_default = nullptr;
+  if (g_synth_ctx == c) g_synth_ctx = nullptr;
+  delete c;
+  return DLA_OK;
+}
+
+dla_ctx* dla_default_ctx(void)
+{
+  if (!g_default) {
+    dla_ctx* c = nullptr;
+    if (dla_create(&c, -1) != DLA_OK) {
+      // fail loudly: the product has no CPU path
+      std::fprintf(stderr, "diaglib_amd: no usable MI355X/HIP device -- aborting (there is no CPU fallback)\n");
+      std::abort();
+    }
+    g_default = c;
+  }
+  return g_default;
+}
+
+int dla_set_option(dla_ctx* c, int option, int value)
+{
+  if (!c) return DLA_ERR_ARG;
+  switch (option) {
+    case DLA_OPT_CALLBACKS_ON_DEVICE: c->callbacks_on_device = value; break;
+    case DLA_OPT_EVEC_ON_DEVICE: c->evec_on_device = value; break;
+    case DLA_OPT_PROFILE: c->eng->profile = value != 0; break;
+    case DLA_OPT_VERBOSE_ORTHO: c->verbose_ortho = value; break;
+    default: return fail(c, DLA_ERR_ARG, "unknown option");
+  }
+  return DLA_OK;
+}
+
+int dla_get_option(dla_ctx* c, int option)
+{
+  if (!c) return -1;
+  switch (option) {
+    case DLA_OPT_CALLBACKS_ON_DEVICE: return c->callbacks_on_device;
+    case DLA_OPT_EVEC_ON_DEVICE: return c->evec_on_device;
+    case DLA_OPT_PROFILE: return c->eng->profile ? 1 : 0;
+    case DLA_OPT_VERBOSE_ORTHO: return c->verbose_ortho;
+    default: return -1;
+  }
+}
+
+const char* dla_last_error(dla_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* dla_backend_name(dla_ctx* c) { return c ? c->eng->name() : "none"; }
+void* dla_stream(dla_ctx* c) { return c ? c->eng->stream() : nullptr; }
+
+int dla_get_stats(dla_ctx* c, dla_stats* out)
+{
+  if (!c || !out) return DLA_ERR_ARG;
+  c->eng->collect_times();
+  *out = c->eng->stats;
+  return DLA_OK;
+}
+
+int dla_reset_stats(dla_ctx* c)
+{
+  if (!c) return DLA_ERR_ARG;
+  c->eng->collect_times();
+  std::memset(&c->eng->stats, 0, sizeof(dla_stats));
+  return DLA_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU
+int dla_comm_unique_id(char id[128]) { return dla::engine_unique_id(id); }
+
+int dla_comm_init(dla_ctx* c, int nranks, int rank, const char id[128])
+{
+  if (!c) return DLA_ERR_ARG;
+  return engfail(c, c->eng->comm_init(nranks, rank, id));
+}
+
+int dla_comm_info(dla_ctx* c, int* nranks, int* rank)
+{
+  if (!c) return DLA_ERR_ARG;
+  if (nranks) *nranks = c->eng->nranks;
+  if (rank) *rank = c->eng->rank;
+  return DLA_OK;
+}
+
+int dla_set_allreduce_hook(dla_ctx* c, dla_allreduce_fn fn, void* user, int nranks, int rank)
+{
+  if (!c) return DLA_ERR_ARG;
+  c->eng->hook = fn;
+  c->eng->hook_user = user;
+  c->eng->nranks = nranks;
+  c->eng->rank = rank;
+  return DLA_OK;
+}
+
+int dla_set_shard(dla_ctx* c, long long n_global, long long row0)
+{
+  if (!c) return DLA_ERR_ARG;
+  c->n_global = n_global;
+  c->row0 = row0;
+  return DLA_OK;
+}
+
+// ------------------------------------------------------------------ memory
+int dla_alloc(dla_ctx* c, size_t bytes, void** dev) { return engfail(c, c->eng->alloc(bytes, dev)); }
+int dla_free(dla_ctx* c, void* dev) { return engfail(c, c->eng->free_(dev)); }
+int dla_zero(dla_ctx* c, void* dev, size_t bytes) { return engfail(c, c->eng->zero(dev, bytes)); }
+int dla_upload(dla_ctx* c, void* dev, const void* host, size_t bytes) { return engfail(c, c->eng->h2d(dev, host, bytes)); }
+int dla_download(dla_ctx* c, void* host, const void* dev, size_t bytes) { return engfail(c, c->eng->d2h(host, dev, bytes)); }
+int dla_copy(dla_ctx* c, void* dst, const void* src, size_t bytes) { return engfail(c, c->eng->d2d(dst, src, bytes)); }
+int dla_sync(dla_ctx* c) { return engfail(c, c->eng->sync()); }
+
+// ------------------------------------------------------------------ block algebra
+int dla_gram(dla_ctx* c, int n, int l, const double* x, int k, const double* u, double* ch, int ldc)
+{
+  if (l <= 0 || k <= 0) return DLA_OK;
+  return engfail(c, c->eng->gram(n, l, x, k, u, ch, ldc));
+}
+
+int dla_panel_gemm(dla_ctx* c, int n, int l, const double* x, int k, const double* ch, int ldc, double* z)
+{
+  if (k <= 0) return DLA_OK;
+  return engfail(c, c->eng->gemm(n, l, x, k, ch, ldc, z, 0));
+}
+
+int dla_panel_update(dla_ctx* c, int n, int l, const double* x, int k, const double* ch, int ldc, double* u)
+{
+  if (k <= 0 || l <= 0) return DLA_OK;
+  return engfail(c, c->eng->gemm(n, l, x, k, ch, ldc, u, 1));
+}
+
+int dla_trmm_linvt(dla_ctx* c, int n, int k, double* u, const double* linv, int ld)
+{
+  // U <- U * Linv^T : W = Linv^T is upper triangular, W(p,j) = Linv(j,p) for p <= j
+  std::vector<double> w((size_t)k * k, 0.0);
+  for (int j = 0; j < k; ++j)
+    for (int p = 0; p <= j; ++p) w[(size_t)p + (size_t)j * k] = linv[(size_t)j + (size_t)p * ld];
+  return engfail(c, c->eng->trmm(n, k, u, w.data(), k));
+}
+
+int dla_ritz_residual(dla_ctx* c, int n, int l, int m, const double* v, const double* av, const double* y, int ldy,
+                      const double* eig, int n_res, const int* skip, double* evec, double* r, double* avy,
+                      double* rnorm)
+{
+  std::vector<double> sm((size_t)2 * (n_res > 0 ? n_res : 1), 0.0);
+  int st = c->eng->ritz_residual(n, l, m, v, av, y, ldy, eig, n_res, skip, evec, r, avy, sm.data());
+  if (st) return engfail(c, st);
+  double sqrtn = std::sqrt((double)global_rows(c, n));
+  for (int i = 0; i < n_res; ++i) {
+    if (skip && skip[i]) continue;
+    rnorm[2 * i] = std::sqrt(sm[2 * i]) / sqrtn;     // dnrm2/sqrtn, diaglib.f90:1730
+    rnorm[2 * i + 1] = sm[2 * i + 1];                // maxval(abs(r)), :1731
+  }
+  return DLA_OK;
+}
+
+int dla_axpy(dla_ctx* c, size_t len, double alpha, const double* x, double* y)
+{
+  return engfail(c, c->eng->axpy(len, alpha, x, y));
+}
+
+int dla_nrm2(dla_ctx* c, size_t len, const double* x, double* out)
+{
+  double s = 0.0;
+  int st = c->eng->sumsq(len, x, &s);
+  if (st) return engfail(c, st);
+  *out = std::sqrt(s);
+  return DLA_OK;
+}
+
+int dla_random_fill(dla_ctx* c, int n, int m, double* evec) { return engfail(c, c->eng->random_fill(n, m, evec, c->row0)); }
+
+// ------------------------------------------------------------------ orthogonalisation
+// ortho_cd, diaglib.f90:3185-3341.  Per macro-iteration: one Gram sweep, host Cholesky /
+// triangular inverse / norm estimates, one in-place triangular update sweep.
+int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
+{
+  *growth = 1.0;
+  *ok = 0;
+  if (k <= 0) { *ok = 1; return DLA_OK; }
+  std::vector<double> metric((size_t)k * k), msave((size_t)k * k);
+  int it = 0;
+  bool macro_done = false;
+  while (!macro_done) {
+    if (++it > kMaxIt) {
+      // reference prints and returns with ok=.false. (:3252-3254)
+      std::printf("  ortho_cd failed with the following error: maximum number of iterations reached.\n");
+      *ok = 0;
+      return DLA_OK;
+    }
+    int st = c->eng->gram(n, k, u, k, u, metric.data(), k);
+    if (st) return engfail(c, st);
+    msave = metric;
+    int info = dla_potrf_lower(k, metric.data(), k);
+    if (info != 0) {
+      // level-shift ladder (:3265-3295): shift = max(eps*alpha*||U||_F, 2 eps), alpha = 100, 1000, ...
+      double alpha = 100.0;
+      double tr = 0.0;
+      for (int i = 0; i < k; ++i) tr += msave[(size_t)i + (size_t)i * k];
+      double unorm = std::sqrt(tr > 0.0 ? tr : 0.0);  // ||U||_F = sqrt(trace(U^T U)), dnrm2 at :3268
+      int it_micro = 0;
+      bool micro_done = false;
+      while (!micro_done) {
+        if (++it_micro > kMaxIt) {
+          std::printf("  ortho_cd failed with the following error: maximum number of iterations for factorization reached.\n");
+          *ok = 0;
+          return fail(c, DLA_ERR_ORTHO, "ortho_cd: factorization failed after level shifting");  // reference: stop (:3283)
+        }
+        double shift = std::fmax(kEps * alpha * unorm, kTolOrtho);
+        metric = msave;
+        for (int i = 0; i < k; ++i) metric[(size_t)i + (size_t)i * k] += shift;
+        info = dla_potrf_lower(k, metric.data(), k);
+        alpha *= 10.0;
+        micro_done = (info == 0);
+      }
+    }
+    msave = metric;
+    dla_trtri_lower(k, msave.data(), k);
+    double l_norm = dla_norm_est(k, metric.data(), k);
+    double linv_norm = dla_norm_est(k, msave.data(), k);
+    double rcond = l_norm * linv_norm;
+    *growth *= linv_norm;
+    st = dla_trmm_linvt(c, n, k, u, msave.data(), k);
+    if (st) return st;
+    double error = kEps * rcond * rcond;
+    macro_done = error < kTolOrtho;
+  }
+  if (c->verbose_ortho) std::printf("  [dla] ortho_cd: %d macro iterations, growth %.3e\n", it, *growth);
+  *ok = 1;
+  return DLA_OK;
+}
+
+// Column-wise modified Gram-Schmidt (twice) on the device: the stand-in for the reference's
+// Householder fallback `ortho` (diaglib.f90:3052-3092), reached only when ortho_cd gives up.
+// Same span and orthonormality as U R^-1 from a QR factorisation; column signs follow the
+// input columns (R with positive diagonal).
+static int ortho_fallback(dla_ctx* c, int n, int k, double* u)
+{
+  for (int pass = 0; pass < 2; ++pass)
+    for (int j = 0; j < k; ++j) {
+      double* uj = u + (size_t)n * j;
+      if (j > 0) {
+        std::vector<double> h(j);
+        int st = c->eng->gram(n, j, u, 1, uj, h.data(), j);
+        if (st) return engfail(c, st);
+        st = c->eng->gemm(n, j, u, 1, h.data(), j, uj, 1);
+        if (st) return engfail(c, st);
+      }
+      double g = 0.0;
+      int st = c->eng->gram(n, 1, uj, 1, uj, &g, 1);
+      if (st) return engfail(c, st);
+      if (!(g > 0.0)) return fail(c, DLA_ERR_ORTHO, "ortho fallback: zero column");
+      double w = 1.0 / std::sqrt(g);
+      st = c->eng->trmm(n, 1, uj, &w, 1);
+      if (st) return engfail(c, st);
+    }
+  return DLA_OK;
+}
+
+static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, const double* bx, double* u)
+{
+  if (k <= 0) return DLA_OK;
+  int ok = 0, it = 0;
+  bool done = false;
+  double growth = 1.0, xu_norm;
+  std::vector<double> xu((size_t)(m > 0 ? m : 1) * k);
+  int st = dla_ortho_cd(c, n, k, u, &growth, &ok);        // :3533
+  if (st) return st;
+  if (!ok) { st = ortho_fallback(c, n, k, u); if (st) return st; }
+  while (!done) {
+    ++it;
+    if (m > 0) {
+      st = c->eng->gram(n, m, bx, k, u, xu.data(), m);     // xu = X^T U  (:3543) / (BX)^T U (:3632)
+      if (st) return engfail(c, st);
+      st = c->eng->gemm(n, m, x, k, xu.data(), m, u, 1);   // U -= X xu  (:3544)
+      if (st) return engfail(c, st);
+    }
+    st = dla_ortho_cd(c, n, k, u, &growth, &ok);           // :3548
+    if (st) return st;
+    if (!ok) {
+      st = ortho_fallback(c, n, k, u);
+      if (st) return st;
+      double s = 0.0;
+      if (m > 0) {
+        st = c->eng->gram(n, m, bx, k, u, xu.data(), m);   // :3559-3560
+        if (st) return engfail(c, st);
+        for (size_t i = 0; i < (size_t)m * k; ++i) s += xu[i] * xu[i];
+      }
+      xu_norm = std::sqrt(s);
+    } else {
+      xu_norm = growth * kEps;                             // :3562
+    }
+    done = xu_norm < kTolOrtho;                            // :3564
+    if (it > kMaxIt) return fail(c, DLA_ERR_ORTHO, " catastrophic failure of ortho_vs_x");  // :3568
+  }
+  if (c->verbose_ortho) std::printf("  [dla] ortho_vs_x: %d outer iterations\n", it);
+  return DLA_OK;
+}
+
+int dla_ortho_vs_x(dla_ctx* c, int n, int m, int k, const double* x, double* u)
+{
+  return ortho_vs_x_impl(c, n, m, k, x, x, u);
+}
+
+int dla_b_ortho_vs_x(dla_ctx* c, int n, int m, int k, const double* x, const double* bx, double* u)
+{
+  return ortho_vs_x_impl(c, n, m, k, x, bx, u);
+}
+
+// b_ortho, diaglib.f90:3094-3183 (use_svd=.false.): M = U^T BU, L = chol(M) (no failure
+// handling in the reference: a failed factorisation is reported here as an error), then
+// U <- U L^-T, BU <- BU L^-T.  The reference solves with dtrsm (:3177-3178); we apply the
+// explicit inverse like ortho_cd does, which is the same linear map.
+int dla_b_ortho(dla_ctx* c, int n, int m, double* u, double* bu)
+{
+  if (m <= 0) return DLA_OK;
+  std::vector<double> metric((size_t)m * m);
+  int st = c->eng->gram(n, m, u, m, bu, metric.data(), m);
+  if (st) return engfail(c, st);
+  if (dla_potrf_lower(m, metric.data(), m) != 0) return fail(c, DLA_ERR_LAPACK, "b_ortho: metric not positive definite");
+  dla_trtri_lower(m, metric.data(), m);
+  st = dla_trmm_linvt(c, n, m, u, metric.data(), m);
+  if (st) return st;
+  return dla_trmm_linvt(c, n, m, bu, metric.data(), m);
+}
+
+// check_guess, diaglib.f90:3734-3786
+int dla_check_guess(dla_ctx* c, int n, int m, double* evec)
+{
+  double fac = 0.0, growth;
+  int ok;
+  int st = dla_nrm2(c, (size_t)n * m, evec, &fac);
+  if (st) return st;
+  if (fac == 0.0) {
+    st = dla_random_fill(c, n, m, evec);
+    if (st) return st;
+    return dla_ortho_cd(c, n, m, evec, &growth, &ok);
+  }
+  std::vector<double> ov((size_t)m * m);
+  st = c->eng->gram(n, m, evec, m, evec, ov.data(), m);
+  if (st) return engfail(c, st);
+  double dn = 0.0, on = 0.0;
+  for (int i = 0; i < m; ++i) {
+    dn += ov[(size_t)i + (size_t)i * m] * ov[(size_t)i + (size_t)i * m];
+    for (int j = 0; j < i; ++j) on += ov[(size_t)j + (size_t)i * m] * ov[(size_t)j + (size_t)i * m];
+  }
+  dn /= (double)m;
+  if (dn != 1.0 || on != 0.0) return dla_ortho_cd(c, n, m, evec, &growth, &ok);   // :3774-3779
+  return DLA_OK;
+}
+
+// get_coeffs, diaglib.f90:3686-3732.  Host-size (len_u <= 3 n_max) problem: the same
+// ortho_vs_x runs on small device panels, so the numerics are those of the big sweeps.
+// The coefficient vectors are replicated on every rank, hence reductions must NOT be
+// summed over ranks here: the call runs with the communicator masked.
+int dla_get_coeffs(dla_ctx* c, int len_a, int len_u, int n_max, int n_act, const double* a_red, double* u_x, double* u_p)
+{
+  int off_x = n_max - n_act;
+  for (int j = 0; j < n_max; ++j)
+    for (int i = 0; i < len_u; ++i) u_x[(size_t)i + (size_t)j * len_u] = a_red[(size_t)i + (size_t)j * len_a];
+  for (int j = 0; j < n_act; ++j)
+    for (int i = 0; i < len_u; ++i) u_p[(size_t)i + (size_t)j * len_u] = u_x[(size_t)i + (size_t)(off_x + j) * len_u];
+  for (int j = 0; j < n_act; ++j) u_p[(size_t)(off_x + j) + (size_t)j * len_u] -= 1.0;
+  if (n_act <= 0) return DLA_OK;
+  void *dx = nullptr, *dp = nullptr;
+  size_t bx = sizeof(double) * (size_t)len_u * n_max, bp = sizeof(double) * (size_t)len_u * n_act;
+  int st = c->eng->alloc(bx, &dx);
+  if (st) return engfail(c, st);
+  st = c->eng->alloc(bp, &dp);
+  if (st) { c->eng->free_(dx); return engfail(c, st); }
+  c->eng->h2d(dx, u_x, bx);
+  c->eng->h2d(dp, u_p, bp);
+  int save_nr = c->eng->nranks;
+  c->eng->nranks = 1;  // replicated data: local reductions only
+  st = dla_ortho_vs_x(c, len_u, n_max, n_act, (const double*)dx, (double*)dp);
+  c->eng->nranks = save_nr;
+  if (st == DLA_OK) st = engfail(c, c->eng->d2h(u_p, dp, bp));
+  c->eng->free_(dx);
+  c->eng->free_(dp);
+  return st;
+}
+
+// ------------------------------------------------------------------ callbacks
+static int ensure_stage(dla_ctx* c, size_t bytes)
+{
+  if (bytes <= c->stage_bytes) return DLA_OK;
+  if (c->stage_x) c->eng->host_free(c->stage_x);
+  if (c->stage_y) c->eng->host_free(c->stage_y);
+  c->stage_x = c->stage_y = nullptr;
+  c->stage_bytes = 0;
+  void *a = nullptr, *b = nullptr;
+  if (c->eng->host_alloc(bytes, &a) || c->eng->host_alloc(bytes, &b)) return fail(c, DLA_ERR_ALLOC, "pinned staging allocation failed");
+  c->stage_x = (double*)a;
+  c->stage_y = (double*)b;
+  c->stage_bytes = bytes;
+  return DLA_OK;
+}
+
+int dla_call_matvec(dla_ctx* c, dla_matvec_fn fn, int n, int m, const double* x, double* ax)
+{
+  if (m <= 0) return DLA_OK;
+  if (c->callbacks_on_device) {
+    fn(&n, &m, x, ax);
+    return DLA_OK;
+  }
+  size_t bytes = sizeof(double) * (size_t)n * m;
+  int st = ensure_stage(c, bytes);
+  if (st) return st;
+  st = c->eng->d2h(c->stage_x, x, bytes);
+  if (st) return engfail(c, st);
+  fn(&n, &m, c->stage_x, c->stage_y);
+  return engfail(c, c->eng->h2d(ax, c->stage_y, bytes));
+}
+
+int dla_call_precnd(dla_ctx* c, dla_precnd_fn fn, int n, int m, double fac, const double* x, double* px)
+{
+  if (m <= 0) return DLA_OK;
+  if (c->callbacks_on_device) {
+    fn(&n, &m, &fac, x, px);
+    return DLA_OK;
+  }
+  size_t bytes = sizeof(double) * (size_t)n * m;
+  int st = ensure_stage(c, bytes);
+  if (st) return st;
+  st = c->eng->d2h(c->stage_x, x, bytes);
+  if (st) return engfail(c, st);
+  fn(&n, &m, &fac, c->stage_x, c->stage_y);
+  return engfail(c, c->eng->h2d(px, c->stage_y, bytes));
+}
+
+// ------------------------------------------------------------------ solve report
+static int g_info[3] = {0, 0, 0};
+void dla_set_solve_info(int iters, int matvec_cols, int restarts) { g_info[0] = iters; g_info[1] = matvec_cols; g_info[2] = restarts; }
+void dla_last_solve_info(int* iters, int* matvec_cols, int* restarts)
+{
+  if (iters) *iters = g_info[0];
+  if (matvec_cols) *matvec_cols = g_info[1];
+  if (restarts) *restarts = g_info[2];
+}
+
+// ------------------------------------------------------------------ built-in operator
+int dla_synth_setup(dla_ctx* c, long long n_global, long long row0, int n_local, int rank_w, double sigma)
+{
+  if (!c) return DLA_ERR_ARG;
+  g_synth_ctx = c;
+  return engfail(c, c->eng->synth_setup(n_global, row0, n_local, rank_w, sigma));
+}
+
+void dla_synth_matvec(const int* n, const int* m, const double* x, double* ax)
+{
+  dla_ctx* c = g_synth_ctx;
+  if (!c) { std::fprintf(stderr, "diaglib_amd: dla_synth_matvec before dla_synth_setup\n"); std::abort(); }
+  if (c->eng->synth_matvec(*n, *m, x, ax)) { std::fprintf(stderr, "diaglib_amd: synth_matvec failed: %s\n", c->eng->err.c_str()); std::abort(); }
+}
+
+void dla_synth_precnd(const int* n, const int* m, const double* fac, const double* x, double* px)
+{
+  dla_ctx* c = g_synth_ctx;
+  if (!c) { std::fprintf(stderr, "diaglib_amd: dla_synth_precnd before dla_synth_setup\n"); std::abort(); }
+  if (c->eng->synth_precnd(*n, *m, *fac, x, px)) { std::fprintf(stderr, "diaglib_amd: synth_precnd failed: %s\n", c->eng->err.c_str()); std::abort(); }
+}
+
+}  // extern "C"

@@ -1,0 +1,799 @@
+!
+! diaglib (MI355X-native) -- drop-in for the public interface of Molecolab-Pisa/diaglib.
+!
+! Same module name, same public procedures and argument lists as the reference
+! (reference diaglib.f90:166-167, 1483-1539, 171-228, 3185, 3481, 3094, 3576, 3052), so an
+! existing CI / augmented-Hessian caller only re-links.  What differs is where the work
+! happens: the drivers below keep the host control flow (iteration, locking, restart,
+! the small Rayleigh-Ritz problem) and every O(n) operation is a call through
+! ISO_C_BINDING into the HIP engine (include/diaglib_amd.h).  The expansion panels
+! space/aspace/r live in HBM for the whole solve; only lda x lda matrices visit the host.
+!
+! Callbacks keep the reference shape  matvec(n,m,x,ax) / precnd(n,m,fac,x,px)
+! (reference README.md:34-35).  By default they receive HOST arrays (the engine stages
+! blocks through pinned memory); after  call diaglib_amd_config(callbacks_on_device=.true.)
+! they receive DEVICE addresses under the same signature (SURVEY.md 8b).
+!
+! Not provided (out of scope for this path, SURVEY.md 2 rows 3-5): gen_david_driver,
+! caslr_driver, caslr_eff_driver, nonsym_driver.
+!
+module diaglib
+  use real_precision
+  use iso_c_binding
+  implicit none
+  private
+!
+  public :: lobpcg_driver, davidson_driver, ortho, b_ortho, ortho_cd, ortho_vs_x, b_ortho_vs_x
+  public :: diaglib_amd_config
+!
+  real(dp), parameter :: zero = 0.0_dp, one = 1.0_dp, ten = 10.0_dp
+  integer,  parameter :: min_dav = 10          ! reference diaglib.f90:1544
+!
+! option ids of include/diaglib_amd.h
+!
+  integer(c_int), parameter :: opt_cb_dev = 1, opt_evec_dev = 2
+!
+! timers: (cpu, wall) pairs like the reference's t_mv, t_diag, t_ortho, t_tot
+!
+  real(dp) :: t_mv(2), t_diag(2), t_ortho(2), t_tot(2), t1(2), t2(2)
+!
+  interface
+    function dla_default_ctx() bind(C,name='dla_default_ctx') result(ctx)
+      import :: c_ptr
+      type(c_ptr) :: ctx
+    end function
+    function dla_set_option(ctx,opt,val) bind(C,name='dla_set_option') result(st)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: opt, val
+      integer(c_int) :: st
+    end function
+    function dla_get_option(ctx,opt) bind(C,name='dla_get_option') result(val)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: opt
+      integer(c_int) :: val
+    end function
+    function dla_last_error(ctx) bind(C,name='dla_last_error') result(msg)
+      import :: c_ptr
+      type(c_ptr), value :: ctx
+      type(c_ptr) :: msg
+    end function
+    function dla_alloc(ctx,bytes,dev) bind(C,name='dla_alloc') result(st)
+      import :: c_ptr, c_int, c_size_t
+      type(c_ptr), value :: ctx
+      integer(c_size_t), value :: bytes
+      type(c_ptr) :: dev
+      integer(c_int) :: st
+    end function
+    function dla_free(ctx,dev) bind(C,name='dla_free') result(st)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, dev
+      integer(c_int) :: st
+    end function
+    function dla_zero(ctx,dev,bytes) bind(C,name='dla_zero') result(st)
+      import :: c_ptr, c_int, c_size_t
+      type(c_ptr), value :: ctx, dev
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: st
+    end function
+    function dla_upload(ctx,dev,host,bytes) bind(C,name='dla_upload') result(st)
+      import :: c_ptr, c_int, c_size_t
+      type(c_ptr), value :: ctx, dev, host
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: st
+    end function
+    function dla_download(ctx,host,dev,bytes) bind(C,name='dla_download') result(st)
+      import :: c_ptr, c_int, c_size_t
+      type(c_ptr), value :: ctx, dev, host
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: st
+    end function
+    function dla_copy(ctx,dst,src,bytes) bind(C,name='dla_copy') result(st)
+      import :: c_ptr, c_int, c_size_t
+      type(c_ptr), value :: ctx, dst, src
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: st
+    end function
+    function dla_gram(ctx,n,l,x,k,u,c,ldc) bind(C,name='dla_gram') result(st)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, x, u
+      integer(c_int), value :: n, l, k, ldc
+      real(c_double) :: c(*)
+      integer(c_int) :: st
+    end function
+    function dla_panel_gemm(ctx,n,l,x,k,c,ldc,z) bind(C,name='dla_panel_gemm') result(st)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, x, z
+      integer(c_int), value :: n, l, k, ldc
+      real(c_double) :: c(*)
+      integer(c_int) :: st
+    end function
+    function dla_ritz_residual(ctx,n,l,m,v,av,y,ldy,eig,n_res,skip,evec,r,avy,rnorm) &
+             bind(C,name='dla_ritz_residual') result(st)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, v, av, evec, r, avy
+      integer(c_int), value :: n, l, m, ldy, n_res
+      real(c_double) :: y(*), eig(*), rnorm(*)
+      integer(c_int) :: skip(*)
+      integer(c_int) :: st
+    end function
+    function dla_axpy(ctx,len,alpha,x,y) bind(C,name='dla_axpy') result(st)
+      import :: c_ptr, c_int, c_double, c_size_t
+      type(c_ptr), value :: ctx, x, y
+      integer(c_size_t), value :: len
+      real(c_double), value :: alpha
+      integer(c_int) :: st
+    end function
+    function dla_ortho_cd(ctx,n,k,u,growth,ok) bind(C,name='dla_ortho_cd') result(st)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, u
+      integer(c_int), value :: n, k
+      real(c_double) :: growth
+      integer(c_int) :: ok
+      integer(c_int) :: st
+    end function
+    function dla_ortho_vs_x(ctx,n,m,k,x,u) bind(C,name='dla_ortho_vs_x') result(st)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, x, u
+      integer(c_int), value :: n, m, k
+      integer(c_int) :: st
+    end function
+    function dla_b_ortho(ctx,n,m,u,bu) bind(C,name='dla_b_ortho') result(st)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, u, bu
+      integer(c_int), value :: n, m
+      integer(c_int) :: st
+    end function
+    function dla_b_ortho_vs_x(ctx,n,m,k,x,bx,u) bind(C,name='dla_b_ortho_vs_x') result(st)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, x, bx, u
+      integer(c_int), value :: n, m, k
+      integer(c_int) :: st
+    end function
+    function dla_check_guess(ctx,n,m,evec) bind(C,name='dla_check_guess') result(st)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, evec
+      integer(c_int), value :: n, m
+      integer(c_int) :: st
+    end function
+    function dla_get_coeffs(ctx,len_a,len_u,n_max,n_act,a_red,u_x,u_p) bind(C,name='dla_get_coeffs') result(st)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: len_a, len_u, n_max, n_act
+      real(c_double) :: a_red(*), u_x(*), u_p(*)
+      integer(c_int) :: st
+    end function
+    function dla_call_matvec(ctx,fn,n,m,x,ax) bind(C,name='dla_call_matvec') result(st)
+      import :: c_ptr, c_funptr, c_int
+      type(c_ptr), value :: ctx, x, ax
+      type(c_funptr), value :: fn
+      integer(c_int), value :: n, m
+      integer(c_int) :: st
+    end function
+    function dla_call_precnd(ctx,fn,n,m,fac,x,px) bind(C,name='dla_call_precnd') result(st)
+      import :: c_ptr, c_funptr, c_int, c_double
+      type(c_ptr), value :: ctx, x, px
+      type(c_funptr), value :: fn
+      integer(c_int), value :: n, m
+      real(c_double), value :: fac
+      integer(c_int) :: st
+    end function
+    function dla_syev(uplo,n,a,lda,w) bind(C,name='dla_syev') result(info)
+      import :: c_char, c_int, c_double
+      character(kind=c_char), value :: uplo
+      integer(c_int), value :: n, lda
+      real(c_double) :: a(*), w(*)
+      integer(c_int) :: info
+    end function
+    subroutine dla_set_solve_info(iters,cols,restarts) bind(C,name='dla_set_solve_info')
+      import :: c_int
+      integer(c_int), value :: iters, cols, restarts
+    end subroutine
+    function c_strlen(s) bind(C,name='strlen') result(l)
+      import :: c_ptr, c_size_t
+      type(c_ptr), value :: s
+      integer(c_size_t) :: l
+    end function
+  end interface
+!
+contains
+!
+! ---------------------------------------------------------------------------------------
+! configuration (extension; defaults reproduce the reference contract: host callbacks,
+! host eig/evec)
+! ---------------------------------------------------------------------------------------
+  subroutine diaglib_amd_config(callbacks_on_device, evec_on_device)
+    logical, intent(in), optional :: callbacks_on_device, evec_on_device
+    type(c_ptr)    :: ctx
+    integer(c_int) :: st
+    ctx = dla_default_ctx()
+    if (present(callbacks_on_device)) st = dla_set_option(ctx, opt_cb_dev, merge(1_c_int,0_c_int,callbacks_on_device))
+    if (present(evec_on_device))      st = dla_set_option(ctx, opt_evec_dev, merge(1_c_int,0_c_int,evec_on_device))
+  end subroutine diaglib_amd_config
+!
+! address of column j (1-based) of a device panel with leading dimension n
+!
+  function colp(base,n,j) result(p)
+    type(c_ptr), intent(in) :: base
+    integer,     intent(in) :: n, j
+    type(c_ptr)             :: p
+    integer(c_intptr_t)     :: a
+    a = transfer(base, a) + 8_c_intptr_t * int(n,c_intptr_t) * int(j-1,c_intptr_t)
+    p = transfer(a, p)
+  end function colp
+!
+  function nbytes(n,m) result(b)
+    integer, intent(in) :: n, m
+    integer(c_size_t)   :: b
+    b = 8_c_size_t * int(n,c_size_t) * int(m,c_size_t)
+  end function nbytes
+!
+! any engine failure is fatal, like the reference's `stop` paths (diaglib.f90:414,3283,3568,3800)
+!
+  subroutine chk(ctx,st,what)
+    type(c_ptr),      intent(in) :: ctx
+    integer(c_int),   intent(in) :: st
+    character(len=*), intent(in) :: what
+    type(c_ptr) :: msg
+    character(kind=c_char), pointer :: cm(:)
+    integer :: i, ln
+    if (st.eq.0) return
+    msg = dla_last_error(ctx)
+    ln  = int(c_strlen(msg))
+    call c_f_pointer(msg, cm, [ln])
+    write(6,'(t3,a,a,a,i4)') 'diaglib_amd: ', what, ' failed with status ', st
+    write(6,'(t3,200a1)') (cm(i), i = 1, min(ln,200))
+    if (st.eq.5) stop ' catastrophic failure of ortho_vs_x'
+    stop
+  end subroutine chk
+!
+  subroutine get_time(t)
+    real(dp), intent(inout) :: t(2)
+    integer(8) :: cnt, rate
+    call cpu_time(t(1))
+    call system_clock(cnt, rate)
+    t(2) = real(cnt,dp)/real(rate,dp)
+  end subroutine get_time
+!
+! ---------------------------------------------------------------------------------------
+! Davidson-Liu (reference diaglib.f90:1483-1853)
+! ---------------------------------------------------------------------------------------
+  subroutine davidson_driver(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift,matvec,precnd,eig,evec,ok)
+    logical,                              intent(in)    :: verbose
+    integer,                              intent(in)    :: n, n_targ, n_max
+    integer,                              intent(in)    :: max_iter, max_dav
+    real(dp),                             intent(in)    :: tol, shift
+    real(dp), dimension(n_max),           intent(inout) :: eig
+    real(dp), dimension(n,n_max), target, intent(inout) :: evec
+    logical,                              intent(inout) :: ok
+    external                                            :: matvec, precnd
+!
+    type(c_ptr)    :: ctx, space, aspace, r, evd
+    type(c_funptr) :: mv, pc
+    integer        :: dim_dav, lda, n_act, ind, i_beg, m_dim, ldu, n_frozen, it, i_eig, n_rst, c0
+    integer        :: n_mv, n_restarts
+    logical        :: restart, evec_dev
+    real(dp)       :: tol_rms, tol_max
+    logical,        allocatable :: done(:)
+    integer(c_int), allocatable :: skip(:)
+    real(dp),       allocatable :: a_red(:,:), a_copy(:,:), e_red(:), r_norm(:,:)
+    integer(c_int) :: info
+!
+    ctx = dla_default_ctx()
+    mv  = c_funloc(matvec)
+    pc  = c_funloc(precnd)
+    evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
+!
+!   expansion space size: never smaller than 10 blocks (reference :1595-1596)
+!
+    dim_dav = max(min_dav,max_dav)
+    lda     = dim_dav*n_max
+!
+!   device panels (reference :1607) and host-size matrices (:1612-1617)
+!
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), space),  'allocation of space')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), aspace), 'allocation of aspace')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), r),    'allocation of r')
+    if (evec_dev) then
+      evd = c_loc(evec)
+    else
+      call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), evd), 'allocation of evec')
+      call chk(ctx, dla_upload(ctx, evd, c_loc(evec), nbytes(n,n_max)), 'upload of the guess')
+    end if
+    allocate (done(n_max), skip(n_max), r_norm(2,n_max), a_red(lda,lda), a_copy(lda,lda), e_red(lda))
+!
+    tol_rms = tol
+    tol_max = ten * tol
+    t_diag  = zero
+    t_ortho = zero
+    t_mv    = zero
+    t_tot   = zero
+    call chk(ctx, dla_zero(ctx, space,  nbytes(n,lda)), 'zero')
+    call chk(ctx, dla_zero(ctx, aspace, nbytes(n,lda)), 'zero')
+    a_red   = zero
+    r_norm  = zero
+    ok      = .false.
+    done    = .false.
+!
+    call get_time(t_tot)
+!
+!   guess: orthonormalise if needed, random if zero (reference :1644), then copy (:1648)
+!
+    call chk(ctx, dla_check_guess(ctx, n, n_max, evd), 'check_guess')
+    call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
+!
+    n_act = n_max
+    ind   = 1
+    i_beg = 1
+    m_dim = 1
+    ldu   = 0
+    restart = .false.
+    n_rst   = 0
+    n_frozen = 0
+    n_mv = 0
+    n_restarts = 0
+!
+    1030 format(t5,'Davidson-Liu iterations (tol=',d10.2,'):',/, &
+                t5,'------------------------------------------------------------------',/, &
+                t7,'  iter  root              eigenvalue','         rms         max ok',/, &
+                t5,'------------------------------------------------------------------')
+    1040 format(t9,i4,2x,i4,f24.12,2d12.4,l3)
+    if (verbose) write(6,1030) tol
+!
+    do it = 1, max_iter
+      ldu = ldu + n_act
+      c0  = i_beg + n_rst
+!
+!     A times the new block (reference :1685)
+!
+      call get_time(t1)
+      call chk(ctx, dla_call_matvec(ctx, mv, n, n_act, colp(space,n,c0), colp(aspace,n,c0)), 'matvec')
+      call get_time(t2)
+      t_mv = t_mv + t2 - t1
+      n_mv = n_mv + n_act
+!
+!     new columns of the projected matrix (reference :1691)
+!
+      call chk(ctx, dla_gram(ctx, n, ldu, space, n_act, colp(aspace,n,c0), a_red(1,c0), lda), 'projection')
+!
+!     after a restart the locked roots enter through their eigenvalues (reference :1696-1702)
+!
+      if (restart) then
+        do i_eig = 1, n_rst
+          a_red(i_eig,i_eig) = e_red(i_eig)
+        end do
+        restart = .false.
+        n_rst   = 0
+      end if
+      a_copy = a_red
+!
+      call get_time(t1)
+      info = dla_syev('u', ldu, a_copy, lda, e_red)
+      call get_time(t2)
+      t_diag = t_diag + t2 - t1
+      if (info.ne.0) then
+        write(6,'(t3,a,i6)') 'dsyev failed. info = ',info
+        stop
+      end if
+      eig = e_red(1:n_max)
+!
+!     Ritz vectors, residuals and their norms in one sweep (reference :1717-1732)
+!
+      do i_eig = 1, n_max
+        skip(i_eig) = merge(1_c_int, 0_c_int, done(i_eig))
+      end do
+      call chk(ctx, dla_ritz_residual(ctx, n, ldu, n_max, space, aspace, a_copy, lda, eig, n_targ, skip, &
+                                      evd, r, c_null_ptr, r_norm), 'ritz/residual')
+!
+!     lock the leading converged roots (reference :1737-1746)
+!
+      do i_eig = 1, n_targ
+        if (done(i_eig)) cycle
+        done(i_eig) = r_norm(1,i_eig).lt.tol_rms .and. r_norm(2,i_eig).lt.tol_max .and. it.gt.1
+        if (.not.done(i_eig)) then
+          done(i_eig+1:n_max) = .false.
+          exit
+        end if
+      end do
+!
+      if (verbose) then
+        do i_eig = 1, n_targ
+          write(6,1040) it, i_eig, eig(i_eig) - shift, r_norm(:,i_eig), done(i_eig)
+        end do
+        write(6,*)
+      end if
+!
+      if (all(done(1:n_targ))) then
+        ok = .true.
+        exit
+      end if
+!
+      if (m_dim .lt. dim_dav) then
+!
+!       expand: precondition the active residuals, orthogonalise against the space
+!       (reference :1773-1794)
+!
+        m_dim = m_dim + 1
+        i_beg = i_beg + n_act
+        n_act = n_max
+        n_frozen = 0
+        do i_eig = 1, n_targ
+          if (done(i_eig)) then
+            n_act = n_act - 1
+            n_frozen = n_frozen + 1
+          else
+            exit
+          end if
+        end do
+        ind = n_max - n_act + 1
+        call chk(ctx, dla_call_precnd(ctx, pc, n, n_act, -eig(ind), colp(r,n,ind), colp(space,n,i_beg)), 'precnd')
+        call get_time(t1)
+        call chk(ctx, dla_ortho_vs_x(ctx, n, ldu, n_act, space, colp(space,n,i_beg)), 'ortho_vs_x')
+        call get_time(t2)
+        t_ortho = t_ortho + t2 - t1
+      else
+!
+!       restart from the current Ritz vectors (reference :1796-1824)
+!
+        if (verbose) write(6,'(t7,a)') 'Restarting davidson.'
+        n_restarts = n_restarts + 1
+        n_act = n_max
+        call chk(ctx, dla_zero(ctx, space, nbytes(n,lda)), 'zero')
+        call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
+        call chk(ctx, dla_zero(ctx, aspace, nbytes(n,lda)), 'zero')
+        a_red = zero
+        ldu   = 0
+        i_beg = 1
+        m_dim = 1
+        n_rst = 0
+        do i_eig = 1, n_targ
+          if (done(i_eig)) then
+            n_rst = n_rst + 1
+          else
+            exit
+          end if
+        end do
+        restart = .true.
+      end if
+      if (verbose) write(6,1050) n_targ, n_act, n_frozen
+    end do
+!
+    call get_time(t2)
+    t_tot = t2 - t_tot
+    call dla_set_solve_info(int(min(it,max_iter),c_int), int(n_mv,c_int), int(n_restarts,c_int))
+!
+    1000 format(t3,'timings for davidson (cpu/wall): ',/, &
+                t3,'  matrix-vector multiplications: ',2f12.4,/, &
+                t3,'  diagonalization:               ',2f12.4,/, &
+                t3,'  orthogonalization:             ',2f12.4,/, &
+                t3,'                                 ',24('='),/,  &
+                t3,'  total:                         ',2f12.4)
+    if (verbose) write(6,1000) t_mv, t_diag, t_ortho, t_tot
+!
+!   hand the Ritz vectors back (evec holds them on every exit, like the reference) and free
+!
+    if (.not.evec_dev) then
+      call chk(ctx, dla_download(ctx, c_loc(evec), evd, nbytes(n,n_max)), 'download of evec')
+      call chk(ctx, dla_free(ctx, evd), 'free')
+    end if
+    call chk(ctx, dla_free(ctx, space), 'free')
+    call chk(ctx, dla_free(ctx, aspace), 'free')
+    call chk(ctx, dla_free(ctx, r), 'free')
+    deallocate (done, skip, r_norm, a_red, a_copy, e_red)
+!
+    1050 format(t5,'----------------------------------------',/,&
+                t7,'# target vectors:    ',i4,/,&
+                t7,'# new vectors added: ',i4,/,&
+                t7,'# converged vectors: ',i4,/,&
+                t5,'----------------------------------------')
+    return
+  end subroutine davidson_driver
+!
+! ---------------------------------------------------------------------------------------
+! LOBPCG (reference diaglib.f90:171-556).  gen_eig=.true. is not on this path yet.
+! ---------------------------------------------------------------------------------------
+  subroutine lobpcg_driver(verbose,gen_eig,n,n_targ,n_max,max_iter,tol,shift,matvec,precnd,bvec,eig,evec,ok)
+    logical,                              intent(in)    :: verbose, gen_eig
+    integer,                              intent(in)    :: n, n_targ, n_max, max_iter
+    real(dp),                             intent(in)    :: tol, shift
+    real(dp), dimension(n_max),           intent(inout) :: eig
+    real(dp), dimension(n,n_max), target, intent(inout) :: evec
+    logical,                              intent(inout) :: ok
+    external                                            :: matvec, precnd, bvec
+!
+    type(c_ptr)    :: ctx, space, aspace, r, x_new, ax_new, evd
+    type(c_funptr) :: mv, pc
+    integer        :: it, i_eig, n_act, ind_x, ind_w, ind_p, len_a, len_u, n_mv
+    logical        :: evec_dev
+    real(dp)       :: tol_rms, tol_max
+    logical,        allocatable :: done(:)
+    integer(c_int), allocatable :: skip(:)
+    real(dp),       allocatable :: a_red(:,:), e_red(:), r_norm(:,:), u_x(:,:), u_p(:,:)
+    integer(c_int) :: info
+!
+    if (gen_eig) then
+      write(6,'(t3,a)') 'diaglib_amd: lobpcg_driver with gen_eig=.true. is not available in this build.'
+      stop
+    end if
+    ctx = dla_default_ctx()
+    mv  = c_funloc(matvec)
+    pc  = c_funloc(precnd)
+    evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
+!
+    len_a = 3*n_max
+    call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), space),  'allocation of space')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), aspace), 'allocation of aspace')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), r),      'allocation of r')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), x_new),  'allocation of x_new')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), ax_new), 'allocation of ax_new')
+    if (evec_dev) then
+      evd = c_loc(evec)
+    else
+      call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), evd), 'allocation of evec')
+      call chk(ctx, dla_upload(ctx, evd, c_loc(evec), nbytes(n,n_max)), 'upload of the guess')
+    end if
+    allocate (a_red(len_a,len_a), e_red(len_a), done(n_max), skip(n_max), r_norm(2,n_max))
+!
+    t_diag  = zero
+    t_ortho = zero
+    t_mv    = zero
+    t_tot   = zero
+    call chk(ctx, dla_zero(ctx, space,  nbytes(n,len_a)), 'zero')
+    call chk(ctx, dla_zero(ctx, aspace, nbytes(n,len_a)), 'zero')
+    a_red  = zero
+    r_norm = zero
+    n_mv   = 0
+!
+    call get_time(t_tot)
+    call chk(ctx, dla_check_guess(ctx, n, n_max, evd), 'check_guess')
+!
+!   first Rayleigh-Ritz step on the guess (reference :306-325)
+!
+    call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
+    call get_time(t1)
+    call chk(ctx, dla_call_matvec(ctx, mv, n, n_max, space, aspace), 'matvec')
+    call get_time(t2)
+    t_mv = t_mv + t2 - t1
+    n_mv = n_mv + n_max
+    if (shift.ne.zero) call chk(ctx, dla_axpy(ctx, int(n,c_size_t)*int(n_max,c_size_t), shift, space, aspace), 'axpy')
+    call chk(ctx, dla_gram(ctx, n, n_max, space, n_max, aspace, a_red, len_a), 'projection')
+    call get_time(t1)
+    info = dla_syev('l', n_max, a_red, len_a, e_red)
+    call get_time(t2)
+    t_diag = t_diag + t2 - t1
+    eig = e_red(1:n_max)
+!
+!   Ritz vectors x, a x and the first residuals r = a x - eig x in one sweep (:322-345)
+!
+    skip = 0
+    call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, space, aspace, a_red, len_a, eig, n_max, skip, &
+                                    x_new, r, ax_new, r_norm), 'ritz/residual')
+    call chk(ctx, dla_copy(ctx, space,  x_new,  nbytes(n,n_max)), 'copy')
+    call chk(ctx, dla_copy(ctx, aspace, ax_new, nbytes(n,n_max)), 'copy')
+!
+!   first block of preconditioned residuals (:350-367)
+!
+    ind_x = 1
+    ind_w = ind_x + n_max
+    call chk(ctx, dla_call_precnd(ctx, pc, n, n_max, shift-eig(ind_x), colp(r,n,ind_x), colp(space,n,ind_w)), 'precnd')
+    call get_time(t1)
+    call chk(ctx, dla_ortho_vs_x(ctx, n, n_max, n_max, space, colp(space,n,ind_w)), 'ortho_vs_x')
+    call get_time(t2)
+    t_ortho = t_ortho + t2 - t1
+!
+    tol_rms = tol
+    tol_max = ten*tol
+    ok      = .false.
+    done    = .false.
+    n_act   = n_max
+!
+    1030 format(t5,'LOBPCG iterations (tol=',d10.2,'):',/, &
+                t5,'------------------------------------------------------------------',/, &
+                t7,'  iter  root              eigenvalue','         rms         max ok',/, &
+                t5,'------------------------------------------------------------------')
+    1040 format(t9,i4,2x,i4,f24.12,2d12.4,l3)
+    if (verbose) write(6,1030) tol
+!
+    do it = 1, max_iter
+!
+!     A times the W block (:394-397)
+!
+      call get_time(t1)
+      call chk(ctx, dla_call_matvec(ctx, mv, n, n_act, colp(space,n,ind_w), colp(aspace,n,ind_w)), 'matvec')
+      call get_time(t2)
+      t_mv = t_mv + t2 - t1
+      n_mv = n_mv + n_act
+      if (shift.ne.zero) call chk(ctx, dla_axpy(ctx, int(n,c_size_t)*int(n_act,c_size_t), shift, &
+                                                colp(space,n,ind_w), colp(aspace,n,ind_w)), 'axpy')
+!
+!     reduced matrix S^T A S, all of it, every iteration (:401-403)
+!
+      len_u = n_max + 2*n_act
+      if (it.eq.1) len_u = 2*n_max
+      call chk(ctx, dla_gram(ctx, n, len_u, space, len_u, aspace, a_red, len_a), 'projection')
+      call get_time(t1)
+      info = dla_syev('l', len_u, a_red, len_a, e_red)
+      call get_time(t2)
+      t_diag = t_diag + t2 - t1
+      if (info.ne.0) then
+        write(6,'(t3,a,i6)') 'dsyev failed. info = ',info
+        stop
+      end if
+      eig = e_red(1:n_max)
+!
+!     x_new, ax_new, residuals and norms in one sweep (:420-442)
+!
+      do i_eig = 1, n_max
+        skip(i_eig) = merge(1_c_int, 0_c_int, done(i_eig))
+      end do
+      call chk(ctx, dla_ritz_residual(ctx, n, len_u, n_max, space, aspace, a_red, len_a, eig, n_max, skip, &
+                                      x_new, r, ax_new, r_norm), 'ritz/residual')
+!
+!     lock the leading converged roots (:446-455)
+!
+      do i_eig = 1, n_max
+        if (done(i_eig)) cycle
+        done(i_eig) = r_norm(1,i_eig).lt.tol_rms .and. r_norm(2,i_eig).lt.tol_max .and. it.gt.1
+        if (.not.done(i_eig)) then
+          done(i_eig+1:n_max) = .false.
+          exit
+        end if
+      end do
+!
+      if (verbose) then
+        do i_eig = 1, n_targ
+          write(6,1040) it, i_eig, eig(i_eig) - shift, r_norm(:,i_eig), done(i_eig)
+        end do
+        write(6,*)
+      end if
+      if (all(done(1:n_targ))) then
+        ok = .true.
+        exit
+      end if
+!
+      n_act = n_max - count(done)
+      ind_x = n_max - n_act + 1
+      ind_p = ind_x + n_act
+      ind_w = ind_p + n_act
+!
+!     coefficients of the new P block (:485-488), then P = S u_p, AP = AS u_p (:495-498)
+!
+      allocate (u_x(len_u,n_max), u_p(len_u,max(n_act,1)))
+      call chk(ctx, dla_get_coeffs(ctx, len_a, len_u, n_max, n_act, a_red, u_x, u_p), 'get_coeffs')
+      call chk(ctx, dla_panel_gemm(ctx, n, len_u, space,  n_act, u_p, len_u, evd), 'p block')
+      call chk(ctx, dla_copy(ctx, colp(space,n,ind_p), evd, nbytes(n,n_act)), 'copy')
+      call chk(ctx, dla_panel_gemm(ctx, n, len_u, aspace, n_act, u_p, len_u, evd), 'ap block')
+      call chk(ctx, dla_copy(ctx, colp(aspace,n,ind_p), evd, nbytes(n,n_act)), 'copy')
+      deallocate (u_x, u_p)
+!
+!     x_new, ax_new become the X block (:510-511)
+!
+      call chk(ctx, dla_copy(ctx, space,  x_new,  nbytes(n,n_max)), 'copy')
+      call chk(ctx, dla_copy(ctx, aspace, ax_new, nbytes(n,n_max)), 'copy')
+!
+!     new W block: preconditioned active residuals, orthogonalised against [X P] (:518-528)
+!
+      call chk(ctx, dla_call_precnd(ctx, pc, n, n_act, shift-eig(1), colp(r,n,ind_x), colp(space,n,ind_w)), 'precnd')
+      call get_time(t1)
+      call chk(ctx, dla_ortho_vs_x(ctx, n, n_max+n_act, n_act, space, colp(space,n,ind_w)), 'ortho_vs_x')
+      call get_time(t2)
+      t_ortho = t_ortho + t2 - t1
+    end do
+!
+    call get_time(t2)
+    t_tot = t2 - t_tot
+    call dla_set_solve_info(int(min(it,max_iter),c_int), int(n_mv,c_int), 0_c_int)
+!
+!   the current Ritz vectors go back in evec (the reference does this on convergence, :466;
+!   on a non-converged exit it leaves its P-block scratch there -- we return x_new in both cases)
+!
+    call chk(ctx, dla_copy(ctx, evd, x_new, nbytes(n,n_max)), 'copy')
+!
+    1000 format(t3,'timings for lobpcg (cpu/wall):   ',/, &
+                t3,'  matrix-vector multiplications: ',2f12.4,/, &
+                t3,'  diagonalization:               ',2f12.4,/, &
+                t3,'  orthogonalization:             ',2f12.4,/, &
+                t3,'                                 ',24('='),/,  &
+                t3,'  total:                         ',2f12.4)
+    if (verbose) write(6,1000) t_mv, t_diag, t_ortho, t_tot
+!
+    if (.not.evec_dev) then
+      call chk(ctx, dla_download(ctx, c_loc(evec), evd, nbytes(n,n_max)), 'download of evec')
+      call chk(ctx, dla_free(ctx, evd), 'free')
+    end if
+    call chk(ctx, dla_free(ctx, space), 'free')
+    call chk(ctx, dla_free(ctx, aspace), 'free')
+    call chk(ctx, dla_free(ctx, r), 'free')
+    call chk(ctx, dla_free(ctx, x_new), 'free')
+    call chk(ctx, dla_free(ctx, ax_new), 'free')
+    deallocate (a_red, e_red, done, skip, r_norm)
+    return
+  end subroutine lobpcg_driver
+!
+! ---------------------------------------------------------------------------------------
+! public orthogonalisation routines on HOST arrays (reference signatures); each uploads,
+! runs the device path and downloads.  The drivers never use these wrappers.
+! ---------------------------------------------------------------------------------------
+  subroutine ortho_cd(n,m,u,growth,ok)
+    integer,                          intent(in)    :: n, m
+    real(dp), dimension(n,m), target, intent(inout) :: u
+    real(dp),                         intent(inout) :: growth
+    logical,                          intent(inout) :: ok
+    type(c_ptr)    :: ctx, ud
+    integer(c_int) :: iok
+    ctx = dla_default_ctx()
+    call chk(ctx, dla_alloc(ctx, nbytes(n,m), ud), 'allocation')
+    call chk(ctx, dla_upload(ctx, ud, c_loc(u), nbytes(n,m)), 'upload')
+    call chk(ctx, dla_ortho_cd(ctx, n, m, ud, growth, iok), 'ortho_cd')
+    ok = iok .ne. 0
+    call chk(ctx, dla_download(ctx, c_loc(u), ud, nbytes(n,m)), 'download')
+    call chk(ctx, dla_free(ctx, ud), 'free')
+  end subroutine ortho_cd
+!
+  subroutine ortho_vs_x(n,m,k,x,u,ax,au)
+    integer,                          intent(in)    :: n, m, k
+    real(dp), dimension(n,m), target, intent(in)    :: x
+    real(dp), dimension(n,k), target, intent(inout) :: u
+    real(dp), dimension(*)                          :: ax, au     ! dead in the reference too (SURVEY App. B 5)
+    type(c_ptr) :: ctx, xd, ud
+    ctx = dla_default_ctx()
+    call chk(ctx, dla_alloc(ctx, nbytes(n,max(m,1)), xd), 'allocation')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,k), ud), 'allocation')
+    if (m.gt.0) call chk(ctx, dla_upload(ctx, xd, c_loc(x), nbytes(n,m)), 'upload')
+    call chk(ctx, dla_upload(ctx, ud, c_loc(u), nbytes(n,k)), 'upload')
+    call chk(ctx, dla_ortho_vs_x(ctx, n, m, k, xd, ud), 'ortho_vs_x')
+    call chk(ctx, dla_download(ctx, c_loc(u), ud, nbytes(n,k)), 'download')
+    call chk(ctx, dla_free(ctx, xd), 'free')
+    call chk(ctx, dla_free(ctx, ud), 'free')
+  end subroutine ortho_vs_x
+!
+  subroutine ortho(n,m,u,w)
+    integer,                          intent(in)    :: n, m
+    real(dp), dimension(n,m), target, intent(inout) :: u
+    real(dp), dimension(*)                          :: w          ! never touched by the reference either
+    real(dp) :: growth
+    logical  :: ok
+!   the reference orthonormalises by Householder QR here; the device path offers the
+!   Cholesky-QR family only, which spans the same space with the same orthonormality
+    call ortho_cd(n,m,u,growth,ok)
+  end subroutine ortho
+!
+  subroutine b_ortho(n,m,u,bu)
+    integer,                          intent(in)    :: n, m
+    real(dp), dimension(n,m), target, intent(inout) :: u, bu
+    type(c_ptr) :: ctx, ud, bd
+    ctx = dla_default_ctx()
+    call chk(ctx, dla_alloc(ctx, nbytes(n,m), ud), 'allocation')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,m), bd), 'allocation')
+    call chk(ctx, dla_upload(ctx, ud, c_loc(u), nbytes(n,m)), 'upload')
+    call chk(ctx, dla_upload(ctx, bd, c_loc(bu), nbytes(n,m)), 'upload')
+    call chk(ctx, dla_b_ortho(ctx, n, m, ud, bd), 'b_ortho')
+    call chk(ctx, dla_download(ctx, c_loc(u), ud, nbytes(n,m)), 'download')
+    call chk(ctx, dla_download(ctx, c_loc(bu), bd, nbytes(n,m)), 'download')
+    call chk(ctx, dla_free(ctx, ud), 'free')
+    call chk(ctx, dla_free(ctx, bd), 'free')
+  end subroutine b_ortho
+!
+  subroutine b_ortho_vs_x(n,m,k,x,bx,u)
+    integer,                          intent(in)    :: n, m, k
+    real(dp), dimension(n,m), target, intent(in)    :: x, bx
+    real(dp), dimension(n,k), target, intent(inout) :: u
+    type(c_ptr) :: ctx, xd, bd, ud
+    ctx = dla_default_ctx()
+    call chk(ctx, dla_alloc(ctx, nbytes(n,max(m,1)), xd), 'allocation')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,max(m,1)), bd), 'allocation')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,k), ud), 'allocation')
+    if (m.gt.0) then
+      call chk(ctx, dla_upload(ctx, xd, c_loc(x), nbytes(n,m)), 'upload')
+      call chk(ctx, dla_upload(ctx, bd, c_loc(bx), nbytes(n,m)), 'upload')
+    end if
+    call chk(ctx, dla_upload(ctx, ud, c_loc(u), nbytes(n,k)), 'upload')
+    call chk(ctx, dla_b_ortho_vs_x(ctx, n, m, k, xd, bd, ud), 'b_ortho_vs_x')
+    call chk(ctx, dla_download(ctx, c_loc(u), ud, nbytes(n,k)), 'download')
+    call chk(ctx, dla_free(ctx, xd), 'free')
+    call chk(ctx, dla_free(ctx, bd), 'free')
+    call chk(ctx, dla_free(ctx, ud), 'free')
+  end subroutine b_ortho_vs_x
+!
+end module diaglib

@@ -1,0 +1,190 @@
+/*
+ * include/diaglib_amd.h -- C-ABI of the MI355X-native diaglib hot path.
+ *
+ * This is the drop-in boundary.  The reference (Molecolab-Pisa/diaglib)
+ * is a Fortran module whose drivers do all O(n) work through BLAS calls on column-major
+ * n x k panels (ld = n).  Here the Fortran drivers (diaglib_amd/fortran/diaglib.f90,
+ * same public names and argument lists as reference diaglib.f90:166-167) keep only the
+ * control flow and reach the device through the entry points below via ISO_C_BINDING.
+ * Every entry point names the reference line(s) it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - "dev" pointers are device (HBM) addresses obtained from dla_alloc(); panels are
+ *     column-major float64 with leading dimension n (the local row count), columns
+ *     contiguous -- exactly the reference layout, so a block of columns can be handed
+ *     to a matvec(n,m,x,ax) callback unchanged.
+ *   - small matrices (<= lda x lda) live on the host, column-major.
+ *   - every function returns 0 on success, a DLA_ERR_* code otherwise; nothing calls
+ *     exit().  dla_last_error() gives the message.  The Fortran layer maps failures to
+ *     the reference behaviour (ok=.false. / stop with the reference's message).
+ *   - with a communicator (dla_comm_init) n is the LOCAL row count of this rank's shard;
+ *     every reduction below is summed (or max-ed) over ranks before it is returned, so the
+ *     callers are unchanged.
+ */
+#ifndef DIAGLIB_AMD_H
+#define DIAGLIB_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dla_ctx dla_ctx;
+
+enum {
+  DLA_OK = 0,
+  DLA_ERR_NO_DEVICE = 1,   /* no HIP device / extension not usable: fail loudly      */
+  DLA_ERR_ALLOC = 2,       /* reference: check_mem, diaglib.f90:3789-3803            */
+  DLA_ERR_ARG = 3,
+  DLA_ERR_RUNTIME = 4,     /* a HIP/RCCL call failed                                  */
+  DLA_ERR_ORTHO = 5,       /* reference: "catastrophic failure of ortho_vs_x", :3568  */
+  DLA_ERR_LAPACK = 6,      /* reference: "dsyev failed", :412-415                     */
+  DLA_ERR_COMM = 7
+};
+
+/* reference callback shapes, README.md:34-35 (F77 ABI: everything by reference) */
+typedef void (*dla_matvec_fn)(const int* n, const int* m, const double* x, double* ax);
+typedef void (*dla_precnd_fn)(const int* n, const int* m, const double* fac, const double* x, double* px);
+
+/* options for dla_set_option */
+enum {
+  DLA_OPT_CALLBACKS_ON_DEVICE = 1, /* 0 (default, drop-in): callbacks get HOST arrays, staged through pinned
+                                      buffers; 1: callbacks get DEVICE addresses (SURVEY 8b "callback residency") */
+  DLA_OPT_EVEC_ON_DEVICE = 2,      /* 0 (default): eig/evec of the drivers are host arrays as in the reference;
+                                      1: evec is a device address (guess in, Ritz vectors out), eig stays host  */
+  DLA_OPT_PROFILE = 3,             /* 1: bracket every kernel launch with HIP events (dla_get_stats)          */
+  DLA_OPT_VERBOSE_ORTHO = 4        /* 1: print ortho_cd/ortho_vs_x pass counts                                 */
+};
+
+/* op classes for statistics */
+enum {
+  DLA_OP_GRAM = 0,      /* C = X^T U                         */
+  DLA_OP_GEMM = 1,      /* Z = X C   /  U -= X C             */
+  DLA_OP_TRMM = 2,      /* U <- U L^-T                       */
+  DLA_OP_RITZ = 3,      /* fused Ritz vectors + residuals    */
+  DLA_OP_ELEM = 4,      /* copy / zero / axpy / fill         */
+  DLA_OP_MATVEC = 5,    /* built-in operator                 */
+  DLA_OP_PRECND = 6,    /* built-in preconditioner           */
+  DLA_OP_COUNT = 7
+};
+
+typedef struct {
+  long long launches[DLA_OP_COUNT];   /* kernel launches per class                          */
+  double    alg_bytes[DLA_OP_COUNT];  /* algorithmic (compulsory) HBM bytes, SURVEY 8d      */
+  double    flops[DLA_OP_COUNT];      /* reference-schedule flops, SURVEY 8d                */
+  double    ms[DLA_OP_COUNT];         /* HIP-event time (only with DLA_OPT_PROFILE)         */
+  long long allreduces;               /* cross-rank reductions issued                       */
+  long long host_syncs;               /* stream synchronisations for host-visible results   */
+} dla_stats;
+
+/* ---------------------------------------------------------------- context */
+int  dla_create(dla_ctx** ctx, int device);          /* device < 0: $LOCAL_RANK or 0 */
+int  dla_destroy(dla_ctx* ctx);
+dla_ctx* dla_default_ctx(void);                      /* the context the Fortran drivers use (the reference is
+                                                        non-reentrant too: module state, diaglib.f90:155-161) */
+int  dla_set_option(dla_ctx* ctx, int option, int value);
+int  dla_get_option(dla_ctx* ctx, int option);
+const char* dla_last_error(dla_ctx* ctx);
+const char* dla_backend_name(dla_ctx* ctx);          /* "hip:gfx950" for the product */
+int  dla_get_stats(dla_ctx* ctx, dla_stats* out);
+int  dla_reset_stats(dla_ctx* ctx);
+void* dla_stream(dla_ctx* ctx);                      /* hipStream_t the kernels run on */
+
+/* ---------------------------------------------------------------- multi-GPU */
+int  dla_comm_unique_id(char id[128]);                                       /* ncclGetUniqueId          */
+int  dla_comm_init(dla_ctx* ctx, int nranks, int rank, const char id[128]);  /* ncclCommInitRank         */
+int  dla_comm_info(dla_ctx* ctx, int* nranks, int* rank);
+/* host-buffer reduction hook (op 0 = sum, 1 = max); lets a caller supply the collective
+ * (e.g. MPI or torch.distributed/gloo).  Used when no RCCL communicator is attached. */
+typedef void (*dla_allreduce_fn)(void* user, double* buf, int count, int op);
+int  dla_set_allreduce_hook(dla_ctx* ctx, dla_allreduce_fn fn, void* user, int nranks, int rank);
+int  dla_set_shard(dla_ctx* ctx, long long n_global, long long row0);        /* global rows of this rank */
+
+/* ---------------------------------------------------------------- device memory
+ * replaces allocate/zero/dcopy of the panels: diaglib.f90:1607-1638,1648,1798-1805, 258-287 */
+int  dla_alloc(dla_ctx* ctx, size_t bytes, void** dev);
+int  dla_free(dla_ctx* ctx, void* dev);
+int  dla_zero(dla_ctx* ctx, void* dev, size_t bytes);
+int  dla_upload(dla_ctx* ctx, void* dev, const void* host, size_t bytes);
+int  dla_download(dla_ctx* ctx, void* host, const void* dev, size_t bytes);
+int  dla_copy(dla_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);   /* dcopy on panels */
+int  dla_sync(dla_ctx* ctx);
+
+/* ---------------------------------------------------------------- block algebra */
+/* C(l x k) = X(n x l)^T U(n x k), result on the host.  dgemm('t','n') at
+ * diaglib.f90:1691 (projection), 3256 (ortho_cd Gram), 3543 (X^T U), 403/313 (LOBPCG S^T AS), 3762. */
+int  dla_gram(dla_ctx* ctx, int n, int l, const double* x_dev, int k, const double* u_dev,
+              double* c_host, int ldc);
+/* Z(n x k) = X(n x l) C(l x k).  dgemm('n','n') at diaglib.f90:1717, 420-424, 495-501, 322-324. */
+int  dla_panel_gemm(dla_ctx* ctx, int n, int l, const double* x_dev, int k, const double* c_host, int ldc,
+                    double* z_dev);
+/* U(n x k) -= X(n x l) C(l x k).  dgemm('n','n',-one,...,one) at diaglib.f90:3544, 3633. */
+int  dla_panel_update(dla_ctx* ctx, int n, int l, const double* x_dev, int k, const double* c_host, int ldc,
+                      double* u_dev);
+/* U <- U Linv^T with Linv lower triangular (k x k, host).  dtrmm('r','l','t','n') at diaglib.f90:3327. */
+int  dla_trmm_linvt(dla_ctx* ctx, int n, int k, double* u_dev, const double* linv_host, int ld);
+/* Fused Ritz step.  evec = V Y(:,1:m), r = AV Y(:,1:m); then for i < n_res with skip[i]==0:
+ * r_i -= eig_i evec_i, rnorm[2i] = ||r_i||_2/sqrt(n_global), rnorm[2i+1] = max|r_i|.
+ * avy_dev (may be NULL) also receives the uncorrected AV Y (LOBPCG's ax_new).
+ * diaglib.f90:1717-1732 (Davidson, n_res = n_targ) and 420-442 (LOBPCG, n_res = n_max). */
+int  dla_ritz_residual(dla_ctx* ctx, int n, int l, int m, const double* v_dev, const double* av_dev,
+                       const double* y_host, int ldy, const double* eig, int n_res, const int* skip,
+                       double* evec_dev, double* r_dev, double* avy_dev, double* rnorm);
+/* y += alpha x over len contiguous doubles.  daxpy at diaglib.f90:312,397 (LOBPCG shift). */
+int  dla_axpy(dla_ctx* ctx, size_t len, double alpha, const double* x_dev, double* y_dev);
+/* sqrt(sum x^2) over len contiguous doubles (all ranks).  dnrm2 at diaglib.f90:3749, 3268. */
+int  dla_nrm2(dla_ctx* ctx, size_t len, const double* x_dev, double* out);
+/* fill evec(n x m) with the documented counter-based uniform [0,1) stream (replaces the
+ * compiler-specific random_number at diaglib.f90:3754). */
+int  dla_random_fill(dla_ctx* ctx, int n, int m, double* evec_dev);
+
+/* ---------------------------------------------------------------- orthogonalisation */
+int  dla_ortho_cd(dla_ctx* ctx, int n, int k, double* u_dev, double* growth, int* ok);      /* diaglib.f90:3185-3341 */
+int  dla_ortho_vs_x(dla_ctx* ctx, int n, int m, int k, const double* x_dev, double* u_dev); /* diaglib.f90:3481-3574 */
+int  dla_b_ortho(dla_ctx* ctx, int n, int m, double* u_dev, double* bu_dev);                /* diaglib.f90:3094-3183 */
+int  dla_b_ortho_vs_x(dla_ctx* ctx, int n, int m, int k, const double* x_dev, const double* bx_dev,
+                      double* u_dev);                                                       /* diaglib.f90:3576-3663 */
+int  dla_check_guess(dla_ctx* ctx, int n, int m, double* evec_dev);                         /* diaglib.f90:3734-3786 */
+/* host-size coefficient step of LOBPCG, diaglib.f90:3686-3732 (arrays on the host) */
+int  dla_get_coeffs(dla_ctx* ctx, int len_a, int len_u, int n_max, int n_act, const double* a_red,
+                    double* u_x, double* u_p);
+
+/* ---------------------------------------------------------------- user callbacks
+ * call matvec(n,m,x,ax) / precnd(n,m,fac,x,px) on blocks of device panels
+ * (diaglib.f90:1685,1786, 309,352,394,518).  Host-callback mode stages through pinned memory. */
+int  dla_call_matvec(dla_ctx* ctx, dla_matvec_fn fn, int n, int m, const double* x_dev, double* ax_dev);
+int  dla_call_precnd(dla_ctx* ctx, dla_precnd_fn fn, int n, int m, double fac, const double* x_dev, double* px_dev);
+
+/* ---------------------------------------------------------------- small dense, host (LAPACK in the reference) */
+int    dla_syev(char uplo, int n, double* a, int lda, double* w);   /* dsyev('v',uplo): :315,406,1708 */
+int    dla_potrf_lower(int m, double* a, int lda);                  /* dpotrf('l'): :3261             */
+int    dla_trtri_lower(int m, double* a, int lda);                  /* dtrtri('l','n'): :3310         */
+double dla_norm_est(int m, const double* a, int lda);               /* norm_est: :3447-3479           */
+
+/* ---------------------------------------------------------------- built-in device operator (bench / tests)
+ * A = diag(i+1) + sigma W W^T, W(i,j) = (2 u01(1,i,j)-1)/sqrt(i), i = 1-based global row;
+ * preconditioner = main.f90:146-171 (mprec) semantics.  The two callbacks have the reference's shape
+ * and expect DEVICE addresses (use with DLA_OPT_CALLBACKS_ON_DEVICE = 1). */
+int  dla_synth_setup(dla_ctx* ctx, long long n_global, long long row0, int n_local, int rank_w, double sigma);
+void dla_synth_matvec(const int* n, const int* m, const double* x_dev, double* ax_dev);
+void dla_synth_precnd(const int* n, const int* m, const double* fac, const double* x_dev, double* px_dev);
+
+/* ---------------------------------------------------------------- drivers (Fortran, bind(C) twins of the
+ * module procedures davidson_driver / lobpcg_driver; argument meaning as reference
+ * diaglib.f90:1483-1539 and 171-228; logicals as int 0/1) */
+void dla_davidson_driver(int verbose, int n, int n_targ, int n_max, int max_iter, double tol, int max_dav,
+                         double shift, dla_matvec_fn matvec, dla_precnd_fn precnd,
+                         double* eig, double* evec, int* ok);
+void dla_lobpcg_driver(int verbose, int gen_eig, int n, int n_targ, int n_max, int max_iter, double tol,
+                       double shift, dla_matvec_fn matvec, dla_precnd_fn precnd, dla_matvec_fn bvec,
+                       double* eig, double* evec, int* ok);
+/* iteration report of the last driver call (iterations, matvec columns, restarts) */
+void dla_last_solve_info(int* iters, int* matvec_cols, int* restarts);
+void dla_set_solve_info(int iters, int matvec_cols, int restarts);   /* used by the Fortran drivers */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,122 @@
+"""GPU parity: each HIP block-algebra kernel, through the C-ABI, against the oracle's
+restatement of the BLAS call it replaces.
+
+Floating point: the kernels sum in a different order than the oracle, so the bar is a relative
+tolerance on float64 results: |got - want| <= 64 eps * (|X|^T |U|) elementwise, i.e. the
+standard dot-product error bound with a small constant.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+def _bound(ax, au, n):
+    return 64 * EPS * (ax.T @ au) + 1e-300
+
+
+SHAPES = [  # n, l, k
+    (257, 1, 1), (257, 13, 5), (1000, 13, 13), (1000, 26, 13), (1024, 16, 16), (1001, 39, 13),
+    (4096, 100, 13), (5000, 260, 13), (3000, 420, 21), (2000, 111, 37), (2000, 111, 111), (640, 200, 70),
+]
+
+
+@pytest.mark.parametrize("n,l,k", SHAPES)
+def test_gram(ctx, oracle, rng, n, l, k):
+    x = np.asfortranarray(rng.standard_normal((n, l)))
+    u = np.asfortranarray(rng.standard_normal((n, k)))
+    got = ctx.gram(ctx.panel(x), ctx.panel(u))
+    want = oracle.gemm_tn(x, u)
+    assert np.all(np.abs(got - want) <= _bound(np.abs(x), np.abs(u), n))
+
+
+def test_gram_self_and_column_views(ctx, oracle, rng):
+    n, lda, k = 2000, 60, 13
+    big = np.asfortranarray(rng.standard_normal((n, lda)))
+    p = ctx.panel(big)
+    got = ctx.gram(p.col(0, 26), p.col(26, k))          # projection-style call on views of one panel
+    want = oracle.gemm_tn(big[:, :26], big[:, 26:26 + k])
+    assert np.all(np.abs(got - want) <= _bound(np.abs(big[:, :26]), np.abs(big[:, 26:26 + k]), n))
+    g = ctx.gram(p.col(5, k), p.col(5, k))
+    assert np.allclose(g, g.T, rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("n,l,k", SHAPES[:11])
+def test_panel_gemm_and_update(ctx, oracle, rng, n, l, k):
+    if k > 48 * 3:
+        pytest.skip("wide")
+    x = np.asfortranarray(rng.standard_normal((n, l)))
+    c = np.asfortranarray(rng.standard_normal((l, k)))
+    u = np.asfortranarray(rng.standard_normal((n, k)))
+    px, pz, pu = ctx.panel(x), ctx.panel(n, k), ctx.panel(u)
+    ctx.panel_gemm(px, c, pz)
+    want = oracle.gemm_nn(x, c)
+    bound = 64 * EPS * (np.abs(x) @ np.abs(c)) + 1e-300
+    assert np.all(np.abs(pz.download() - want) <= bound)
+    ctx.panel_update(px, c, pu)
+    want2 = oracle.gemm_nn(x, c, alpha=-1.0, beta=1.0, z=u)
+    assert np.all(np.abs(pu.download() - want2) <= bound + 4 * EPS * np.abs(u))
+
+
+@pytest.mark.parametrize("n,k", [(257, 1), (257, 5), (1000, 13), (4098, 16), (3000, 21), (2001, 37)])
+def test_trmm_linvt(ctx, rng, n, k):
+    u = np.asfortranarray(rng.standard_normal((n, k)))
+    linv = np.asfortranarray(np.tril(rng.standard_normal((k, k))) + 3 * np.eye(k))
+    linv_dirty = linv + np.triu(rng.standard_normal((k, k)), 1)   # the strict upper part must be ignored
+    pu = ctx.panel(u)
+    ctx.trmm_linvt(pu, linv_dirty)
+    want = u @ linv.T
+    bound = 64 * EPS * (np.abs(u) @ np.abs(linv.T)) + 1e-300
+    assert np.all(np.abs(pu.download() - want) <= bound)
+
+
+@pytest.mark.parametrize("n,l,m,n_res", [(257, 13, 13, 8), (1000, 26, 13, 8), (1000, 160, 8, 4), (5000, 260, 13, 8),
+                                         (2000, 111, 37, 37), (2001, 63, 21, 16)])
+def test_ritz_residual(ctx, oracle, rng, n, l, m, n_res):
+    v = np.asfortranarray(rng.standard_normal((n, l)))
+    av = np.asfortranarray(rng.standard_normal((n, l)))
+    y = np.asfortranarray(rng.standard_normal((l + 3, m)))     # ldy > l on purpose
+    eig = rng.standard_normal(m)
+    skip = np.zeros(m, np.int32)
+    skip[1] = 1 if n_res > 1 else 0
+    pe, pr, pa = ctx.panel(n, m), ctx.panel(n, m), ctx.panel(n, m)
+    rn = ctx.ritz_residual(ctx.panel(v), ctx.panel(av), y, eig, n_res, skip, pe, pr, pa)
+    ev_want = oracle.gemm_nn(v, y[:l])
+    avy_want = oracle.gemm_nn(av, y[:l])
+    r_want = avy_want.copy()
+    b1 = 64 * EPS * (np.abs(v) @ np.abs(y[:l])) + 1e-300
+    b2 = 64 * EPS * (np.abs(av) @ np.abs(y[:l])) + 1e-300
+    for i in range(n_res):
+        if not skip[i]:
+            r_want[:, i] -= eig[i] * ev_want[:, i]
+    assert np.all(np.abs(pe.download() - ev_want) <= b1)
+    assert np.all(np.abs(pa.download() - avy_want) <= b2)
+    r_got = pr.download()
+    assert np.all(np.abs(r_got - r_want) <= b2 + np.abs(eig)[None, :] * b1 + 4 * EPS * np.abs(r_want))
+    for i in range(n_res):
+        if skip[i]:
+            assert rn[0, i] == 0.0 and rn[1, i] == 0.0     # untouched, like the reference's `cycle`
+        else:
+            assert np.isclose(rn[0, i], np.linalg.norm(r_got[:, i]) / np.sqrt(n), rtol=1e-13)
+            assert rn[1, i] == np.abs(r_got[:, i]).max()
+
+
+def test_axpy_nrm2_random_fill(ctx, oracle, rng):
+    n, m = 3001, 7
+    x = np.asfortranarray(rng.standard_normal((n, m))); y = np.asfortranarray(rng.standard_normal((n, m)))
+    px, py = ctx.panel(x), ctx.panel(y)
+    ctx.axpy(0.37, px, py)
+    assert np.array_equal(py.download(), y + 0.37 * x) or np.allclose(py.download(), y + 0.37 * x, rtol=4 * EPS, atol=0)
+    assert np.isclose(ctx.nrm2(px), np.linalg.norm(x), rtol=1e-14)
+    ctx.random_fill(px)
+    got = px.download()
+    for (i, j) in [(0, 0), (17, 3), (n - 1, m - 1)]:
+        assert got[i, j] == oracle.u01(7, i + 1, j + 1)       # bit-exact: integer hash -> double
+    assert 0.0 <= got.min() and got.max() < 1.0
+
+
+def test_empty_and_degenerate(ctx):
+    p = ctx.panel(np.zeros((64, 3)))
+    assert ctx.gram(p, p).tolist() == np.zeros((3, 3)).tolist()
+    assert ctx.nrm2(p) == 0.0
