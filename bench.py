@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the diaglib hot path on MI355X.
+
+Workload (BASELINE.json metric / SURVEY.md 8d): block Davidson-Liu on the matrix-free dense
+symmetric operator A = diag(i+1) + 0.5 W W^T (rank 4), n = 2e6 rows, 8 wanted roots, block
+n_max = 13, max_dav = 20, unit-vector guess, device-resident callbacks and eigenvector block.
+One "step" = one complete solve (guess -> converged eigenpairs).  With --gpus N the n rows are
+sharded row-wise over N ranks (strong scaling, as the metric is quoted: same n on 1/2/4/8 GPUs);
+the only cross-rank traffic is the RCCL all-reduce of the small m x m products.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `value` = reference-schedule GFLOP (the flops of the
+BLAS calls the reference would issue for the iterations performed) / wall time of the solves,
+inputs resident in HBM.  `roofline` is the dominant kernel class measured with HIP events on the
+engine's stream during the timed region; `cpu_baseline` times the UNMODIFIED reference
+(oracle/_ref, flang+MKL) -- or the oracle's C port when that library cannot be loaded -- on this
+box's host cores on a bounded sample (same operator, n = 2.5e5).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+CPU_THREADS = int(os.environ.get("DIAGLIB_BENCH_CPU_THREADS", "16"))
+os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS))
+os.environ.setdefault("MKL_NUM_THREADS", str(CPU_THREADS))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def shard_rows(n: int, nranks: int, rank: int):
+    """Contiguous row blocks, multiples of 64 rows except the last."""
+    per = ((n + nranks - 1) // nranks + 63) // 64 * 64
+    r0 = min(n, rank * per)
+    r1 = min(n, r0 + per)
+    return r0, r1 - r0
+
+
+def cpu_baseline(n_sample: int, n_targ: int, n_max: int, max_dav: int, tol: float, flops_per_row: float):
+    """Reference (or port) on the host cores, bounded sample of the same workload."""
+    from oracle.pyoracle import Oracle, Reference
+    o = Oracle()
+    o.synth_setup(n_sample, 0, n_sample)
+    guess = np.zeros((n_sample, n_max), order="F")
+    guess[np.arange(n_max), np.arange(n_max)] = 1.0
+    mv, pc = o.fn("orc_synth_matvec"), o.fn("orc_synth_precnd")
+    kind = "port"
+    t0 = time.perf_counter()
+    try:
+        ref = Reference()
+        kind = "reference"
+        t0 = time.perf_counter()
+        _, _, ok = ref.davidson(n_sample, n_targ, n_max, 100, tol, max_dav, 0.0, mv, pc, guess)
+    except (OSError, FileNotFoundError):
+        t0 = time.perf_counter()
+        _, _, ok, _ = o.davidson(n_sample, n_targ, n_max, 100, tol, max_dav, 0.0, mv, pc, guess)
+    dt = time.perf_counter() - t0
+    return {"value": flops_per_row * n_sample / dt / 1e9, "unit": "GFLOP/s", "cores": CPU_THREADS, "kind": kind,
+            "sample": f"same Davidson-Liu solve (synthetic operator, {n_targ} roots, n_max={n_max}, tol={tol:g}) at "
+                      f"n={n_sample} rows, whole call incl. allocation, {dt:.2f} s, converged={bool(ok)}; "
+                      "flops = GPU run's reference-schedule flops per row x n_sample"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=2_000_000)
+    ap.add_argument("--roots", type=int, default=8)
+    ap.add_argument("--solver", default="davidson", choices=["davidson", "lobpcg"])
+    ap.add_argument("--tol", type=float, default=1e-13)
+    ap.add_argument("--max-dav", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=250_000)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+
+    from diaglib_amd import capi
+    ctx = capi.Context()
+    assert ctx.backend.startswith("hip:"), ctx.backend
+
+    n, n_targ = args.n, args.roots
+    n_max = min(2 * n_targ, n_targ + 5)            # harness convention, reference main.f90:354
+    row0, n_loc = shard_rows(n, world, rank)
+    if world > 1:
+        uid = [ctx.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+        ctx.set_shard(n, row0)
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+    ctx.synth_setup(n, row0, n_loc)
+    mv, pc = capi.fn_address("dla_synth_matvec"), capi.fn_address("dla_synth_precnd")
+
+    guess = np.zeros((n_loc, n_max), order="F")
+    for j in range(n_max):                          # unit vectors e_1..e_M of the GLOBAL problem
+        if row0 <= j < row0 + n_loc:
+            guess[j - row0, j] = 1.0
+    g_dev = ctx.panel(guess)
+    ev = ctx.panel(n_loc, n_max)
+
+    def solve():
+        ctx.lib.dla_copy(ctx.h, ev.ptr, g_dev.ptr, 8 * n_loc * n_max)
+        if args.solver == "davidson":
+            return ctx.davidson_driver(n_loc, n_targ, n_max, 200, args.tol, args.max_dav, 0.0, mv, pc, ev)
+        return ctx.lobpcg_driver(n_loc, n_targ, n_max, 200, args.tol, 0.0, mv, pc, ev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solve()
+    ctx.set_option(capi.OPT_PROFILE, 1)
+    ctx.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eig, _, ok, info = solve()
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = ctx.stats()
+    ctx.set_option(capi.OPT_PROFILE, 0)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+
+    # ---- residual check of the returned pairs: ||A x - lambda x||_2 / |lambda| (north star <= 1e-10)
+    ax = ctx.panel(n_loc, n_max)
+    ctx.synth_matvec(ev, ax)
+    x_h, ax_h = ev.download(), ax.download()
+    r2 = ((ax_h - x_h * eig[None, :]) ** 2).sum(0)
+    if world > 1:
+        rt = torch.from_numpy(r2.copy())
+        dist.all_reduce(rt)
+        r2 = rt.numpy()
+    rel_res = float((np.sqrt(r2[:n_targ]) / np.abs(eig[:n_targ])).max())
+
+    # ---- flops / bytes (each rank counted its local rows; shards are equal up to 64 rows)
+    classes = ["gram", "gemm", "trmm", "ritz", "elem"]
+    flops_local = sum(stats[c]["flops"] for c in classes)
+    flops_total = flops_local * (n / n_loc)
+    value = flops_total / dt / 1e9
+    dom = max(classes, key=lambda c: stats[c]["ms"])
+    kern = {c: {"launches": stats[c]["launches"], "ms": round(stats[c]["ms"], 3),
+                "GBps": round(stats[c]["alg_bytes"] / max(stats[c]["ms"], 1e-9) / 1e6, 1)}
+            for c in classes + ["matvec", "precnd"]}
+    ach = stats[dom]["alg_bytes"] / max(stats[dom]["ms"], 1e-9) / 1e6
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "launches": stats[dom]["launches"],
+                "avg_launch_ms": round(stats[dom]["ms"] / max(1, stats[dom]["launches"]), 4),
+                "alg_bytes_per_launch": round(stats[dom]["alg_bytes"] / max(1, stats[dom]["launches"]), 1)}
+
+    out = {
+        "metric": "eigensolver GFLOP/s + iters-to-converge, n=2e6 m=8 Davidson, 1/2/4/8 GPU",
+        "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.solver} n={n} roots={n_targ} n_max={n_max} max_dav={args.max_dav} tol={args.tol:g} "
+                               "operator=diag(i+1)+0.5*W*W^T(rank 4) guess=unit callbacks=device",
+                   "iters": info["iters"], "matvec_cols": info["matvec_cols"], "restarts": info["restarts"],
+                   "converged": bool(ok), "max_rel_residual": rel_res, "rows_per_gpu": n_loc,
+                   "eig": [round(float(e), 9) for e in eig[:n_targ]]},
+        "roofline": roofline,
+        "kernels": kern,
+        "host": {"allreduces": stats["allreduces"], "host_syncs": stats["host_syncs"]},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, n_targ, n_max, args.max_dav, args.tol,
+                                               flops_total / args.steps / n)
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": CPU_THREADS, "kind": "port",
+                                   "sample": f"failed: {e!r}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

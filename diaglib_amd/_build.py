@@ -86,7 +86,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if force or _newer(objs, LIB):
         _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs +
              ["-L" + os.path.join(ROCM, "lib"), "-lrccl", "-L" + _flang_rt_dir(), "-lflang_rt.runtime",
-              "-Wl,-rpath," + os.path.join(ROCM, "lib")], verbose)
+              "-Wl,-rpath," + os.path.join(ROCM, "lib"),
+              # bind the module procedures (_QMdiaglibP...) inside the library: a caller process may also
+              # hold another library that defines the same Fortran module name
+              "-Wl,-Bsymbolic"], verbose)
     return LIB
 
 

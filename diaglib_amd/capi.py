@@ -69,7 +69,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     if not os.path.exists(path):
         raise DlaError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)")
-    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(path, mode=C.RTLD_LOCAL)
     vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
     sig = {
         "dla_create": (i, [C.POINTER(vp), i]), "dla_destroy": (i, [vp]), "dla_default_ctx": (vp, []),

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "dla_internal.h"
@@ -567,7 +568,8 @@ struct HipEngine : dla::Engine {
   long long syn_row0 = 0; int syn_n = 0, syn_rw = 0; double syn_sigma = 0.0;
   // rccl
   ncclComm_t comm = nullptr;
-  // timing
+  // timing / tracing ($DIAGLIB_AMD_TRACE=1: print and synchronise around every launch)
+  bool trace = false;
   std::vector<TimedLaunch> timed;
   std::vector<hipEvent_t> ev_pool;
 
@@ -598,6 +600,7 @@ struct HipEngine : dla::Engine {
     if (cnt <= 0) { err = "no HIP device"; return DLA_ERR_NO_DEVICE; }
     if (dev >= cnt) dev = dev % cnt;
     device = dev;
+    trace = std::getenv("DIAGLIB_AMD_TRACE") != nullptr;
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t p;
     HIPCHK(hipGetDeviceProperties(&p, device));
@@ -615,6 +618,7 @@ struct HipEngine : dla::Engine {
     HipEngine* e; int cls; hipEvent_t a = nullptr, b = nullptr;
     Scope(HipEngine* e_, int cls_, double bytes, double flops) : e(e_), cls(cls_)
     {
+      if (e->trace) { std::fprintf(stderr, "[dla] launch class %d, %.3e alg bytes\n", cls_, bytes); std::fflush(stderr); }
       e->stats.launches[cls] += 1;
       e->stats.alg_bytes[cls] += bytes;
       e->stats.flops[cls] += flops;
@@ -625,6 +629,10 @@ struct HipEngine : dla::Engine {
     }
     ~Scope()
     {
+      if (e->trace) {
+        hipError_t er = hipStreamSynchronize(e->st);
+        std::fprintf(stderr, "[dla]   done: %s\n", hipGetErrorString(er)); std::fflush(stderr);
+      }
       if (e->profile) {
         (void)hipEventRecord(b, e->st);
         e->timed.push_back({a, b, cls});
@@ -771,7 +779,7 @@ struct HipEngine : dla::Engine {
   }
 
   // result stays on the device in d_small (l x k, ld = l), reduced over ranks
-  int gram_dev(int n, int l, const double* x, int k, const double* u)
+  int gram_dev(int n, int l, const double* x, int k, const double* u, int cls = DLA_OP_GRAM)
   {
     const int tx = (l + 15) / 16, tu = (k + 15) / 16;
     // tile shape of one pass: KT U-tiles x TLW X-tiles, at most 12 accumulators
@@ -803,7 +811,7 @@ struct HipEngine : dla::Engine {
     dim3 grid(blocks_per_pass, passes);
     {
       const bool same = (x == u) && (l == k);
-      Scope s(this, DLA_OP_GRAM, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k);
+      Scope s(this, cls, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k);
 #define GL(T, K) if (tlw == T && kt == K) launch_gram<T, K>(a, grid, vec2); else
       GL(1, 1) GL(2, 1) GL(3, 1) GL(4, 1) GL(6, 1) GL(8, 1) GL(12, 1)
       GL(1, 2) GL(2, 2) GL(4, 2) GL(6, 2)
@@ -1036,7 +1044,7 @@ struct HipEngine : dla::Engine {
   {
     if (n != syn_n) { err = "synth_matvec: n differs from setup"; return DLA_ERR_ARG; }
     if (m > 64) { err = "synth_matvec: m > 64"; return DLA_ERR_ARG; }
-    int stc = gram_dev(n, syn_rw, d_w, m, x);     // t = W^T x  (4 x m), reduced over ranks, on device
+    int stc = gram_dev(n, syn_rw, d_w, m, x, DLA_OP_MATVEC);   // t = W^T x (4 x m), reduced over ranks, on device
     if (stc) return stc;
     Scope s(this, DLA_OP_MATVEC, 8.0 * n * (2.0 * m + syn_rw), 2.0 * (double)n * m * (2 * syn_rw + 1));
     HIPCHK(hipMemcpyAsync(d_t, d_small, sizeof(double) * syn_rw * m, hipMemcpyDeviceToDevice, st));

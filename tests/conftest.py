@@ -7,6 +7,10 @@ path through the C-ABI and compare with the oracle (oracle/) and the golden fixt
 import os
 import sys
 
+# the oracle's OpenMP loops are tiny in the tests: a 256-core GPU box must not spawn 256 threads
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("MKL_NUM_THREADS", "8")
+
 import numpy as np
 import pytest
 
