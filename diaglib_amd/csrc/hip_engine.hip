@@ -159,35 +159,60 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
     }
 }
 
-// second stage: sum the block partials in a fixed order and scatter into column-major C (ld = l)
+// second stage: sum the block partials in a fixed order and scatter into column-major C (ld = l).
+// One launch, two levels: block (ps, grp) sums its share of the partials into lvl2[ps][grp]; the
+// block that draws the last ticket for ps adds the `groups` level-2 rows in index order (so the
+// result does not depend on arrival order) and writes C to the device buffer and to its pinned
+// host mirror.  Hand-off = agent-scope release / acquire around a relaxed ticket
+// (cdna_hip_programming.md guideline 16); the ticket is reset by its last arriver.
 struct GramReduceArgs {
   const double* partial;
-  double* c;         // l x k, ld = l
+  double* lvl2;        // [passes*slots][groups][256]
+  unsigned* ticket;    // [passes*slots], zero between launches
+  double* c;           // l x k, ld = l (device)
+  double* c_host;      // same, pinned host mirror (device-visible address)
   int nblk, l, k, tlw, kt, passes_x;
 };
 
-__global__ __launch_bounds__(1024) void gram_reduce_kernel(GramReduceArgs a)
+__global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
 {
-  // blockIdx.x = pass * slots + slot ; 1024 threads = 4 groups x 256 elements
   const int slots = a.tlw * a.kt;
-  const int pass = blockIdx.x / slots, slot = blockIdx.x % slots;
-  const int e = threadIdx.x & 255, grp = threadIdx.x >> 8;
+  const int ps = blockIdx.x, grp = blockIdx.y, G = gridDim.y;
+  const int pass = ps / slots, slot = ps % slots;
+  const int e = threadIdx.x;
   const double* p = a.partial + ((size_t)pass * a.nblk) * (size_t)slots * 256 + (size_t)slot * 256 + e;
-  const int per = (a.nblk + 3) / 4;
+  const int per = (a.nblk + G - 1) / G;
   const int b0 = grp * per, b1 = min(a.nblk, b0 + per);
   double s = 0.0;
   for (int b = b0; b < b1; ++b) s += p[(size_t)b * slots * 256];
-  __shared__ double red[4][256];
-  red[grp][e] = s;
+  a.lvl2[((size_t)ps * G + grp) * 256 + e] = s;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (grp == 0) {
-    double tot = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
-    const int xg = pass % a.passes_x, ug = pass / a.passes_x;
-    const int t = slot / a.kt, q = slot % a.kt;
-    const int reg = e >> 6, lane = e & 63;
-    const int xcol = (xg * a.tlw + t) * 16 + (lane >> 4) + 4 * reg;
-    const int ucol = (ug * a.kt + q) * 16 + (lane & 15);
-    if (xcol < a.l && ucol < a.k) a.c[(size_t)xcol + (size_t)ucol * a.l] = tot;
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(&a.ticket[ps], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == (unsigned)(G - 1));
+    if (last) {
+      __hip_atomic_store(&a.ticket[ps], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double tot = 0.0;
+  for (int g2 = 0; g2 < G; ++g2) tot += a.lvl2[((size_t)ps * G + g2) * 256 + e];
+  const int xg = pass % a.passes_x, ug = pass / a.passes_x;
+  const int t = slot / a.kt, q = slot % a.kt;
+  const int reg = e >> 6, lane = e & 63;
+  const int xcol = (xg * a.tlw + t) * 16 + (lane >> 4) + 4 * reg;
+  const int ucol = (ug * a.kt + q) * 16 + (lane & 15);
+  if (xcol < a.l && ucol < a.k) {
+    a.c[(size_t)xcol + (size_t)ucol * a.l] = tot;
+    a.c_host[(size_t)xcol + (size_t)ucol * a.l] = tot;
   }
 }
 
@@ -207,9 +232,20 @@ struct GemmArgs {
   int l, l4, k;
 };
 
+// small C (l <= 16, k <= 16) travels inside the kernel arguments: no staging copy, no extra launch
+struct GemmArgsInl {
+  const double* x;
+  double* z;
+  long long n;
+  int l, l4, k;
+  double cin[256];     // packed C: [l4 <= 16][16]
+};
+__device__ __forceinline__ const double* packed_c(const GemmArgs& a) { return a.cpk; }
+__device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return a.cin; }
+
 // MODE 0: Z = XC   1: Z -= XC   2: in place U <- U W (x == z)   3: Z += XC
-template <int KT, int VEC, int MODE>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a)
+template <int KT, int VEC, int MODE, typename ARGS>
+__global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 {
   constexpr int RT = 2;                    // row groups per wave tile
   constexpr int RG = 16 * VEC;             // rows per group
@@ -218,7 +254,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a)
   typedef typename VecOf<VEC>::type vec_t;
   const long long n = a.n;
   const int l = a.l, l4 = a.l4;
-  for (int idx = threadIdx.x; idx < KT * l4 * 16; idx += 256) cs[idx] = a.cpk[idx];
+  {
+    const double* csrc = packed_c(a);
+    for (int idx = threadIdx.x; idx < KT * l4 * 16; idx += 256) cs[idx] = csrc[idx];
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -425,18 +464,36 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
   }
 }
 
-// out[j] = { sum_b red[b][j][0], max_b red[b][j][1] }, fixed order
-__global__ void ritz_reduce_kernel(const double* red, int nblk, int ncol, double* out)
+// fixed-shape block reduction (shuffle tree inside each wave, then the 4 waves in order)
+__device__ __forceinline__ void block_sum_max(double& s, double& m, double* sh /* >= 8 doubles */)
 {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ncol) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    m = fmax(m, __shfl_down(m, off, 64));
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w] = s; sh[4 + w] = m; }
+  __syncthreads();
+  s = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+  m = fmax(fmax(sh[4], sh[5]), fmax(sh[6], sh[7]));
+}
+
+// out[j] = sum_b red[b][j][0], out[ncol + j] = max_b red[b][j][1]; one block per column j
+__global__ __launch_bounds__(256) void ritz_reduce_kernel(const double* red, int nblk, int ncol, double* out, double* out_host)
+{
+  const int j = blockIdx.x;
   double s = 0.0, m = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = threadIdx.x; b < nblk; b += 256) {
     s += red[((size_t)b * ncol + j) * 2 + 0];
     m = fmax(m, red[((size_t)b * ncol + j) * 2 + 1]);
   }
-  out[j] = s;
-  out[ncol + j] = m;
+  __shared__ double sh[8];
+  block_sum_max(s, m, sh);
+  if (threadIdx.x == 0) {
+    out[j] = s; out[ncol + j] = m;
+    out_host[j] = s; out_host[ncol + j] = m;
+  }
 }
 
 // ======================================================================================
@@ -464,13 +521,13 @@ __global__ __launch_bounds__(256) void sumsq_kernel(size_t len, const double* __
   if (threadIdx.x == 0) partial[blockIdx.x] = ((w[0] + w[1]) + w[2]) + w[3];
 }
 
-__global__ void sum_partials_kernel(const double* partial, int nblk, double* out)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* partial, int nblk, double* out, double* out_host)
 {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[b];
-    out[0] = s;
-  }
+  double s = 0.0, m = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += partial[b];
+  __shared__ double sh[8];
+  block_sum_max(s, m, sh);
+  if (threadIdx.x == 0) { out[0] = s; out_host[0] = s; }
 }
 
 // documented counter-based generator (same as oracle/oracle.c orc_u01)
@@ -559,7 +616,10 @@ struct HipEngine : dla::Engine {
   // workspaces
   double* d_partial = nullptr; size_t partial_bytes = 0;
   double* d_small = nullptr;   size_t small_bytes = 0;    // reduced results (device)
-  double* h_small = nullptr;                              // pinned mirror
+  double* h_small = nullptr;                              // pinned, device-mapped host mirror
+  double* h_small_dev = nullptr;                          // its device-visible address
+  double* d_lvl2 = nullptr;    size_t lvl2_bytes = 0;     // second-level partials of the Gram reduction
+  unsigned* d_ticket = nullptr;
   static const int RING = 8;
   double* h_ring[RING] = {nullptr}; hipEvent_t ring_ev[RING]; size_t ring_bytes = 0; int ring_pos = 0;
   double* d_cpk = nullptr; size_t cpk_bytes = 0;
@@ -585,6 +645,8 @@ struct HipEngine : dla::Engine {
     if (d_partial) (void)hipFree(d_partial);
     if (d_small) (void)hipFree(d_small);
     if (h_small) (void)hipHostFree(h_small);
+    if (d_lvl2) (void)hipFree(d_lvl2);
+    if (d_ticket) (void)hipFree(d_ticket);
     for (int i = 0; i < RING; ++i) if (h_ring[i]) { (void)hipHostFree(h_ring[i]); (void)hipEventDestroy(ring_ev[i]); }
     if (d_cpk) (void)hipFree(d_cpk);
     if (d_w) (void)hipFree(d_w);
@@ -609,7 +671,10 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     small_bytes = sizeof(double) * 512 * 512;
     HIPCHK(hipMalloc((void**)&d_small, small_bytes));
-    HIPCHK(hipHostMalloc((void**)&h_small, small_bytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&h_small, small_bytes, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&h_small_dev, h_small, 0));
+    HIPCHK(hipMalloc((void**)&d_ticket, sizeof(unsigned) * 4096));
+    HIPCHK(hipMemset(d_ticket, 0, sizeof(unsigned) * 4096));
     return DLA_OK;
   }
 
@@ -711,7 +776,17 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipFree(d_small)); HIPCHK(hipHostFree(h_small));
     small_bytes = bytes;
     HIPCHK(hipMalloc((void**)&d_small, small_bytes));
-    HIPCHK(hipHostMalloc((void**)&h_small, small_bytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&h_small, small_bytes, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&h_small_dev, h_small, 0));
+    return DLA_OK;
+  }
+  // reduced small result -> host: single rank reads the pinned mirror the kernel wrote,
+  // multi-rank copies the all-reduced device buffer
+  int small_to_host(size_t count)
+  {
+    if (nranks > 1) HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    stats.host_syncs++;
     return DLA_OK;
   }
 
@@ -819,8 +894,17 @@ struct HipEngine : dla::Engine {
       GL(1, 4) GL(2, 4) GL(3, 4)
       { err = "gram: no kernel instance"; return DLA_ERR_RUNTIME; }
 #undef GL
-      GramReduceArgs ra{d_partial, d_small, blocks_per_pass, l, k, tlw, kt, px};
-      hipLaunchKernelGGL(gram_reduce_kernel, dim3(passes * slots), dim3(1024), 0, st, ra);
+      const int groups = std::max(1, std::min(16, (blocks_per_pass + 31) / 32));
+      const size_t need2 = sizeof(double) * (size_t)passes * slots * groups * 256;
+      if (need2 > lvl2_bytes) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (d_lvl2) HIPCHK(hipFree(d_lvl2));
+        lvl2_bytes = std::max(need2, (size_t)1 << 20);
+        HIPCHK(hipMalloc((void**)&d_lvl2, lvl2_bytes));
+      }
+      if (passes * slots > 4096) { err = "gram: too many output tiles"; return DLA_ERR_ARG; }
+      GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, h_small_dev, blocks_per_pass, l, k, tlw, kt, px};
+      hipLaunchKernelGGL(gram_reduce_kernel, dim3(passes * slots, groups), dim3(256), 0, st, ra);
     }
     HIPCHK(hipGetLastError());
     return allreduce_dev(d_small, l * k, 0, h_small);
@@ -830,9 +914,8 @@ struct HipEngine : dla::Engine {
   {
     int stc = gram_dev(n, l, x, k, u);
     if (stc) return stc;
-    HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * (size_t)l * k, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    stats.host_syncs++;
+    stc = small_to_host((size_t)l * k);
+    if (stc) return stc;
     for (int j = 0; j < k; ++j) std::memcpy(c_host + (size_t)j * ldc, h_small + (size_t)j * l, sizeof(double) * l);
     return DLA_OK;
   }
@@ -855,10 +938,10 @@ struct HipEngine : dla::Engine {
     return stage_to_device(pk.data(), sizeof(double) * cnt, d_cpk);
   }
 
-  template <int KT>
-  void launch_gemm(const GemmArgs& a, int blocks, size_t lds, bool vec2, int mode)
+  template <int KT, typename ARGS>
+  void launch_gemm(const ARGS& a, int blocks, size_t lds, bool vec2, int mode)
   {
-#define GM(V, M) hipLaunchKernelGGL((gemm_kernel<KT, V, M>), dim3(blocks), dim3(256), lds, st, a)
+#define GM(V, M) hipLaunchKernelGGL((gemm_kernel<KT, V, M, ARGS>), dim3(blocks), dim3(256), lds, st, a)
     if (vec2) { if (mode == 0) GM(2, 0); else if (mode == 1) GM(2, 1); else if (mode == 2) GM(2, 2); else GM(2, 3); }
     else      { if (mode == 0) GM(1, 0); else if (mode == 1) GM(1, 1); else if (mode == 2) GM(1, 2); else GM(1, 3); }
 #undef GM
@@ -868,8 +951,11 @@ struct HipEngine : dla::Engine {
   {
     const int kt = (k + 15) / 16;
     const int l4 = ((l + 3) / 4) * 4;
-    int stc = upload_packed(c_host, ldc, l0, l, k, kt, l4);
-    if (stc) return stc;
+    const bool inl = (kt == 1 && l4 <= 16);
+    if (!inl) {
+      int stc = upload_packed(c_host, ldc, l0, l, k, kt, l4);
+      if (stc) return stc;
+    }
     const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)z) % 16 == 0);
     const int wt = vec2 ? 64 : 32;
     const long long ntiles = ((long long)n + wt - 1) / wt;
@@ -880,6 +966,15 @@ struct HipEngine : dla::Engine {
     a.x = x + (size_t)l0 * n; a.cpk = d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k;
     const double rd = (mode == 0) ? 8.0 * n * (double)l : (mode == 2 ? 8.0 * n * (double)k : 8.0 * n * (double)(l + k));
     Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k);
+    if (inl) {
+      GemmArgsInl ai{};
+      ai.x = a.x; ai.z = z; ai.n = n; ai.l = l; ai.l4 = l4; ai.k = k;
+      for (int j = 0; j < k; ++j)
+        for (int p = 0; p < l; ++p) ai.cin[p * 16 + j] = c_host[(size_t)(l0 + p) + (size_t)j * ldc];
+      launch_gemm<1>(ai, blocks, lds, vec2, mode);
+      HIPCHK(hipGetLastError());
+      return DLA_OK;
+    }
     switch (kt) {
       case 1: launch_gemm<1>(a, blocks, lds, vec2, mode); break;
       case 2: launch_gemm<2>(a, blocks, lds, vec2, mode); break;
@@ -969,16 +1064,16 @@ struct HipEngine : dla::Engine {
         else if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 1>), dim3(blocks), dim3(256), lds, st, a);
         else hipLaunchKernelGGL((ritz_kernel<3, 1>), dim3(blocks), dim3(256), lds, st, a);
       }
-      hipLaunchKernelGGL(ritz_reduce_kernel, dim3(1), dim3(64), 0, st, d_partial, blocks, ncol, d_small);
+      hipLaunchKernelGGL(ritz_reduce_kernel, dim3(ncol), dim3(256), 0, st, (const double*)d_partial, blocks, ncol, d_small,
+                         h_small_dev);
     }
     HIPCHK(hipGetLastError());
     stc = allreduce_dev(d_small, ncol, 0, h_small);
     if (stc) return stc;
     stc = allreduce_dev(d_small + ncol, ncol, 1, h_small + ncol);
     if (stc) return stc;
-    HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * 2 * ncol, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    stats.host_syncs++;
+    stc = small_to_host((size_t)2 * ncol);
+    if (stc) return stc;
     for (int j = 0; j < n_res; ++j) { out[2 * j] = h_small[j]; out[2 * j + 1] = h_small[ncol + j]; }
     return DLA_OK;
   }
@@ -1000,14 +1095,13 @@ struct HipEngine : dla::Engine {
     {
       Scope s(this, DLA_OP_ELEM, 8.0 * (double)len, 2.0 * (double)len);
       hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, len, x, d_partial);
-      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, d_partial, blocks, d_small);
+      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const double*)d_partial, blocks, d_small, h_small_dev);
     }
     HIPCHK(hipGetLastError());
     stc = allreduce_dev(d_small, 1, 0, h_small);
     if (stc) return stc;
-    HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    stats.host_syncs++;
+    stc = small_to_host(1);
+    if (stc) return stc;
     *out = h_small[0];
     return DLA_OK;
   }
