@@ -71,7 +71,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         src = os.path.join(PKG, s)
         o = os.path.join(OBJ, os.path.basename(s) + ".o")
         if force or _newer([src] + hdrs, o):
-            _run([HIPCC, "-x", "c++", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", o], verbose)
+            # host-size dense kernels want AVX2/FMA (every x86 host of an MI355X node has them)
+            _run([HIPCC, "-x", "c++", "-O3", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-c", src, "-o", o], verbose)
         objs.append(o)
     f_objs = []
     rebuild_f = force

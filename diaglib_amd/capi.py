@@ -36,7 +36,7 @@ EXPORTS = [
     "dla_nrm2", "dla_random_fill",
     "dla_ortho_cd", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
     "dla_call_matvec", "dla_call_precnd",
-    "dla_syev", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
+    "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
     "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd",
     "dla_davidson_driver", "dla_lobpcg_driver", "dla_last_solve_info", "dla_set_solve_info",
 ]
@@ -94,7 +94,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_check_guess": (i, [vp, i, i, vp]),
         "dla_get_coeffs": (i, [vp, i, i, i, i, c_dp, c_dp, c_dp]),
         "dla_call_matvec": (i, [vp, vp, i, i, vp, vp]), "dla_call_precnd": (i, [vp, vp, i, i, d, vp, vp]),
-        "dla_syev": (i, [C.c_char, i, c_dp, i, c_dp]), "dla_potrf_lower": (i, [i, c_dp, i]),
+        "dla_syev": (i, [C.c_char, i, c_dp, i, c_dp]), "dla_syev_lowest": (i, [C.c_char, i, c_dp, i, c_dp, i]),
+        "dla_potrf_lower": (i, [i, c_dp, i]),
         "dla_trtri_lower": (i, [i, c_dp, i]), "dla_norm_est": (d, [i, c_dp, i]),
         "dla_synth_setup": (i, [vp, C.c_longlong, C.c_longlong, i, i, d]),
         "dla_davidson_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, c_ip]),
@@ -379,6 +380,17 @@ def syev(a: np.ndarray, uplo: str = "l"):
     if info != 0:
         raise DlaError(f"dla_syev info={info}")
     return w, a
+
+
+def syev_lowest(a: np.ndarray, m: int, uplo: str = "l"):
+    L = load()
+    a = np.asfortranarray(a, dtype=np.float64).copy(order="F")
+    n = a.shape[0]
+    w = np.zeros(n)
+    info = L.dla_syev_lowest(uplo.encode(), n, _dp(a), n, _dp(w), m)
+    if info != 0:
+        raise DlaError(f"dla_syev_lowest info={info}")
+    return w, a[:, :m]
 
 
 def potrf_lower(a: np.ndarray):

@@ -183,8 +183,17 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
   const double* p = a.partial + ((size_t)pass * a.nblk) * (size_t)slots * 256 + (size_t)slot * 256 + e;
   const int per = (a.nblk + G - 1) / G;
   const int b0 = grp * per, b1 = min(a.nblk, b0 + per);
+  // loads are issued in batches of 8 (independent), the adds stay in index order
   double s = 0.0;
-  for (int b = b0; b < b1; ++b) s += p[(size_t)b * slots * 256];
+  int b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + q) * slots * 256];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+  }
+  for (; b < b1; ++b) s += p[(size_t)b * slots * 256];
   a.lvl2[((size_t)ps * G + grp) * 256 + e] = s;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -204,7 +213,13 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
   __syncthreads();
   if (!s_last) return;
   double tot = 0.0;
-  for (int g2 = 0; g2 < G; ++g2) tot += a.lvl2[((size_t)ps * G + g2) * 256 + e];
+  {
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = (q < G) ? a.lvl2[((size_t)ps * G + q) * 256 + e] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += v[q];   // G <= 16; padding zeros do not change the sum
+  }
   const int xg = pass % a.passes_x, ug = pass / a.passes_x;
   const int t = slot / a.kt, q = slot % a.kt;
   const int reg = e >> 6, lane = e & 63;

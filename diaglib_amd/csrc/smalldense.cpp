@@ -13,6 +13,10 @@
 
 namespace {
 
+// sqrt(a^2+b^2); the matrices handled here are projected operators (|entries| << 1e150), so the
+// plain form is safe and several times faster than std::hypot
+inline double pythag(double a, double b) { return std::sqrt(a * a + b * b); }
+
 inline double& at(double* a, int ld, int i, int j) { return a[(size_t)i + (size_t)j * ld]; }
 inline double at(const double* a, int ld, int i, int j) { return a[(size_t)i + (size_t)j * ld]; }
 
@@ -103,13 +107,13 @@ int sym_eig(int n, std::vector<double>& s, std::vector<double>& d, std::vector<d
       if (m == l) break;
       if (++iter > 60) return l + 1;
       double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-      double r = std::hypot(g, 1.0);
+      double r = pythag(g, 1.0);
       g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? r : -r));
       double sn = 1.0, cs = 1.0, pp = 0.0;
       int i = m - 1;
       for (; i >= l; --i) {
         double f = sn * e[i], b = cs * e[i];
-        r = std::hypot(f, g);
+        r = pythag(f, g);
         e[i + 1] = r;
         if (r == 0.0) { d[i + 1] -= pp; e[m] = 0.0; break; }
         sn = f / r; cs = g / r;
@@ -128,6 +132,236 @@ int sym_eig(int n, std::vector<double>& s, std::vector<double>& d, std::vector<d
       }
       if (r == 0.0 && i >= l) continue;
       d[l] -= pp; e[l] = g; e[m] = 0.0;
+    }
+  }
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Partial solver: the drivers only ever use the lowest n_max eigenpairs of the projected
+// matrix (reference diaglib.f90:1715-1721 uses a_copy(:,1:n_max), get_coeffs :3712 uses
+// a_red(:,1:n_max)).  Householder tridiagonalisation, all eigenvalues by implicit QL without
+// vectors, the m lowest eigenvectors by inverse iteration on the tridiagonal matrix with
+// re-orthogonalisation inside clusters, back-transformation with the stored reflectors.
+// Cost 4/3 n^3 + O(m n^2) instead of ~9 n^3.
+// ---------------------------------------------------------------------------------------
+struct Tridiag {
+  int n;
+  std::vector<double> d, e;       // diagonal, sub-diagonal (e[i] couples i and i+1)
+  std::vector<double> hv, hbeta;  // reflectors: row k of hv (entries k+1..n-1), beta_k
+};
+
+void tridiagonalize(int n, std::vector<double>& s, Tridiag& t)
+{
+  t.n = n;
+  t.d.assign(n, 0.0); t.e.assign(n, 0.0);
+  t.hv.assign((size_t)n * n, 0.0); t.hbeta.assign(n, 0.0);
+  std::vector<double> v(n), p(n);
+  auto S = [&](int i, int j) -> double& { return s[(size_t)i * n + j]; };
+  for (int k = 0; k + 2 < n; ++k) {
+    const int m = n - k - 1;
+    double scale = 0.0;
+    for (int i = 0; i < m; ++i) scale = std::max(scale, std::fabs(S(k + 1 + i, k)));
+    if (scale == 0.0) continue;
+    double nrm = 0.0;
+    for (int i = 0; i < m; ++i) { v[i] = S(k + 1 + i, k) / scale; nrm += v[i] * v[i]; }
+    nrm = std::sqrt(nrm);
+    const double alpha = (v[0] >= 0.0) ? -nrm : nrm;
+    double rest = 0.0;
+    for (int i = 1; i < m; ++i) rest += v[i] * v[i];
+    if (rest == 0.0) continue;
+    v[0] -= alpha;
+    const double beta = 2.0 / (v[0] * v[0] + rest);
+    // p = beta * S22 v, accumulated column-wise (S22 is symmetric: row j == column j) so that the
+    // inner loop is an axpy the compiler vectorises without re-associating any sum
+    for (int i = 0; i < m; ++i) p[i] = 0.0;
+    for (int j = 0; j < m; ++j) {
+      const double* row = &s[(size_t)(k + 1 + j) * n + (k + 1)];
+      const double vj = v[j];
+      for (int i = 0; i < m; ++i) p[i] += row[i] * vj;
+    }
+    for (int i = 0; i < m; ++i) p[i] *= beta;
+    double pv = 0.0;
+    for (int i = 0; i < m; ++i) pv += p[i] * v[i];
+    const double kk = 0.5 * beta * pv;
+    for (int i = 0; i < m; ++i) p[i] -= kk * v[i];
+    for (int i = 0; i < m; ++i) {
+      double* row = &s[(size_t)(k + 1 + i) * n + (k + 1)];
+      const double vi = v[i], wi = p[i];
+      for (int j = 0; j < m; ++j) row[j] -= vi * p[j] + wi * v[j];
+    }
+    S(k + 1, k) = alpha * scale;
+    S(k, k + 1) = alpha * scale;
+    for (int i = 1; i < m; ++i) { S(k + 1 + i, k) = 0.0; S(k, k + 1 + i) = 0.0; }
+    t.hbeta[k] = beta;
+    std::memcpy(&t.hv[(size_t)k * n + (k + 1)], v.data(), sizeof(double) * m);
+  }
+  for (int i = 0; i < n; ++i) t.d[i] = S(i, i);
+  for (int i = 0; i + 1 < n; ++i) t.e[i] = S(i + 1, i);
+}
+
+// implicit QL, eigenvalues only (d is overwritten, unsorted on exit); e is destroyed
+int ql_values(int n, std::vector<double>& d, std::vector<double>& e)
+{
+  const double eps = 2.220446049250313e-16;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0;
+    while (true) {
+      int m = l;
+      for (; m + 1 < n; ++m) {
+        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+        if (std::fabs(e[m]) <= eps * dd) break;
+      }
+      if (m == l) break;
+      if (++iter > 60) return l + 1;
+      double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+      double r = pythag(g, 1.0);
+      g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? r : -r));
+      double sn = 1.0, cs = 1.0, pp = 0.0;
+      int i = m - 1;
+      for (; i >= l; --i) {
+        const double f = sn * e[i], b = cs * e[i];
+        r = pythag(f, g);
+        e[i + 1] = r;
+        if (r == 0.0) { d[i + 1] -= pp; e[m] = 0.0; break; }
+        sn = f / r; cs = g / r;
+        g = d[i + 1] - pp;
+        r = (d[i] - g) * sn + 2.0 * cs * b;
+        pp = sn * r;
+        d[i + 1] = g + pp;
+        g = cs * r - b;
+      }
+      if (r == 0.0 && i >= l) continue;
+      d[l] -= pp; e[l] = g; e[m] = 0.0;
+    }
+  }
+  return 0;
+}
+
+// Solve (T - lam I) x = b in place (x holds b on entry) by Gaussian elimination with partial
+// pivoting on the tridiagonal matrix; tiny pivots are replaced by +-tiny (inverse iteration
+// only needs the direction).  d, e: diagonal / sub-diagonal of T.
+void tridiag_solve(int n, const std::vector<double>& d, const std::vector<double>& e, double lam, double tiny,
+                   std::vector<double>& x, std::vector<double>& a, std::vector<double>& b, std::vector<double>& c,
+                   std::vector<double>& l, std::vector<int>& piv)
+{
+  // a: diagonal of U, b: first super-diagonal of U, c: second super-diagonal of U, l: multipliers
+  for (int i = 0; i < n; ++i) { a[i] = d[i] - lam; b[i] = (i + 1 < n) ? e[i] : 0.0; c[i] = 0.0; }
+  for (int i = 0; i + 1 < n; ++i) {
+    const double sub = e[i];                 // T(i+1,i)
+    if (std::fabs(a[i]) >= std::fabs(sub)) {
+      piv[i] = 0;
+      if (a[i] == 0.0) a[i] = tiny;
+      const double mlt = sub / a[i];
+      l[i] = mlt;
+      a[i + 1] -= mlt * b[i];
+      // b[i+1] unchanged, c[i] = 0
+    } else {
+      piv[i] = 1;                            // swap rows i and i+1
+      const double mlt = a[i] / sub;
+      l[i] = mlt;
+      const double ai1 = a[i + 1], bi = b[i], bi1 = b[i + 1];
+      a[i] = sub; b[i] = ai1; c[i] = bi1;
+      a[i + 1] = bi - mlt * ai1;
+      b[i + 1] = -mlt * bi1;
+    }
+  }
+  if (a[n - 1] == 0.0) a[n - 1] = tiny;
+  // forward: apply the row operations to the right-hand side
+  for (int i = 0; i + 1 < n; ++i) {
+    if (piv[i]) std::swap(x[i], x[i + 1]);
+    x[i + 1] -= l[i] * x[i];
+  }
+  // back substitution with the two super-diagonals
+  for (int i = n - 1; i >= 0; --i) {
+    double t = x[i];
+    if (i + 1 < n) t -= b[i] * x[i + 1];
+    if (i + 2 < n) t -= c[i] * x[i + 2];
+    double piv_a = a[i];
+    if (std::fabs(piv_a) < tiny) piv_a = (piv_a < 0.0 ? -tiny : tiny);
+    x[i] = t / piv_a;
+  }
+}
+
+// lowest m eigenpairs; zt rows 0..m-1 receive the eigenvectors of the ORIGINAL matrix
+int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_all, std::vector<double>& zt)
+{
+  Tridiag t;
+  tridiagonalize(n, s, t);
+  std::vector<double> dv = t.d, ev = t.e;
+  int info = ql_values(n, dv, ev);
+  if (info) return info;
+  std::sort(dv.begin(), dv.end());
+  w_all = dv;
+  double onenrm = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double r = std::fabs(t.d[i]) + (i > 0 ? std::fabs(t.e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(t.e[i]) : 0.0);
+    onenrm = std::max(onenrm, r);
+  }
+  if (onenrm == 0.0) onenrm = 1.0;
+  const double eps = 2.220446049250313e-16;
+  const double ortol = 1.0e-3 * onenrm;     // cluster criterion (as LAPACK dstein)
+  const double sep = 10.0 * eps * onenrm;   // minimal separation of the shifts inside a cluster
+  const double tiny = eps * onenrm;
+  std::vector<double> x(n), a(n), b(n), c(n), l(n);
+  std::vector<int> piv(n);
+  unsigned long long seed = 0x243F6A8885A308D3ULL;
+  auto rnd = [&]() {   // deterministic start vectors
+    seed = seed * 6364136223846793005ULL + 1442695040888963407ULL;
+    return ((double)(seed >> 11) * (1.0 / 9007199254740992.0)) - 0.5;
+  };
+  int cluster_start = 0;
+  double lam_prev = 0.0;
+  for (int j = 0; j < m; ++j) {
+    double lam = w_all[j];
+    if (j > 0 && std::fabs(w_all[j] - w_all[j - 1]) >= ortol) cluster_start = j;
+    if (j > cluster_start && lam - lam_prev < sep) lam = lam_prev + sep;
+    lam_prev = lam;
+    double* z = &zt[(size_t)j * n];
+    for (int i = 0; i < n; ++i) x[i] = rnd();
+    for (int it = 0; it < 8; ++it) {
+      tridiag_solve(n, t.d, t.e, lam, tiny, x, a, b, c, l, piv);
+      // re-orthogonalise against the earlier members of the cluster (modified Gram-Schmidt);
+      // zt rows are still in tridiagonal coordinates here (back-transformation comes last)
+      for (int q = cluster_start; q < j; ++q) {
+        const double* zq = &zt[(size_t)q * n];
+        double dot = 0.0;
+        for (int i = 0; i < n; ++i) dot += zq[i] * x[i];
+        for (int i = 0; i < n; ++i) x[i] -= dot * zq[i];
+      }
+      double xinf = 0.0;
+      for (int i = 0; i < n; ++i) xinf = std::max(xinf, std::fabs(x[i]));
+      if (!(xinf > 0.0) || !std::isfinite(xinf)) { for (int i = 0; i < n; ++i) x[i] = rnd(); continue; }
+      double nrm = 0.0;
+      for (int i = 0; i < n; ++i) { x[i] /= xinf; nrm += x[i] * x[i]; }
+      nrm = std::sqrt(nrm);
+      for (int i = 0; i < n; ++i) x[i] /= nrm;
+      if (it >= 1) {
+        // converged when the eigen-residual is at rounding level (plus the shift perturbation)
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) {
+          double ti = (t.d[i] - w_all[j]) * x[i];
+          if (i > 0) ti += t.e[i - 1] * x[i - 1];
+          if (i + 1 < n) ti += t.e[i] * x[i + 1];
+          res += ti * ti;
+        }
+        if (std::sqrt(res) <= 64.0 * eps * onenrm + 2.0 * std::fabs(lam - w_all[j])) break;
+      }
+    }
+    std::memcpy(z, x.data(), sizeof(double) * n);
+  }
+  // back-transformation: eigenvector of S = H_0 H_1 ... H_{n-3} z  (apply the last reflector first)
+  for (int j = 0; j < m; ++j) {
+    double* z = &zt[(size_t)j * n];
+    for (int k = n - 3; k >= 0; --k) {
+      const double beta = t.hbeta[k];
+      if (beta == 0.0) continue;
+      const double* vk = &t.hv[(size_t)k * n];
+      double acc = 0.0;
+      for (int r = k + 1; r < n; ++r) acc += vk[r] * z[r];
+      acc *= beta;
+      for (int r = k + 1; r < n; ++r) z[r] -= acc * vk[r];
     }
   }
   return 0;
@@ -159,6 +393,36 @@ int dla_syev(char uplo, int n, double* a, int lda, double* w)
     const double* z = &zt[(size_t)idx[j] * n];
     // fix the sign so that the result does not depend on reflector conventions:
     // largest-magnitude component positive
+    int imax = 0;
+    for (int i = 1; i < n; ++i) if (std::fabs(z[i]) > std::fabs(z[imax])) imax = i;
+    double sg = (z[imax] < 0.0) ? -1.0 : 1.0;
+    for (int i = 0; i < n; ++i) at(a, lda, i, j) = sg * z[i];
+  }
+  return 0;
+}
+
+// lowest m eigenpairs only: w(1:n) all eigenvalues ascending, a(:,1:m) the m lowest eigenvectors
+// (columns m+1..n of a are left undefined).  Same role as dsyev at diaglib.f90:1708 / :406, whose
+// callers use the first n_max eigenpairs only.
+int dla_syev_lowest(char uplo, int n, double* a, int lda, double* w, int m)
+{
+  if (n <= 0) return 0;
+  if (lda < n) return -1;
+  if (m > n) m = n;
+  if (n <= 32 || 2 * m >= n) return dla_syev(uplo, n, a, lda, w);   // small or mostly-wanted: full solve
+  bool up = (uplo == 'u' || uplo == 'U');
+  std::vector<double> s((size_t)n * n), wall, zt((size_t)m * n);
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i <= j; ++i) {
+      double x = up ? at(a, lda, i, j) : at(a, lda, j, i);
+      s[(size_t)i * n + j] = x;
+      s[(size_t)j * n + i] = x;
+    }
+  int info = sym_eig_lowest(n, s, m, wall, zt);
+  if (info != 0) return info;
+  for (int j = 0; j < n; ++j) w[j] = wall[j];
+  for (int j = 0; j < m; ++j) {
+    const double* z = &zt[(size_t)j * n];
     int imax = 0;
     for (int i = 1; i < n; ++i) if (std::fabs(z[i]) > std::fabs(z[imax])) imax = i;
     double sg = (z[imax] < 0.0) ? -1.0 : 1.0;

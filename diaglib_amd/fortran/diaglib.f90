@@ -179,10 +179,10 @@ module diaglib
       real(c_double), value :: fac
       integer(c_int) :: st
     end function
-    function dla_syev(uplo,n,a,lda,w) bind(C,name='dla_syev') result(info)
+    function dla_syev_lowest(uplo,n,a,lda,w,m) bind(C,name='dla_syev_lowest') result(info)
       import :: c_char, c_int, c_double
       character(kind=c_char), value :: uplo
-      integer(c_int), value :: n, lda
+      integer(c_int), value :: n, lda, m
       real(c_double) :: a(*), w(*)
       integer(c_int) :: info
     end function
@@ -309,8 +309,12 @@ contains
     t_ortho = zero
     t_mv    = zero
     t_tot   = zero
-    call chk(ctx, dla_zero(ctx, space,  nbytes(n,lda)), 'zero')
-    call chk(ctx, dla_zero(ctx, aspace, nbytes(n,lda)), 'zero')
+!
+!   the reference zero-fills both n x lda panels here (:1632-1633).  On the device no column is
+!   ever read before it has been written (guess copy, matvec output, ortho_vs_x output), so the
+!   two 8*n*lda-byte memsets are skipped; the columns the restart quirk reads as zeros are
+!   zeroed at the restart (below).
+!
     a_red   = zero
     r_norm  = zero
     ok      = .false.
@@ -369,7 +373,7 @@ contains
       a_copy = a_red
 !
       call get_time(t1)
-      info = dla_syev('u', ldu, a_copy, lda, e_red)
+      info = dla_syev_lowest('u', ldu, a_copy, lda, e_red, n_max)   ! only a_copy(:,1:n_max) is used below
       call get_time(t2)
       t_diag = t_diag + t2 - t1
       if (info.ne.0) then
@@ -439,9 +443,7 @@ contains
         if (verbose) write(6,'(t7,a)') 'Restarting davidson.'
         n_restarts = n_restarts + 1
         n_act = n_max
-        call chk(ctx, dla_zero(ctx, space, nbytes(n,lda)), 'zero')
         call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
-        call chk(ctx, dla_zero(ctx, aspace, nbytes(n,lda)), 'zero')
         a_red = zero
         ldu   = 0
         i_beg = 1
@@ -454,6 +456,16 @@ contains
             exit
           end if
         end do
+!
+!       the reference zeroes space and aspace entirely (:1798,1804).  What the next iteration
+!       actually reads from those zeros: matvec takes n_max columns starting at column 1+n_rst,
+!       i.e. it runs n_rst columns past the Ritz block (they must be zero), and the locked
+!       columns 1..n_rst of aspace stay zero (their eigenvalues are patched into a_red, :1696-1702).
+!
+        if (n_rst.gt.0) then
+          call chk(ctx, dla_zero(ctx, colp(space,n,n_max+1), nbytes(n,n_rst)), 'zero')
+          call chk(ctx, dla_zero(ctx, aspace, nbytes(n,n_rst)), 'zero')
+        end if
         restart = .true.
       end if
       if (verbose) write(6,1050) n_targ, n_act, n_frozen
@@ -539,8 +551,8 @@ contains
     t_ortho = zero
     t_mv    = zero
     t_tot   = zero
-    call chk(ctx, dla_zero(ctx, space,  nbytes(n,len_a)), 'zero')
-    call chk(ctx, dla_zero(ctx, aspace, nbytes(n,len_a)), 'zero')
+!   (the reference zero-fills space/aspace/bspace, :284-286; every column is written before
+!   it is read on this path, so the device panels are left uninitialised)
     a_red  = zero
     r_norm = zero
     n_mv   = 0
@@ -559,7 +571,7 @@ contains
     if (shift.ne.zero) call chk(ctx, dla_axpy(ctx, int(n,c_size_t)*int(n_max,c_size_t), shift, space, aspace), 'axpy')
     call chk(ctx, dla_gram(ctx, n, n_max, space, n_max, aspace, a_red, len_a), 'projection')
     call get_time(t1)
-    info = dla_syev('l', n_max, a_red, len_a, e_red)
+    info = dla_syev_lowest('l', n_max, a_red, len_a, e_red, n_max)
     call get_time(t2)
     t_diag = t_diag + t2 - t1
     eig = e_red(1:n_max)
@@ -613,7 +625,7 @@ contains
       if (it.eq.1) len_u = 2*n_max
       call chk(ctx, dla_gram(ctx, n, len_u, space, len_u, aspace, a_red, len_a), 'projection')
       call get_time(t1)
-      info = dla_syev('l', len_u, a_red, len_a, e_red)
+      info = dla_syev_lowest('l', len_u, a_red, len_a, e_red, n_max)   ! get_coeffs uses a_red(:,1:n_max) only
       call get_time(t2)
       t_diag = t_diag + t2 - t1
       if (info.ne.0) then
