@@ -1,0 +1,154 @@
+"""GPU parity against the committed golden fixtures (outputs of the UNMODIFIED reference, see
+tests/golden/make_golden.py) and, at BASELINE.json's full sizes, through size-independent
+properties (orthonormality, linearity, Ritz identities, residual of the returned eigenpairs)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from diaglib_amd import capi
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+EPS = np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(HERE, "golden", "reference_fixtures.npz"), allow_pickle=False)
+
+
+def test_ortho_cd_vs_reference(ctx, gold):
+    for i in range(int(gold["ocd_count"])):
+        u, want, g_want = gold[f"ocd{i}_in"], gold[f"ocd{i}_out"], float(gold[f"ocd{i}_growth"])
+        p = ctx.panel(u)
+        g, ok = ctx.ortho_cd(p)
+        got = p.download()
+        k = u.shape[1]
+        sv = np.linalg.svd(u, compute_uv=False)
+        cond = sv[0] / max(sv[-1], 1e-300)
+        assert ok == bool(gold[f"ocd{i}_ok"])
+        if cond < 1e4:
+            assert np.abs(got - want).max() < 1e-12 and g == pytest.approx(g_want, rel=1e-9)
+        elif cond < 1e14:
+            assert np.abs(got.T @ got - np.eye(k)).max() < 50 * EPS
+            assert np.abs(got @ (got.T @ want) - want).max() < 100 * cond * EPS
+        else:
+            assert np.all(np.isfinite(got))
+
+
+def test_ortho_vs_x_b_ortho_helpers_vs_reference(ctx, gold):
+    for i in range(int(gold["ovx_count"])):
+        x, u, want = gold[f"ovx{i}_x"], gold[f"ovx{i}_u"], gold[f"ovx{i}_out"]
+        pu = ctx.panel(u)
+        ctx.ortho_vs_x(ctx.panel(x), pu)
+        assert np.abs(pu.download() - want).max() < 1e-11
+    pu = ctx.panel(gold["bo_u"])
+    ctx.b_ortho_vs_x(ctx.panel(gold["bo_x"]), ctx.panel(gold["bo_bx"]), pu)
+    assert np.abs(pu.download() - gold["bo_vsx_out"]).max() < 1e-11
+    p1, p2 = ctx.panel(gold["bo_vsx_out"]), ctx.panel(gold["bo_bu"])
+    ctx.b_ortho(p1, p2)
+    assert np.abs(p1.download() - gold["bo_u_out"]).max() < 1e-12 and np.abs(p2.download() - gold["bo_bu_out"]).max() < 1e-12
+    p = ctx.panel(gold["cg_in"]); ctx.check_guess(p)
+    assert np.abs(p.download() - gold["cg_out"]).max() < 1e-12
+    ux, up = ctx.get_coeffs(gold["gc_a_red"], int(gold["gc_len_u"]), int(gold["gc_n_max"]), int(gold["gc_n_act"]))
+    assert np.array_equal(ux, gold["gc_ux"]) and np.abs(up - gold["gc_up"]).max() < 1e-12
+    assert capi.norm_est(gold["ne_in"]) == pytest.approx(float(gold["ne_out"]), rel=1e-15)
+
+
+def _guess(kind, n, m, seed):
+    if kind == "unit":
+        g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
+        return g
+    return np.asfortranarray(np.random.default_rng(seed).random((n, m)) - 0.5)
+
+
+@pytest.mark.parametrize("name", ["dav_n1000_unit", "dav_n2000_unit", "dav_n2000_rand", "dav_n600_rand_dav10",
+                                  "lob_n1000_unit", "lob_n2000_unit", "lob_n2000_rand", "lob_n800_shift"])
+def test_drivers_vs_reference_results(ctx, oracle, gold, name):
+    """Reference's dense test matrix (main.f90:311-317), host callbacks: eigenvalues, eigenvectors and
+    iteration counts against what the unmodified reference produced for the same guess."""
+    sp = next(s for s in json.loads(str(gold["driver_specs"])) if s["name"] == name)
+    n, t, m = sp["n"], sp["n_targ"], sp["n_max"]
+    g = _guess(sp["guess"], n, m, sp["seed"])
+    oracle.dense_setup(n)                      # the C operator is only the callback here
+    mv, pc = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd")
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+    if sp["solver"] == "davidson":
+        eig, vec, ok, info = ctx.davidson_driver(n, t, m, sp["max_iter"], sp["tol"], sp["max_dav"], sp["shift"], mv, pc, g)
+    else:
+        eig, vec, ok, info = ctx.lobpcg_driver(n, t, m, sp["max_iter"], sp["tol"], sp["shift"], mv, pc, g)
+    assert ok and bool(gold[name + "_ok"])
+    assert np.allclose(eig[:t], gold[name + "_eig"][:t], rtol=1e-10, atol=0)
+    it_ref = int(gold[name + "_tr_iters"])
+    if sp["guess"] == "unit":
+        assert info["iters"] == it_ref
+    else:
+        assert abs(info["iters"] - it_ref) <= max(1, it_ref // 10), (info, it_ref)
+    if sp["solver"] == "davidson" and sp["guess"] == "unit":
+        assert info["restarts"] == int(gold[name + "_tr_restarts"])
+    if name + "_evec" in gold.files:
+        ev = vec[:, :t]; ev = ev * np.sign(ev[np.abs(ev).argmax(0), np.arange(t)])
+        assert np.abs(ev - gold[name + "_evec"]).max() < 1e-5
+
+
+# ------------------------------------------------------------------ full BASELINE sizes: properties
+def _rand_panel(ctx, n, m):
+    p = ctx.panel(n, m)
+    ctx.random_fill(p)            # device-side generator: no 200 MB host arrays
+    return p
+
+
+@pytest.mark.parametrize("n,l,k", [(500_000, 260, 13), (2_000_000, 39, 13)])
+def test_full_size_block_algebra_properties(ctx, n, l, k):
+    x, u1, u2 = _rand_panel(ctx, n, l), _rand_panel(ctx, n, k), ctx.panel(n, k)
+    # u2 = u1 + 0.5 * (X C): linearity of the Gram kernel in U
+    rng = np.random.default_rng(7)
+    c = np.asfortranarray(rng.standard_normal((l, k)) * 1e-2)
+    ctx.lib.dla_copy(ctx.h, u2.ptr, u1.ptr, 8 * n * k)
+    ctx.panel_update(x, -c, u2)                       # u2 = u1 + X c
+    g1, g2, gx = ctx.gram(x, u1), ctx.gram(x, u2), ctx.gram(x, x)
+    assert np.allclose(g2, g1 + gx @ c, rtol=1e-11, atol=1e-9 * np.abs(gx).max())
+    assert np.abs(gx - gx.T).max() <= 1e-12 * np.abs(gx).max()
+    # ortho_vs_x on a trusted orthonormal X: result orthonormal and orthogonal to X
+    ctx.ortho_cd(x)
+    ctx.ortho_vs_x(x, u2)
+    assert np.abs(ctx.gram(u2, u2) - np.eye(k)).max() < 50 * EPS
+    assert np.abs(ctx.gram(x, u2)).max() < 50 * EPS
+    # ortho_cd is idempotent on an orthonormal block: growth ~ 1, nothing moves beyond rounding
+    before = ctx.gram(x, u2)
+    g, ok = ctx.ortho_cd(u2)
+    assert ok and abs(g - 1.0) < 1e-10
+    assert np.abs(ctx.gram(x, u2) - before).max() < 50 * EPS
+
+
+@pytest.mark.parametrize("solver,n", [("davidson", 500_000), ("lobpcg", 2_000_000)])
+def test_full_size_solve_residual(ctx, solver, n):
+    """BASELINE cfg 2 (Davidson n=5e5) and cfg 3 (LOBPCG n=2e6), 8 roots, n_max=13: the returned pairs
+    satisfy ||A x - lambda x||_2 / |lambda| <= 1e-10 (north star) and X^T X = I."""
+    t, m = 8, 13
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+    try:
+        ctx.synth_setup(n, 0, n)
+        g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
+        ev = ctx.panel(g)
+        mv, pc = capi.fn_address("dla_synth_matvec"), capi.fn_address("dla_synth_precnd")
+        if solver == "davidson":
+            eig, _, ok, info = ctx.davidson_driver(n, t, m, 200, 1e-13, 20, 0.0, mv, pc, ev)
+        else:
+            eig, _, ok, info = ctx.lobpcg_driver(n, t, m, 200, 1e-13, 0.0, mv, pc, ev)
+        assert ok, info
+        ax = ctx.panel(n, m)
+        ctx.synth_matvec(ev, ax)
+        xt = ev.col(0, t)
+        h = ctx.gram(xt, ax.col(0, t))                      # X^T A X = diag(eig)
+        assert np.abs(h - np.diag(eig[:t])).max() < 1e-9
+        assert np.abs(ctx.gram(xt, xt) - np.eye(t)).max() < 1e-12
+        # residual norms through the fused kernel itself: r = AX I - eig * X I
+        r = ctx.panel(n, t); e2 = ctx.panel(n, t)
+        rn = ctx.ritz_residual(xt, ax.col(0, t), np.eye(t), eig[:t], t, np.zeros(t, np.int32), e2, r)
+        rel = rn[0, :] * np.sqrt(n) / np.abs(eig[:t])
+        assert rel.max() <= 1e-10, rel
+    finally:
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)

@@ -1,0 +1,155 @@
+"""CPU: pins the oracle (oracle/oracle.c, the C restatement) to the UNMODIFIED reference through
+the committed fixtures in tests/golden/reference_fixtures.npz (made by tests/golden/make_golden.py
+from oracle/_ref = reference compiled with flang + MKL).  No GPU needed.
+
+Tolerances: the oracle's triple-loop BLAS and Jacobi eigensolver round differently from MKL, so
+  * well-conditioned panels: 1e-12 entry-wise;  ill-conditioned: invariants + growth within 10x;
+  * eigenvalues: 1e-10 relative; traces: iteration counts exact where the convergence history is
+    not threshold-sensitive (unit guess), +-10 % with a random guess (the reference's own count
+    moves by that much with the BLAS summation order, see DESIGN.md "Parity notes").
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EPS = np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(HERE, "golden", "reference_fixtures.npz"), allow_pickle=False)
+
+
+def test_small_dense_against_numpy(oracle, rng):
+    a = rng.standard_normal((40, 40)); s = a @ a.T + 40 * np.eye(40)
+    l, info = oracle.potrf_lower(s)
+    assert info == 0 and np.abs(np.tril(l) - np.linalg.cholesky(s)).max() < 1e-12
+    li, _ = oracle.trtri_lower(l)
+    assert np.abs(np.tril(li) - np.linalg.inv(np.linalg.cholesky(s))).max() < 1e-13
+    for uplo in ("u", "l"):
+        tri = np.triu(s) if uplo == "u" else np.tril(s)
+        w, v = oracle.syev(tri + (np.tril(rng.standard_normal((40, 40)), -1) if uplo == "u" else
+                                  np.triu(rng.standard_normal((40, 40)), 1)), uplo)   # other triangle is garbage
+        assert np.allclose(w, np.linalg.eigvalsh(s), rtol=1e-12)
+        assert np.abs(s @ v - v * w).max() < 1e-10 and np.abs(v.T @ v - np.eye(40)).max() < 1e-13
+    bad = s.copy(); bad[7, 7] = -1.0
+    assert oracle.potrf_lower(bad)[1] == 8
+
+
+def test_norm_est_get_coeffs_check_guess(oracle, gold):
+    assert oracle.norm_est(gold["ne_in"]) == pytest.approx(float(gold["ne_out"]), rel=1e-15)
+    ux, up = oracle.get_coeffs(gold["gc_a_red"], int(gold["gc_len_u"]), int(gold["gc_n_max"]), int(gold["gc_n_act"]))
+    assert np.array_equal(ux, gold["gc_ux"])
+    assert np.abs(up - gold["gc_up"]).max() < 1e-12
+    assert np.abs(oracle.check_guess(gold["cg_in"]) - gold["cg_out"]).max() < 1e-12
+    assert bool(gold["cg_unit_unchanged"])
+    e = np.zeros((257, 6), order="F"); e[np.arange(6), np.arange(6)] = 1.0
+    assert np.array_equal(oracle.check_guess(e), e)
+
+
+def test_ortho_cd(oracle, gold):
+    for i in range(int(gold["ocd_count"])):
+        u, want, g_want, ok_want = gold[f"ocd{i}_in"], gold[f"ocd{i}_out"], float(gold[f"ocd{i}_growth"]), bool(gold[f"ocd{i}_ok"])
+        got, g, ok, n_macro = oracle.ortho_cd(u)
+        k = u.shape[1]
+        assert ok == ok_want
+        sv = np.linalg.svd(u, compute_uv=False)
+        cond = sv[0] / max(sv[-1], 1e-300)
+        if cond < 1e4:
+            assert np.abs(got - want).max() < 1e-12
+            assert g == pytest.approx(g_want, rel=1e-9)
+            assert np.abs(got.T @ got - np.eye(k)).max() < 50 * EPS
+        elif cond < 1e14:
+            assert np.abs(got.T @ got - np.eye(k)).max() < 50 * EPS
+            assert np.abs(want.T @ want - np.eye(k)).max() < 50 * EPS
+            assert np.abs(got @ (got.T @ want) - want).max() < 100 * cond * EPS
+            assert 0.1 < g / g_want < 10
+        else:   # rank deficient: both took the level-shift ladder (diaglib.f90:3265-3295) and stayed finite
+            assert np.all(np.isfinite(got)) and np.all(np.isfinite(want))
+            assert np.abs(got[:, : k - 1].T @ got[:, : k - 1] - np.eye(k - 1)).max() < 1e-9
+
+
+def test_ortho_vs_x(oracle, gold):
+    for i in range(int(gold["ovx_count"])):
+        x, u, want = gold[f"ovx{i}_x"], gold[f"ovx{i}_u"], gold[f"ovx{i}_out"]
+        got, n_outer, st = oracle.ortho_vs_x(x, u)
+        assert st == 0
+        assert np.abs(got - want).max() < 1e-11
+        assert np.abs(x.T @ got).max() < 50 * EPS and np.abs(got.T @ got - np.eye(u.shape[1])).max() < 50 * EPS
+
+
+def test_b_ortho(oracle, gold):
+    got, st = oracle.b_ortho_vs_x(gold["bo_x"], gold["bo_bx"], gold["bo_u"])
+    assert st == 0 and np.abs(got - gold["bo_vsx_out"]).max() < 1e-11
+    u2, bu2 = oracle.b_ortho(gold["bo_vsx_out"], gold["bo_bu"])
+    assert np.abs(u2 - gold["bo_u_out"]).max() < 1e-12 and np.abs(bu2 - gold["bo_bu_out"]).max() < 1e-12
+
+
+def _guess(kind, n, m, seed):
+    if kind == "unit":
+        g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
+        return g
+    return np.asfortranarray(np.random.default_rng(seed).random((n, m)) - 0.5)
+
+
+def _specs(gold):
+    return json.loads(str(gold["driver_specs"]))
+
+
+@pytest.mark.parametrize("name", ["dav_n1000_unit", "dav_n2000_unit", "dav_n2000_rand", "dav_n600_rand_dav10",
+                                  "lob_n1000_unit", "lob_n2000_unit", "lob_n2000_rand", "lob_n800_shift",
+                                  "dav_synth_n100000", "lob_synth_n100000"])
+def test_drivers_against_reference_traces(oracle, gold, name):
+    sp = next(s for s in _specs(gold) if s["name"] == name)
+    n, t, m = sp["n"], sp["n_targ"], sp["n_max"]
+    g = _guess(sp["guess"], n, m, sp["seed"])
+    if sp["op"] == "dense":
+        oracle.dense_setup(n); mv, pc = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd")
+    else:
+        oracle.synth_setup(n, 0, n); mv, pc = oracle.fn("orc_synth_matvec"), oracle.fn("orc_synth_precnd")
+    if sp["solver"] == "davidson":
+        eig, vec, ok, tr = oracle.davidson(n, t, m, sp["max_iter"], sp["tol"], sp["max_dav"], sp["shift"], mv, pc, g)
+    else:
+        eig, vec, ok, tr = oracle.lobpcg(n, t, m, sp["max_iter"], sp["tol"], sp["shift"], mv, pc, g)
+    assert ok and bool(gold[name + "_ok"])
+    assert np.allclose(eig[:t], gold[name + "_eig"][:t], rtol=1e-10, atol=0)
+    it_ref = int(gold[name + "_tr_iters"])
+    robust = sp["guess"] == "unit" and sp["op"] == "dense"
+    if robust:
+        assert tr.iters == it_ref
+        # the reference prints eigenvalue - shift with 12 decimals and norms with 4 digits
+        assert np.abs(tr.eig - gold[name + "_tr_eig"]).max() < 1e-9
+        big = gold[name + "_tr_rms"] > 1e-9
+        assert np.allclose(tr.rms[big], gold[name + "_tr_rms"][big], rtol=2e-3)
+        assert np.array_equal(tr.done, gold[name + "_tr_done"])
+    else:
+        assert abs(tr.iters - it_ref) <= max(1, it_ref // 10), (tr.iters, it_ref)
+    if sp["solver"] == "davidson":
+        assert tr.restarts == int(gold[name + "_tr_restarts"]) or not robust
+    if name + "_evec" in gold.files:
+        ev = vec[:, :t]; ev = ev * np.sign(ev[np.abs(ev).argmax(0), np.arange(t)])
+        assert np.abs(ev - gold[name + "_evec"]).max() < 1e-5    # tol=1e-8 solves: vectors agree to ~tol/gap
+    if sp["op"] == "dense" and n in (1000, 2000):
+        assert np.allclose(eig[:t], gold[f"dense_eigs_n{n}"][:t], atol=1e-7)   # main.f90's LAPACK cross-check
+
+
+def test_live_reference_if_present(oracle, rng):
+    """When oracle/_ref exists (build container, GPU box) compare directly, beyond the stored fixtures."""
+    from oracle.pyoracle import Reference
+    if not Reference.available():
+        pytest.skip("oracle/_ref not built")
+    ref = Reference()
+    u = np.asfortranarray(rng.standard_normal((500, 9)))
+    a, ga, oka, _ = oracle.ortho_cd(u)
+    b, gb, okb = ref.ortho_cd(u)
+    assert oka and okb and np.abs(a - b).max() < 1e-12 and ga == pytest.approx(gb, rel=1e-9)
+    n, t, m = 800, 5, 9
+    oracle.dense_setup(n)
+    mv, pc = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd")
+    g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
+    eo, vo, oko, tr = oracle.davidson(n, t, m, 100, 1e-9, 20, 0.0, mv, pc, g)
+    er, vr, okr = ref.davidson(n, t, m, 100, 1e-9, 20, 0.0, mv, pc, g)
+    assert oko and okr and np.allclose(eo[:t], er[:t], rtol=1e-11)
