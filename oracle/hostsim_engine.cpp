@@ -1,0 +1,150 @@
+// oracle/hostsim_engine.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// A stand-in for the HIP engine that keeps "device" panels in host memory and runs the oracle's
+// plain-C kernels (oracle.c).  tests/hostsim.py links it with the PRODUCT's host logic
+// (diaglib_amd/csrc/host_logic.cpp, smalldense.cpp) and the PRODUCT's Fortran drivers into
+// tests/_build/libdiaglib_hostsim.so so that
+//   * the host control flow (drivers, ortho_cd / ortho_vs_x loops, callback trampolines) is
+//     exercised on machines without a GPU (`pytest -m "not gpu"`), and
+//   * the row-sharded multi-rank path (every reduction point of the C-ABI) is covered by
+//     world_size-2 gloo tests through the dla_set_allreduce_hook door.
+// It is never part of diaglib_amd/lib/libdiaglib_amd.so: the product has no CPU path.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../diaglib_amd/csrc/dla_internal.h"
+#include "oracle.h"
+
+namespace {
+
+struct HostSimEngine : dla::Engine {
+  std::string nm = "hostsim:oracle-kernels";
+  long long syn_row0 = 0; int syn_n = 0, syn_rw = 0; double syn_sigma = 0.0;
+
+  const char* name() const override { return nm.c_str(); }
+  void* stream() override { return nullptr; }
+  int alloc(size_t bytes, void** dev) override { *dev = std::malloc(bytes ? bytes : 8); return *dev ? 0 : DLA_ERR_ALLOC; }
+  int free_(void* dev) override { std::free(dev); return 0; }
+  int zero(void* dev, size_t bytes) override { std::memset(dev, 0, bytes); return 0; }
+  int h2d(void* d, const void* h, size_t b) override { std::memcpy(d, h, b); return 0; }
+  int d2h(void* h, const void* d, size_t b) override { std::memcpy(h, d, b); stats.host_syncs++; return 0; }
+  int d2d(void* d, const void* s, size_t b) override { std::memmove(d, s, b); return 0; }
+  int sync() override { return 0; }
+  int host_alloc(size_t b, void** p) override { *p = std::malloc(b ? b : 8); return *p ? 0 : DLA_ERR_ALLOC; }
+  int host_free(void* p) override { std::free(p); return 0; }
+  int comm_init(int, int, const char*) override { err = "hostsim: use dla_set_allreduce_hook"; return DLA_ERR_COMM; }
+
+  int reduce(double* buf, int count, int op)
+  {
+    if (nranks <= 1) return 0;
+    if (!hook) { err = "hostsim: nranks > 1 without a reduction hook"; return DLA_ERR_COMM; }
+    stats.allreduces++;
+    hook(hook_user, buf, count, op);
+    return 0;
+  }
+
+  int gram(int n, int l, const double* x, int k, const double* u, double* c, int ldc) override
+  {
+    std::vector<double> t((size_t)l * k);
+    orc_gemm_tn(n, l, k, x, n, u, n, t.data(), l);
+    int st = reduce(t.data(), l * k, 0);
+    if (st) return st;
+    for (int j = 0; j < k; ++j) std::memcpy(c + (size_t)j * ldc, t.data() + (size_t)j * l, sizeof(double) * l);
+    stats.launches[DLA_OP_GRAM]++;
+    return 0;
+  }
+  int gemm(int n, int l, const double* x, int k, const double* c, int ldc, double* z, int mode) override
+  {
+    if (l == 0) { if (mode == 0) std::memset(z, 0, sizeof(double) * (size_t)n * k); return 0; }
+    if (mode == 0) orc_gemm_nn(n, l, k, 1.0, x, n, c, ldc, 0.0, z, n);
+    else orc_gemm_nn(n, l, k, -1.0, x, n, c, ldc, 1.0, z, n);
+    stats.launches[DLA_OP_GEMM]++;
+    return 0;
+  }
+  int trmm(int n, int k, double* u, const double* w, int ld) override
+  {
+    std::vector<double> t((size_t)n * k);
+    std::memcpy(t.data(), u, sizeof(double) * (size_t)n * k);
+    orc_gemm_nn(n, k, k, 1.0, t.data(), n, w, ld, 0.0, u, n);
+    stats.launches[DLA_OP_TRMM]++;
+    return 0;
+  }
+  int ritz_residual(int n, int l, int m, const double* v, const double* av, const double* y, int ldy, const double* eig,
+                    int n_res, const int* skip, double* evec, double* r, double* avy, double* out) override
+  {
+    orc_gemm_nn(n, l, m, 1.0, v, n, y, ldy, 0.0, evec, n);
+    orc_gemm_nn(n, l, m, 1.0, av, n, y, ldy, 0.0, r, n);
+    if (avy) std::memcpy(avy, r, sizeof(double) * (size_t)n * m);
+    std::vector<double> ss(n_res > 0 ? n_res : 1, 0.0), mx(n_res > 0 ? n_res : 1, 0.0);
+    for (int i = 0; i < n_res; ++i) {
+      if (skip && skip[i]) continue;
+      double s = 0.0, q = 0.0;
+      double* ri = r + (size_t)n * i; const double* ei = evec + (size_t)n * i;
+      for (int p = 0; p < n; ++p) { ri[p] -= eig[i] * ei[p]; s += ri[p] * ri[p]; q = std::fmax(q, std::fabs(ri[p])); }
+      ss[i] = s; mx[i] = q;
+    }
+    int st = reduce(ss.data(), n_res, 0);
+    if (st) return st;
+    st = reduce(mx.data(), n_res, 1);
+    if (st) return st;
+    for (int i = 0; i < n_res; ++i) { out[2 * i] = ss[i]; out[2 * i + 1] = mx[i]; }
+    stats.launches[DLA_OP_RITZ]++;
+    return 0;
+  }
+  int axpy(size_t len, double alpha, const double* x, double* y) override
+  {
+    for (size_t i = 0; i < len; ++i) y[i] += alpha * x[i];
+    return 0;
+  }
+  int sumsq(size_t len, const double* x, double* out) override
+  {
+    double s = 0.0;
+    for (size_t i = 0; i < len; ++i) s += x[i] * x[i];
+    int st = reduce(&s, 1, 0);
+    *out = s;
+    return st;
+  }
+  int random_fill(int n, int m, double* evec, long long row0) override
+  {
+    for (int j = 0; j < m; ++j)
+      for (int i = 0; i < n; ++i)
+        evec[(size_t)j * n + i] = orc_u01(7ULL, (unsigned long long)(row0 + i + 1), (unsigned long long)(j + 1));
+    return 0;
+  }
+  int synth_setup(long long n_global, long long row0, int n_local, int rank_w, double sigma) override
+  {
+    orc_synth_setup(n_global, row0, n_local, rank_w, sigma);
+    syn_row0 = row0; syn_n = n_local; syn_rw = rank_w; syn_sigma = sigma;
+    return 0;
+  }
+  int synth_matvec(int n, int m, const double* x, double* ax) override
+  {
+    const double* w = orc_synth_w();
+    std::vector<double> t((size_t)syn_rw * m);
+    orc_gemm_tn(n, syn_rw, m, w, n, x, n, t.data(), syn_rw);
+    int st = reduce(t.data(), syn_rw * m, 0);     // the operator's only exchange: r x m all-reduce
+    if (st) return st;
+    for (int c = 0; c < m; ++c)
+      for (int i = 0; i < n; ++i) {
+        const double d = (double)(syn_row0 + i + 1) + 1.0;
+        double s = 0.0;
+        for (int q = 0; q < syn_rw; ++q) s += w[(size_t)q * n + i] * t[q + (size_t)c * syn_rw];
+        ax[(size_t)c * n + i] = d * x[(size_t)c * n + i] + syn_sigma * s;
+      }
+    return 0;
+  }
+  int synth_precnd(int n, int m, double fac, const double* x, double* px) override
+  {
+    orc_synth_precnd(&n, &m, &fac, x, px);
+    return 0;
+  }
+};
+
+}  // namespace
+
+namespace dla {
+Engine* make_engine(int, std::string&) { return new HostSimEngine(); }
+int engine_unique_id(char id[128]) { std::memset(id, 0, 128); return DLA_ERR_COMM; }
+}  // namespace dla
