@@ -1035,8 +1035,20 @@ struct HipEngine : dla::Engine {
 
   int trmm(int n, int k, double* u, const double* w_host, int ld) override
   {
-    if (k > 48) { err = "trmm: block wider than 48 columns"; return DLA_ERR_ARG; }
-    return gemm_cols(n, k, u, k, w_host, ld, u, 2, DLA_OP_TRMM);
+    if (k <= 48) return gemm_cols(n, k, u, k, w_host, ld, u, 2, DLA_OP_TRMM);
+    // wide block (cold path: the drivers never exceed n_max columns): W is upper triangular, so column
+    // block J of U W needs columns <= max(J) only; go right to left through a scratch panel
+    double* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, sizeof(double) * (size_t)n * 48));
+    int stc = DLA_OK;
+    for (int j1 = k; j1 > 0 && stc == DLA_OK; j1 -= 48) {
+      const int j0 = std::max(0, j1 - 48), kc = j1 - j0;
+      stc = gemm_cols(n, j1, u, kc, w_host + (size_t)j0 * ld, ld, tmp, 0, DLA_OP_TRMM);
+      if (stc == DLA_OK) stc = d2d(u + (size_t)j0 * n, tmp, sizeof(double) * (size_t)n * kc);
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    return stc;
   }
 
   int ritz_residual(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
