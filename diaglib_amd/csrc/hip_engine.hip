@@ -74,6 +74,7 @@ template <int TLW, int KT, int VEC, int RSTEP>
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 {
   constexpr int CH = 4 * VEC * RSTEP;  // rows per chunk
+  constexpr bool PREFETCH = (TLW * KT <= 8);   // the second register stage must not cost a wave per SIMD
   typedef typename VecOf<VEC>::type vec_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -100,36 +101,25 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 #pragma unroll
     for (int q = 0; q < KT; ++q) acc[t][q] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  const long long nchunks = (n + CH - 1) / CH;
-  for (long long ch = (long long)blockIdx.x * 4 + wave; ch < nchunks; ch += (long long)gridDim.x * 4) {
-    const long long rbase = ch * CH;
-    vec_t xv[TLW][RSTEP], uv[KT][RSTEP];
-    if (rbase + CH <= n) {
+  // Full chunks run through a two-stage software pipeline (the loads of the wave's next chunk are
+  // in flight while the MFMAs of the current one issue); the single partial chunk at the end of the
+  // panel, if any, is done by the wave it falls to with row predication.
+  const long long nfull = n / CH;
+  const long long stride = (long long)gridDim.x * 4;
+  long long ch = (long long)blockIdx.x * 4 + wave;
+  vec_t xv[TLW][RSTEP], uv[KT][RSTEP];
+  auto load_chunk = [&](long long c, vec_t (&xd)[TLW][RSTEP], vec_t (&ud)[KT][RSTEP]) {
+    const long long rbase = c * CH;
 #pragma unroll
-      for (int q = 0; q < KT; ++q)
+    for (int q = 0; q < KT; ++q)
 #pragma unroll
-        for (int s = 0; s < RSTEP; ++s) uv[q][s] = *(const vec_t*)(up[q] + rbase + 4 * VEC * s);
+      for (int s = 0; s < RSTEP; ++s) ud[q][s] = *(const vec_t*)(up[q] + rbase + 4 * VEC * s);
 #pragma unroll
-      for (int t = 0; t < TLW; ++t)
+    for (int t = 0; t < TLW; ++t)
 #pragma unroll
-        for (int s = 0; s < RSTEP; ++s) xv[t][s] = *(const vec_t*)(xp[t] + rbase + 4 * VEC * s);
-    } else {
-      // tail chunk: rows >= n contribute zero (n even when VEC == 2, so pairs are all-in or all-out)
-#pragma unroll
-      for (int s = 0; s < RSTEP; ++s) {
-        const bool ok = rbase + 4 * VEC * s + VEC * g < n;
-#pragma unroll
-        for (int q = 0; q < KT; ++q) {
-          uv[q][s] = vzero<VEC>();
-          if (ok) uv[q][s] = *(const vec_t*)(up[q] + rbase + 4 * VEC * s);
-        }
-#pragma unroll
-        for (int t = 0; t < TLW; ++t) {
-          xv[t][s] = vzero<VEC>();
-          if (ok) xv[t][s] = *(const vec_t*)(xp[t] + rbase + 4 * VEC * s);
-        }
-      }
-    }
+      for (int s = 0; s < RSTEP; ++s) xd[t][s] = *(const vec_t*)(xp[t] + rbase + 4 * VEC * s);
+  };
+  auto mfma_chunk = [&](const vec_t (&xd)[TLW][RSTEP], const vec_t (&ud)[KT][RSTEP]) {
 #pragma unroll
     for (int s = 0; s < RSTEP; ++s)
 #pragma unroll
@@ -137,10 +127,53 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 #pragma unroll
         for (int t = 0; t < TLW; ++t)
 #pragma unroll
-          for (int q = 0; q < KT; ++q) {
-            acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vget<VEC>(xv[t][s], e), vget<VEC>(uv[q][s], e),
+          for (int q = 0; q < KT; ++q)
+            acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vget<VEC>(xd[t][s], e), vget<VEC>(ud[q][s], e),
                                                              acc[t][q], 0, 0, 0);
-          }
+  };
+  if constexpr (PREFETCH) {
+    if (ch < nfull) {
+      load_chunk(ch, xv, uv);
+      for (; ch + stride < nfull; ch += stride) {
+        vec_t xn[TLW][RSTEP], un[KT][RSTEP];
+        load_chunk(ch + stride, xn, un);
+        mfma_chunk(xv, uv);
+#pragma unroll
+        for (int t = 0; t < TLW; ++t)
+#pragma unroll
+          for (int s = 0; s < RSTEP; ++s) xv[t][s] = xn[t][s];
+#pragma unroll
+        for (int q = 0; q < KT; ++q)
+#pragma unroll
+          for (int s = 0; s < RSTEP; ++s) uv[q][s] = un[q][s];
+      }
+      mfma_chunk(xv, uv);
+      ch += stride;
+    }
+  } else {
+    for (; ch < nfull; ch += stride) {
+      load_chunk(ch, xv, uv);
+      mfma_chunk(xv, uv);
+    }
+  }
+  if (ch == nfull && nfull * CH < n) {
+    // tail chunk: rows >= n contribute zero (n even when VEC == 2, so pairs are all-in or all-out)
+    const long long rbase = nfull * CH;
+#pragma unroll
+    for (int s = 0; s < RSTEP; ++s) {
+      const bool ok = rbase + 4 * VEC * s + VEC * g < n;
+#pragma unroll
+      for (int q = 0; q < KT; ++q) {
+        uv[q][s] = vzero<VEC>();
+        if (ok) uv[q][s] = *(const vec_t*)(up[q] + rbase + 4 * VEC * s);
+      }
+#pragma unroll
+      for (int t = 0; t < TLW; ++t) {
+        xv[t][s] = vzero<VEC>();
+        if (ok) xv[t][s] = *(const vec_t*)(xp[t] + rbase + 4 * VEC * s);
+      }
+    }
+    mfma_chunk(xv, uv);
   }
 
   // deterministic in-block reduction over the 4 waves, one slot at a time
@@ -334,6 +367,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
           if (j >= a.k) continue;
           double* zp = a.z + (size_t)j * (size_t)n + row[rt];
           vec_t v = vmake<VEC>(acc[rt][0][q][reg], acc[rt][VEC - 1][q][reg]);
+          // (loading the old values ahead of the sweep costs 32 VGPRs = 3 waves per SIMD and is slower)
           if constexpr (MODE == 1) { vec_t old = *(const vec_t*)zp; v = old - v; }
           if constexpr (MODE == 3) { vec_t old = *(const vec_t*)zp; v = old + v; }
           *(vec_t*)zp = v;
@@ -876,7 +910,7 @@ struct HipEngine : dla::Engine {
     int kt = std::min(tu, 4);
     const int passes_u = (tu + kt - 1) / kt;
     kt = (tu + passes_u - 1) / passes_u;
-    static const int maxtl[5] = {0, 12, 6, 4, 3};
+    static const int maxtl[5] = {0, 8, 6, 4, 3};   // wider passes lose the register prefetch stage (measured)
     const int passes_x = (tx + maxtl[kt] - 1) / maxtl[kt];
     int tlw = (tx + passes_x - 1) / passes_x;
     // round up to an instantiated width
