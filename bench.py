@@ -213,6 +213,8 @@ def main() -> None:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if os.environ.get("DIAGLIB_AMD_HOSTTIME"):
+        ctx.lib.dla_destroy(ctx.h)       # prints the engine's host-wait totals
 
 
 if __name__ == "__main__":

@@ -30,6 +30,17 @@ struct Engine {
   virtual int gemm(int n, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode) = 0;
   // in place U <- U W, W (k x k, host, general) -- used for the triangular update
   virtual int trmm(int n, int k, double* u, const double* w_host, int ld) = 0;
+  // fused sweeps: the update plus the Gram matrix of its result.  Default = two sweeps.
+  virtual int trmm_gram(int n, int k, double* u, const double* w_host, int ld, double* g_host, int ldg)
+  {
+    int st = trmm(n, k, u, w_host, ld);
+    return st ? st : gram(n, k, u, k, u, g_host, ldg);
+  }
+  virtual int update_gram(int n, int l, const double* x, int k, const double* c_host, int ldc, double* u, double* g_host, int ldg)
+  {
+    int st = gemm(n, l, x, k, c_host, ldc, u, 1);
+    return st ? st : gram(n, k, u, k, u, g_host, ldg);
+  }
   virtual int ritz_residual(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
                             const double* eig, int n_res, const int* skip, double* evec, double* r,
                             double* avy /* optional n x m: uncorrected AV*Y */,

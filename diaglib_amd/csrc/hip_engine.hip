@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <vector>
 #include "dla_internal.h"
 
@@ -276,6 +277,7 @@ struct GemmArgs {
   const double* x;     // n x l
   const double* cpk;   // packed C: [KT][l4][16] (zero padded), device
   double* z;           // n x k
+  double* gpart;       // GRAM variants: per-block partial of Z^T Z, [nblk][256]
   long long n;
   int l, l4, k;
 };
@@ -284,6 +286,7 @@ struct GemmArgs {
 struct GemmArgsInl {
   const double* x;
   double* z;
+  double* gpart;
   long long n;
   int l, l4, k;
   double cin[256];     // packed C: [l4 <= 16][16]
@@ -292,9 +295,14 @@ __device__ __forceinline__ const double* packed_c(const GemmArgs& a) { return a.
 __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return a.cin; }
 
 // MODE 0: Z = XC   1: Z -= XC   2: in place U <- U W (x == z)   3: Z += XC
-template <int KT, int VEC, int MODE, typename ARGS>
+// GRAM (KT == 1 only): the same sweep also accumulates G = Z^T Z of the values it stores -- the next
+// Gram matrix of the Cholesky-QR loop (diaglib.f90:3256) without re-reading the panel.  The stored
+// rows of a 16*VEC-row group are transposed through a wave-private LDS tile (row stride 24 doubles:
+// conflict-free for the fragment reads) into MFMA operands: lane (c, g) reads Z[row(g)][c].
+template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false>
 __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 {
+  static_assert(!GRAM || KT == 1, "fused Gram needs a single 16-column output tile");
   constexpr int RT = 2;                    // row groups per wave tile
   constexpr int RG = 16 * VEC;             // rows per group
   constexpr int WT = RT * RG;              // rows per wave tile (64 for VEC=2)
@@ -312,6 +320,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
   const int i = lane & 15, g = lane >> 4;
   const long long ntiles = (n + WT - 1) / WT;
   const int nsteps = l4 / 4;
+  constexpr int ZS = 24;                                   // LDS row stride of the transpose tile (doubles)
+  double* zs = cs + (size_t)KT * l4 * 16 + (size_t)wave * RG * ZS;   // [RG rows][ZS] per wave (GRAM only)
+  v4d gacc = (v4d){0.0, 0.0, 0.0, 0.0};
 
   for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
     const long long r0 = tile * WT;
@@ -358,21 +369,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
     // epilogue
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      if (!rok[rt]) continue;
+      if (!GRAM && !rok[rt]) continue;
 #pragma unroll
       for (int q = 0; q < KT; ++q)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int j = 16 * q + g + 4 * reg;
-          if (j >= a.k) continue;
-          double* zp = a.z + (size_t)j * (size_t)n + row[rt];
-          vec_t v = vmake<VEC>(acc[rt][0][q][reg], acc[rt][VEC - 1][q][reg]);
-          // (loading the old values ahead of the sweep costs 32 VGPRs = 3 waves per SIMD and is slower)
-          if constexpr (MODE == 1) { vec_t old = *(const vec_t*)zp; v = old - v; }
-          if constexpr (MODE == 3) { vec_t old = *(const vec_t*)zp; v = old + v; }
-          *(vec_t*)zp = v;
+          vec_t v = vzero<VEC>();
+          if (rok[rt] && j < a.k) {
+            double* zp = a.z + (size_t)j * (size_t)n + row[rt];
+            v = vmake<VEC>(acc[rt][0][q][reg], acc[rt][VEC - 1][q][reg]);
+            // (loading the old values ahead of the sweep costs 32 VGPRs = 3 waves per SIMD and is slower)
+            if constexpr (MODE == 1) { vec_t old = *(const vec_t*)zp; v = old - v; }
+            if constexpr (MODE == 3) { vec_t old = *(const vec_t*)zp; v = old + v; }
+            *(vec_t*)zp = v;
+          }
+          if constexpr (GRAM) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) zs[(VEC * i + e) * ZS + j] = vget<VEC>(v, e);
+          }
         }
+      if constexpr (GRAM) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const double zv = zs[(4 * VEC * s4 + VEC * g + e) * ZS + i];
+            gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(zv, zv, gacc, 0, 0, 0);
+          }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
+  }
+  if constexpr (GRAM) {
+    // deterministic sum over the 4 waves; D layout as in gram_kernel (slot 0 of a 1x1 pass)
+    __syncthreads();
+    double* red = cs;   // the copy of C is no longer needed: 4 x 256 doubles
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = gacc[r];
+    __syncthreads();
+    const int t = threadIdx.x;
+    a.gpart[(size_t)blockIdx.x * 256 + t] = ((red[t] + red[256 + t]) + red[512 + t]) + red[768 + t];
   }
 }
 
@@ -679,6 +717,10 @@ struct HipEngine : dla::Engine {
   ncclComm_t comm = nullptr;
   // timing / tracing ($DIAGLIB_AMD_TRACE=1: print and synchronise around every launch)
   bool trace = false;
+  // where the HOST waits ($DIAGLIB_AMD_HOSTTIME=1 prints the totals at destruction)
+  double t_sync = 0.0, t_evsync = 0.0, t_alloc = 0.0, t_free = 0.0;
+  long n_sync = 0;
+  static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
   std::vector<TimedLaunch> timed;
   std::vector<hipEvent_t> ev_pool;
 
@@ -687,6 +729,9 @@ struct HipEngine : dla::Engine {
 
   ~HipEngine() override
   {
+    if (std::getenv("DIAGLIB_AMD_HOSTTIME"))
+      std::fprintf(stderr, "[dla] host waits: stream sync %.3f s (%ld), ring event sync %.3f s, alloc %.3f s, free %.3f s\n",
+                   t_sync, n_sync, t_evsync, t_alloc, t_free);
     if (st) (void)hipStreamSynchronize(st);
     if (comm) ncclCommDestroy(comm);
     for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -696,6 +741,7 @@ struct HipEngine : dla::Engine {
     if (h_small) (void)hipHostFree(h_small);
     if (d_lvl2) (void)hipFree(d_lvl2);
     if (d_ticket) (void)hipFree(d_ticket);
+    if (ev_wait) (void)hipEventDestroy(ev_wait);
     for (int i = 0; i < RING; ++i) if (h_ring[i]) { (void)hipHostFree(h_ring[i]); (void)hipEventDestroy(ring_ev[i]); }
     if (d_cpk) (void)hipFree(d_cpk);
     if (d_w) (void)hipFree(d_w);
@@ -732,7 +778,11 @@ struct HipEngine : dla::Engine {
     HipEngine* e; int cls; hipEvent_t a = nullptr, b = nullptr;
     Scope(HipEngine* e_, int cls_, double bytes, double flops) : e(e_), cls(cls_)
     {
-      if (e->trace) { std::fprintf(stderr, "[dla] launch class %d, %.3e alg bytes\n", cls_, bytes); std::fflush(stderr); }
+      if (e->trace) {
+        timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        std::fprintf(stderr, "[dla] %ld.%06ld launch class %d, %.3e alg bytes\n", (long)ts.tv_sec, ts.tv_nsec / 1000, cls_, bytes);
+        std::fflush(stderr);
+      }
       e->stats.launches[cls] += 1;
       e->stats.alg_bytes[cls] += bytes;
       e->stats.flops[cls] += flops;
@@ -745,7 +795,8 @@ struct HipEngine : dla::Engine {
     {
       if (e->trace) {
         hipError_t er = hipStreamSynchronize(e->st);
-        std::fprintf(stderr, "[dla]   done: %s\n", hipGetErrorString(er)); std::fflush(stderr);
+        timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        std::fprintf(stderr, "[dla] %ld.%06ld   done: %s\n", (long)ts.tv_sec, ts.tv_nsec / 1000, hipGetErrorString(er)); std::fflush(stderr);
       }
       if (e->profile) {
         (void)hipEventRecord(b, e->st);
@@ -776,11 +827,21 @@ struct HipEngine : dla::Engine {
   {
     *dev = nullptr;
     if (bytes == 0) bytes = 8;
+    const double t0 = now();
     hipError_t e = hipMalloc(dev, bytes);
+    t_alloc += now() - t0;
     if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return DLA_ERR_ALLOC; }
     return DLA_OK;
   }
-  int free_(void* dev) override { if (dev) { (void)hipStreamSynchronize(st); HIPCHK(hipFree(dev)); } return DLA_OK; }
+  int free_(void* dev) override
+  {
+    if (!dev) return DLA_OK;
+    const double t0 = now();
+    (void)hipStreamSynchronize(st);
+    HIPCHK(hipFree(dev));
+    t_free += now() - t0;
+    return DLA_OK;
+  }
   int zero(void* dev, size_t bytes) override
   {
     Scope s(this, DLA_OP_ELEM, (double)bytes, 0.0);
@@ -829,12 +890,33 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipHostGetDevicePointer((void**)&h_small_dev, h_small, 0));
     return DLA_OK;
   }
+  // Host wait for the stream: poll an event instead of blocking in the driver.  A blocking
+  // hipStreamSynchronize sleeps on an interrupt and pays a scheduler wake-up per call (tens of
+  // microseconds on an idle host, milliseconds on a busy one); a solve makes ~90 such waits.
+  hipEvent_t ev_wait = nullptr;
+  int wait_stream()
+  {
+    if (!ev_wait) HIPCHK(hipEventCreateWithFlags(&ev_wait, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev_wait, st));
+    const double t0 = now();
+    hipError_t q;
+    while ((q = hipEventQuery(ev_wait)) == hipErrorNotReady) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    t_sync += now() - t0; n_sync++;
+    if (q != hipSuccess) { err = std::string("hipEventQuery: ") + hipGetErrorString(q); return DLA_ERR_RUNTIME; }
+    return DLA_OK;
+  }
+
   // reduced small result -> host: single rank reads the pinned mirror the kernel wrote,
   // multi-rank copies the all-reduced device buffer
   int small_to_host(size_t count)
   {
     if (nranks > 1) HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * count, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    int stw = wait_stream();
+    if (stw) return stw;
     stats.host_syncs++;
     return DLA_OK;
   }
@@ -852,7 +934,9 @@ struct HipEngine : dla::Engine {
     }
     const int slot = ring_pos;
     ring_pos = (ring_pos + 1) % RING;
+    const double t0 = now();
     HIPCHK(hipEventSynchronize(ring_ev[slot]));
+    t_evsync += now() - t0;
     std::memcpy(h_ring[slot], host_packed, bytes);
     HIPCHK(hipMemcpyAsync(dev, h_ring[slot], bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(ring_ev[slot], st));
@@ -969,6 +1053,55 @@ struct HipEngine : dla::Engine {
     return DLA_OK;
   }
 
+  int fused_blocks = 0;
+
+  // second stage + host copy of a Gram whose per-block partials a fused kernel left in d_partial
+  int finish_fused_gram(int k, double* g_host, int ldg)
+  {
+    int stc = ensure_small(sizeof(double) * (size_t)k * k);
+    if (stc) return stc;
+    const int groups = std::max(1, std::min(16, (fused_blocks + 31) / 32));
+    const size_t need2 = sizeof(double) * (size_t)groups * 256;
+    if (need2 > lvl2_bytes) {
+      HIPCHK(hipStreamSynchronize(st));
+      if (d_lvl2) HIPCHK(hipFree(d_lvl2));
+      lvl2_bytes = std::max(need2, (size_t)1 << 20);
+      HIPCHK(hipMalloc((void**)&d_lvl2, lvl2_bytes));
+    }
+    GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, h_small_dev, fused_blocks, k, k, 1, 1, 1};
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(1, groups), dim3(256), 0, st, ra);
+    HIPCHK(hipGetLastError());
+    stc = allreduce_dev(d_small, k * k, 0, h_small);
+    if (stc) return stc;
+    stc = small_to_host((size_t)k * k);
+    if (stc) return stc;
+    for (int j = 0; j < k; ++j) std::memcpy(g_host + (size_t)j * ldg, h_small + (size_t)j * k, sizeof(double) * k);
+    return DLA_OK;
+  }
+
+  // U <- U W and G = U^T U of the result, one sweep (k <= 16); otherwise two sweeps
+  int trmm_gram(int n, int k, double* u, const double* w_host, int ld, double* g_host, int ldg) override
+  {
+    if (k > 16) return Engine::trmm_gram(n, k, u, w_host, ld, g_host, ldg);
+    {
+      // accounted as TRMM traffic (16nk) -- the Gram rides along
+      int stc = gemm_chunk(n, 0, k, u, k, w_host, ld, u, 2, DLA_OP_TRMM, true);
+      if (stc) return stc;
+    }
+    stats.flops[DLA_OP_GRAM] += 2.0 * (double)n * k * k;   // reference-schedule flops of the Gram it replaces
+    return finish_fused_gram(k, g_host, ldg);
+  }
+
+  // U -= X C and G = U^T U of the result, one sweep (k <= 16, C fits one LDS chunk)
+  int update_gram(int n, int l, const double* x, int k, const double* c_host, int ldc, double* u, double* g_host, int ldg) override
+  {
+    if (k > 16 || l > 448 || l == 0) return Engine::update_gram(n, l, x, k, c_host, ldc, u, g_host, ldg);
+    int stc = gemm_chunk(n, 0, l, x, k, c_host, ldc, u, 1, DLA_OP_GEMM, true);
+    if (stc) return stc;
+    stats.flops[DLA_OP_GRAM] += 2.0 * (double)n * k * k;
+    return finish_fused_gram(k, g_host, ldg);
+  }
+
   // ---- packed C upload: [KT][l4][16], zero padded
   int upload_packed(const double* c_host, int ldc, int l0, int l, int k, int kt, int l4)
   {
@@ -987,6 +1120,15 @@ struct HipEngine : dla::Engine {
     return stage_to_device(pk.data(), sizeof(double) * cnt, d_cpk);
   }
 
+  template <typename ARGS>
+  void launch_gemm_gram(const ARGS& a, int blocks, size_t lds, bool vec2, int mode)
+  {
+#define GG(V, M) hipLaunchKernelGGL((gemm_kernel<1, V, M, ARGS, true>), dim3(blocks), dim3(256), lds, st, a)
+    if (vec2) { if (mode == 1) GG(2, 1); else GG(2, 2); }
+    else      { if (mode == 1) GG(1, 1); else GG(1, 2); }
+#undef GG
+  }
+
   template <int KT, typename ARGS>
   void launch_gemm(const ARGS& a, int blocks, size_t lds, bool vec2, int mode)
   {
@@ -996,7 +1138,8 @@ struct HipEngine : dla::Engine {
 #undef GM
   }
 
-  int gemm_chunk(int n, int l0, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode, int cls)
+  int gemm_chunk(int n, int l0, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode, int cls,
+                 bool fuse = false)
   {
     const int kt = (k + 15) / 16;
     const int l4 = ((l + 3) / 4) * 4;
@@ -1008,19 +1151,32 @@ struct HipEngine : dla::Engine {
     const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)z) % 16 == 0);
     const int wt = vec2 ? 64 : 32;
     const long long ntiles = ((long long)n + wt - 1) / wt;
-    const size_t lds = sizeof(double) * (size_t)kt * l4 * 16;
+    // fused variant: + 4 wave tiles of (16*VEC rows) x 24 doubles, and >= 8 KiB for the final reduction
+    const size_t lds_c = sizeof(double) * (size_t)kt * l4 * 16;
+    const size_t lds = fuse ? std::max(lds_c + sizeof(double) * 4 * (vec2 ? 32 : 16) * 24, (size_t)8192) : lds_c;
     const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
     const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu, (ntiles + 3) / 4));
+    if (fuse) {
+      int stp = ensure_partial(sizeof(double) * (size_t)blocks * 256);
+      if (stp) return stp;
+      fused_blocks = blocks;
+    }
     GemmArgs a{};
-    a.x = x + (size_t)l0 * n; a.cpk = d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k;
+    a.x = x + (size_t)l0 * n; a.cpk = d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k; a.gpart = d_partial;
     const double rd = (mode == 0) ? 8.0 * n * (double)l : (mode == 2 ? 8.0 * n * (double)k : 8.0 * n * (double)(l + k));
     Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k);
     if (inl) {
       GemmArgsInl ai{};
-      ai.x = a.x; ai.z = z; ai.n = n; ai.l = l; ai.l4 = l4; ai.k = k;
+      ai.x = a.x; ai.z = z; ai.n = n; ai.l = l; ai.l4 = l4; ai.k = k; ai.gpart = d_partial;
       for (int j = 0; j < k; ++j)
         for (int p = 0; p < l; ++p) ai.cin[p * 16 + j] = c_host[(size_t)(l0 + p) + (size_t)j * ldc];
-      launch_gemm<1>(ai, blocks, lds, vec2, mode);
+      if (fuse) launch_gemm_gram(ai, blocks, lds, vec2, mode);
+      else launch_gemm<1>(ai, blocks, lds, vec2, mode);
+      HIPCHK(hipGetLastError());
+      return DLA_OK;
+    }
+    if (fuse) {
+      launch_gemm_gram(a, blocks, lds, vec2, mode);
       HIPCHK(hipGetLastError());
       return DLA_OK;
     }

@@ -241,14 +241,19 @@ int dla_nrm2(dla_ctx* c, size_t len, const double* x, double* out)
 int dla_random_fill(dla_ctx* c, int n, int m, double* evec) { return engfail(c, c->eng->random_fill(n, m, evec, c->row0)); }
 
 // ------------------------------------------------------------------ orthogonalisation
-// ortho_cd, diaglib.f90:3185-3341.  Per macro-iteration: one Gram sweep, host Cholesky /
-// triangular inverse / norm estimates, one in-place triangular update sweep.
-int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
+// ortho_cd, diaglib.f90:3185-3341.  The reference's macro-iteration is: Gram sweep, host Cholesky /
+// triangular inverse / norm estimates, triangular update sweep.  Here the update sweep also returns
+// the Gram matrix of the panel it has just written (Engine::trmm_gram), which is exactly the matrix
+// the next macro-iteration starts from, so a macro-iteration costs one sweep instead of two.
+// g_in (optional): Gram matrix of u already known to the caller (k x k, ld k).
+static int ortho_cd_impl(dla_ctx* c, int n, int k, double* u, double* growth, int* ok, const double* g_in)
 {
   *growth = 1.0;
   *ok = 0;
   if (k <= 0) { *ok = 1; return DLA_OK; }
-  std::vector<double> metric((size_t)k * k), msave((size_t)k * k);
+  std::vector<double> metric((size_t)k * k), msave((size_t)k * k), gnext((size_t)k * k), w((size_t)k * k);
+  bool have_g = (g_in != nullptr);
+  if (have_g) gnext.assign(g_in, g_in + (size_t)k * k);
   int it = 0;
   bool macro_done = false;
   while (!macro_done) {
@@ -258,8 +263,12 @@ int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
       *ok = 0;
       return DLA_OK;
     }
-    int st = c->eng->gram(n, k, u, k, u, metric.data(), k);
-    if (st) return engfail(c, st);
+    if (have_g) {
+      metric = gnext;
+    } else {
+      int st = c->eng->gram(n, k, u, k, u, metric.data(), k);   // :3256
+      if (st) return engfail(c, st);
+    }
     msave = metric;
     int info = dla_potrf_lower(k, metric.data(), k);
     if (info != 0) {
@@ -290,14 +299,25 @@ int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
     double linv_norm = dla_norm_est(k, msave.data(), k);
     double rcond = l_norm * linv_norm;
     *growth *= linv_norm;
-    st = dla_trmm_linvt(c, n, k, u, msave.data(), k);
-    if (st) return st;
     double error = kEps * rcond * rcond;
     macro_done = error < kTolOrtho;
+    // U <- U Linv^T (:3327): W = Linv^T is upper triangular, W(p,j) = Linv(j,p) for p <= j
+    std::fill(w.begin(), w.end(), 0.0);
+    for (int j = 0; j < k; ++j)
+      for (int p = 0; p <= j; ++p) w[(size_t)p + (size_t)j * k] = msave[(size_t)j + (size_t)p * k];
+    int st;
+    if (macro_done) st = c->eng->trmm(n, k, u, w.data(), k);                          // last pass: no further Gram needed
+    else { st = c->eng->trmm_gram(n, k, u, w.data(), k, gnext.data(), k); have_g = true; }
+    if (st) return engfail(c, st);
   }
   if (c->verbose_ortho) std::printf("  [dla] ortho_cd: %d macro iterations, growth %.3e\n", it, *growth);
   *ok = 1;
   return DLA_OK;
+}
+
+int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
+{
+  return ortho_cd_impl(c, n, k, u, growth, ok, nullptr);
 }
 
 // Column-wise modified Gram-Schmidt (twice) on the device: the stand-in for the reference's
@@ -333,7 +353,7 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
   int ok = 0, it = 0;
   bool done = false;
   double growth = 1.0, xu_norm;
-  std::vector<double> xu((size_t)(m > 0 ? m : 1) * k);
+  std::vector<double> xu((size_t)(m > 0 ? m : 1) * k), gu((size_t)k * k);
   int st = dla_ortho_cd(c, n, k, u, &growth, &ok);        // :3533
   if (st) return st;
   if (!ok) { st = ortho_fallback(c, n, k, u); if (st) return st; }
@@ -342,10 +362,10 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
     if (m > 0) {
       st = c->eng->gram(n, m, bx, k, u, xu.data(), m);     // xu = X^T U  (:3543) / (BX)^T U (:3632)
       if (st) return engfail(c, st);
-      st = c->eng->gemm(n, m, x, k, xu.data(), m, u, 1);   // U -= X xu  (:3544)
+      st = c->eng->update_gram(n, m, x, k, xu.data(), m, u, gu.data(), k);   // U -= X xu (:3544) + U^T U for :3548
       if (st) return engfail(c, st);
     }
-    st = dla_ortho_cd(c, n, k, u, &growth, &ok);           // :3548
+    st = ortho_cd_impl(c, n, k, u, &growth, &ok, m > 0 ? gu.data() : nullptr);   // :3548
     if (st) return st;
     if (!ok) {
       st = ortho_fallback(c, n, k, u);
