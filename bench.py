@@ -100,7 +100,9 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        # control plane (rendezvous, id broadcast, barriers, max-over-ranks of the time) on gloo;
+        # the data path's collectives run on the engine's own RCCL communicator (ncclCommInitRank below)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     from diaglib_amd import capi
     ctx = capi.Context()

@@ -30,7 +30,7 @@ OP_NAMES = ["gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd"]
 EXPORTS = [
     "dla_create", "dla_destroy", "dla_default_ctx", "dla_set_option", "dla_get_option", "dla_last_error",
     "dla_backend_name", "dla_get_stats", "dla_reset_stats", "dla_stream",
-    "dla_comm_unique_id", "dla_comm_init", "dla_comm_info", "dla_set_allreduce_hook", "dla_set_shard",
+    "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_set_allreduce_hook", "dla_set_shard",
     "dla_alloc", "dla_free", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
     "dla_gram", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_ritz_residual", "dla_axpy",
     "dla_nrm2", "dla_random_fill",
@@ -77,7 +77,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_last_error": (C.c_char_p, [vp]), "dla_backend_name": (C.c_char_p, [vp]),
         "dla_get_stats": (i, [vp, C.POINTER(Stats)]), "dla_reset_stats": (i, [vp]), "dla_stream": (vp, [vp]),
         "dla_comm_unique_id": (i, [C.c_char_p]), "dla_comm_init": (i, [vp, i, i, C.c_char_p]),
-        "dla_comm_info": (i, [vp, c_ip, c_ip]),
+        "dla_comm_info": (i, [vp, c_ip, c_ip]), "dla_comm_finalize": (i, [vp]),
         "dla_set_allreduce_hook": (i, [vp, vp, vp, i, i]), "dla_set_shard": (i, [vp, C.c_longlong, C.c_longlong]),
         "dla_alloc": (i, [vp, sz, C.POINTER(vp)]), "dla_free": (i, [vp, vp]), "dla_zero": (i, [vp, vp, sz]),
         "dla_upload": (i, [vp, vp, vp, sz]), "dla_download": (i, [vp, vp, vp, sz]), "dla_copy": (i, [vp, vp, vp, sz]),
@@ -214,6 +214,9 @@ class Context:
 
     def comm_init(self, nranks: int, rank: int, uid: bytes) -> None:
         self._chk(self.lib.dla_comm_init(self.h, nranks, rank, uid))
+
+    def comm_finalize(self) -> None:
+        self._chk(self.lib.dla_comm_finalize(self.h))
 
     def set_shard(self, n_global: int, row0: int) -> None:
         self._chk(self.lib.dla_set_shard(self.h, n_global, row0))

@@ -59,7 +59,9 @@ struct Engine {
 
   // collectives
   virtual int comm_init(int nranks, int rank, const char id[128]) = 0;
+  virtual int comm_finalize() { nranks = 1; rank = 0; hook = nullptr; return 0; }
   int nranks = 1, rank = 0;
+  bool local_only = false;   // true while working on data that is replicated on every rank (no reductions)
   dla_allreduce_fn hook = nullptr;
   void* hook_user = nullptr;
 

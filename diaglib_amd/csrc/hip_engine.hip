@@ -914,7 +914,7 @@ struct HipEngine : dla::Engine {
   // multi-rank copies the all-reduced device buffer
   int small_to_host(size_t count)
   {
-    if (nranks > 1) HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    if (!local_only && (nranks > 1 || comm)) HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * count, hipMemcpyDeviceToHost, st));
     int stw = wait_stream();
     if (stw) return stw;
     stats.host_syncs++;
@@ -946,7 +946,7 @@ struct HipEngine : dla::Engine {
   // ---- collectives on small device buffers
   int allreduce_dev(double* dev, int count, int op /*0 sum, 1 max*/, double* host_mirror)
   {
-    if (nranks <= 1) return DLA_OK;
+    if (local_only || (nranks <= 1 && !comm)) return DLA_OK;
     stats.allreduces++;
     if (comm) {
       ncclResult_t r = ncclAllReduce(dev, dev, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax, comm, st);
@@ -963,6 +963,12 @@ struct HipEngine : dla::Engine {
     }
     err = "nranks > 1 but neither an RCCL communicator nor a reduction hook is attached";
     return DLA_ERR_COMM;
+  }
+  int comm_finalize() override
+  {
+    if (comm) { (void)hipStreamSynchronize(st); ncclCommDestroy(comm); comm = nullptr; }
+    nranks = 1; rank = 0;
+    return DLA_OK;
   }
   int comm_init(int nr, int rk, const char id[128]) override
   {

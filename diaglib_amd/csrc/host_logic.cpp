@@ -145,6 +145,12 @@ int dla_comm_init(dla_ctx* c, int nranks, int rank, const char id[128])
   return engfail(c, c->eng->comm_init(nranks, rank, id));
 }
 
+int dla_comm_finalize(dla_ctx* c)
+{
+  if (!c) return DLA_ERR_ARG;
+  return engfail(c, c->eng->comm_finalize());
+}
+
 int dla_comm_info(dla_ctx* c, int* nranks, int* rank)
 {
   if (!c) return DLA_ERR_ARG;
@@ -460,10 +466,9 @@ int dla_get_coeffs(dla_ctx* c, int len_a, int len_u, int n_max, int n_act, const
   if (st) { c->eng->free_(dx); return engfail(c, st); }
   c->eng->h2d(dx, u_x, bx);
   c->eng->h2d(dp, u_p, bp);
-  int save_nr = c->eng->nranks;
-  c->eng->nranks = 1;  // replicated data: local reductions only
+  c->eng->local_only = true;   // replicated data: local reductions only
   st = dla_ortho_vs_x(c, len_u, n_max, n_act, (const double*)dx, (double*)dp);
-  c->eng->nranks = save_nr;
+  c->eng->local_only = false;
   if (st == DLA_OK) st = engfail(c, c->eng->d2h(u_p, dp, bp));
   c->eng->free_(dx);
   c->eng->free_(dp);

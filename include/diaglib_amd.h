@@ -95,6 +95,7 @@ void* dla_stream(dla_ctx* ctx);                      /* hipStream_t the kernels 
 /* ---------------------------------------------------------------- multi-GPU */
 int  dla_comm_unique_id(char id[128]);                                       /* ncclGetUniqueId          */
 int  dla_comm_init(dla_ctx* ctx, int nranks, int rank, const char id[128]);  /* ncclCommInitRank         */
+int  dla_comm_finalize(dla_ctx* ctx);                                        /* ncclCommDestroy          */
 int  dla_comm_info(dla_ctx* ctx, int* nranks, int* rank);
 /* host-buffer reduction hook (op 0 = sum, 1 = max); lets a caller supply the collective
  * (e.g. MPI or torch.distributed/gloo).  Used when no RCCL communicator is attached. */

@@ -38,7 +38,7 @@ struct HostSimEngine : dla::Engine {
 
   int reduce(double* buf, int count, int op)
   {
-    if (nranks <= 1) return 0;
+    if (local_only || nranks <= 1) return 0;
     if (!hook) { err = "hostsim: nranks > 1 without a reduction hook"; return DLA_ERR_COMM; }
     stats.allreduces++;
     hook(hook_user, buf, count, op);

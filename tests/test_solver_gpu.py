@@ -255,3 +255,32 @@ def test_lobpcg_shift(ctx, oracle, rng):
     eo, vo, oko, tr = oracle.lobpcg(n, n_targ, n_max, 100, 1e-8, 0.75, mv, pc, g)
     assert ok and oko
     _cmp_trace(info, tr, eig, eo, n_targ, exact=False)   # returned eig includes the shift (diaglib.f90:416, App. B 1)
+
+
+def test_rccl_communicator_single_rank(ctx, oracle, rng):
+    """The RCCL door on one GPU: a 1-rank communicator routes every reduction through ncclAllReduce on the
+    engine's stream (N > 1 needs N GPUs; the sharded arithmetic itself is covered by tests/test_hostsim.py)."""
+    x = np.asfortranarray(rng.standard_normal((4000, 20))); u = np.asfortranarray(rng.standard_normal((4000, 7)))
+    want = ctx.gram(ctx.panel(x), ctx.panel(u))
+    before = ctx.stats()["allreduces"]
+    ctx.comm_init(1, 0, ctx.unique_id())
+    try:
+        ctx.set_shard(4000, 0)
+        got = ctx.gram(ctx.panel(x), ctx.panel(u))
+        assert np.array_equal(got, want)
+        assert ctx.stats()["allreduces"] > before
+        n, t, m = 3000, 3, 6
+        oracle.dense_setup(n)
+        g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
+        ctx.set_shard(n, 0)
+        eig, v, ok, info = ctx.davidson_driver(n, t, m, 100, 1e-8, 20, 0.0, oracle.fn("orc_dense_matvec"),
+                                               oracle.fn("orc_dense_precnd"), g)
+        eo, vo, oko, tr = oracle.davidson(n, t, m, 100, 1e-8, 20, 0.0, oracle.fn("orc_dense_matvec"),
+                                          oracle.fn("orc_dense_precnd"), g)
+        assert ok and oko and info["iters"] == tr.iters and np.allclose(eig[:t], eo[:t], rtol=1e-11)
+        eig, v, ok, info = ctx.lobpcg_driver(n, t, m, 100, 1e-8, 0.0, oracle.fn("orc_dense_matvec"),
+                                             oracle.fn("orc_dense_precnd"), g)
+        assert ok and np.allclose(eig[:t], eo[:t], rtol=1e-9)
+    finally:
+        ctx.comm_finalize()
+        ctx.set_shard(-1, 0)
