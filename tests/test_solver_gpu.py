@@ -284,3 +284,54 @@ def test_rccl_communicator_single_rank(ctx, oracle, rng):
     finally:
         ctx.comm_finalize()
         ctx.set_shard(-1, 0)
+
+
+@pytest.mark.parametrize("solver,n,n_targ,n_max", [("davidson", 3001, 4, 8),      # odd n: 8-byte access path (VEC=1)
+                                                   ("lobpcg", 2001, 4, 8),
+                                                   ("davidson", 3000, 16, 21),    # BASELINE cfg 4 block width (2 column tiles)
+                                                   ("lobpcg", 3000, 16, 21),
+                                                   ("davidson", 2500, 32, 37),    # BASELINE cfg 5 block width (3 column tiles)
+                                                   ("lobpcg", 2500, 32, 37)])
+def test_block_widths_and_odd_n(ctx, oracle, solver, n, n_targ, n_max):
+    """Shapes of BASELINE configs 4 and 5 (n_max = 21, 37: multi-tile kernels, unfused ortho path, LOBPCG's
+    111 x 111 projected matrix) and odd row counts, on the reference's dense test matrix with a unit guess."""
+    oracle.dense_setup(n)
+    mv, pc = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd")
+    g = np.zeros((n, n_max), order="F"); g[np.arange(n_max), np.arange(n_max)] = 1.0
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+    if solver == "davidson":
+        eig, v, ok, info = ctx.davidson_driver(n, n_targ, n_max, 100, 1e-8, 20, 0.0, mv, pc, g)
+        eo, vo, oko, tr = oracle.davidson(n, n_targ, n_max, 100, 1e-8, 20, 0.0, mv, pc, g)
+    else:
+        eig, v, ok, info = ctx.lobpcg_driver(n, n_targ, n_max, 100, 1e-8, 0.0, mv, pc, g)
+        eo, vo, oko, tr = oracle.lobpcg(n, n_targ, n_max, 100, 1e-8, 0.0, mv, pc, g)
+    assert ok and oko
+    assert info["iters"] == tr.iters
+    assert abs(info["matvec_cols"] - tr.matvec_cols) <= 2      # one root may lock an iteration earlier/later at the tol edge
+    assert np.allclose(eig[:n_targ], eo[:n_targ], rtol=1e-11, atol=0)
+    _cmp_vecs(v, vo, n_targ, 1e-6)
+
+
+def test_davidson_restarts_with_device_callbacks(ctx, oracle, rng):
+    """Restart path (diaglib.f90:1795-1825 incl. the n_rst zero-column quirk) with device-resident callbacks:
+    12 of 13 roots wanted, max_dav=10 -> the basis fills up and restarts once with locked roots."""
+    n, t, m = 40000, 12, 13
+    g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+    try:
+        ctx.synth_setup(n, 0, n); oracle.synth_setup(n, 0, n)
+        ev = ctx.panel(g)
+        eig, _, ok, info = ctx.davidson_driver(n, t, m, 400, 1e-13, 10, 0.0, capi.fn_address("dla_synth_matvec"),
+                                               capi.fn_address("dla_synth_precnd"), ev)
+    finally:
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+    eo, vo, oko, tr = oracle.davidson(n, t, m, 400, 1e-13, 10, 0.0, oracle.fn("orc_synth_matvec"),
+                                      oracle.fn("orc_synth_precnd"), g)
+    assert ok and oko and info["restarts"] >= 1 and tr.restarts >= 1, (ok, oko, info, tr.iters, tr.restarts)
+    # tol=1e-13 sits close to the rounding floor of the 12th root: the tail of the history (how many 2-column
+    # iterations the last root needs) differs between implementations, so only the outcome is compared
+    assert abs(info["iters"] - tr.iters) <= max(2, tr.iters // 3)
+    assert np.allclose(eig[:t], eo[:t], rtol=1e-11, atol=0)
+    x = ev.download()[:, :t]
+    assert np.abs(x.T @ x - np.eye(t)).max() < 1e-12
+    _cmp_vecs(ev.download(), vo, t, 1e-6)
