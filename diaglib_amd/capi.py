@@ -38,7 +38,7 @@ EXPORTS = [
     "dla_call_matvec", "dla_call_precnd",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
     "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd",
-    "dla_davidson_driver", "dla_lobpcg_driver", "dla_last_solve_info", "dla_set_solve_info",
+    "dla_davidson_driver", "dla_gen_david_driver", "dla_lobpcg_driver", "dla_last_solve_info", "dla_set_solve_info",
 ]
 
 
@@ -100,6 +100,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_synth_setup": (i, [vp, C.c_longlong, C.c_longlong, i, i, d]),
         "dla_davidson_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, c_ip]),
         "dla_lobpcg_driver": (None, [i, i, i, i, i, i, d, d, vp, vp, vp, vp, vp, c_ip]),
+        "dla_gen_david_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, vp, c_ip]),
         "dla_last_solve_info": (None, [c_ip, c_ip, c_ip]),
     }
     for name, (res, args) in sig.items():
@@ -352,9 +353,9 @@ class Context:
                                      eig.ctypes.data, ev_ptr, C.byref(ok))
         return eig, out, bool(ok.value), self.last_solve_info()
 
-    def lobpcg_driver(self, n: int, n_targ: int, n_max: int, max_iter: int, tol: float, shift: float,
-                      matvec: Callback, precnd: Callback, evec, verbose: bool = False):
-        mv, pc = self._wrap_mv(matvec), self._wrap_pc(precnd)
+    def gen_david_driver(self, n: int, n_targ: int, n_max: int, max_iter: int, tol: float, max_dav: int, shift: float,
+                         matvec: Callback, precnd: Callback, bvec: Callback, evec, verbose: bool = False):
+        mv, pc, bv = self._wrap_mv(matvec), self._wrap_pc(precnd), self._wrap_mv(bvec)
         eig = np.zeros(n_max); ok = C.c_int(0)
         if isinstance(evec, DevPanel):
             self.set_option(OPT_EVEC_ON_DEVICE, 1)
@@ -363,7 +364,23 @@ class Context:
             self.set_option(OPT_EVEC_ON_DEVICE, 0)
             out = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
             ev_ptr = out.ctypes.data
-        self.lib.dla_lobpcg_driver(int(verbose), 0, n, n_targ, n_max, max_iter, tol, shift, mv, pc, mv,
+        self.lib.dla_gen_david_driver(int(verbose), n, n_targ, n_max, max_iter, tol, max_dav, shift, mv, pc, bv,
+                                      eig.ctypes.data, ev_ptr, C.byref(ok))
+        return eig, out, bool(ok.value), self.last_solve_info()
+
+    def lobpcg_driver(self, n: int, n_targ: int, n_max: int, max_iter: int, tol: float, shift: float,
+                      matvec: Callback, precnd: Callback, evec, verbose: bool = False, bvec: Optional[Callback] = None):
+        mv, pc = self._wrap_mv(matvec), self._wrap_pc(precnd)
+        bv = self._wrap_mv(bvec) if bvec is not None else mv
+        eig = np.zeros(n_max); ok = C.c_int(0)
+        if isinstance(evec, DevPanel):
+            self.set_option(OPT_EVEC_ON_DEVICE, 1)
+            ev_ptr, out = evec.ptr, evec
+        else:
+            self.set_option(OPT_EVEC_ON_DEVICE, 0)
+            out = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
+            ev_ptr = out.ctypes.data
+        self.lib.dla_lobpcg_driver(int(verbose), 0 if bvec is None else 1, n, n_targ, n_max, max_iter, tol, shift, mv, pc, bv,
                                    eig.ctypes.data, ev_ptr, C.byref(ok))
         return eig, out, bool(ok.value), self.last_solve_info()
 

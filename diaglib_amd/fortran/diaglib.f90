@@ -14,8 +14,10 @@
 ! blocks through pinned memory); after  call diaglib_amd_config(callbacks_on_device=.true.)
 ! they receive DEVICE addresses under the same signature (SURVEY.md 8b).
 !
-! Not provided (out of scope for this path, SURVEY.md 2 rows 3-5): gen_david_driver,
-! caslr_driver, caslr_eff_driver, nonsym_driver.
+! The generalised problem (metric B through a bvec callback) is served by gen_david_driver and by
+! lobpcg_driver with gen_eig=.true. (reference diaglib.f90:1855-2250, 299-302/357-364/523-526).
+! Not provided (out of scope for this path, SURVEY.md 2 rows 4-5): caslr_driver, caslr_eff_driver,
+! nonsym_driver.
 !
 module diaglib
   use real_precision
@@ -23,7 +25,7 @@ module diaglib
   implicit none
   private
 !
-  public :: lobpcg_driver, davidson_driver, ortho, b_ortho, ortho_cd, ortho_vs_x, b_ortho_vs_x
+  public :: lobpcg_driver, davidson_driver, gen_david_driver, ortho, b_ortho, ortho_cd, ortho_vs_x, b_ortho_vs_x
   public :: diaglib_amd_config
 !
   real(dp), parameter :: zero = 0.0_dp, one = 1.0_dp, ten = 10.0_dp
@@ -503,6 +505,271 @@ contains
   end subroutine davidson_driver
 !
 ! ---------------------------------------------------------------------------------------
+! Davidson-Liu with a metric B (reference diaglib.f90:1855-2250): same loop plus bspace = B*space.
+! Deliberate deviation at the restart (SURVEY 8a A13): the reference zeroes all of bspace right after
+! B-orthonormalising the kept Ritz block (:2196-2200) and never refills it, so its residuals after a
+! restart miss theta*B*x of that block; here the kept block's B*x stays in bspace(:,1:n_max).
+! ---------------------------------------------------------------------------------------
+  subroutine gen_david_driver(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift,matvec,precnd,bvec,eig,evec,ok)
+    logical,                              intent(in)    :: verbose
+    integer,                              intent(in)    :: n, n_targ, n_max
+    integer,                              intent(in)    :: max_iter, max_dav
+    real(dp),                             intent(in)    :: tol, shift
+    real(dp), dimension(n_max),           intent(inout) :: eig
+    real(dp), dimension(n,n_max), target, intent(inout) :: evec
+    logical,                              intent(inout) :: ok
+    external                                            :: matvec, precnd, bvec
+!
+    type(c_ptr)    :: ctx, space, aspace, bspace, b_evec, r, evd
+    type(c_funptr) :: mv, pc, bv
+    integer        :: dim_dav, lda, n_act, ind, i_beg, m_dim, ldu, n_frozen, it, i_eig, n_rst, c0
+    integer        :: n_mv, n_restarts
+    logical        :: restart, evec_dev
+    real(dp)       :: tol_rms, tol_max
+    logical,        allocatable :: done(:)
+    integer(c_int), allocatable :: skip(:)
+    real(dp),       allocatable :: a_red(:,:), a_copy(:,:), e_red(:), r_norm(:,:)
+    integer(c_int) :: info
+!
+    ctx = dla_default_ctx()
+    mv  = c_funloc(matvec)
+    pc  = c_funloc(precnd)
+    bv  = c_funloc(bvec)
+    evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
+!
+!   expansion space size: never smaller than 10 blocks (reference :1595-1596)
+!
+    dim_dav = max(min_dav,max_dav)
+    lda     = dim_dav*n_max
+!
+!   device panels (reference :1607) and host-size matrices (:1612-1617)
+!
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), space),  'allocation of space')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), aspace), 'allocation of aspace')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), r),    'allocation of r')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), bspace), 'allocation of bspace')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), b_evec), 'allocation of b_evec')
+    if (evec_dev) then
+      evd = c_loc(evec)
+    else
+      call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), evd), 'allocation of evec')
+      call chk(ctx, dla_upload(ctx, evd, c_loc(evec), nbytes(n,n_max)), 'upload of the guess')
+    end if
+    allocate (done(n_max), skip(n_max), r_norm(2,n_max), a_red(lda,lda), a_copy(lda,lda), e_red(lda))
+!
+    tol_rms = tol
+    tol_max = ten * tol
+    t_diag  = zero
+    t_ortho = zero
+    t_mv    = zero
+    t_tot   = zero
+!
+!   the reference zero-fills both n x lda panels here (:1632-1633).  On the device no column is
+!   ever read before it has been written (guess copy, matvec output, ortho_vs_x output), so the
+!   two 8*n*lda-byte memsets are skipped; the columns the restart quirk reads as zeros are
+!   zeroed at the restart (below).
+!
+    a_red   = zero
+    r_norm  = zero
+    ok      = .false.
+    done    = .false.
+!
+    call get_time(t_tot)
+!
+!   guess: orthonormalise if needed, random if zero (reference :1644), then copy (:1648)
+!
+    call chk(ctx, dla_check_guess(ctx, n, n_max, evd), 'check_guess')
+    call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
+!
+!   B times the guess, then B-orthonormalise it (reference :2033-2034)
+!
+    call chk(ctx, dla_call_matvec(ctx, bv, n, n_max, space, bspace), 'bvec')
+    call chk(ctx, dla_b_ortho(ctx, n, n_max, space, bspace), 'b_ortho')
+!
+    n_act = n_max
+    ind   = 1
+    i_beg = 1
+    m_dim = 1
+    ldu   = 0
+    restart = .false.
+    n_rst   = 0
+    n_frozen = 0
+    n_mv = 0
+    n_restarts = 0
+!
+    1030 format(t5,'Generalized Davidson-Liu iterations (tol=',d10.2,'):',/, &
+                t5,'------------------------------------------------------------------',/, &
+                t7,'  iter  root              eigenvalue','         rms         max ok',/, &
+                t5,'------------------------------------------------------------------')
+    1040 format(t9,i4,2x,i4,f24.12,2d12.4,l3)
+    if (verbose) write(6,1030) tol
+!
+    do it = 1, max_iter
+      ldu = ldu + n_act
+      c0  = i_beg + n_rst
+!
+!     A times the new block (reference :1685)
+!
+      call get_time(t1)
+      call chk(ctx, dla_call_matvec(ctx, mv, n, n_act, colp(space,n,c0), colp(aspace,n,c0)), 'matvec')
+      call get_time(t2)
+      t_mv = t_mv + t2 - t1
+      n_mv = n_mv + n_act
+!
+!     new columns of the projected matrix (reference :1691)
+!
+      call chk(ctx, dla_gram(ctx, n, ldu, space, n_act, colp(aspace,n,c0), a_red(1,c0), lda), 'projection')
+!
+!     after a restart the locked roots enter through their eigenvalues (reference :1696-1702)
+!
+      if (restart) then
+        do i_eig = 1, n_rst
+          a_red(i_eig,i_eig) = e_red(i_eig)
+        end do
+        restart = .false.
+        n_rst   = 0
+      end if
+      a_copy = a_red
+!
+      call get_time(t1)
+      info = dla_syev_lowest('u', ldu, a_copy, lda, e_red, n_max)   ! only a_copy(:,1:n_max) is used below
+      call get_time(t2)
+      t_diag = t_diag + t2 - t1
+      if (info.ne.0) then
+        write(6,'(t3,a,i6)') 'dsyev failed. info = ',info
+        stop
+      end if
+      eig = e_red(1:n_max)
+!
+!     Ritz vectors, residuals and their norms in one sweep (reference :1717-1732)
+!
+      do i_eig = 1, n_max
+        skip(i_eig) = merge(1_c_int, 0_c_int, done(i_eig))
+      end do
+!     b_evec = BS y and r = AS y - eig * b_evec in one sweep, then evec = S y (reference :2108-2123)
+      call chk(ctx, dla_ritz_residual(ctx, n, ldu, n_max, bspace, aspace, a_copy, lda, eig, n_targ, skip, &
+                                      b_evec, r, c_null_ptr, r_norm), 'ritz/residual')
+      call chk(ctx, dla_panel_gemm(ctx, n, ldu, space, n_max, a_copy, lda, evd), 'ritz vectors')
+!
+!     lock the leading converged roots (reference :1737-1746)
+!
+      do i_eig = 1, n_targ
+        if (done(i_eig)) cycle
+        done(i_eig) = r_norm(1,i_eig).lt.tol_rms .and. r_norm(2,i_eig).lt.tol_max .and. it.gt.1
+        if (.not.done(i_eig)) then
+          done(i_eig+1:n_max) = .false.
+          exit
+        end if
+      end do
+!
+      if (verbose) then
+        do i_eig = 1, n_targ
+          write(6,1040) it, i_eig, eig(i_eig) - shift, r_norm(:,i_eig), done(i_eig)
+        end do
+        write(6,*)
+      end if
+!
+      if (all(done(1:n_targ))) then
+        ok = .true.
+        exit
+      end if
+!
+      if (m_dim .lt. dim_dav) then
+!
+!       expand: precondition the active residuals, orthogonalise against the space
+!       (reference :1773-1794)
+!
+        m_dim = m_dim + 1
+        i_beg = i_beg + n_act
+        n_act = n_max
+        n_frozen = 0
+        do i_eig = 1, n_targ
+          if (done(i_eig)) then
+            n_act = n_act - 1
+            n_frozen = n_frozen + 1
+          else
+            exit
+          end if
+        end do
+        ind = n_max - n_act + 1
+        call chk(ctx, dla_call_precnd(ctx, pc, n, n_act, -eig(ind), colp(r,n,ind), colp(space,n,i_beg)), 'precnd')
+        call get_time(t1)
+        call chk(ctx, dla_b_ortho_vs_x(ctx, n, ldu, n_act, space, bspace, colp(space,n,i_beg)), 'b_ortho_vs_x')
+        call chk(ctx, dla_call_matvec(ctx, bv, n, n_act, colp(space,n,i_beg), colp(bspace,n,i_beg)), 'bvec')
+        call chk(ctx, dla_b_ortho(ctx, n, n_act, colp(space,n,i_beg), colp(bspace,n,i_beg)), 'b_ortho')
+        call get_time(t2)
+        t_ortho = t_ortho + t2 - t1
+      else
+!
+!       restart from the current Ritz vectors (reference :1796-1824)
+!
+        if (verbose) write(6,'(t7,a)') 'Restarting davidson.'
+        n_restarts = n_restarts + 1
+        n_act = n_max
+        call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
+        call chk(ctx, dla_copy(ctx, bspace, b_evec, nbytes(n,n_max)), 'copy')
+        call chk(ctx, dla_b_ortho(ctx, n, n_max, space, bspace), 'b_ortho')     ! reference :2195-2197
+        a_red = zero
+        ldu   = 0
+        i_beg = 1
+        m_dim = 1
+        n_rst = 0
+        do i_eig = 1, n_targ
+          if (done(i_eig)) then
+            n_rst = n_rst + 1
+          else
+            exit
+          end if
+        end do
+!
+!       the reference zeroes space and aspace entirely (:1798,1804).  What the next iteration
+!       actually reads from those zeros: matvec takes n_max columns starting at column 1+n_rst,
+!       i.e. it runs n_rst columns past the Ritz block (they must be zero), and the locked
+!       columns 1..n_rst of aspace stay zero (their eigenvalues are patched into a_red, :1696-1702).
+!
+        if (n_rst.gt.0) then
+          call chk(ctx, dla_zero(ctx, colp(space,n,n_max+1), nbytes(n,n_rst)), 'zero')
+          call chk(ctx, dla_zero(ctx, aspace, nbytes(n,n_rst)), 'zero')
+        end if
+        restart = .true.
+      end if
+      if (verbose) write(6,1050) n_targ, n_act, n_frozen
+    end do
+!
+    call get_time(t2)
+    t_tot = t2 - t_tot
+    call dla_set_solve_info(int(min(it,max_iter),c_int), int(n_mv,c_int), int(n_restarts,c_int))
+!
+    1000 format(t3,'timings for davidson (cpu/wall): ',/, &
+                t3,'  matrix-vector multiplications: ',2f12.4,/, &
+                t3,'  diagonalization:               ',2f12.4,/, &
+                t3,'  orthogonalization:             ',2f12.4,/, &
+                t3,'                                 ',24('='),/,  &
+                t3,'  total:                         ',2f12.4)
+    if (verbose) write(6,1000) t_mv, t_diag, t_ortho, t_tot
+!
+!   hand the Ritz vectors back (evec holds them on every exit, like the reference) and free
+!
+    if (.not.evec_dev) then
+      call chk(ctx, dla_download(ctx, c_loc(evec), evd, nbytes(n,n_max)), 'download of evec')
+      call chk(ctx, dla_free(ctx, evd), 'free')
+    end if
+    call chk(ctx, dla_free(ctx, space), 'free')
+    call chk(ctx, dla_free(ctx, aspace), 'free')
+    call chk(ctx, dla_free(ctx, r), 'free')
+    call chk(ctx, dla_free(ctx, bspace), 'free')
+    call chk(ctx, dla_free(ctx, b_evec), 'free')
+    deallocate (done, skip, r_norm, a_red, a_copy, e_red)
+!
+    1050 format(t5,'----------------------------------------',/,&
+                t7,'# target vectors:    ',i4,/,&
+                t7,'# new vectors added: ',i4,/,&
+                t7,'# converged vectors: ',i4,/,&
+                t5,'----------------------------------------')
+    return
+  end subroutine gen_david_driver
+!
+! ---------------------------------------------------------------------------------------
 ! LOBPCG (reference diaglib.f90:171-556).  gen_eig=.true. is not on this path yet.
 ! ---------------------------------------------------------------------------------------
   subroutine lobpcg_driver(verbose,gen_eig,n,n_targ,n_max,max_iter,tol,shift,matvec,precnd,bvec,eig,evec,ok)
@@ -514,8 +781,8 @@ contains
     logical,                              intent(inout) :: ok
     external                                            :: matvec, precnd, bvec
 !
-    type(c_ptr)    :: ctx, space, aspace, r, x_new, ax_new, evd
-    type(c_funptr) :: mv, pc
+    type(c_ptr)    :: ctx, space, aspace, bspace, r, x_new, ax_new, bx_new, evd
+    type(c_funptr) :: mv, pc, bv
     integer        :: it, i_eig, n_act, ind_x, ind_w, ind_p, len_a, len_u, n_mv
     logical        :: evec_dev
     real(dp)       :: tol_rms, tol_max
@@ -524,14 +791,13 @@ contains
     real(dp),       allocatable :: a_red(:,:), e_red(:), r_norm(:,:), u_x(:,:), u_p(:,:)
     integer(c_int) :: info
 !
-    if (gen_eig) then
-      write(6,'(t3,a)') 'diaglib_amd: lobpcg_driver with gen_eig=.true. is not available in this build.'
-      stop
-    end if
     ctx = dla_default_ctx()
     mv  = c_funloc(matvec)
     pc  = c_funloc(precnd)
+    bv  = c_funloc(bvec)
     evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
+    bspace = c_null_ptr
+    bx_new = c_null_ptr
 !
     len_a = 3*n_max
     call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), space),  'allocation of space')
@@ -539,6 +805,11 @@ contains
     call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), r),      'allocation of r')
     call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), x_new),  'allocation of x_new')
     call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), ax_new), 'allocation of ax_new')
+    if (gen_eig) then
+!     (the reference allocates bspace/bx_new also for the standard problem, :259,270; here only when used)
+      call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), bspace), 'allocation of bspace')
+      call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), bx_new), 'allocation of bx_new')
+    end if
     if (evec_dev) then
       evd = c_loc(evec)
     else
@@ -560,6 +831,14 @@ contains
     call get_time(t_tot)
     call chk(ctx, dla_check_guess(ctx, n, n_max, evd), 'check_guess')
 !
+!   generalised problem: B times the guess, then B-orthonormalise it (reference :299-302)
+!
+    if (gen_eig) then
+      call chk(ctx, dla_call_matvec(ctx, bv, n, n_max, evd, bx_new), 'bvec')
+      call chk(ctx, dla_b_ortho(ctx, n, n_max, evd, bx_new), 'b_ortho')
+      call chk(ctx, dla_copy(ctx, bspace, bx_new, nbytes(n,n_max)), 'copy')
+    end if
+!
 !   first Rayleigh-Ritz step on the guess (reference :306-325)
 !
     call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
@@ -579,8 +858,16 @@ contains
 !   Ritz vectors x, a x and the first residuals r = a x - eig x in one sweep (:322-345)
 !
     skip = 0
-    call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, space, aspace, a_red, len_a, eig, n_max, skip, &
-                                    x_new, r, ax_new, r_norm), 'ritz/residual')
+    if (gen_eig) then
+!     b x = BS y and r = AS y - eig * (BS y) in one sweep over bspace/aspace, then x = S y (:322-346)
+      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, bspace, aspace, a_red, len_a, eig, n_max, skip, &
+                                      bx_new, r, ax_new, r_norm), 'ritz/residual')
+      call chk(ctx, dla_panel_gemm(ctx, n, n_max, space, n_max, a_red, len_a, x_new), 'ritz vectors')
+      call chk(ctx, dla_copy(ctx, bspace, bx_new, nbytes(n,n_max)), 'copy')
+    else
+      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, space, aspace, a_red, len_a, eig, n_max, skip, &
+                                      x_new, r, ax_new, r_norm), 'ritz/residual')
+    end if
     call chk(ctx, dla_copy(ctx, space,  x_new,  nbytes(n,n_max)), 'copy')
     call chk(ctx, dla_copy(ctx, aspace, ax_new, nbytes(n,n_max)), 'copy')
 !
@@ -590,7 +877,13 @@ contains
     ind_w = ind_x + n_max
     call chk(ctx, dla_call_precnd(ctx, pc, n, n_max, shift-eig(ind_x), colp(r,n,ind_x), colp(space,n,ind_w)), 'precnd')
     call get_time(t1)
-    call chk(ctx, dla_ortho_vs_x(ctx, n, n_max, n_max, space, colp(space,n,ind_w)), 'ortho_vs_x')
+    if (gen_eig) then
+      call chk(ctx, dla_b_ortho_vs_x(ctx, n, n_max, n_max, space, bspace, colp(space,n,ind_w)), 'b_ortho_vs_x')
+      call chk(ctx, dla_call_matvec(ctx, bv, n, n_max, colp(space,n,ind_w), colp(bspace,n,ind_w)), 'bvec')
+      call chk(ctx, dla_b_ortho(ctx, n, n_max, colp(space,n,ind_w), colp(bspace,n,ind_w)), 'b_ortho')
+    else
+      call chk(ctx, dla_ortho_vs_x(ctx, n, n_max, n_max, space, colp(space,n,ind_w)), 'ortho_vs_x')
+    end if
     call get_time(t2)
     t_ortho = t_ortho + t2 - t1
 !
@@ -639,8 +932,14 @@ contains
       do i_eig = 1, n_max
         skip(i_eig) = merge(1_c_int, 0_c_int, done(i_eig))
       end do
-      call chk(ctx, dla_ritz_residual(ctx, n, len_u, n_max, space, aspace, a_red, len_a, eig, n_max, skip, &
-                                      x_new, r, ax_new, r_norm), 'ritz/residual')
+      if (gen_eig) then
+        call chk(ctx, dla_ritz_residual(ctx, n, len_u, n_max, bspace, aspace, a_red, len_a, eig, n_max, skip, &
+                                        bx_new, r, ax_new, r_norm), 'ritz/residual')
+        call chk(ctx, dla_panel_gemm(ctx, n, len_u, space, n_max, a_red, len_a, x_new), 'ritz vectors')
+      else
+        call chk(ctx, dla_ritz_residual(ctx, n, len_u, n_max, space, aspace, a_red, len_a, eig, n_max, skip, &
+                                        x_new, r, ax_new, r_norm), 'ritz/residual')
+      end if
 !
 !     lock the leading converged roots (:446-455)
 !
@@ -677,18 +976,29 @@ contains
       call chk(ctx, dla_copy(ctx, colp(space,n,ind_p), evd, nbytes(n,n_act)), 'copy')
       call chk(ctx, dla_panel_gemm(ctx, n, len_u, aspace, n_act, u_p, len_u, evd), 'ap block')
       call chk(ctx, dla_copy(ctx, colp(aspace,n,ind_p), evd, nbytes(n,n_act)), 'copy')
+      if (gen_eig) then
+        call chk(ctx, dla_panel_gemm(ctx, n, len_u, bspace, n_act, u_p, len_u, evd), 'bp block')
+        call chk(ctx, dla_copy(ctx, colp(bspace,n,ind_p), evd, nbytes(n,n_act)), 'copy')
+      end if
       deallocate (u_x, u_p)
 !
 !     x_new, ax_new become the X block (:510-511)
 !
       call chk(ctx, dla_copy(ctx, space,  x_new,  nbytes(n,n_max)), 'copy')
       call chk(ctx, dla_copy(ctx, aspace, ax_new, nbytes(n,n_max)), 'copy')
+      if (gen_eig) call chk(ctx, dla_copy(ctx, bspace, bx_new, nbytes(n,n_max)), 'copy')
 !
 !     new W block: preconditioned active residuals, orthogonalised against [X P] (:518-528)
 !
       call chk(ctx, dla_call_precnd(ctx, pc, n, n_act, shift-eig(1), colp(r,n,ind_x), colp(space,n,ind_w)), 'precnd')
       call get_time(t1)
-      call chk(ctx, dla_ortho_vs_x(ctx, n, n_max+n_act, n_act, space, colp(space,n,ind_w)), 'ortho_vs_x')
+      if (gen_eig) then
+        call chk(ctx, dla_b_ortho_vs_x(ctx, n, n_max+n_act, n_act, space, bspace, colp(space,n,ind_w)), 'b_ortho_vs_x')
+        call chk(ctx, dla_call_matvec(ctx, bv, n, n_act, colp(space,n,ind_w), colp(bspace,n,ind_w)), 'bvec')
+        call chk(ctx, dla_b_ortho(ctx, n, n_act, colp(space,n,ind_w), colp(bspace,n,ind_w)), 'b_ortho')
+      else
+        call chk(ctx, dla_ortho_vs_x(ctx, n, n_max+n_act, n_act, space, colp(space,n,ind_w)), 'ortho_vs_x')
+      end if
       call get_time(t2)
       t_ortho = t_ortho + t2 - t1
     end do
@@ -719,6 +1029,10 @@ contains
     call chk(ctx, dla_free(ctx, r), 'free')
     call chk(ctx, dla_free(ctx, x_new), 'free')
     call chk(ctx, dla_free(ctx, ax_new), 'free')
+    if (gen_eig) then
+      call chk(ctx, dla_free(ctx, bspace), 'free')
+      call chk(ctx, dla_free(ctx, bx_new), 'free')
+    end if
     deallocate (a_red, e_red, done, skip, r_norm)
     return
   end subroutine lobpcg_driver

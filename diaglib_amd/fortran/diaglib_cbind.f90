@@ -6,7 +6,7 @@
 !
 module diaglib_cbind
   use iso_c_binding
-  use diaglib, only : davidson_driver, lobpcg_driver
+  use diaglib, only : davidson_driver, lobpcg_driver, gen_david_driver
   implicit none
 !
   abstract interface
@@ -41,6 +41,24 @@ contains
     call davidson_driver(verbose.ne.0,n,n_targ,n_max,max_iter,tol,max_dav,shift,mv,pc,eig,evec,lok)
     ok = merge(1_c_int, 0_c_int, lok)
   end subroutine dla_davidson_driver
+!
+  subroutine dla_gen_david_driver(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift, &
+                                  matvec,precnd,bvec,eig,evec,ok) bind(C,name='dla_gen_david_driver')
+    integer(c_int), value :: verbose, n, n_targ, n_max, max_iter, max_dav
+    real(c_double), value :: tol, shift
+    type(c_funptr), value :: matvec, precnd, bvec
+    real(c_double)        :: eig(n_max), evec(n,n_max)
+    integer(c_int)        :: ok
+    procedure(mv_iface), pointer :: mv, bv
+    procedure(pc_iface), pointer :: pc
+    logical :: lok
+    call c_f_procpointer(matvec, mv)
+    call c_f_procpointer(precnd, pc)
+    call c_f_procpointer(bvec, bv)
+    lok = .false.
+    call gen_david_driver(verbose.ne.0,n,n_targ,n_max,max_iter,tol,max_dav,shift,mv,pc,bv,eig,evec,lok)
+    ok = merge(1_c_int, 0_c_int, lok)
+  end subroutine dla_gen_david_driver
 !
   subroutine dla_lobpcg_driver(verbose,gen_eig,n,n_targ,n_max,max_iter,tol,shift, &
                                matvec,precnd,bvec,eig,evec,ok) bind(C,name='dla_lobpcg_driver')

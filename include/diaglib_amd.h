@@ -175,11 +175,14 @@ void dla_synth_matvec(const int* n, const int* m, const double* x_dev, double* a
 void dla_synth_precnd(const int* n, const int* m, const double* fac, const double* x_dev, double* px_dev);
 
 /* ---------------------------------------------------------------- drivers (Fortran, bind(C) twins of the
- * module procedures davidson_driver / lobpcg_driver; argument meaning as reference
+ * module procedures davidson_driver / gen_david_driver / lobpcg_driver; argument meaning as reference
  * diaglib.f90:1483-1539 and 171-228; logicals as int 0/1) */
 void dla_davidson_driver(int verbose, int n, int n_targ, int n_max, int max_iter, double tol, int max_dav,
                          double shift, dla_matvec_fn matvec, dla_precnd_fn precnd,
                          double* eig, double* evec, int* ok);
+void dla_gen_david_driver(int verbose, int n, int n_targ, int n_max, int max_iter, double tol, int max_dav,
+                          double shift, dla_matvec_fn matvec, dla_precnd_fn precnd, dla_matvec_fn bvec,
+                          double* eig, double* evec, int* ok);      /* reference diaglib.f90:1855-2250 */
 void dla_lobpcg_driver(int verbose, int gen_eig, int n, int n_targ, int n_max, int max_iter, double tol,
                        double shift, dla_matvec_fn matvec, dla_precnd_fn precnd, dla_matvec_fn bvec,
                        double* eig, double* evec, int* ok);

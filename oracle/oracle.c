@@ -601,10 +601,11 @@ void orc_davidson(int verbose, int n, int n_targ, int n_max, int max_iter, doubl
   free(space); free(aspace); free(r); free(a_red); free(a_copy); free(e_red); free(rn); free(done);
 }
 
-/* diaglib.f90:171-556, gen_eig=.false. branch. */
-void orc_lobpcg(int verbose, int n, int n_targ, int n_max, int max_iter, double tol,
-                double shift, orc_matvec_t matvec, orc_precnd_t precnd,
-                double* eig, double* evec, int* ok, orc_trace* tr)
+/* diaglib.f90:171-556.  gen != 0 follows the gen_eig=.true. statements (bvec callback, bspace panel,
+ * b_ortho / b_ortho_vs_x); gen == 0 is the standard problem. */
+static void lobpcg_impl(int verbose, int gen, int n, int n_targ, int n_max, int max_iter, double tol,
+                        double shift, orc_matvec_t matvec, orc_precnd_t precnd, orc_matvec_t bvec,
+                        double* eig, double* evec, int* ok, orc_trace* tr)
 {
   int len_a = 3 * n_max;                                    /* 258 */
   size_t nn = (size_t)n;
@@ -613,6 +614,8 @@ void orc_lobpcg(int verbose, int n, int n_targ, int n_max, int max_iter, double 
   double* r      = (double*)calloc(nn * n_max, sizeof(double));
   double* x_new  = (double*)calloc(nn * n_max, sizeof(double));
   double* ax_new = (double*)calloc(nn * n_max, sizeof(double));
+  double* bspace = (double*)calloc(nn * len_a, sizeof(double));   /* allocated also for gen=0 in the reference (259) */
+  double* bx_new = (double*)calloc(nn * n_max, sizeof(double));
   double* a_red  = (double*)calloc((size_t)len_a * len_a, sizeof(double));
   double* e_red  = (double*)calloc((size_t)len_a, sizeof(double));
   double* rn     = (double*)calloc((size_t)2 * n_max, sizeof(double));
@@ -620,7 +623,12 @@ void orc_lobpcg(int verbose, int n, int n_targ, int n_max, int max_iter, double 
   if (tr) { tr->iters = 0; tr->matvec_cols = 0; tr->restarts = 0; }
 
   orc_check_guess(n, n_max, evec);                          /* 295 */
+  if (gen) {                                                /* 299-302 */
+    bvec(&n, &n_max, evec, bx_new);
+    orc_b_ortho(n, n_max, evec, bx_new);
+  }
   memcpy(space, evec, sizeof(double) * nn * n_max);         /* 306 */
+  if (gen) memcpy(bspace, bx_new, sizeof(double) * nn * n_max);   /* 307 */
   matvec(&n, &n_max, space, aspace);                        /* 309 */
   if (tr) tr->matvec_cols += n_max;
   if (shift != 0.0)                                         /* 312 */
@@ -632,15 +640,28 @@ void orc_lobpcg(int verbose, int n, int n_targ, int n_max, int max_iter, double 
   memcpy(space, evec, sizeof(double) * nn * n_max);
   orc_gemm_nn(n, n_max, n_max, 1.0, aspace, n, a_red, len_a, 0.0, evec, n); /* 324-325 */
   memcpy(aspace, evec, sizeof(double) * nn * n_max);
+  if (gen) {                                                /* 329-332 */
+    orc_gemm_nn(n, n_max, n_max, 1.0, bspace, n, a_red, len_a, 0.0, evec, n);
+    memcpy(bspace, evec, sizeof(double) * nn * n_max);
+  }
   memcpy(r, aspace, sizeof(double) * nn * n_max);           /* 337 */
-  for (int i = 0; i < n_max; ++i)                           /* 343-345 */
-    for (size_t p = 0; p < nn; ++p) r[nn * i + p] -= eig[i] * space[nn * i + p];
+  {
+    const double* xb = gen ? bspace : space;                /* 338-346 */
+    for (int i = 0; i < n_max; ++i)
+      for (size_t p = 0; p < nn; ++p) r[nn * i + p] -= eig[i] * xb[nn * i + p];
+  }
   int ind_x = 0, ind_w = n_max, ind_p = 0;                  /* 350-351 */
   {
     double fac = shift - eig[ind_x];
     precnd(&n, &n_max, &fac, r + nn * ind_x, space + nn * ind_w);           /* 352 */
   }
-  orc_ortho_vs_x(n, n_max, n_max, space, space + nn * ind_w, NULL);         /* 366 */
+  if (gen) {                                                /* 357-364 */
+    orc_b_ortho_vs_x(n, n_max, n_max, space, bspace, space + nn * ind_w);
+    bvec(&n, &n_max, space + nn * ind_w, bspace + nn * ind_w);
+    orc_b_ortho(n, n_max, space + nn * ind_w, bspace + nn * ind_w);
+  } else {
+    orc_ortho_vs_x(n, n_max, n_max, space, space + nn * ind_w, NULL);       /* 366 */
+  }
 
   double tol_rms = tol, tol_max = 10.0 * tol, sqrtn = sqrt((double)n);      /* 374-376 */
   *ok = 0;
@@ -659,10 +680,11 @@ void orc_lobpcg(int verbose, int n, int n_targ, int n_max, int max_iter, double 
     for (int i = 0; i < n_max; ++i) eig[i] = e_red[i];      /* 416 */
     orc_gemm_nn(n, len_u, n_max, 1.0, space, n, a_red, len_a, 0.0, x_new, n);   /* 420 */
     orc_gemm_nn(n, len_u, n_max, 1.0, aspace, n, a_red, len_a, 0.0, ax_new, n); /* 421 */
+    if (gen) orc_gemm_nn(n, len_u, n_max, 1.0, bspace, n, a_red, len_a, 0.0, bx_new, n); /* 423 */
     memcpy(r, ax_new, sizeof(double) * nn * n_max);         /* 428 */
     for (int i = 0; i < n_max; ++i) {                       /* 429-442 */
       if (done[i]) continue;
-      double* ri = r + nn * i; const double* xi = x_new + nn * i;
+      double* ri = r + nn * i; const double* xi = (gen ? bx_new : x_new) + nn * i;
       double s = 0.0, mx = 0.0;
       for (size_t p = 0; p < nn; ++p) {
         ri[p] -= eig[i] * xi[p];
@@ -702,14 +724,142 @@ void orc_lobpcg(int verbose, int n, int n_targ, int n_max, int max_iter, double 
     orc_gemm_nn(n, len_u, n_act, 1.0, aspace, n, u_p, len_u, 0.0, evec, n);
     memcpy(space + nn * ind_p, ptmp, sizeof(double) * nn * n_act);
     memcpy(aspace + nn * ind_p, evec, sizeof(double) * nn * n_act);
+    if (gen) {                                              /* 500-503 */
+      orc_gemm_nn(n, len_u, n_act, 1.0, bspace, n, u_p, len_u, 0.0, evec, n);
+      memcpy(bspace + nn * ind_p, evec, sizeof(double) * nn * n_act);
+    }
     free(ptmp); free(u_x); free(u_p);
     memcpy(space, x_new, sizeof(double) * nn * n_max);      /* 510 */
     memcpy(aspace, ax_new, sizeof(double) * nn * n_max);    /* 511 */
+    if (gen) memcpy(bspace, bx_new, sizeof(double) * nn * n_max);   /* 513 */
     {
       double fac = shift - eig[0];                          /* 518 */
       precnd(&n, &n_act, &fac, r + nn * ind_x, space + nn * ind_w);
     }
-    orc_ortho_vs_x(n, n_max + n_act, n_act, space, space + nn * ind_w, NULL); /* 528 */
+    if (gen) {                                              /* 523-526 */
+      orc_b_ortho_vs_x(n, n_max + n_act, n_act, space, bspace, space + nn * ind_w);
+      bvec(&n, &n_act, space + nn * ind_w, bspace + nn * ind_w);
+      orc_b_ortho(n, n_act, space + nn * ind_w, bspace + nn * ind_w);
+    } else {
+      orc_ortho_vs_x(n, n_max + n_act, n_act, space, space + nn * ind_w, NULL); /* 528 */
+    }
   }
-  free(space); free(aspace); free(r); free(x_new); free(ax_new); free(a_red); free(e_red); free(rn); free(done);
+  free(space); free(aspace); free(bspace); free(bx_new); free(r); free(x_new); free(ax_new); free(a_red); free(e_red);
+  free(rn); free(done);
+}
+
+void orc_lobpcg(int verbose, int n, int n_targ, int n_max, int max_iter, double tol,
+                double shift, orc_matvec_t matvec, orc_precnd_t precnd,
+                double* eig, double* evec, int* ok, orc_trace* tr)
+{
+  lobpcg_impl(verbose, 0, n, n_targ, n_max, max_iter, tol, shift, matvec, precnd, matvec, eig, evec, ok, tr);
+}
+
+void orc_lobpcg_gen(int verbose, int n, int n_targ, int n_max, int max_iter, double tol,
+                    double shift, orc_matvec_t matvec, orc_precnd_t precnd, orc_matvec_t bvec,
+                    double* eig, double* evec, int* ok, orc_trace* tr)
+{
+  lobpcg_impl(verbose, 1, n, n_targ, n_max, max_iter, tol, shift, matvec, precnd, bvec, eig, evec, ok, tr);
+}
+
+/* diaglib.f90:1855-2250: Davidson-Liu with a metric B (bvec callback).  Same loop as orc_davidson plus the
+ * bspace = B*space panel: the guess is B-orthonormalised (2033-2034), residuals are A x - theta B x (2113-2123),
+ * new blocks go through b_ortho_vs_x + bvec + b_ortho (2183-2185).
+ * DELIBERATE DEVIATION at the restart: the reference zeroes ALL of bspace right after it has
+ * B-orthonormalised the kept Ritz block (2196-2200) and never refills it (the bvec call at 2072 is commented
+ * out), so every residual after a restart misses theta*B*x of the kept block.  Here the kept block's B*x
+ * (already available, b_ortho updates it) stays in bspace(:,1:n_max); everything else follows the reference.
+ * Runs without a restart are identical to the reference. */
+void orc_gen_davidson(int verbose, int n, int n_targ, int n_max, int max_iter, double tol, int max_dav,
+                      double shift, orc_matvec_t matvec, orc_precnd_t precnd, orc_matvec_t bvec,
+                      double* eig, double* evec, int* ok, orc_trace* tr)
+{
+  const int min_dav = 10;
+  int dim_dav = max_dav > min_dav ? max_dav : min_dav;
+  int lda = dim_dav * n_max;
+  size_t nn = (size_t)n;
+  double* space  = (double*)calloc(nn * lda, sizeof(double));
+  double* aspace = (double*)calloc(nn * lda, sizeof(double));
+  double* bspace = (double*)calloc(nn * lda, sizeof(double));
+  double* r      = (double*)calloc(nn * n_max, sizeof(double));
+  double* b_evec = (double*)calloc(nn * n_max, sizeof(double));
+  double* a_red  = (double*)calloc((size_t)lda * lda, sizeof(double));
+  double* a_copy = (double*)calloc((size_t)lda * lda, sizeof(double));
+  double* e_red  = (double*)calloc((size_t)lda, sizeof(double));
+  double* rn     = (double*)calloc((size_t)2 * n_max, sizeof(double));
+  int*    done   = (int*)calloc((size_t)n_max, sizeof(int));
+  double sqrtn = sqrt((double)n), tol_rms = tol, tol_max = 10.0 * tol;
+  *ok = 0;
+  if (tr) { tr->iters = 0; tr->matvec_cols = 0; tr->restarts = 0; }
+
+  orc_check_guess(n, n_max, evec);                          /* 2025 */
+  memcpy(space, evec, sizeof(double) * nn * n_max);         /* 2029 */
+  bvec(&n, &n_max, space, bspace);                          /* 2033 */
+  orc_b_ortho(n, n_max, space, bspace);                     /* 2034 */
+
+  int n_act = n_max, i_beg = 0, m_dim = 1, ldu = 0, restart = 0, n_rst = 0;
+  if (verbose) printf("    Generalized Davidson-Liu iterations (tol=%10.2E):\n", tol);
+  for (int it = 1; it <= max_iter; ++it) {
+    ldu += n_act;
+    int c0 = i_beg + n_rst;
+    matvec(&n, &n_act, space + nn * c0, aspace + nn * c0);  /* 2071 */
+    if (tr) tr->matvec_cols += n_act;
+    orc_gemm_tn(n, ldu, n_act, space, n, aspace + nn * c0, n, a_red + (size_t)lda * c0, lda);  /* 2079 */
+    if (restart) {
+      for (int i = 0; i < n_rst; ++i) A_(a_red, lda, i, i) = e_red[i];
+      restart = 0; n_rst = 0;
+    }
+    memcpy(a_copy, a_red, sizeof(double) * (size_t)lda * lda);
+    orc_syev('u', ldu, a_copy, lda, e_red);                 /* 2099 */
+    for (int i = 0; i < n_max; ++i) eig[i] = e_red[i];
+    orc_gemm_nn(n, ldu, n_max, 1.0, space, n, a_copy, lda, 0.0, evec, n);    /* 2108 */
+    orc_gemm_nn(n, ldu, n_max, 1.0, aspace, n, a_copy, lda, 0.0, r, n);      /* 2112 */
+    orc_gemm_nn(n, ldu, n_max, 1.0, bspace, n, a_copy, lda, 0.0, b_evec, n); /* 2113 */
+    for (int i = 0; i < n_targ; ++i) {                      /* 2115-2124 */
+      if (done[i]) continue;
+      double* ri = r + nn * i; const double* bi = b_evec + nn * i;
+      double s = 0.0, mx = 0.0;
+      for (size_t p = 0; p < nn; ++p) {
+        ri[p] -= eig[i] * bi[p];
+        s += ri[p] * ri[p];
+        double a = fabs(ri[p]); if (a > mx) mx = a;
+      }
+      rn[2 * i] = sqrt(s) / sqrtn; rn[2 * i + 1] = mx;
+    }
+    for (int i = 0; i < n_targ; ++i) {
+      if (done[i]) continue;
+      done[i] = (rn[2 * i] < tol_rms) && (rn[2 * i + 1] < tol_max) && (it > 1);
+      if (!done[i]) { for (int j = i + 1; j < n_max; ++j) done[j] = 0; break; }
+    }
+    trace_put(tr, it - 1, n_targ, n_act, ldu, eig, shift, rn, done);
+    if (verbose) print_iter(it, n_targ, eig, shift, rn, done);
+    int all = 1;
+    for (int i = 0; i < n_targ; ++i) all = all && done[i];
+    if (all) { *ok = 1; break; }
+    if (m_dim < dim_dav) {
+      m_dim++; i_beg += n_act; n_act = n_max;
+      for (int i = 0; i < n_targ; ++i) { if (done[i]) n_act--; else break; }
+      int ind0 = n_max - n_act;
+      double fac = -eig[ind0];
+      precnd(&n, &n_act, &fac, r + nn * ind0, space + nn * i_beg);                    /* 2177 */
+      if (orc_b_ortho_vs_x(n, ldu, n_act, space, bspace, space + nn * i_beg)) break;  /* 2183 */
+      bvec(&n, &n_act, space + nn * i_beg, bspace + nn * i_beg);                      /* 2184 */
+      orc_b_ortho(n, n_act, space + nn * i_beg, bspace + nn * i_beg);                 /* 2185 */
+    } else {
+      if (verbose) printf("      Restarting davidson.\n");
+      if (tr) tr->restarts++;
+      n_act = n_max;
+      memset(space, 0, sizeof(double) * nn * lda);
+      memcpy(space, evec, sizeof(double) * nn * n_max);     /* 2195 */
+      memset(bspace, 0, sizeof(double) * nn * lda);
+      memcpy(bspace, b_evec, sizeof(double) * nn * n_max);  /* 2196 */
+      orc_b_ortho(n, n_max, space, bspace);                 /* 2197; bspace(:,1:n_max) is KEPT, see header */
+      memset(aspace, 0, sizeof(double) * nn * lda);
+      memset(a_red, 0, sizeof(double) * (size_t)lda * lda);
+      ldu = 0; i_beg = 0; m_dim = 1; n_rst = 0;
+      for (int i = 0; i < n_targ; ++i) { if (done[i]) n_rst++; else break; }
+      restart = 1;
+    }
+  }
+  free(space); free(aspace); free(bspace); free(r); free(b_evec); free(a_red); free(a_copy); free(e_red); free(rn); free(done);
 }

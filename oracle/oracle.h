@@ -69,6 +69,13 @@ void orc_lobpcg(int verbose, int n, int n_targ, int n_max, int max_iter, double 
                 double shift, orc_matvec_t matvec, orc_precnd_t precnd,
                 double* eig, double* evec, int* ok, orc_trace* tr);                     /* diaglib.f90:171-556, gen_eig=.false. */
 
+void orc_lobpcg_gen(int verbose, int n, int n_targ, int n_max, int max_iter, double tol,
+                    double shift, orc_matvec_t matvec, orc_precnd_t precnd, orc_matvec_t bvec,
+                    double* eig, double* evec, int* ok, orc_trace* tr);                 /* diaglib.f90:171-556, gen_eig=.true. */
+void orc_gen_davidson(int verbose, int n, int n_targ, int n_max, int max_iter, double tol, int max_dav,
+                      double shift, orc_matvec_t matvec, orc_precnd_t precnd, orc_matvec_t bvec,
+                      double* eig, double* evec, int* ok, orc_trace* tr);               /* diaglib.f90:1855-2250 */
+
 /* ---- portable counter-based generator shared by oracle and product ---- */
 double orc_u01(unsigned long long seed, unsigned long long i, unsigned long long j);    /* uniform [0,1) */
 
@@ -83,6 +90,12 @@ const double* orc_synth_diag(void);  /* a_ii = d_i + sigma*|W_i|^2 */
 void orc_dense_setup(int n);
 void orc_dense_matvec(const int* n, const int* m, const double* x, double* ax);
 void orc_dense_precnd(const int* n, const int* m, const double* fac, const double* x, double* px);
+/* dense SPD metric for the generalised problem: S = I + (0.5/8) G G^T, G n x 8, G(i,j) = u01(3,i,j) - 0.5
+ * (the reference harness uses S = R^T R with R uniform random, main.f90:429-430: same role, but that one is
+ * numerically singular; tests want a metric both solvers can factor) */
+void orc_metric_setup(int n);
+void orc_metric_matvec(const int* n, const int* m, const double* x, double* sx);
+const double* orc_metric(void);
 
 #ifdef __cplusplus
 }

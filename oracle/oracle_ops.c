@@ -63,6 +63,46 @@ void orc_dense_precnd(const int* pn, const int* pm, const double* fac, const dou
     }
 }
 
+/* ---------------- dense SPD metric (generalised problem) ---------------- */
+static int     g_mn = 0;
+static double* g_ms = NULL;
+
+void orc_metric_setup(int n)
+{
+  free(g_ms);
+  g_mn = n;
+  g_ms = (double*)calloc((size_t)n * n, sizeof(double));
+  const int kw = 8;   /* S = I + (0.5/kw) G G^T with G n x kw: SPD, condition number O(1 + n/kw) */
+  double* g = (double*)malloc(sizeof(double) * (size_t)n * kw);
+  for (int j = 0; j < kw; ++j)
+    for (int i = 0; i < n; ++i) g[(size_t)j * n + i] = orc_u01(3ULL, (unsigned long long)(i + 1), (unsigned long long)(j + 1)) - 0.5;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double s = 0.0;
+      for (int q = 0; q < kw; ++q) s += g[(size_t)q * n + i] * g[(size_t)q * n + j];
+      g_ms[(size_t)j * n + i] = (0.5 / kw) * s + (i == j ? 1.0 : 0.0);
+    }
+  free(g);
+}
+
+const double* orc_metric(void) { return g_ms; }
+
+void orc_metric_matvec(const int* pn, const int* pm, const double* x, double* sx)
+{
+  int n = *pn, m = *pm;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    const double* row = g_ms + (size_t)i * n;
+    for (int c = 0; c < m; ++c) {
+      const double* xc = x + (size_t)c * n;
+      double s = 0.0;
+      for (int j = 0; j < n; ++j) s += row[j] * xc[j];
+      sx[(size_t)c * n + i] = s;
+    }
+  }
+}
+
 /* ---------------- synthetic matrix-free ---------------- */
 static long long g_row0 = 0;
 static int       g_nl = 0, g_rw = 0;

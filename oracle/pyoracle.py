@@ -80,6 +80,11 @@ class Oracle:
                                                    c_dp, c_dp, c_ip, C.c_void_p]
         L.orc_lobpcg.argtypes = [C.c_int] * 5 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                                  c_dp, c_dp, c_ip, C.c_void_p]
+        L.orc_lobpcg_gen.argtypes = [C.c_int] * 5 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     c_dp, c_dp, c_ip, C.c_void_p]
+        L.orc_gen_davidson.argtypes = [C.c_int] * 5 + [C.c_double, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       c_dp, c_dp, c_ip, C.c_void_p]
+        L.orc_metric.restype = c_dp
         L.orc_gemm_nn.argtypes = [C.c_int] * 3 + [C.c_double, c_dp, C.c_int, c_dp, C.c_int, C.c_double, c_dp, C.c_int]
 
     # ---- callbacks as raw addresses (usable by oracle, reference and product alike)
@@ -169,6 +174,10 @@ class Oracle:
     def dense_setup(self, n):
         self.lib.orc_dense_setup(n)
 
+    def metric_setup(self, n):
+        self.lib.orc_metric_setup(n)
+        return np.ctypeslib.as_array(self.lib.orc_metric(), (n, n)).copy(order="F")
+
     def synth_setup(self, n_global, row0, n_local, rank_w=4, sigma=0.5):
         self.lib.orc_synth_setup(n_global, row0, n_local, rank_w, sigma)
         self._synth = (n_local, rank_w)
@@ -217,6 +226,30 @@ class Oracle:
         return eig, evec, bool(ok.value), self._fin_trace(t, ct)
 
 
+def _gen_methods():
+    def lobpcg_gen(self, n, n_targ, n_max, max_iter, tol, shift, matvec, precnd, bvec, evec, verbose=False):
+        evec = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
+        eig = np.zeros(n_max); ok = C.c_int(0)
+        t, ct = self._mk_trace(max_iter, n_targ)
+        self.lib.orc_lobpcg_gen(int(verbose), n, n_targ, n_max, max_iter, tol, shift, matvec, precnd, bvec,
+                                _p(eig), _p(evec), C.byref(ok), C.addressof(ct))
+        return eig, evec, bool(ok.value), self._fin_trace(t, ct)
+
+    def gen_davidson(self, n, n_targ, n_max, max_iter, tol, max_dav, shift, matvec, precnd, bvec, evec, verbose=False):
+        evec = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
+        eig = np.zeros(n_max); ok = C.c_int(0)
+        t, ct = self._mk_trace(max_iter, n_targ)
+        self.lib.orc_gen_davidson(int(verbose), n, n_targ, n_max, max_iter, tol, max_dav, shift, matvec, precnd, bvec,
+                                  _p(eig), _p(evec), C.byref(ok), C.addressof(ct))
+        return eig, evec, bool(ok.value), self._fin_trace(t, ct)
+
+    Oracle.lobpcg_gen = lobpcg_gen
+    Oracle.gen_davidson = gen_davidson
+
+
+_gen_methods()
+
+
 class Reference:
     """The unmodified reference, compiled by oracle/Makefile into _ref/ (flang + MKL)."""
 
@@ -228,6 +261,9 @@ class Reference:
                                                    c_dp, c_dp, c_ip]
         L.ref_lobpcg.argtypes = [C.c_int] * 6 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  c_dp, c_dp, c_ip]
+        if hasattr(L, "ref_gen_david"):
+            L.ref_gen_david.argtypes = [C.c_int] * 5 + [C.c_double, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                        c_dp, c_dp, c_ip]
         # private module procedures are still global symbols in the object (flang mangling)
         self._norm_est = getattr(L, "_QMdiaglibPnorm_est")
         self._norm_est.restype = C.c_double
@@ -286,9 +322,16 @@ class Reference:
                               _p(eig), _p(evec), C.byref(ok))
         return eig, evec, bool(ok.value)
 
+    def gen_davidson(self, n, n_targ, n_max, max_iter, tol, max_dav, shift, matvec, precnd, bvec, evec, verbose=False):
+        evec = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
+        eig = np.zeros(n_max); ok = C.c_int(0)
+        self.lib.ref_gen_david(int(verbose), n, n_targ, n_max, max_iter, tol, max_dav, shift, matvec, precnd, bvec,
+                               _p(eig), _p(evec), C.byref(ok))
+        return eig, evec, bool(ok.value)
+
     def lobpcg(self, n, n_targ, n_max, max_iter, tol, shift, matvec, precnd, evec, verbose=False, bvec=None):
         evec = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
         eig = np.zeros(n_max); ok = C.c_int(0)
-        self.lib.ref_lobpcg(int(verbose), 0, n, n_targ, n_max, max_iter, tol, shift, matvec, precnd,
+        self.lib.ref_lobpcg(int(verbose), 0 if bvec is None else 1, n, n_targ, n_max, max_iter, tol, shift, matvec, precnd,
                             bvec if bvec is not None else matvec, _p(eig), _p(evec), C.byref(ok))
         return eig, evec, bool(ok.value)

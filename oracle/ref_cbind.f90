@@ -12,7 +12,7 @@
 !
 module ref_cbind
   use iso_c_binding
-  use diaglib, only : davidson_driver, lobpcg_driver, ortho_cd, ortho_vs_x, &
+  use diaglib, only : davidson_driver, lobpcg_driver, gen_david_driver, ortho_cd, ortho_vs_x, &
                       b_ortho, b_ortho_vs_x
   implicit none
 !
@@ -71,6 +71,26 @@ contains
     ok = 0
     if (lok) ok = 1
   end subroutine ref_lobpcg
+!
+  subroutine ref_gen_david(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift, &
+                           matvec,precnd,bvec,eig,evec,ok) bind(C,name='ref_gen_david')
+    integer(c_int), value :: verbose, n, n_targ, n_max, max_iter, max_dav
+    real(c_double), value :: tol, shift
+    type(c_funptr), value :: matvec, precnd, bvec
+    real(c_double)        :: eig(n_max), evec(n,n_max)
+    integer(c_int)        :: ok
+    procedure(mv_iface), pointer :: mv, bv
+    procedure(pc_iface), pointer :: pc
+    logical :: lok, lverb
+    call c_f_procpointer(matvec, mv)
+    call c_f_procpointer(precnd, pc)
+    call c_f_procpointer(bvec, bv)
+    lok = .false.
+    lverb = verbose .ne. 0
+    call gen_david_driver(lverb,n,n_targ,n_max,max_iter,tol,max_dav,shift,mv,pc,bv,eig,evec,lok)
+    ok = 0
+    if (lok) ok = 1
+  end subroutine ref_gen_david
 !
   subroutine ref_ortho_cd(n,m,u,growth,ok) bind(C,name='ref_ortho_cd')
     integer(c_int), value :: n, m

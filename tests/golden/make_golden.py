@@ -63,7 +63,13 @@ if spec['op'] == 'dense':
 else:
     o.synth_setup(n, 0, n); mv, pc = o.fn('orc_synth_matvec'), o.fn('orc_synth_precnd')
 g = np.load(spec['guess'])
-if spec['solver'] == 'davidson':
+if spec.get('gen'):
+    o.metric_setup(n); bv = o.fn('orc_metric_matvec')
+if spec['solver'] == 'gen_davidson':
+    e, v, ok = r.gen_davidson(n, T, M, spec['max_iter'], spec['tol'], spec['max_dav'], spec['shift'], mv, pc, bv, g, verbose=True)
+elif spec['solver'] == 'lobpcg' and spec.get('gen'):
+    e, v, ok = r.lobpcg(n, T, M, spec['max_iter'], spec['tol'], spec['shift'], mv, pc, g, verbose=True, bvec=bv)
+elif spec['solver'] == 'davidson':
     e, v, ok = r.davidson(n, T, M, spec['max_iter'], spec['tol'], spec['max_dav'], spec['shift'], mv, pc, g, verbose=True)
 else:
     e, v, ok = r.lobpcg(n, T, M, spec['max_iter'], spec['tol'], spec['shift'], mv, pc, g, verbose=True)
@@ -154,6 +160,9 @@ def main():
         dict(name="lob_n2000_unit", solver="lobpcg", op="dense", n=2000, n_targ=4, n_max=8, max_dav=0, guess="unit"),
         dict(name="lob_n2000_rand", solver="lobpcg", op="dense", n=2000, n_targ=4, n_max=8, max_dav=0, guess="rand"),
         dict(name="lob_n800_shift", solver="lobpcg", op="dense", n=800, n_targ=3, n_max=6, max_dav=0, guess="rand", shift=0.75),
+        dict(name="gdav_n600_unit", solver="gen_davidson", op="dense", gen=True, n=600, n_targ=4, n_max=8, max_dav=20, guess="unit"),
+        dict(name="gdav_n600_rand", solver="gen_davidson", op="dense", gen=True, n=600, n_targ=4, n_max=8, max_dav=20, guess="rand"),
+        dict(name="glob_n600_unit", solver="lobpcg", op="dense", gen=True, n=600, n_targ=4, n_max=8, max_dav=0, guess="unit"),
         dict(name="dav_synth_n100000", solver="davidson", op="synth", n=100000, n_targ=8, n_max=13, max_dav=20, guess="unit"),
         dict(name="lob_synth_n100000", solver="lobpcg", op="synth", n=100000, n_targ=8, n_max=13, max_dav=0, guess="unit"),
     ]

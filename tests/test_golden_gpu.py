@@ -65,7 +65,8 @@ def _guess(kind, n, m, seed):
 
 
 @pytest.mark.parametrize("name", ["dav_n1000_unit", "dav_n2000_unit", "dav_n2000_rand", "dav_n600_rand_dav10",
-                                  "lob_n1000_unit", "lob_n2000_unit", "lob_n2000_rand", "lob_n800_shift"])
+                                  "lob_n1000_unit", "lob_n2000_unit", "lob_n2000_rand", "lob_n800_shift",
+                                  "gdav_n600_unit", "gdav_n600_rand", "glob_n600_unit"])
 def test_drivers_vs_reference_results(ctx, oracle, gold, name):
     """Reference's dense test matrix (main.f90:311-317), host callbacks: eigenvalues, eigenvectors and
     iteration counts against what the unmodified reference produced for the same guess."""
@@ -75,18 +76,35 @@ def test_drivers_vs_reference_results(ctx, oracle, gold, name):
     oracle.dense_setup(n)                      # the C operator is only the callback here
     mv, pc = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd")
     ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
-    if sp["solver"] == "davidson":
+    if sp.get("gen"):
+        oracle.metric_setup(n); bv = oracle.fn("orc_metric_matvec")      # generalised problem: B through a host callback
+    if sp["solver"] == "gen_davidson":
+        eig, vec, ok, info = ctx.gen_david_driver(n, t, m, sp["max_iter"], sp["tol"], sp["max_dav"], sp["shift"], mv, pc, bv, g)
+    elif sp["solver"] == "lobpcg" and sp.get("gen"):
+        eig, vec, ok, info = ctx.lobpcg_driver(n, t, m, sp["max_iter"], sp["tol"], sp["shift"], mv, pc, g, bvec=bv)
+    elif sp["solver"] == "davidson":
         eig, vec, ok, info = ctx.davidson_driver(n, t, m, sp["max_iter"], sp["tol"], sp["max_dav"], sp["shift"], mv, pc, g)
     else:
         eig, vec, ok, info = ctx.lobpcg_driver(n, t, m, sp["max_iter"], sp["tol"], sp["shift"], mv, pc, g)
     assert ok and bool(gold[name + "_ok"])
+    if name == "gdav_n600_rand":
+        # This run restarts once (iteration 20).  The UNMODIFIED reference zeroes bspace at the restart
+        # (diaglib.f90:2196-2200) and then "converges" with ok=.true. to eigenvalues ~1e-15 --
+        # the fixture records that.  Our drivers keep the kept block's B*x and must
+        # return the true generalised eigenvalues instead.
+        import scipy.linalg as sla
+        assert np.abs(gold[name + "_eig"][:t]).max() < 1e-10
+        idx = np.arange(1, n + 1.0); a = 1.0 / (idx[:, None] + idx[None, :]); np.fill_diagonal(a, idx + 1.0)
+        smat = oracle.metric_setup(n)
+        assert np.allclose(eig[:t], sla.eigh(a, smat, eigvals_only=True)[:t], rtol=0, atol=1e-7)
+        return
     assert np.allclose(eig[:t], gold[name + "_eig"][:t], rtol=1e-10, atol=0)
     it_ref = int(gold[name + "_tr_iters"])
     if sp["guess"] == "unit":
         assert info["iters"] == it_ref
     else:
         assert abs(info["iters"] - it_ref) <= max(1, it_ref // 10), (info, it_ref)
-    if sp["solver"] == "davidson" and sp["guess"] == "unit":
+    if sp["solver"] in ("davidson", "gen_davidson") and sp["guess"] == "unit":
         assert info["restarts"] == int(gold[name + "_tr_restarts"])
     if name + "_evec" in gold.files:
         ev = vec[:, :t]; ev = ev * np.sign(ev[np.abs(ev).argmax(0), np.arange(t)])
@@ -152,3 +170,22 @@ def test_full_size_solve_residual(ctx, solver, n):
         assert rel.max() <= 1e-10, rel
     finally:
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+
+
+def test_gen_davidson_restart_keeps_metric_block(ctx, oracle, rng):
+    """Restart of the generalised Davidson: the kept block's B*x stays in bspace (deliberate fix of the
+    reference's zeroing, SURVEY 8a A13 / DESIGN.md) -- the solve converges to the true generalised eigenvalues."""
+    import scipy.linalg as sla
+    n, t, m = 600, 4, 8
+    oracle.dense_setup(n); s = oracle.metric_setup(n)
+    mv, pc, bv = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd"), oracle.fn("orc_metric_matvec")
+    g = np.asfortranarray(rng.random((n, m)) - 0.5)
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+    eig, vec, ok, info = ctx.gen_david_driver(n, t, m, 400, 1e-8, 5, 0.0, mv, pc, bv, g)
+    eo, vo, oko, tr = oracle.gen_davidson(n, t, m, 400, 1e-8, 5, 0.0, mv, pc, bv, g)
+    assert ok and oko and info["restarts"] >= 1 and tr.restarts >= 1
+    idx = np.arange(1, n + 1.0); a = 1.0 / (idx[:, None] + idx[None, :]); np.fill_diagonal(a, idx + 1.0)
+    want = sla.eigh(a, s, eigvals_only=True)[:t]
+    assert np.allclose(eig[:t], want, rtol=0, atol=1e-7) and np.allclose(eo[:t], want, rtol=0, atol=1e-7)
+    x = vec[:, :t]
+    assert np.abs(x.T @ s @ x - np.eye(t)).max() < 1e-8          # B-orthonormal eigenvectors
