@@ -214,6 +214,7 @@ def main() -> None:
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        ctx.comm_finalize()
         dist.destroy_process_group()
     if os.environ.get("DIAGLIB_AMD_HOSTTIME"):
         ctx.lib.dla_destroy(ctx.h)       # prints the engine's host-wait totals

@@ -733,6 +733,8 @@ struct HipEngine : dla::Engine {
       std::fprintf(stderr, "[dla] host waits: stream sync %.3f s (%ld), ring event sync %.3f s, alloc %.3f s, free %.3f s\n",
                    t_sync, n_sync, t_evsync, t_alloc, t_free);
     if (st) (void)hipStreamSynchronize(st);
+    for (auto& b : cache) (void)hipFree(b.ptr);
+    for (auto& b : live) (void)hipFree(b.ptr);
     if (comm) ncclCommDestroy(comm);
     for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -823,22 +825,61 @@ struct HipEngine : dla::Engine {
   }
 
   // ---- memory
+  // Panels are GiB-sized and a driver call allocates/frees the same sizes every solve; hipMalloc/hipFree of
+  // such blocks can take tens of milliseconds each (measured 39 ms per 4 GiB hipMalloc on some boxes, versus
+  // ~3 ms of device work per iteration), so freed blocks are kept and handed out again (exact size class,
+  // 2 MiB granules).  dla_destroy releases everything; the cache is capped at cache_limit bytes.
+  struct Block { size_t bytes; void* ptr; };
+  std::vector<Block> cache;
+  std::vector<Block> live;
+  size_t cached_bytes = 0, cache_limit = (size_t)96 << 30;
   int alloc(size_t bytes, void** dev) override
   {
     *dev = nullptr;
-    if (bytes == 0) bytes = 8;
+    const size_t gran = (size_t)2 << 20;
+    bytes = ((std::max(bytes, (size_t)8) + gran - 1) / gran) * gran;
+    for (size_t i = 0; i < cache.size(); ++i)
+      if (cache[i].bytes == bytes) {
+        *dev = cache[i].ptr;
+        cached_bytes -= bytes;
+        cache.erase(cache.begin() + i);
+        live.push_back({bytes, *dev});
+        return DLA_OK;
+      }
     const double t0 = now();
     hipError_t e = hipMalloc(dev, bytes);
+    if (e != hipSuccess && !cache.empty()) {       // out of memory: drop the cache and retry once
+      release_cache();
+      e = hipMalloc(dev, bytes);
+    }
     t_alloc += now() - t0;
     if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return DLA_ERR_ALLOC; }
+    live.push_back({bytes, *dev});
     return DLA_OK;
+  }
+  void release_cache()
+  {
+    (void)hipStreamSynchronize(st);
+    for (auto& b : cache) (void)hipFree(b.ptr);
+    cache.clear();
+    cached_bytes = 0;
   }
   int free_(void* dev) override
   {
     if (!dev) return DLA_OK;
     const double t0 = now();
-    (void)hipStreamSynchronize(st);
-    HIPCHK(hipFree(dev));
+    (void)hipStreamSynchronize(st);      // nothing queued may still touch the block
+    size_t bytes = 0;
+    for (size_t i = 0; i < live.size(); ++i)
+      if (live[i].ptr == dev) { bytes = live[i].bytes; live.erase(live.begin() + i); break; }
+    if (bytes == 0) {                    // not ours (should not happen): plain free
+      HIPCHK(hipFree(dev));
+    } else if (cached_bytes + bytes > cache_limit) {
+      HIPCHK(hipFree(dev));
+    } else {
+      cache.push_back({bytes, dev});
+      cached_bytes += bytes;
+    }
     t_free += now() - t0;
     return DLA_OK;
   }

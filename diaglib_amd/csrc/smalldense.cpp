@@ -284,22 +284,81 @@ void tridiag_solve(int n, const std::vector<double>& d, const std::vector<double
   }
 }
 
+// The m lowest eigenvalues of the symmetric tridiagonal (d, e) by simultaneous bisection on Sturm
+// counts: count(x) = number of eigenvalues < x = number of negative pivots of T - x I.  All m
+// intervals advance together, 16 shifts per pass, so that the (latency-bound) pivot recurrences of
+// several SIMD vectors overlap.
+// Cost O(60 m n) against O(n^2) with a large constant for QL on all n values.
+void bisect_lowest(int n, const std::vector<double>& d, const std::vector<double>& e, int m, double onenrm,
+                   std::vector<double>& w)
+{
+  const double eps = 2.220446049250313e-16;
+  const double pivmin = std::max(1e-300, eps * eps * onenrm * onenrm * 1e-4);   // smallest pivot magnitude allowed
+  std::vector<double> e2(n > 0 ? n : 1, 0.0);
+  for (int i = 0; i + 1 < n; ++i) e2[i] = e[i] * e[i];
+  // Gershgorin bounds
+  double gl = d[0], gu = d[0];
+  for (int i = 0; i < n; ++i) {
+    const double r = (i > 0 ? std::fabs(e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(e[i]) : 0.0);
+    gl = std::min(gl, d[i] - r);
+    gu = std::max(gu, d[i] + r);
+  }
+  const double pad = 2.0 * eps * onenrm * n + 2.0 * pivmin;
+  gl -= pad; gu += pad;
+  constexpr int W = 16;   // 4 AVX2 vectors: four independent division chains in flight
+  const int mp = ((m + W - 1) / W) * W;
+  std::vector<double> lo(mp, gl), hi(mp, gu), mid(mp, 0.0);
+  std::vector<int> cnt(mp, 0);
+  auto sturm = [&](const double* x, int* c) {   // counts for W shifts at once
+    double q[W];
+    int neg[W];
+    for (int s = 0; s < W; ++s) { q[s] = d[0] - x[s]; neg[s] = 0; }
+    for (int s = 0; s < W; ++s) {
+      if (std::fabs(q[s]) < pivmin) q[s] = -pivmin;
+      neg[s] += (q[s] < 0.0);
+    }
+    for (int i = 1; i < n; ++i) {
+      const double di = d[i], ei2 = e2[i - 1];
+      for (int s = 0; s < W; ++s) {
+        double t = di - x[s] - ei2 / q[s];
+        t = (std::fabs(t) < pivmin) ? -pivmin : t;
+        q[s] = t;
+        neg[s] += (t < 0.0);
+      }
+    }
+    for (int s = 0; s < W; ++s) c[s] = neg[s];
+  };
+  const double tol_abs = eps * onenrm;
+  for (int it = 0; it < 120; ++it) {
+    bool any = false;
+    for (int j = 0; j < mp; ++j) {
+      mid[j] = 0.5 * (lo[j] + hi[j]);
+      if (j < m && hi[j] - lo[j] > 2.0 * eps * std::max(std::fabs(lo[j]), std::fabs(hi[j])) + tol_abs) any = true;
+    }
+    if (!any) break;
+    for (int j = 0; j < mp; j += W) sturm(&mid[j], &cnt[j]);
+    for (int j = 0; j < m; ++j) {
+      // eigenvalue j (0-based, ascending) lies in [lo, hi): count(mid) >= j+1  <=>  lambda_j < mid
+      if (cnt[j] >= j + 1) hi[j] = mid[j]; else lo[j] = mid[j];
+    }
+  }
+  w.resize(m);
+  for (int j = 0; j < m; ++j) w[j] = 0.5 * (lo[j] + hi[j]);
+  for (int j = 1; j < m; ++j) if (w[j] < w[j - 1]) w[j] = w[j - 1];   // keep the order monotone
+}
+
 // lowest m eigenpairs; zt rows 0..m-1 receive the eigenvectors of the ORIGINAL matrix
 int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_all, std::vector<double>& zt)
 {
   Tridiag t;
   tridiagonalize(n, s, t);
-  std::vector<double> dv = t.d, ev = t.e;
-  int info = ql_values(n, dv, ev);
-  if (info) return info;
-  std::sort(dv.begin(), dv.end());
-  w_all = dv;
   double onenrm = 0.0;
   for (int i = 0; i < n; ++i) {
     double r = std::fabs(t.d[i]) + (i > 0 ? std::fabs(t.e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(t.e[i]) : 0.0);
     onenrm = std::max(onenrm, r);
   }
   if (onenrm == 0.0) onenrm = 1.0;
+  bisect_lowest(n, t.d, t.e, m, onenrm, w_all);        // w_all[0..m-1]
   const double eps = 2.220446049250313e-16;
   const double ortol = 1.0e-3 * onenrm;     // cluster criterion (as LAPACK dstein)
   const double sep = 10.0 * eps * onenrm;   // minimal separation of the shifts inside a cluster
@@ -401,8 +460,8 @@ int dla_syev(char uplo, int n, double* a, int lda, double* w)
   return 0;
 }
 
-// lowest m eigenpairs only: w(1:n) all eigenvalues ascending, a(:,1:m) the m lowest eigenvectors
-// (columns m+1..n of a are left undefined).  Same role as dsyev at diaglib.f90:1708 / :406, whose
+// lowest m eigenpairs only: w(1:m) ascending (w(m+1:n) is set to w(m): the drivers never read it, reference
+// :1715 eig = e_red(1:n_max), :1698 e_red(1:n_rst)), a(:,1:m) the eigenvectors (columns m+1..n undefined).  Same role as dsyev at diaglib.f90:1708 / :406, whose
 // callers use the first n_max eigenpairs only.
 int dla_syev_lowest(char uplo, int n, double* a, int lda, double* w, int m)
 {
@@ -420,7 +479,7 @@ int dla_syev_lowest(char uplo, int n, double* a, int lda, double* w, int m)
     }
   int info = sym_eig_lowest(n, s, m, wall, zt);
   if (info != 0) return info;
-  for (int j = 0; j < n; ++j) w[j] = wall[j];
+  for (int j = 0; j < n; ++j) w[j] = wall[j < m ? j : m - 1];
   for (int j = 0; j < m; ++j) {
     const double* z = &zt[(size_t)j * n];
     int imax = 0;

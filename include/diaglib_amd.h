@@ -161,7 +161,7 @@ int  dla_call_precnd(dla_ctx* ctx, dla_precnd_fn fn, int n, int m, double fac, c
 /* ---------------------------------------------------------------- small dense, host (LAPACK in the reference) */
 int    dla_syev(char uplo, int n, double* a, int lda, double* w);   /* dsyev('v',uplo): :315,406,1708 */
 int    dla_syev_lowest(char uplo, int n, double* a, int lda, double* w, int m); /* same call sites: only the m
-                                                                       lowest eigenVECTORS are formed (all the drivers use) */
+                                                                       lowest eigenPAIRS are formed (all the drivers use) */
 int    dla_potrf_lower(int m, double* a, int lda);                  /* dpotrf('l'): :3261             */
 int    dla_trtri_lower(int m, double* a, int lda);                  /* dtrtri('l','n'): :3310         */
 double dla_norm_est(int m, const double* a, int lda);               /* norm_est: :3447-3479           */
