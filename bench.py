@@ -17,7 +17,7 @@ BLAS calls the reference would issue for the iterations performed) / wall time o
 inputs resident in HBM.  `roofline` is the dominant kernel class measured with HIP events on the
 engine's stream during the timed region; `cpu_baseline` times the UNMODIFIED reference
 (oracle/_ref, flang+MKL) -- or the oracle's C port when that library cannot be loaded -- on this
-box's host cores on a bounded sample (same operator and solver settings, n = 1e6 rows).
+box's host cores on the same workload (one solve at n = 2e6 rows, about 10 s of CPU work).
 """
 from __future__ import annotations
 
@@ -85,7 +85,7 @@ def main() -> None:
     ap.add_argument("--tol", type=float, default=1e-13)
     ap.add_argument("--max-dav", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-n", type=int, default=2_000_000)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
