@@ -41,6 +41,10 @@ struct Engine {
     int st = gemm(n, l, x, k, c_host, ldc, u, 1);
     return st ? st : gram(n, k, u, k, u, g_host, ldg);
   }
+  // One sweep over the contiguous panel [X | U] (n x (m+k)):  U <- [X | U] * C'  (C' is (m+k) x k) plus the
+  // Gram matrix of the new U.  Used to fold a pending triangular update into the projection step.
+  virtual bool can_combo(int /*m*/, int /*k*/) { return false; }
+  virtual int combo_gram(int, int, const double*, int, const double*, int, double*, double*, int) { return DLA_ERR_ARG; }
   virtual int ritz_residual(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
                             const double* eig, int n_res, const int* skip, double* evec, double* r,
                             double* avy /* optional n x m: uncorrected AV*Y */,

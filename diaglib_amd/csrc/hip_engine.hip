@@ -1139,6 +1139,21 @@ struct HipEngine : dla::Engine {
     return finish_fused_gram(k, g_host, ldg);
   }
 
+  // U <- [X | U] C' and G = U^T U of the result in one sweep; U is the last k columns of the same
+  // contiguous panel (each wave reads all m+k columns of its rows before it stores, so in place is safe)
+  bool can_combo(int m, int k) override { return k <= 16 && m > 0 && m + k <= 448; }
+  int combo_gram(int n, int m, const double* x, int k, const double* c_host, int ldc, double* u, double* g_host, int ldg) override
+  {
+    if (!can_combo(m, k) || u != x + (size_t)n * m) { err = "combo_gram: unsupported shape"; return DLA_ERR_ARG; }
+    int stc = gemm_chunk(n, 0, m + k, x, k, c_host, ldc, u, 0, DLA_OP_GEMM, true);
+    if (stc) return stc;
+    // reference-schedule flops of what was folded in: dtrmm (n k^2) + the Gram (2 n k^2); the 2 n m k of the
+    // update itself were counted by gemm_chunk (it counted 2 n (m+k) k)
+    stats.flops[DLA_OP_GRAM] += 2.0 * (double)n * k * k;
+    stats.flops[DLA_OP_GEMM] -= 1.0 * (double)n * k * k;
+    return finish_fused_gram(k, g_host, ldg);
+  }
+
   // U -= X C and G = U^T U of the result, one sweep (k <= 16, C fits one LDS chunk)
   int update_gram(int n, int l, const double* x, int k, const double* c_host, int ldc, double* u, double* g_host, int ldg) override
   {
@@ -1171,8 +1186,8 @@ struct HipEngine : dla::Engine {
   void launch_gemm_gram(const ARGS& a, int blocks, size_t lds, bool vec2, int mode)
   {
 #define GG(V, M) hipLaunchKernelGGL((gemm_kernel<1, V, M, ARGS, true>), dim3(blocks), dim3(256), lds, st, a)
-    if (vec2) { if (mode == 1) GG(2, 1); else GG(2, 2); }
-    else      { if (mode == 1) GG(1, 1); else GG(1, 2); }
+    if (vec2) { if (mode == 1) GG(2, 1); else if (mode == 2) GG(2, 2); else GG(2, 0); }
+    else      { if (mode == 1) GG(1, 1); else if (mode == 2) GG(1, 2); else GG(1, 0); }
 #undef GG
   }
 

@@ -252,10 +252,16 @@ int dla_random_fill(dla_ctx* c, int n, int m, double* evec) { return engfail(c, 
 // the Gram matrix of the panel it has just written (Engine::trmm_gram), which is exactly the matrix
 // the next macro-iteration starts from, so a macro-iteration costs one sweep instead of two.
 // g_in (optional): Gram matrix of u already known to the caller (k x k, ld k).
-static int ortho_cd_impl(dla_ctx* c, int n, int k, double* u, double* growth, int* ok, const double* g_in)
+// w_defer (optional, k x k): when given, the LAST triangular update may be left pending: if the caller is
+// going to project U against X next anyway (always = force_defer, or only when growth*eps >= tol_ortho,
+// i.e. when ortho_vs_x will do another pass), W = Linv^T is returned in w_defer with *deferred = true and
+// the panel in memory still holds U before that update.  The caller folds W into its next sweep.
+static int ortho_cd_impl(dla_ctx* c, int n, int k, double* u, double* growth, int* ok, const double* g_in,
+                         double* w_defer = nullptr, bool* deferred = nullptr, bool force_defer = false)
 {
   *growth = 1.0;
   *ok = 0;
+  if (deferred) *deferred = false;
   if (k <= 0) { *ok = 1; return DLA_OK; }
   std::vector<double> metric((size_t)k * k), msave((size_t)k * k), gnext((size_t)k * k), w((size_t)k * k);
   bool have_g = (g_in != nullptr);
@@ -312,8 +318,16 @@ static int ortho_cd_impl(dla_ctx* c, int n, int k, double* u, double* growth, in
     for (int j = 0; j < k; ++j)
       for (int p = 0; p <= j; ++p) w[(size_t)p + (size_t)j * k] = msave[(size_t)j + (size_t)p * k];
     int st;
-    if (macro_done) st = c->eng->trmm(n, k, u, w.data(), k);                          // last pass: no further Gram needed
-    else { st = c->eng->trmm_gram(n, k, u, w.data(), k, gnext.data(), k); have_g = true; }
+    if (macro_done && w_defer && (force_defer || *growth * kEps >= kTolOrtho)) {
+      std::copy(w.begin(), w.end(), w_defer);                                         // caller applies it in its next sweep
+      *deferred = true;
+      st = DLA_OK;
+    } else if (macro_done) {
+      st = c->eng->trmm(n, k, u, w.data(), k);                                        // last pass: no further Gram needed
+    } else {
+      st = c->eng->trmm_gram(n, k, u, w.data(), k, gnext.data(), k);
+      have_g = true;
+    }
     if (st) return engfail(c, st);
   }
   if (c->verbose_ortho) std::printf("  [dla] ortho_cd: %d macro iterations, growth %.3e\n", it, *growth);
@@ -360,7 +374,14 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
   bool done = false;
   double growth = 1.0, xu_norm;
   std::vector<double> xu((size_t)(m > 0 ? m : 1) * k), gu((size_t)k * k);
-  int st = dla_ortho_cd(c, n, k, u, &growth, &ok);        // :3533
+  // When U is the block that follows X in the same panel (the drivers' layout: space(:,i_beg) after
+  // space(:,1:ldu)), the last triangular update of an ortho_cd that is followed by a projection pass is not
+  // applied on its own: with W = Linv^T pending,  X^T (U W) = (X^T U) W  and  U W - X (X^T U W) = [X | U] [-xu; W],
+  // so the pass costs one Gram sweep and ONE sweep over [X | U] instead of a U sweep more (16 n k B).
+  const bool combo = m > 0 && u == x + (size_t)n * m && c->eng->can_combo(m, k);
+  std::vector<double> wdef(combo ? (size_t)k * k : 1), cprime(combo ? (size_t)(m + k) * k : 1);
+  bool pending = false;
+  int st = ortho_cd_impl(c, n, k, u, &growth, &ok, nullptr, combo ? wdef.data() : nullptr, &pending, true);   // :3533
   if (st) return st;
   if (!ok) { st = ortho_fallback(c, n, k, u); if (st) return st; }
   while (!done) {
@@ -368,10 +389,26 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
     if (m > 0) {
       st = c->eng->gram(n, m, bx, k, u, xu.data(), m);     // xu = X^T U  (:3543) / (BX)^T U (:3632)
       if (st) return engfail(c, st);
-      st = c->eng->update_gram(n, m, x, k, xu.data(), m, u, gu.data(), k);   // U -= X xu (:3544) + U^T U for :3548
+      if (pending) {
+        // xu <- xu W ; C' = [-xu ; W]
+        const int ldc = m + k;
+        for (int j = 0; j < k; ++j) {
+          for (int i = 0; i < m; ++i) {
+            double sacc = 0.0;
+            for (int p = 0; p <= j; ++p) sacc += xu[(size_t)i + (size_t)p * m] * wdef[(size_t)p + (size_t)j * k];
+            cprime[(size_t)i + (size_t)j * ldc] = -sacc;
+          }
+          for (int p = 0; p < k; ++p) cprime[(size_t)(m + p) + (size_t)j * ldc] = wdef[(size_t)p + (size_t)j * k];
+        }
+        st = c->eng->combo_gram(n, m, x, k, cprime.data(), ldc, u, gu.data(), k);
+        pending = false;
+      } else {
+        st = c->eng->update_gram(n, m, x, k, xu.data(), m, u, gu.data(), k);   // U -= X xu (:3544) + U^T U for :3548
+      }
       if (st) return engfail(c, st);
     }
-    st = ortho_cd_impl(c, n, k, u, &growth, &ok, m > 0 ? gu.data() : nullptr);   // :3548
+    st = ortho_cd_impl(c, n, k, u, &growth, &ok, m > 0 ? gu.data() : nullptr,
+                       combo ? wdef.data() : nullptr, &pending, false);          // :3548
     if (st) return st;
     if (!ok) {
       st = ortho_fallback(c, n, k, u);
@@ -386,7 +423,7 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
     } else {
       xu_norm = growth * kEps;                             // :3562
     }
-    done = xu_norm < kTolOrtho;                            // :3564
+    done = xu_norm < kTolOrtho;                            // :3564  (pending implies !done, see ortho_cd_impl)
     if (it > kMaxIt) return fail(c, DLA_ERR_ORTHO, " catastrophic failure of ortho_vs_x");  // :3568
   }
   if (c->verbose_ortho) std::printf("  [dla] ortho_vs_x: %d outer iterations\n", it);
