@@ -1259,6 +1259,10 @@ struct HipEngine : dla::Engine {
     int lmax = (int)((64 * 1024) / (sizeof(double) * 16 * kt));
     lmax = std::max(4, (lmax / 4) * 4);
     if (mode == 2 && l > lmax) { err = "trmm: k too large"; return DLA_ERR_ARG; }
+    if (mode != 2 && l > lmax && z >= x && z < x + (size_t)n * l) {
+      err = "panel_gemm: output aliases the input panel but the contraction needs several LDS chunks";
+      return DLA_ERR_ARG;
+    }
     if (l == 0) {
       if (mode == 0) return zero(z, sizeof(double) * (size_t)n * k);
       return DLA_OK;

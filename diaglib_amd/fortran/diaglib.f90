@@ -972,13 +972,23 @@ contains
 !
       allocate (u_x(len_u,n_max), u_p(len_u,max(n_act,1)))
       call chk(ctx, dla_get_coeffs(ctx, len_a, len_u, n_max, n_act, a_red, u_x, u_p), 'get_coeffs')
-      call chk(ctx, dla_panel_gemm(ctx, n, len_u, space,  n_act, u_p, len_u, evd), 'p block')
-      call chk(ctx, dla_copy(ctx, colp(space,n,ind_p), evd, nbytes(n,n_act)), 'copy')
-      call chk(ctx, dla_panel_gemm(ctx, n, len_u, aspace, n_act, u_p, len_u, evd), 'ap block')
-      call chk(ctx, dla_copy(ctx, colp(aspace,n,ind_p), evd, nbytes(n,n_act)), 'copy')
-      if (gen_eig) then
-        call chk(ctx, dla_panel_gemm(ctx, n, len_u, bspace, n_act, u_p, len_u, evd), 'bp block')
-        call chk(ctx, dla_copy(ctx, colp(bspace,n,ind_p), evd, nbytes(n,n_act)), 'copy')
+!     The reference forms each product in the evec scratch and copies it into the P block (:495-503).
+!     dla_panel_gemm may write a column block of its own input panel (every row tile is read completely
+!     before it is stored, include/diaglib_amd.h), so the products go straight into place when the block
+!     fits one output pass (n_act <= 48); wider blocks keep the scratch + copy.
+      if (n_act.le.48) then
+        call chk(ctx, dla_panel_gemm(ctx, n, len_u, space,  n_act, u_p, len_u, colp(space,n,ind_p)), 'p block')
+        call chk(ctx, dla_panel_gemm(ctx, n, len_u, aspace, n_act, u_p, len_u, colp(aspace,n,ind_p)), 'ap block')
+        if (gen_eig) call chk(ctx, dla_panel_gemm(ctx, n, len_u, bspace, n_act, u_p, len_u, colp(bspace,n,ind_p)), 'bp block')
+      else
+        call chk(ctx, dla_panel_gemm(ctx, n, len_u, space,  n_act, u_p, len_u, evd), 'p block')
+        call chk(ctx, dla_copy(ctx, colp(space,n,ind_p), evd, nbytes(n,n_act)), 'copy')
+        call chk(ctx, dla_panel_gemm(ctx, n, len_u, aspace, n_act, u_p, len_u, evd), 'ap block')
+        call chk(ctx, dla_copy(ctx, colp(aspace,n,ind_p), evd, nbytes(n,n_act)), 'copy')
+        if (gen_eig) then
+          call chk(ctx, dla_panel_gemm(ctx, n, len_u, bspace, n_act, u_p, len_u, evd), 'bp block')
+          call chk(ctx, dla_copy(ctx, colp(bspace,n,ind_p), evd, nbytes(n,n_act)), 'copy')
+        end if
       end if
       deallocate (u_x, u_p)
 !

@@ -118,7 +118,9 @@ int  dla_sync(dla_ctx* ctx);
  * diaglib.f90:1691 (projection), 3256 (ortho_cd Gram), 3543 (X^T U), 403/313 (LOBPCG S^T AS), 3762. */
 int  dla_gram(dla_ctx* ctx, int n, int l, const double* x_dev, int k, const double* u_dev,
               double* c_host, int ldc);
-/* Z(n x k) = X(n x l) C(l x k).  dgemm('n','n') at diaglib.f90:1717, 420-424, 495-501, 322-324. */
+/* Z(n x k) = X(n x l) C(l x k).  dgemm('n','n') at diaglib.f90:1717, 420-424, 495-501, 322-324.
+ * Z may be a column block of X itself when k <= 48 and 128*l*ceil(k/16) <= 65536 (one output pass, one
+ * contraction chunk): every row tile is read completely before it is stored. */
 int  dla_panel_gemm(dla_ctx* ctx, int n, int l, const double* x_dev, int k, const double* c_host, int ldc,
                     double* z_dev);
 /* U(n x k) -= X(n x l) C(l x k).  dgemm('n','n',-one,...,one) at diaglib.f90:3544, 3633. */
