@@ -29,7 +29,7 @@ OP_NAMES = ["gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd"]
 # every symbol include/diaglib_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "dla_create", "dla_destroy", "dla_default_ctx", "dla_set_option", "dla_get_option", "dla_last_error",
-    "dla_backend_name", "dla_get_stats", "dla_reset_stats", "dla_stream",
+    "dla_backend_name", "dla_get_stats", "dla_reset_stats", "dla_get_kernel_stats", "dla_stream",
     "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_set_allreduce_hook", "dla_set_shard",
     "dla_alloc", "dla_free", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
     "dla_gram", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_ritz_residual", "dla_axpy",
@@ -54,6 +54,10 @@ class Stats(C.Structure):
         return d
 
 
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_longlong), ("alg_bytes", C.c_double), ("ms", C.c_double)]
+
+
 class DlaError(RuntimeError):
     pass
 
@@ -76,6 +80,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_set_option": (i, [vp, i, i]), "dla_get_option": (i, [vp, i]),
         "dla_last_error": (C.c_char_p, [vp]), "dla_backend_name": (C.c_char_p, [vp]),
         "dla_get_stats": (i, [vp, C.POINTER(Stats)]), "dla_reset_stats": (i, [vp]), "dla_stream": (vp, [vp]),
+        "dla_get_kernel_stats": (i, [vp, C.POINTER(KernelStat), i]),
         "dla_comm_unique_id": (i, [C.c_char_p]), "dla_comm_init": (i, [vp, i, i, C.c_char_p]),
         "dla_comm_info": (i, [vp, c_ip, c_ip]), "dla_comm_finalize": (i, [vp]),
         "dla_set_allreduce_hook": (i, [vp, vp, vp, i, i]), "dla_set_shard": (i, [vp, C.c_longlong, C.c_longlong]),
@@ -195,6 +200,13 @@ class Context:
         s = Stats()
         self._chk(self.lib.dla_get_stats(self.h, C.byref(s)))
         return s.as_dict()
+
+    def kernel_stats(self) -> dict:
+        """Per kernel: launches, algorithmic bytes, HIP-event ms (with OPT_PROFILE)."""
+        buf = (KernelStat * 128)()
+        n = self.lib.dla_get_kernel_stats(self.h, buf, 128)
+        return {buf[j].name.decode(): {"launches": int(buf[j].launches), "alg_bytes": float(buf[j].alg_bytes),
+                                       "ms": float(buf[j].ms)} for j in range(n)}
 
     def reset_stats(self) -> None:
         self._chk(self.lib.dla_reset_stats(self.h))

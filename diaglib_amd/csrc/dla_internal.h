@@ -73,6 +73,9 @@ struct Engine {
   dla_stats stats{};
   bool profile = false;
   virtual void collect_times() {}
+  virtual int kernel_stats(dla_kernel_stat*, int) { return 0; }
+  virtual void reset_kernel_stats() {}
+  virtual void set_tune(int, int) {}
   std::string err;
 };
 

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <map>
 #include <vector>
 #include "dla_internal.h"
 
@@ -40,6 +41,19 @@ template <int V> __device__ __forceinline__ typename VecOf<V>::type vmake(double
 template <> __device__ __forceinline__ double vmake<1>(double a, double) { return a; }
 template <> __device__ __forceinline__ v2d vmake<2>(double a, double b) { return (v2d){a, b}; }
 template <int V> __device__ __forceinline__ typename VecOf<V>::type vzero() { return vmake<V>(0.0, 0.0); }
+// streamed-once panel accesses: NT != 0 marks them non-temporal (no L2 retention wanted)
+template <int V, int NT> __device__ __forceinline__ typename VecOf<V>::type pload(const double* p)
+{
+  typedef typename VecOf<V>::type vt;
+  if constexpr (NT & 1) return __builtin_nontemporal_load((const vt*)p);
+  else return *(const vt*)p;
+}
+template <int V, int NT> __device__ __forceinline__ void pstore(double* p, typename VecOf<V>::type v)
+{
+  typedef typename VecOf<V>::type vt;
+  if constexpr (NT & 2) __builtin_nontemporal_store(v, (vt*)p);
+  else *(vt*)p = v;
+}
 
 #define HIPCHK(call)                                                                  \
   do {                                                                                \
@@ -71,7 +85,9 @@ struct GramArgs {
   int passes_x;
 };
 
-template <int TLW, int KT, int VEC, int RSTEP>
+// (NT stays 0 here: the two 64-byte halves of a line are fetched by consecutive instructions and rely on
+// the cache to merge; non-temporal loads measured -10 %)
+template <int TLW, int KT, int VEC, int RSTEP, int NT = 0>
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 {
   constexpr int CH = 4 * VEC * RSTEP;  // rows per chunk
@@ -114,11 +130,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 #pragma unroll
     for (int q = 0; q < KT; ++q)
 #pragma unroll
-      for (int s = 0; s < RSTEP; ++s) ud[q][s] = *(const vec_t*)(up[q] + rbase + 4 * VEC * s);
+      for (int s = 0; s < RSTEP; ++s) ud[q][s] = pload<VEC, NT>(up[q] + rbase + 4 * VEC * s);
 #pragma unroll
     for (int t = 0; t < TLW; ++t)
 #pragma unroll
-      for (int s = 0; s < RSTEP; ++s) xd[t][s] = *(const vec_t*)(xp[t] + rbase + 4 * VEC * s);
+      for (int s = 0; s < RSTEP; ++s) xd[t][s] = pload<VEC, NT>(xp[t] + rbase + 4 * VEC * s);
   };
   auto mfma_chunk = [&](const vec_t (&xd)[TLW][RSTEP], const vec_t (&ud)[KT][RSTEP]) {
 #pragma unroll
@@ -299,7 +315,9 @@ __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return
 // Gram matrix of the Cholesky-QR loop (diaglib.f90:3256) without re-reading the panel.  The stored
 // rows of a 16*VEC-row group are transposed through a wave-private LDS tile (row stride 24 doubles:
 // conflict-free for the fragment reads) into MFMA operands: lane (c, g) reads Z[row(g)][c].
-template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false>
+// NT: X is read once per sweep -> non-temporal loads (+16..25 % measured on Z = XC / U -= XC, tools/tune_ab.py);
+// the in-place triangular update (MODE 2) re-reads a panel that still sits in the Infinity Cache, so it stays plain.
+template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int UNR = 1, int NT = (MODE == 2 ? 0 : 1)>
 __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 {
   static_assert(!GRAM || KT == 1, "fused Gram needs a single 16-column output tile");
@@ -342,8 +360,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
       rok[rt] = row[rt] < n;               // n even for VEC == 2: the pair is all-in or all-out
       if (!rok[rt]) row[rt] = 0;           // clamp to a valid address; result discarded
     }
-#pragma unroll 4
-    for (int cs4 = 0; cs4 < nsteps; ++cs4) {
+    int cs4 = 0;
+    if constexpr (UNR > 1) {
+      const int nfull4 = l / 4;
+      for (; cs4 + UNR <= nfull4; cs4 += UNR) {
+        vec_t xq[UNR][RT];
+#pragma unroll
+        for (int u4 = 0; u4 < UNR; ++u4) {
+          const double* xc = a.x + (size_t)(4 * (cs4 + u4) + g) * (size_t)n;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) xq[u4][rt] = pload<VEC, NT>(xc + row[rt]);
+        }
+#pragma unroll
+        for (int u4 = 0; u4 < UNR; ++u4) {
+          double cfu[KT];
+#pragma unroll
+          for (int q = 0; q < KT; ++q) cfu[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * (cs4 + u4) + g) * 16 + i];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+#pragma unroll
+              for (int q = 0; q < KT; ++q)
+                acc[rt][e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(xq[u4][rt], e), acc[rt][e][q], 0, 0, 0);
+        }
+      }
+    }
+    for (; cs4 < nsteps; ++cs4) {
       int col = 4 * cs4 + g;
       const bool cok = col < l;
       col = cok ? col : l - 1;
@@ -351,7 +394,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
       vec_t xv[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        vec_t v = *(const vec_t*)(xc + row[rt]);
+        vec_t v = pload<VEC, NT>(xc + row[rt]);
         xv[rt] = cok ? v : vzero<VEC>();
       }
       double cf[KT];
@@ -382,7 +425,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
             // (loading the old values ahead of the sweep costs 32 VGPRs = 3 waves per SIMD and is slower)
             if constexpr (MODE == 1) { vec_t old = *(const vec_t*)zp; v = old - v; }
             if constexpr (MODE == 3) { vec_t old = *(const vec_t*)zp; v = old + v; }
-            *(vec_t*)zp = v;
+            pstore<VEC, NT>(zp, v);
           }
           if constexpr (GRAM) {
 #pragma unroll
@@ -432,7 +475,9 @@ struct RitzArgs {
   int active[48];
 };
 
-template <int KT, int VEC>
+// NT = 3: V / AV are read once and evec / r written once per sweep -> non-temporal loads and stores
+// (+6 % measured, tools/tune_ab.py)
+template <int KT, int VEC, int UNR = 1, int NT = 3>
 __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 {
   constexpr int RG = 16 * VEC;             // rows per wave tile (one row group)
@@ -474,13 +519,39 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
     for (int e = 0; e < VEC; ++e)
 #pragma unroll
       for (int q = 0; q < KT; ++q) { av[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; aav[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; }
-#pragma unroll 4
-    for (int cs4 = 0; cs4 < nsteps; ++cs4) {
+    int cs4 = 0;
+    if constexpr (UNR > 1) {
+      // UNR column steps per trip: all 2*UNR loads are issued before the first MFMA
+      const int nfull4 = l / 4;
+      for (; cs4 + UNR <= nfull4; cs4 += UNR) {
+        vec_t xq[UNR], yq[UNR];
+#pragma unroll
+        for (int u4 = 0; u4 < UNR; ++u4) {
+          const size_t off = (size_t)(4 * (cs4 + u4) + g) * (size_t)n + row;
+          xq[u4] = *(const vec_t*)(a.v + off);
+          yq[u4] = *(const vec_t*)(a.av + off);
+        }
+#pragma unroll
+        for (int u4 = 0; u4 < UNR; ++u4) {
+          double cfu[KT];
+#pragma unroll
+          for (int q = 0; q < KT; ++q) cfu[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * (cs4 + u4) + g) * 16 + i];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {
+              av[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(xq[u4], e), av[e][q], 0, 0, 0);
+              aav[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(yq[u4], e), aav[e][q], 0, 0, 0);
+            }
+        }
+      }
+    }
+    for (; cs4 < nsteps; ++cs4) {
       int col = 4 * cs4 + g;
       const bool cok = col < l;
       col = cok ? col : l - 1;
-      vec_t xv = *(const vec_t*)(a.v + (size_t)col * (size_t)n + row);
-      vec_t yv = *(const vec_t*)(a.av + (size_t)col * (size_t)n + row);
+      vec_t xv = pload<VEC, NT>(a.v + (size_t)col * (size_t)n + row);
+      vec_t yv = pload<VEC, NT>(a.av + (size_t)col * (size_t)n + row);
       xv = cok ? xv : vzero<VEC>();
       yv = cok ? yv : vzero<VEC>();
       double cf[KT];
@@ -503,7 +574,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
           if (j >= a.k) continue;
           const double e0 = av[0][q][reg], e1 = av[VEC - 1][q][reg];
           double r0 = aav[0][q][reg], r1 = aav[VEC - 1][q][reg];
-          if (a.avy) *(vec_t*)(a.avy + (size_t)j * (size_t)n + row) = vmake<VEC>(r0, r1);
+          if (a.avy) pstore<VEC, NT>(a.avy + (size_t)j * (size_t)n + row, vmake<VEC>(r0, r1));
           if (act[q][reg]) {
             r0 = r0 - th[q][reg] * e0;   // daxpy(-eig), reference diaglib.f90:1729
             ssq[q][reg] += r0 * r0;
@@ -514,8 +585,8 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
               smx[q][reg] = fmax(smx[q][reg], fabs(r1));
             }
           }
-          *(vec_t*)(a.evec + (size_t)j * (size_t)n + row) = vmake<VEC>(e0, e1);
-          *(vec_t*)(a.r + (size_t)j * (size_t)n + row) = vmake<VEC>(r0, r1);
+          pstore<VEC, NT>(a.evec + (size_t)j * (size_t)n + row, vmake<VEC>(e0, e1));
+          pstore<VEC, NT>(a.r + (size_t)j * (size_t)n + row, vmake<VEC>(r0, r1));
         }
     }
   }
@@ -693,7 +764,7 @@ __global__ void synth_precnd_kernel(int n, int m, double fac, const double* __re
 // ======================================================================================
 // host side of the engine
 // ======================================================================================
-struct TimedLaunch { hipEvent_t a, b; int cls; };
+struct TimedLaunch { hipEvent_t a, b; int cls; std::string kname; };
 
 struct HipEngine : dla::Engine {
   int device = 0;
@@ -715,6 +786,27 @@ struct HipEngine : dla::Engine {
   long long syn_row0 = 0; int syn_n = 0, syn_rw = 0; double syn_sigma = 0.0;
   // rccl
   ncclComm_t comm = nullptr;
+  // experiment knobs (DLA_OPT_TUNE0 + i) for tools/tune_ab.py: 1 = ritz grid factor, 3 = gemm grid factor,
+  // 4 = gram blocks-per-pass override (0 = built-in choice everywhere)
+  int tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  void set_tune(int i, int v) override { if (i >= 0 && i < 8) tune[i] = v; }
+  // per-kernel statistics (names as rocprofv3 prints them, without namespace / argument list)
+  struct KStat { long long launches = 0; double alg_bytes = 0.0, ms = 0.0; };
+  std::map<std::string, KStat> kstats;
+  int kernel_stats(dla_kernel_stat* out, int cap) override
+  {
+    collect_times();
+    int i = 0;
+    for (auto& kv : kstats) {
+      if (i >= cap) break;
+      std::memset(&out[i], 0, sizeof(out[i]));
+      std::strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
+      out[i].launches = kv.second.launches; out[i].alg_bytes = kv.second.alg_bytes; out[i].ms = kv.second.ms;
+      ++i;
+    }
+    return i;
+  }
+  void reset_kernel_stats() override { kstats.clear(); }
   // timing / tracing ($DIAGLIB_AMD_TRACE=1: print and synchronise around every launch)
   bool trace = false;
   // where the HOST waits ($DIAGLIB_AMD_HOSTTIME=1 prints the totals at destruction)
@@ -777,9 +869,10 @@ struct HipEngine : dla::Engine {
 
   // ---- timing helpers
   struct Scope {
-    HipEngine* e; int cls; hipEvent_t a = nullptr, b = nullptr;
-    Scope(HipEngine* e_, int cls_, double bytes, double flops) : e(e_), cls(cls_)
+    HipEngine* e; int cls; hipEvent_t a = nullptr, b = nullptr; std::string kname;
+    Scope(HipEngine* e_, int cls_, double bytes, double flops, const std::string& kname_ = std::string()) : e(e_), cls(cls_), kname(kname_)
     {
+      if (!kname.empty()) { auto& ks = e->kstats[kname]; ks.launches += 1; ks.alg_bytes += bytes; }
       if (e->trace) {
         timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
         std::fprintf(stderr, "[dla] %ld.%06ld launch class %d, %.3e alg bytes\n", (long)ts.tv_sec, ts.tv_nsec / 1000, cls_, bytes);
@@ -802,7 +895,7 @@ struct HipEngine : dla::Engine {
       }
       if (e->profile) {
         (void)hipEventRecord(b, e->st);
-        e->timed.push_back({a, b, cls});
+        e->timed.push_back({a, b, cls, kname});
         if (e->timed.size() > 4096) e->collect_times();
       }
     }
@@ -818,7 +911,10 @@ struct HipEngine : dla::Engine {
     (void)hipStreamSynchronize(st);
     for (auto& t : timed) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) stats.ms[t.cls] += ms;
+      if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+        stats.ms[t.cls] += ms;
+        if (!t.kname.empty()) kstats[t.kname].ms += ms;
+      }
       ev_pool.push_back(t.a); ev_pool.push_back(t.b);
     }
     timed.clear();
@@ -1056,7 +1152,9 @@ struct HipEngine : dla::Engine {
     const int ch = vec2 ? 32 : 16;
     long long nchunks = ((long long)n + ch - 1) / ch;
     long long want = (nchunks + 4 * 4 - 1) / (4 * 4);   // >= 4 chunks per wave
-    int blocks_per_pass = (int)std::max(1LL, std::min((long long)(2 * ncu) / std::max(1, std::min(passes, 2)), want));
+    // one 4-wave block per CU and pass (256 on MI355X) measured best: 512 is -1.5 %, 384 / 128 are -15 / -30 %
+    int blocks_per_pass = (int)std::max(1LL, std::min((long long)ncu, want));
+    if (tune[4] > 0) blocks_per_pass = (int)std::max(1LL, std::min((long long)tune[4], want));
     const int slots = tlw * kt;
     int stc = ensure_partial(sizeof(double) * (size_t)passes * blocks_per_pass * slots * 256);
     if (stc) return stc;
@@ -1066,7 +1164,10 @@ struct HipEngine : dla::Engine {
     dim3 grid(blocks_per_pass, passes);
     {
       const bool same = (x == u) && (l == k);
-      Scope s(this, cls, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k);
+      const int rs = (tlw * kt >= 6) ? 2 : 4;
+      char kn[64];
+      std::snprintf(kn, sizeof kn, "gram_kernel<%d, %d, %d, %d>", tlw, kt, vec2 ? 2 : 1, rs);
+      Scope s(this, cls, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k, kn);
 #define GL(T, K) if (tlw == T && kt == K) launch_gram<T, K>(a, grid, vec2); else
       GL(1, 1) GL(2, 1) GL(3, 1) GL(4, 1) GL(6, 1) GL(8, 1) GL(12, 1)
       GL(1, 2) GL(2, 2) GL(4, 2) GL(6, 2)
@@ -1074,6 +1175,9 @@ struct HipEngine : dla::Engine {
       GL(1, 4) GL(2, 4) GL(3, 4)
       { err = "gram: no kernel instance"; return DLA_ERR_RUNTIME; }
 #undef GL
+    }
+    {
+      Scope s2(this, cls, 0.0, 0.0, "gram_reduce_kernel");
       const int groups = std::max(1, std::min(16, (blocks_per_pass + 31) / 32));
       const size_t need2 = sizeof(double) * (size_t)passes * slots * groups * 256;
       if (need2 > lvl2_bytes) {
@@ -1116,7 +1220,10 @@ struct HipEngine : dla::Engine {
       HIPCHK(hipMalloc((void**)&d_lvl2, lvl2_bytes));
     }
     GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, h_small_dev, fused_blocks, k, k, 1, 1, 1};
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(1, groups), dim3(256), 0, st, ra);
+    {
+      Scope s2(this, DLA_OP_GRAM, 0.0, 0.0, "gram_reduce_kernel");
+      hipLaunchKernelGGL(gram_reduce_kernel, dim3(1, groups), dim3(256), 0, st, ra);
+    }
     HIPCHK(hipGetLastError());
     stc = allreduce_dev(d_small, k * k, 0, h_small);
     if (stc) return stc;
@@ -1217,7 +1324,7 @@ struct HipEngine : dla::Engine {
     const size_t lds_c = sizeof(double) * (size_t)kt * l4 * 16;
     const size_t lds = fuse ? std::max(lds_c + sizeof(double) * 4 * (vec2 ? 32 : 16) * 24, (size_t)8192) : lds_c;
     const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
-    const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu, (ntiles + 3) / 4));
+    const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu * (tune[3] > 0 ? tune[3] : 1), (ntiles + 3) / 4));
     if (fuse) {
       int stp = ensure_partial(sizeof(double) * (size_t)blocks * 256);
       if (stp) return stp;
@@ -1226,7 +1333,10 @@ struct HipEngine : dla::Engine {
     GemmArgs a{};
     a.x = x + (size_t)l0 * n; a.cpk = d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k; a.gpart = d_partial;
     const double rd = (mode == 0) ? 8.0 * n * (double)l : (mode == 2 ? 8.0 * n * (double)k : 8.0 * n * (double)(l + k));
-    Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k);
+    char kn[96];
+    std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
+                  fuse ? "true" : "false");
+    Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k, kn);
     if (inl) {
       GemmArgsInl ai{};
       ai.x = a.x; ai.z = z; ai.n = n; ai.l = l; ai.l4 = l4; ai.k = k; ai.gpart = d_partial;
@@ -1330,14 +1440,16 @@ struct HipEngine : dla::Engine {
     const long long ntiles = ((long long)n + rg - 1) / rg;
     const size_t lds = std::max(lds_c, sizeof(double) * 4 * 16 * kt * 2);
     const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
-    const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu, (ntiles + 7) / 8));
+    const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu * (tune[1] > 0 ? tune[1] : 1), (ntiles + 7) / 8));
     stc = ensure_partial(sizeof(double) * (size_t)blocks * 16 * kt * 2);
     if (stc) return stc;
     a.v = v; a.av = av; a.cpk = d_cpk; a.evec = evec; a.r = r; a.avy = avy; a.red = d_partial;
     a.n = n; a.l = l; a.l4 = l4; a.k = m;
     const int ncol = 16 * kt;
     {
-      Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact);
+      char kn[64];
+      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d>", kt, vec2 ? 2 : 1);
+      Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
       if (vec2) {
         if (kt == 1) hipLaunchKernelGGL((ritz_kernel<1, 2>), dim3(blocks), dim3(256), lds, st, a);
         else if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 2>), dim3(blocks), dim3(256), lds, st, a);
@@ -1347,6 +1459,9 @@ struct HipEngine : dla::Engine {
         else if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 1>), dim3(blocks), dim3(256), lds, st, a);
         else hipLaunchKernelGGL((ritz_kernel<3, 1>), dim3(blocks), dim3(256), lds, st, a);
       }
+    }
+    {
+      Scope s2(this, DLA_OP_RITZ, 0.0, 0.0, "ritz_reduce_kernel");
       hipLaunchKernelGGL(ritz_reduce_kernel, dim3(ncol), dim3(256), 0, st, (const double*)d_partial, blocks, ncol, d_small,
                          h_small_dev);
     }

@@ -99,7 +99,9 @@ int dla_set_option(dla_ctx* c, int option, int value)
     case DLA_OPT_EVEC_ON_DEVICE: c->evec_on_device = value; break;
     case DLA_OPT_PROFILE: c->eng->profile = value != 0; break;
     case DLA_OPT_VERBOSE_ORTHO: c->verbose_ortho = value; break;
-    default: return fail(c, DLA_ERR_ARG, "unknown option");
+    default:
+      if (option >= DLA_OPT_TUNE0 && option < DLA_OPT_TUNE0 + 8) { c->eng->set_tune(option - DLA_OPT_TUNE0, value); break; }
+      return fail(c, DLA_ERR_ARG, "unknown option");
   }
   return DLA_OK;
 }
@@ -133,7 +135,14 @@ int dla_reset_stats(dla_ctx* c)
   if (!c) return DLA_ERR_ARG;
   c->eng->collect_times();
   std::memset(&c->eng->stats, 0, sizeof(dla_stats));
+  c->eng->reset_kernel_stats();
   return DLA_OK;
+}
+
+int dla_get_kernel_stats(dla_ctx* c, dla_kernel_stat* out, int cap)
+{
+  if (!c || !out || cap <= 0) return 0;
+  return c->eng->kernel_stats(out, cap);
 }
 
 // ------------------------------------------------------------------ multi-GPU

@@ -55,7 +55,8 @@ enum {
   DLA_OPT_EVEC_ON_DEVICE = 2,      /* 0 (default): eig/evec of the drivers are host arrays as in the reference;
                                       1: evec is a device address (guess in, Ritz vectors out), eig stays host  */
   DLA_OPT_PROFILE = 3,             /* 1: bracket every kernel launch with HIP events (dla_get_stats)          */
-  DLA_OPT_VERBOSE_ORTHO = 4        /* 1: print ortho_cd/ortho_vs_x pass counts                                 */
+  DLA_OPT_VERBOSE_ORTHO = 4,       /* 1: print ortho_cd/ortho_vs_x pass counts                                 */
+  DLA_OPT_TUNE0 = 100              /* 100..107: kernel-shape experiment knobs (tools/kernel_bench.py); 0 = default */
 };
 
 /* op classes for statistics */
@@ -79,6 +80,15 @@ typedef struct {
   long long host_syncs;               /* stream synchronisations for host-visible results   */
 } dla_stats;
 
+/* per-kernel statistics: name as rocprofv3 prints it (without namespace and argument list), launches,
+ * algorithmic bytes and HIP-event time (DLA_OPT_PROFILE) */
+typedef struct {
+  char      name[96];
+  long long launches;
+  double    alg_bytes;
+  double    ms;
+} dla_kernel_stat;
+
 /* ---------------------------------------------------------------- context */
 int  dla_create(dla_ctx** ctx, int device);          /* device < 0: $LOCAL_RANK or 0 */
 int  dla_destroy(dla_ctx* ctx);
@@ -90,6 +100,7 @@ const char* dla_last_error(dla_ctx* ctx);
 const char* dla_backend_name(dla_ctx* ctx);          /* "hip:gfx950" for the product */
 int  dla_get_stats(dla_ctx* ctx, dla_stats* out);
 int  dla_reset_stats(dla_ctx* ctx);
+int  dla_get_kernel_stats(dla_ctx* ctx, dla_kernel_stat* out, int cap);   /* returns the number of entries */
 void* dla_stream(dla_ctx* ctx);                      /* hipStream_t the kernels run on */
 
 /* ---------------------------------------------------------------- multi-GPU */

@@ -47,6 +47,12 @@ def load(path, counter):
         per[c][0] += float(r["Counter_Value"])
         if "reduce" not in r["Kernel_Name"]:
             per[c][1] += 1
+        if c != "matvec":
+            # per kernel symbol as well (name as bench.py reports it)
+            m = re.search(r"((gram|gemm|ritz)_kernel<[^>]*>)", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
+            if m:
+                per[m.group(1)][0] += float(r["Counter_Value"])
+                per[m.group(1)][1] += 1
     return per
 
 
