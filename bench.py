@@ -181,6 +181,7 @@ def main() -> None:
     dk = main[dom]
     cls_of = "gram" if dom.startswith("gram") else "ritz" if dom.startswith("ritz") else \
              ("trmm" if re.match(r"gemm_kernel<\d+, \d+, 2,", dom) else "gemm")
+    # (kernel names carry every template argument, exactly as rocprofv3 prints them in profiles/r01/kernel_stats_*.csv)
     kern = {c: {"launches": stats[c]["launches"], "ms": round(stats[c]["ms"], 3),
                 "GBps": round(stats[c]["alg_bytes"] / max(stats[c]["ms"], 1e-9) / 1e6, 1)}
             for c in classes + ["matvec", "precnd"]}

@@ -1166,7 +1166,7 @@ struct HipEngine : dla::Engine {
       const bool same = (x == u) && (l == k);
       const int rs = (tlw * kt >= 6) ? 2 : 4;
       char kn[64];
-      std::snprintf(kn, sizeof kn, "gram_kernel<%d, %d, %d, %d>", tlw, kt, vec2 ? 2 : 1, rs);
+      std::snprintf(kn, sizeof kn, "gram_kernel<%d, %d, %d, %d, 0>", tlw, kt, vec2 ? 2 : 1, rs);
       Scope s(this, cls, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k, kn);
 #define GL(T, K) if (tlw == T && kt == K) launch_gram<T, K>(a, grid, vec2); else
       GL(1, 1) GL(2, 1) GL(3, 1) GL(4, 1) GL(6, 1) GL(8, 1) GL(12, 1)
@@ -1334,8 +1334,8 @@ struct HipEngine : dla::Engine {
     a.x = x + (size_t)l0 * n; a.cpk = d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k; a.gpart = d_partial;
     const double rd = (mode == 0) ? 8.0 * n * (double)l : (mode == 2 ? 8.0 * n * (double)k : 8.0 * n * (double)(l + k));
     char kn[96];
-    std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
-                  fuse ? "true" : "false");
+    std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, 1, %d>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
+                  fuse ? "true" : "false", mode == 2 ? 0 : 1);
     Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k, kn);
     if (inl) {
       GemmArgsInl ai{};
@@ -1448,7 +1448,7 @@ struct HipEngine : dla::Engine {
     const int ncol = 16 * kt;
     {
       char kn[64];
-      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d>", kt, vec2 ? 2 : 1);
+      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 1, 3>", kt, vec2 ? 2 : 1);
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
       if (vec2) {
         if (kt == 1) hipLaunchKernelGGL((ritz_kernel<1, 2>), dim3(blocks), dim3(256), lds, st, a);
