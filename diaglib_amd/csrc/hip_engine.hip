@@ -317,7 +317,7 @@ __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return
 // conflict-free for the fragment reads) into MFMA operands: lane (c, g) reads Z[row(g)][c].
 // NT: X is read once per sweep -> non-temporal loads (+16..25 % measured on Z = XC / U -= XC, tools/tune_ab.py);
 // the in-place triangular update (MODE 2) re-reads a panel that still sits in the Infinity Cache, so it stays plain.
-template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int UNR = 1, int NT = (MODE == 2 ? 0 : 1)>
+template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1)>
 __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 {
   static_assert(!GRAM || KT == 1, "fused Gram needs a single 16-column output tile");
@@ -360,33 +360,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
       rok[rt] = row[rt] < n;               // n even for VEC == 2: the pair is all-in or all-out
       if (!rok[rt]) row[rt] = 0;           // clamp to a valid address; result discarded
     }
-    int cs4 = 0;
-    if constexpr (UNR > 1) {
-      const int nfull4 = l / 4;
-      for (; cs4 + UNR <= nfull4; cs4 += UNR) {
-        vec_t xq[UNR][RT];
-#pragma unroll
-        for (int u4 = 0; u4 < UNR; ++u4) {
-          const double* xc = a.x + (size_t)(4 * (cs4 + u4) + g) * (size_t)n;
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) xq[u4][rt] = pload<VEC, NT>(xc + row[rt]);
-        }
-#pragma unroll
-        for (int u4 = 0; u4 < UNR; ++u4) {
-          double cfu[KT];
-#pragma unroll
-          for (int q = 0; q < KT; ++q) cfu[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * (cs4 + u4) + g) * 16 + i];
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e)
-#pragma unroll
-              for (int q = 0; q < KT; ++q)
-                acc[rt][e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(xq[u4][rt], e), acc[rt][e][q], 0, 0, 0);
-        }
-      }
-    }
-    for (; cs4 < nsteps; ++cs4) {
+    // (batching the loads of several column steps per trip was measured: -5..10 %, the extra VGPRs cost occupancy)
+    for (int cs4 = 0; cs4 < nsteps; ++cs4) {
       int col = 4 * cs4 + g;
       const bool cok = col < l;
       col = cok ? col : l - 1;
@@ -477,7 +452,7 @@ struct RitzArgs {
 
 // NT = 3: V / AV are read once and evec / r written once per sweep -> non-temporal loads and stores
 // (+6 % measured, tools/tune_ab.py)
-template <int KT, int VEC, int UNR = 1, int NT = 3>
+template <int KT, int VEC, int NT = 3>
 __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 {
   constexpr int RG = 16 * VEC;             // rows per wave tile (one row group)
@@ -519,34 +494,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
     for (int e = 0; e < VEC; ++e)
 #pragma unroll
       for (int q = 0; q < KT; ++q) { av[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; aav[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; }
-    int cs4 = 0;
-    if constexpr (UNR > 1) {
-      // UNR column steps per trip: all 2*UNR loads are issued before the first MFMA
-      const int nfull4 = l / 4;
-      for (; cs4 + UNR <= nfull4; cs4 += UNR) {
-        vec_t xq[UNR], yq[UNR];
-#pragma unroll
-        for (int u4 = 0; u4 < UNR; ++u4) {
-          const size_t off = (size_t)(4 * (cs4 + u4) + g) * (size_t)n + row;
-          xq[u4] = *(const vec_t*)(a.v + off);
-          yq[u4] = *(const vec_t*)(a.av + off);
-        }
-#pragma unroll
-        for (int u4 = 0; u4 < UNR; ++u4) {
-          double cfu[KT];
-#pragma unroll
-          for (int q = 0; q < KT; ++q) cfu[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * (cs4 + u4) + g) * 16 + i];
-#pragma unroll
-          for (int e = 0; e < VEC; ++e)
-#pragma unroll
-            for (int q = 0; q < KT; ++q) {
-              av[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(xq[u4], e), av[e][q], 0, 0, 0);
-              aav[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(yq[u4], e), aav[e][q], 0, 0, 0);
-            }
-        }
-      }
-    }
-    for (; cs4 < nsteps; ++cs4) {
+    for (int cs4 = 0; cs4 < nsteps; ++cs4) {
       int col = 4 * cs4 + g;
       const bool cok = col < l;
       col = cok ? col : l - 1;
@@ -1334,7 +1282,7 @@ struct HipEngine : dla::Engine {
     a.x = x + (size_t)l0 * n; a.cpk = d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k; a.gpart = d_partial;
     const double rd = (mode == 0) ? 8.0 * n * (double)l : (mode == 2 ? 8.0 * n * (double)k : 8.0 * n * (double)(l + k));
     char kn[96];
-    std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, 1, %d>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
+    std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, %d>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
                   fuse ? "true" : "false", mode == 2 ? 0 : 1);
     Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k, kn);
     if (inl) {
@@ -1448,7 +1396,7 @@ struct HipEngine : dla::Engine {
     const int ncol = 16 * kt;
     {
       char kn[64];
-      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 1, 3>", kt, vec2 ? 2 : 1);
+      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3>", kt, vec2 ? 2 : 1);
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
       if (vec2) {
         if (kt == 1) hipLaunchKernelGGL((ritz_kernel<1, 2>), dim3(blocks), dim3(256), lds, st, a);

@@ -58,7 +58,14 @@ struct HostSimEngine : dla::Engine {
   int gemm(int n, int l, const double* x, int k, const double* c, int ldc, double* z, int mode) override
   {
     if (l == 0) { if (mode == 0) std::memset(z, 0, sizeof(double) * (size_t)n * k); return 0; }
-    if (mode == 0) orc_gemm_nn(n, l, k, 1.0, x, n, c, ldc, 0.0, z, n);
+    if (mode == 0 && z >= x && z < x + (size_t)n * l) {
+      // the C-ABI lets Z be a column block of X (include/diaglib_amd.h: dla_panel_gemm); the plain-C
+      // kernel works column by column, so go through a scratch panel
+      std::vector<double> t((size_t)n * k);
+      orc_gemm_nn(n, l, k, 1.0, x, n, c, ldc, 0.0, t.data(), n);
+      std::memcpy(z, t.data(), sizeof(double) * (size_t)n * k);
+    }
+    else if (mode == 0) orc_gemm_nn(n, l, k, 1.0, x, n, c, ldc, 0.0, z, n);
     else orc_gemm_nn(n, l, k, -1.0, x, n, c, ldc, 1.0, z, n);
     stats.launches[DLA_OP_GEMM]++;
     return 0;
