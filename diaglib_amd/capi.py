@@ -32,7 +32,7 @@ EXPORTS = [
     "dla_backend_name", "dla_get_stats", "dla_reset_stats", "dla_get_kernel_stats", "dla_stream",
     "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_set_allreduce_hook", "dla_set_shard",
     "dla_alloc", "dla_free", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
-    "dla_gram", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_ritz_residual", "dla_axpy",
+    "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_ritz_residual", "dla_axpy",
     "dla_nrm2", "dla_random_fill",
     "dla_ortho_cd", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
     "dla_call_matvec", "dla_call_precnd",
@@ -88,6 +88,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_upload": (i, [vp, vp, vp, sz]), "dla_download": (i, [vp, vp, vp, sz]), "dla_copy": (i, [vp, vp, vp, sz]),
         "dla_sync": (i, [vp]),
         "dla_gram": (i, [vp, i, i, vp, i, vp, c_dp, i]),
+        "dla_gram_lower": (i, [vp, i, i, vp, vp, c_dp, i]),
         "dla_panel_gemm": (i, [vp, i, i, vp, i, c_dp, i, vp]),
         "dla_panel_update": (i, [vp, i, i, vp, i, c_dp, i, vp]),
         "dla_trmm_linvt": (i, [vp, i, i, vp, c_dp, i]),
@@ -251,6 +252,11 @@ class Context:
     def gram(self, x: DevPanel, u: DevPanel) -> np.ndarray:
         c = np.zeros((x.m, u.m), order="F")
         self._chk(self.lib.dla_gram(self.h, x.n, x.m, x.ptr, u.m, u.ptr, _dp(c), max(1, x.m)))
+        return c
+
+    def gram_lower(self, x: DevPanel, u: DevPanel) -> np.ndarray:
+        c = np.zeros((x.m, x.m), order="F")
+        self._chk(self.lib.dla_gram_lower(self.h, x.n, x.m, x.ptr, u.ptr, _dp(c), max(1, x.m)))
         return c
 
     def panel_gemm(self, x: DevPanel, c: np.ndarray, z: DevPanel) -> None:

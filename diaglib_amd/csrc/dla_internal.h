@@ -26,6 +26,9 @@ struct Engine {
   virtual int sync() = 0;
 
   virtual int gram(int n, int l, const double* x, int k, const double* u, double* c_host, int ldc) = 0;
+  // C = X^T U for two n x l panels when only the lower triangle of C will be read (dsyev 'l'): entries above
+  // the 16 x 16 block diagonal may be left zero.  Default = the full product.
+  virtual int gram_lower(int n, int l, const double* x, const double* u, double* c_host, int ldc) { return gram(n, l, x, l, u, c_host, ldc); }
   // mode 0: Z = X C ; mode 1: Z -= X C (Z read and written)
   virtual int gemm(int n, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode) = 0;
   // in place U <- U W, W (k x k, host, general) -- used for the triangular update

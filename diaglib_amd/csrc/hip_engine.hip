@@ -83,15 +83,16 @@ struct GramArgs {
   long long n;
   int l, k;
   int passes_x;
+  int lower;         // 1: only tile pairs on or below the block diagonal are needed (symmetric result, 'l' consumer)
 };
 
 // (NT stays 0 here: the two 64-byte halves of a line are fetched by consecutive instructions and rely on
 // the cache to merge; non-temporal loads measured -10 %)
-template <int TLW, int KT, int VEC, int RSTEP, int NT = 0>
+template <int TLW, int KT, int VEC, int RSTEP, int NT = 0, int PF = -1>
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 {
   constexpr int CH = 4 * VEC * RSTEP;  // rows per chunk
-  constexpr bool PREFETCH = (TLW * KT <= 8);   // the second register stage must not cost a wave per SIMD
+  constexpr bool PREFETCH = (PF < 0) ? (TLW * KT <= 12) : (PF != 0);   // A/B: also the 12-slot shapes gain (k = 37: +24 %)
   typedef typename VecOf<VEC>::type vec_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -136,6 +137,17 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 #pragma unroll
       for (int s = 0; s < RSTEP; ++s) xd[t][s] = pload<VEC, NT>(xp[t] + rbase + 4 * VEC * s);
   };
+  // tile pair (t, q) of this pass is wanted unless the caller asked for the lower block triangle only and the
+  // X tile index is smaller than the U tile index (wave-uniform)
+  bool want[TLW][KT];
+  bool any_want = false;
+#pragma unroll
+  for (int t = 0; t < TLW; ++t)
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+      want[t][q] = !a.lower || (xg * TLW + t >= ug * KT + q);
+      any_want = any_want || want[t][q];
+    }
   auto mfma_chunk = [&](const vec_t (&xd)[TLW][RSTEP], const vec_t (&ud)[KT][RSTEP]) {
 #pragma unroll
     for (int s = 0; s < RSTEP; ++s)
@@ -145,9 +157,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
         for (int t = 0; t < TLW; ++t)
 #pragma unroll
           for (int q = 0; q < KT; ++q)
-            acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vget<VEC>(xd[t][s], e), vget<VEC>(ud[q][s], e),
-                                                             acc[t][q], 0, 0, 0);
+            if (want[t][q])
+              acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vget<VEC>(xd[t][s], e), vget<VEC>(ud[q][s], e),
+                                                               acc[t][q], 0, 0, 0);
   };
+  if (!any_want) ch = (1LL << 62);   // whole pass above the diagonal: nothing to stream, zeros go out
   if constexpr (PREFETCH) {
     if (ch < nfull) {
       load_chunk(ch, xv, uv);
@@ -317,7 +331,11 @@ __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return
 // conflict-free for the fragment reads) into MFMA operands: lane (c, g) reads Z[row(g)][c].
 // NT: X is read once per sweep -> non-temporal loads (+16..25 % measured on Z = XC / U -= XC, tools/tune_ab.py);
 // the in-place triangular update (MODE 2) re-reads a panel that still sits in the Infinity Cache, so it stays plain.
-template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1)>
+// PIPE > 0 (used for KT >= 2, where 4*KT MFMAs follow every load and the kernel runs at 1-2 waves per SIMD):
+// column steps are processed PIPE at a time through a two-stage register pipeline -- the loads of the next
+// stage are in flight while the MFMAs of the current one issue.  For KT == 1 occupancy hides the latency
+// better than registers do (A/B: batching there costs 5-10 %).
+template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1), int PIPE = (KT >= 2 ? 2 : 0)>
 __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 {
   static_assert(!GRAM || KT == 1, "fused Gram needs a single 16-column output tile");
@@ -360,8 +378,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
       rok[rt] = row[rt] < n;               // n even for VEC == 2: the pair is all-in or all-out
       if (!rok[rt]) row[rt] = 0;           // clamp to a valid address; result discarded
     }
-    // (batching the loads of several column steps per trip was measured: -5..10 %, the extra VGPRs cost occupancy)
-    for (int cs4 = 0; cs4 < nsteps; ++cs4) {
+    int cs4 = 0;
+    if constexpr (PIPE > 0) {
+      const int nfull4 = l / 4;                 // steps whose 4 columns all exist
+      auto load_stage = [&](int c0, vec_t (&xs)[PIPE][RT]) {
+#pragma unroll
+        for (int u4 = 0; u4 < PIPE; ++u4) {
+          const double* xc = a.x + (size_t)(4 * (c0 + u4) + g) * (size_t)n;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) xs[u4][rt] = pload<VEC, NT>(xc + row[rt]);
+        }
+      };
+      auto mfma_stage = [&](int c0, const vec_t (&xs)[PIPE][RT]) {
+#pragma unroll
+        for (int u4 = 0; u4 < PIPE; ++u4) {
+          double cfu[KT];
+#pragma unroll
+          for (int q = 0; q < KT; ++q) cfu[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * (c0 + u4) + g) * 16 + i];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+#pragma unroll
+              for (int q = 0; q < KT; ++q)
+                acc[rt][e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(xs[u4][rt], e), acc[rt][e][q], 0, 0, 0);
+        }
+      };
+      if (PIPE <= nfull4) {
+        vec_t xa[PIPE][RT];
+        load_stage(0, xa);
+        for (; cs4 + 2 * PIPE <= nfull4; cs4 += PIPE) {
+          vec_t xb[PIPE][RT];
+          load_stage(cs4 + PIPE, xb);
+          mfma_stage(cs4, xa);
+#pragma unroll
+          for (int u4 = 0; u4 < PIPE; ++u4)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) xa[u4][rt] = xb[u4][rt];
+        }
+        mfma_stage(cs4, xa);
+        cs4 += PIPE;
+      }
+    }
+    for (; cs4 < nsteps; ++cs4) {
       int col = 4 * cs4 + g;
       const bool cok = col < l;
       col = cok ? col : l - 1;
@@ -452,7 +511,7 @@ struct RitzArgs {
 
 // NT = 3: V / AV are read once and evec / r written once per sweep -> non-temporal loads and stores
 // (+6 % measured, tools/tune_ab.py)
-template <int KT, int VEC, int NT = 3>
+template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 2 ? 2 : 0)>
 __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 {
   constexpr int RG = 16 * VEC;             // rows per wave tile (one row group)
@@ -494,7 +553,48 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
     for (int e = 0; e < VEC; ++e)
 #pragma unroll
       for (int q = 0; q < KT; ++q) { av[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; aav[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; }
-    for (int cs4 = 0; cs4 < nsteps; ++cs4) {
+    int cs4 = 0;
+    if constexpr (PIPE > 0) {
+      // two-stage register pipeline over column steps (see gemm_kernel)
+      const int nfull4 = l / 4;
+      auto load_stage = [&](int c0, vec_t (&xs)[PIPE], vec_t (&ys)[PIPE]) {
+#pragma unroll
+        for (int u4 = 0; u4 < PIPE; ++u4) {
+          const size_t off = (size_t)(4 * (c0 + u4) + g) * (size_t)n + row;
+          xs[u4] = pload<VEC, NT>(a.v + off);
+          ys[u4] = pload<VEC, NT>(a.av + off);
+        }
+      };
+      auto mfma_stage = [&](int c0, const vec_t (&xs)[PIPE], const vec_t (&ys)[PIPE]) {
+#pragma unroll
+        for (int u4 = 0; u4 < PIPE; ++u4) {
+          double cfu[KT];
+#pragma unroll
+          for (int q = 0; q < KT; ++q) cfu[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * (c0 + u4) + g) * 16 + i];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {
+              av[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(xs[u4], e), av[e][q], 0, 0, 0);
+              aav[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(ys[u4], e), aav[e][q], 0, 0, 0);
+            }
+        }
+      };
+      if (PIPE <= nfull4) {
+        vec_t xa[PIPE], ya[PIPE];
+        load_stage(0, xa, ya);
+        for (; cs4 + 2 * PIPE <= nfull4; cs4 += PIPE) {
+          vec_t xb[PIPE], yb[PIPE];
+          load_stage(cs4 + PIPE, xb, yb);
+          mfma_stage(cs4, xa, ya);
+#pragma unroll
+          for (int u4 = 0; u4 < PIPE; ++u4) { xa[u4] = xb[u4]; ya[u4] = yb[u4]; }
+        }
+        mfma_stage(cs4, xa, ya);
+        cs4 += PIPE;
+      }
+    }
+    for (; cs4 < nsteps; ++cs4) {
       int col = 4 * cs4 + g;
       const bool cok = col < l;
       col = cok ? col : l - 1;
@@ -734,7 +834,8 @@ struct HipEngine : dla::Engine {
   long long syn_row0 = 0; int syn_n = 0, syn_rw = 0; double syn_sigma = 0.0;
   // rccl
   ncclComm_t comm = nullptr;
-  // experiment knobs (DLA_OPT_TUNE0 + i) for tools/tune_ab.py: 1 = ritz grid factor, 3 = gemm grid factor,
+  // experiment knobs (DLA_OPT_TUNE0 + i) for tools/tune_ab.py: 0 = ritz pipeline depth for wide blocks (1 = none, 4),
+  // 1 = ritz grid factor, 2 = gemm pipeline depth for wide blocks (1 = none, 4), 3 = gemm grid factor,
   // 4 = gram blocks-per-pass override (0 = built-in choice everywhere)
   int tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void set_tune(int i, int v) override { if (i >= 0 && i < 8) tune[i] = v; }
@@ -1078,7 +1179,7 @@ struct HipEngine : dla::Engine {
   }
 
   // result stays on the device in d_small (l x k, ld = l), reduced over ranks
-  int gram_dev(int n, int l, const double* x, int k, const double* u, int cls = DLA_OP_GRAM)
+  int gram_dev(int n, int l, const double* x, int k, const double* u, int cls = DLA_OP_GRAM, bool lower = false)
   {
     const int tx = (l + 15) / 16, tu = (k + 15) / 16;
     // tile shape of one pass: KT U-tiles x TLW X-tiles, at most 12 accumulators
@@ -1108,7 +1209,7 @@ struct HipEngine : dla::Engine {
     if (stc) return stc;
     stc = ensure_small(sizeof(double) * (size_t)l * k);
     if (stc) return stc;
-    GramArgs a{x, u, d_partial, (long long)n, l, k, px};
+    GramArgs a{x, u, d_partial, (long long)n, l, k, px, lower ? 1 : 0};
     dim3 grid(blocks_per_pass, passes);
     {
       const bool same = (x == u) && (l == k);
@@ -1140,6 +1241,16 @@ struct HipEngine : dla::Engine {
     }
     HIPCHK(hipGetLastError());
     return allreduce_dev(d_small, l * k, 0, h_small);
+  }
+
+  int gram_lower(int n, int l, const double* x, const double* u, double* c_host, int ldc) override
+  {
+    int stc = gram_dev(n, l, x, l, u, DLA_OP_GRAM, true);
+    if (stc) return stc;
+    stc = small_to_host((size_t)l * l);
+    if (stc) return stc;
+    for (int j = 0; j < l; ++j) std::memcpy(c_host + (size_t)j * ldc, h_small + (size_t)j * l, sizeof(double) * l);
+    return DLA_OK;
   }
 
   int gram(int n, int l, const double* x, int k, const double* u, double* c_host, int ldc) override
@@ -1250,9 +1361,16 @@ struct HipEngine : dla::Engine {
   void launch_gemm(const ARGS& a, int blocks, size_t lds, bool vec2, int mode)
   {
 #define GM(V, M) hipLaunchKernelGGL((gemm_kernel<KT, V, M, ARGS>), dim3(blocks), dim3(256), lds, st, a)
+#define GMP(M, P) hipLaunchKernelGGL((gemm_kernel<KT, 2, M, ARGS, false, 1, P>), dim3(blocks), dim3(256), lds, st, a)
+    if (vec2 && KT >= 2 && (mode == 0 || mode == 1) && (tune[2] == 1 || tune[2] == 4)) {
+      if (tune[2] == 1) { if (mode == 0) GMP(0, 0); else GMP(1, 0); }
+      else              { if (mode == 0) GMP(0, 4); else GMP(1, 4); }
+      return;
+    }
     if (vec2) { if (mode == 0) GM(2, 0); else if (mode == 1) GM(2, 1); else if (mode == 2) GM(2, 2); else GM(2, 3); }
     else      { if (mode == 0) GM(1, 0); else if (mode == 1) GM(1, 1); else if (mode == 2) GM(1, 2); else GM(1, 3); }
 #undef GM
+#undef GMP
   }
 
   int gemm_chunk(int n, int l0, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode, int cls,
@@ -1282,8 +1400,8 @@ struct HipEngine : dla::Engine {
     a.x = x + (size_t)l0 * n; a.cpk = d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k; a.gpart = d_partial;
     const double rd = (mode == 0) ? 8.0 * n * (double)l : (mode == 2 ? 8.0 * n * (double)k : 8.0 * n * (double)(l + k));
     char kn[96];
-    std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, %d>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
-                  fuse ? "true" : "false", mode == 2 ? 0 : 1);
+    std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, %d, %d>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
+                  fuse ? "true" : "false", mode == 2 ? 0 : 1, kt >= 2 ? 2 : 0);
     Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k, kn);
     if (inl) {
       GemmArgsInl ai{};
@@ -1396,9 +1514,15 @@ struct HipEngine : dla::Engine {
     const int ncol = 16 * kt;
     {
       char kn[64];
-      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3>", kt, vec2 ? 2 : 1);
+      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d>", kt, vec2 ? 2 : 1, kt >= 2 ? 2 : 0);
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
-      if (vec2) {
+      if (vec2 && kt >= 2 && tune[0] == 1) {
+        if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 2, 3, 0>), dim3(blocks), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((ritz_kernel<3, 2, 3, 0>), dim3(blocks), dim3(256), lds, st, a);
+      } else if (vec2 && kt >= 2 && tune[0] == 4) {
+        if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 2, 3, 4>), dim3(blocks), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((ritz_kernel<3, 2, 3, 4>), dim3(blocks), dim3(256), lds, st, a);
+      } else if (vec2) {
         if (kt == 1) hipLaunchKernelGGL((ritz_kernel<1, 2>), dim3(blocks), dim3(256), lds, st, a);
         else if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 2>), dim3(blocks), dim3(256), lds, st, a);
         else hipLaunchKernelGGL((ritz_kernel<3, 2>), dim3(blocks), dim3(256), lds, st, a);

@@ -202,6 +202,12 @@ int dla_gram(dla_ctx* c, int n, int l, const double* x, int k, const double* u, 
   return engfail(c, c->eng->gram(n, l, x, k, u, ch, ldc));
 }
 
+int dla_gram_lower(dla_ctx* c, int n, int l, const double* x, const double* u, double* ch, int ldc)
+{
+  if (l <= 0) return DLA_OK;
+  return engfail(c, c->eng->gram_lower(n, l, x, u, ch, ldc));
+}
+
 int dla_panel_gemm(dla_ctx* c, int n, int l, const double* x, int k, const double* ch, int ldc, double* z)
 {
   if (k <= 0) return DLA_OK;

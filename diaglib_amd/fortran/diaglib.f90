@@ -104,6 +104,13 @@ module diaglib
       real(c_double) :: c(*)
       integer(c_int) :: st
     end function
+    function dla_gram_lower(ctx,n,l,x,u,c,ldc) bind(C,name='dla_gram_lower') result(st)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, x, u
+      integer(c_int), value :: n, l, ldc
+      real(c_double) :: c(*)
+      integer(c_int) :: st
+    end function
     function dla_panel_gemm(ctx,n,l,x,k,c,ldc,z) bind(C,name='dla_panel_gemm') result(st)
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: ctx, x, z
@@ -916,7 +923,8 @@ contains
 !
       len_u = n_max + 2*n_act
       if (it.eq.1) len_u = 2*n_max
-      call chk(ctx, dla_gram(ctx, n, len_u, space, len_u, aspace, a_red, len_a), 'projection')
+!     (dsyev below reads the lower triangle only, so only that part of the product is formed)
+      call chk(ctx, dla_gram_lower(ctx, n, len_u, space, aspace, a_red, len_a), 'projection')
       call get_time(t1)
       info = dla_syev_lowest('l', len_u, a_red, len_a, e_red, n_max)   ! get_coeffs uses a_red(:,1:n_max) only
       call get_time(t2)

@@ -129,6 +129,9 @@ int  dla_sync(dla_ctx* ctx);
  * diaglib.f90:1691 (projection), 3256 (ortho_cd Gram), 3543 (X^T U), 403/313 (LOBPCG S^T AS), 3762. */
 int  dla_gram(dla_ctx* ctx, int n, int l, const double* x_dev, int k, const double* u_dev,
               double* c_host, int ldc);
+/* Same for two n x l panels when the consumer reads only the LOWER triangle of C (LOBPCG: S^T AS at diaglib.f90:403
+ * goes to dsyev('v','l') at :406): entries strictly above the 16 x 16 block diagonal are returned as zero. */
+int  dla_gram_lower(dla_ctx* ctx, int n, int l, const double* x_dev, const double* u_dev, double* c_host, int ldc);
 /* Z(n x k) = X(n x l) C(l x k).  dgemm('n','n') at diaglib.f90:1717, 420-424, 495-501, 322-324.
  * Z may be a column block of X itself when k <= 48 and 128*l*ceil(k/16) <= 65536 (one output pass, one
  * contraction chunk): every row tile is read completely before it is stored. */

@@ -120,3 +120,17 @@ def test_empty_and_degenerate(ctx):
     p = ctx.panel(np.zeros((64, 3)))
     assert ctx.gram(p, p).tolist() == np.zeros((3, 3)).tolist()
     assert ctx.nrm2(p) == 0.0
+
+
+@pytest.mark.parametrize("n,l", [(1000, 13), (2000, 39), (3000, 111), (1001, 70)])
+def test_gram_lower(ctx, oracle, rng, n, l):
+    """S^T AS for a dsyev('l') consumer: the lower triangle (incl. the 16 x 16 diagonal blocks) is exact,
+    blocks strictly above the block diagonal may be zero."""
+    x = np.asfortranarray(rng.standard_normal((n, l))); u = np.asfortranarray(rng.standard_normal((n, l)))
+    got = ctx.gram_lower(ctx.panel(x), ctx.panel(u))
+    want = oracle.gemm_tn(x, u)
+    bound = _bound(np.abs(x), np.abs(u), n)
+    low = np.tril(np.ones((l, l), bool))
+    assert np.all(np.abs(got - want)[low] <= bound[low])
+    up = ~low
+    assert np.all((np.abs(got - want)[up] <= bound[up]) | (got[up] == 0.0))

@@ -44,10 +44,15 @@ def ab(title, cls, f, knob, values):
     print(f"{title:28s} knob{knob}  {line}", flush=True)
 
 
-u13 = big.col(lmax, k)
-ab("gram self k=13 blocks/pass", "gram", lambda: ctx.gram(u13, u13), 4, [256, 512, 768, 1024, 2048])
-ab("gram L=13 blocks/pass", "gram", lambda: ctx.gram(big.col(0, 13), u13), 4, [256, 512, 768, 1024, 2048])
-ab("gram L=26 blocks/pass", "gram", lambda: ctx.gram(big.col(0, 26), u13), 4, [256, 512, 768, 1024])
-ab("gram L=39 blocks/pass", "gram", lambda: ctx.gram(big.col(0, 39), u13), 4, [256, 512, 768, 1024])
-ab("gram L=52 blocks/pass", "gram", lambda: ctx.gram(big.col(0, 52), u13), 4, [256, 512, 768])
-ab("gram L=65 blocks/pass", "gram", lambda: ctx.gram(big.col(0, 65), u13), 4, [256, 512, 768])
+for (l, kw) in ((100, 21), (111, 37)):
+    x = big.col(0, l); x2 = big2.col(0, l)
+    ow1 = ctx.panel(n, kw); ow2 = ctx.panel(n, kw); ow3 = ctx.panel(n, kw)
+    y = np.asfortranarray(rng.standard_normal((l, kw)))
+    c = np.asfortranarray(rng.standard_normal((l, kw)) * 1e-3)
+    eig = np.ones(kw); skip = np.zeros(kw, np.int32)
+    ab(f"ritz L={l} M={kw} pipeline", "ritz", lambda: ctx.ritz_residual(x, x2, y, eig, kw, skip, ow2, ow3), 0, [1, 0, 4])
+    ab(f"gemm L={l} k={kw} pipeline", "gemm", lambda: ctx.panel_gemm(x, c, ow1), 2, [1, 0, 4])
+    ab(f"update L={l} k={kw} pipeline", "gemm", lambda: ctx.panel_update(x, c, ow1), 2, [1, 0, 4])
+    ab(f"gram L={l} k={kw} prefetch", "gram", lambda: ctx.gram(x, ow1), 5, [0, 1])
+    ab(f"gram {kw}x{kw} self prefetch", "gram", lambda: ctx.gram(ow1, ow1), 5, [0, 1])
+    ab(f"gram L={l} x L (S^T AS) prefetch", "gram", lambda: ctx.gram(x, x2), 5, [0, 1])
