@@ -1,0 +1,103 @@
+"""GPU: the row-sharded path of the HIP engine on real hardware with TWO ranks sharing one GPU.
+RCCL refuses two ranks on one device, so the small cross-rank sums travel through the
+dla_set_allreduce_hook door over gloo; every reduction point of the engine (Gram / fused Gram / Ritz norms /
+nrm2 / the operator's r x m product), the shard offsets of the generator and of the built-in operator, and
+the replicated small-matrix logic are the same code that runs under RCCL (whose transport is exercised by
+tests/test_solver_gpu.py::test_rccl_communicator_single_rank)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, json
+os.environ.setdefault("OMP_NUM_THREADS", "2")
+sys.path.insert(0, {root!r})
+import numpy as np
+from diaglib_amd import capi
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from bench import shard_rows
+spec = json.loads({spec!r})
+n, t, m = spec["n"], spec["n_targ"], spec["n_max"]
+row0, n_loc = shard_rows(n, world, rank)
+ctx = capi.Context()
+assert ctx.backend.startswith("hip:")
+def hook(buf, op):
+    tt = torch.from_numpy(buf)
+    dist.all_reduce(tt, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+if world > 1:
+    ctx.set_allreduce_hook(hook, world, rank)
+    ctx.set_shard(n, row0)
+ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+ctx.synth_setup(n, row0, n_loc)
+g = np.zeros((n_loc, m), order="F")
+if spec["guess"] == "unit":
+    for j in range(m):
+        if row0 <= j < row0 + n_loc: g[j - row0, j] = 1.0
+ev = ctx.panel(g)
+mv, pc = capi.fn_address("dla_synth_matvec"), capi.fn_address("dla_synth_precnd")
+if spec["solver"] == "check_guess":
+    # zero guess -> library-generated random block (global row indices) + sharded ortho_cd
+    ctx.check_guess(ev)
+    eig, ok, info = np.zeros(m), True, dict(iters=0, matvec_cols=0)
+elif spec["solver"] == "davidson":
+    eig, _, ok, info = ctx.davidson_driver(n_loc, t, m, 200, spec["tol"], 20, 0.0, mv, pc, ev)
+else:
+    eig, _, ok, info = ctx.lobpcg_driver(n_loc, t, m, 200, spec["tol"], 0.0, mv, pc, ev)
+np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), eig=eig, ok=ok, iters=info["iters"], cols=info["matvec_cols"],
+         row0=row0, vec=ev.download(), allreduces=ctx.stats()["allreduces"])
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def _run_world(tmp_path, spec, world):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, spec=json.dumps(spec), out=str(tmp_path)))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LOCAL_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+
+
+@pytest.mark.parametrize("solver,guess", [("davidson", "unit"), ("lobpcg", "unit"), ("check_guess", "zero")])
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, solver, guess):
+    spec = dict(n=200_000, n_targ=8, n_max=13, tol=1e-10, solver=solver, guess=guess)
+    d1 = tmp_path / "w1"; d1.mkdir()
+    d2 = tmp_path / "w2"; d2.mkdir()
+    one = _run_world(d1, spec, 1)[0]
+    two = _run_world(d2, spec, 2)
+    t = spec["n_targ"]
+    if solver == "check_guess":
+        v2 = np.vstack([two[0]["vec"], two[1]["vec"]]); v1 = one["vec"]
+        assert np.abs(v2 - v1).max() < 1e-12                         # same random stream, same orthonormalisation
+        assert np.abs(v2.T @ v2 - np.eye(v2.shape[1])).max() < 1e-13
+        assert int(two[0]["allreduces"]) > 0
+        return
+    assert bool(one["ok"]) and all(bool(r["ok"]) for r in two)
+    assert int(two[0]["iters"]) == int(two[1]["iters"]) and int(two[0]["cols"]) == int(two[1]["cols"])
+    assert np.array_equal(two[0]["eig"], two[1]["eig"])            # identical decisions on both ranks
+    assert int(two[0]["allreduces"]) > 0 and int(one["allreduces"]) == 0
+    assert np.allclose(two[0]["eig"][:t], one["eig"][:t], rtol=1e-11, atol=0)
+    assert abs(int(two[0]["iters"]) - int(one["iters"])) <= max(1, int(one["iters"]) // 5)
+    v2 = np.vstack([two[0]["vec"], two[1]["vec"]])
+    assert int(two[1]["row0"]) == two[0]["vec"].shape[0]
+    v1 = one["vec"]
+    sgn = np.sign((v1 * v2).sum(0))
+    assert np.abs(v2 * sgn - v1)[:, :t].max() < 1e-6
+    assert np.abs(v2[:, :t].T @ v2[:, :t] - np.eye(t)).max() < 1e-12
