@@ -325,7 +325,7 @@ __device__ __forceinline__ const double* packed_c(const GemmArgs& a) { return a.
 __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return a.cin; }
 
 // MODE 0: Z = XC   1: Z -= XC   2: in place U <- U W (x == z)   3: Z += XC
-// GRAM (KT == 1 only): the same sweep also accumulates G = Z^T Z of the values it stores -- the next
+// GRAM: the same sweep also accumulates G = Z^T Z of the values it stores (lower block triangle) -- the next
 // Gram matrix of the Cholesky-QR loop (diaglib.f90:3256) without re-reading the panel.  The stored
 // rows of a 16*VEC-row group are transposed through a wave-private LDS tile (row stride 24 doubles:
 // conflict-free for the fragment reads) into MFMA operands: lane (c, g) reads Z[row(g)][c].
@@ -338,7 +338,7 @@ __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return
 template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1), int PIPE = (KT >= 2 ? 2 : 0)>
 __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 {
-  static_assert(!GRAM || KT == 1, "fused Gram needs a single 16-column output tile");
+
   constexpr int RT = 2;                    // row groups per wave tile
   constexpr int RG = 16 * VEC;             // rows per group
   constexpr int WT = RT * RG;              // rows per wave tile (64 for VEC=2)
@@ -356,9 +356,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
   const int i = lane & 15, g = lane >> 4;
   const long long ntiles = (n + WT - 1) / WT;
   const int nsteps = l4 / 4;
-  constexpr int ZS = 24;                                   // LDS row stride of the transpose tile (doubles)
+  // LDS row stride of the transpose tile (doubles): 16*KT + 8 keeps rows two apart 32 banks apart, which makes
+  // the 64-bit fragment reads conflict-free (cdna_hip_programming.md section 2)
+  constexpr int ZS = 16 * KT + 8;
   double* zs = cs + (size_t)KT * l4 * 16 + (size_t)wave * RG * ZS;   // [RG rows][ZS] per wave (GRAM only)
-  v4d gacc = (v4d){0.0, 0.0, 0.0, 0.0};
+  v4d gacc[KT][KT];                                        // tile (qa, qb) of Z^T Z, qa >= qb only
+#pragma unroll
+  for (int qa = 0; qa < KT; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < KT; ++qb) gacc[qa][qb] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
     const long long r0 = tile * WT;
@@ -472,22 +478,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
-            const double zv = zs[(4 * VEC * s4 + VEC * g + e) * ZS + i];
-            gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(zv, zv, gacc, 0, 0, 0);
+            double zv[KT];
+#pragma unroll
+            for (int q = 0; q < KT; ++q) zv[q] = zs[(4 * VEC * s4 + VEC * g + e) * ZS + 16 * q + i];
+#pragma unroll
+            for (int qa = 0; qa < KT; ++qa)
+#pragma unroll
+              for (int qb = 0; qb <= qa; ++qb)
+                gacc[qa][qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[qa], zv[qb], gacc[qa][qb], 0, 0, 0);
           }
         __builtin_amdgcn_wave_barrier();
       }
     }
   }
   if constexpr (GRAM) {
-    // deterministic sum over the 4 waves; D layout as in gram_kernel (slot 0 of a 1x1 pass)
-    __syncthreads();
+    // deterministic sum over the 4 waves, one tile at a time; partial layout = KT x KT slots of a 1-pass Gram
+    // (slot qa*KT + qb; the upper block triangle is sent as zeros and mirrored on the host)
     double* red = cs;   // the copy of C is no longer needed: 4 x 256 doubles
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = gacc[r];
-    __syncthreads();
     const int t = threadIdx.x;
-    a.gpart[(size_t)blockIdx.x * 256 + t] = ((red[t] + red[256 + t]) + red[512 + t]) + red[768 + t];
+#pragma unroll
+    for (int qa = 0; qa < KT; ++qa)
+#pragma unroll
+      for (int qb = 0; qb < KT; ++qb) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = gacc[qa][qb][r];
+        __syncthreads();
+        a.gpart[((size_t)blockIdx.x * (KT * KT) + (qa * KT + qb)) * 256 + t] =
+            ((red[t] + red[256 + t]) + red[512 + t]) + red[768 + t];
+      }
   }
 }
 
@@ -1270,32 +1289,38 @@ struct HipEngine : dla::Engine {
   {
     int stc = ensure_small(sizeof(double) * (size_t)k * k);
     if (stc) return stc;
+    const int kt = (k + 15) / 16;
     const int groups = std::max(1, std::min(16, (fused_blocks + 31) / 32));
-    const size_t need2 = sizeof(double) * (size_t)groups * 256;
+    const size_t need2 = sizeof(double) * (size_t)kt * kt * groups * 256;
     if (need2 > lvl2_bytes) {
       HIPCHK(hipStreamSynchronize(st));
       if (d_lvl2) HIPCHK(hipFree(d_lvl2));
       lvl2_bytes = std::max(need2, (size_t)1 << 20);
       HIPCHK(hipMalloc((void**)&d_lvl2, lvl2_bytes));
     }
-    GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, h_small_dev, fused_blocks, k, k, 1, 1, 1};
+    GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, h_small_dev, fused_blocks, k, k, kt, kt, 1};
     {
       Scope s2(this, DLA_OP_GRAM, 0.0, 0.0, "gram_reduce_kernel");
-      hipLaunchKernelGGL(gram_reduce_kernel, dim3(1, groups), dim3(256), 0, st, ra);
+      hipLaunchKernelGGL(gram_reduce_kernel, dim3(kt * kt, groups), dim3(256), 0, st, ra);
     }
     HIPCHK(hipGetLastError());
     stc = allreduce_dev(d_small, k * k, 0, h_small);
     if (stc) return stc;
     stc = small_to_host((size_t)k * k);
     if (stc) return stc;
-    for (int j = 0; j < k; ++j) std::memcpy(g_host + (size_t)j * ldg, h_small + (size_t)j * k, sizeof(double) * k);
+    // the kernel formed the lower block triangle; mirror it (G is symmetric)
+    for (int j = 0; j < k; ++j)
+      for (int i2 = 0; i2 < k; ++i2) {
+        const bool low = (i2 / 16) >= (j / 16);
+        g_host[(size_t)i2 + (size_t)j * ldg] = low ? h_small[(size_t)i2 + (size_t)j * k] : h_small[(size_t)j + (size_t)i2 * k];
+      }
     return DLA_OK;
   }
 
-  // U <- U W and G = U^T U of the result, one sweep (k <= 16); otherwise two sweeps
+  // U <- U W and G = U^T U of the result, one sweep (k <= 48); otherwise two sweeps
   int trmm_gram(int n, int k, double* u, const double* w_host, int ld, double* g_host, int ldg) override
   {
-    if (k > 16) return Engine::trmm_gram(n, k, u, w_host, ld, g_host, ldg);
+    if (k > 48) return Engine::trmm_gram(n, k, u, w_host, ld, g_host, ldg);
     {
       // accounted as TRMM traffic (16nk) -- the Gram rides along
       int stc = gemm_chunk(n, 0, k, u, k, w_host, ld, u, 2, DLA_OP_TRMM, true);
@@ -1307,7 +1332,11 @@ struct HipEngine : dla::Engine {
 
   // U <- [X | U] C' and G = U^T U of the result in one sweep; U is the last k columns of the same
   // contiguous panel (each wave reads all m+k columns of its rows before it stores, so in place is safe)
-  bool can_combo(int m, int k) override { return k <= 16 && m > 0 && m + k <= 448; }
+  bool can_combo(int m, int k) override
+  {
+    const int kt = (k + 15) / 16;
+    return k <= 48 && m > 0 && (size_t)(m + k + 3) * 16 * kt * sizeof(double) <= (size_t)64 * 1024;   // C' in one LDS chunk
+  }
   int combo_gram(int n, int m, const double* x, int k, const double* c_host, int ldc, double* u, double* g_host, int ldg) override
   {
     if (!can_combo(m, k) || u != x + (size_t)n * m) { err = "combo_gram: unsupported shape"; return DLA_ERR_ARG; }
@@ -1320,10 +1349,11 @@ struct HipEngine : dla::Engine {
     return finish_fused_gram(k, g_host, ldg);
   }
 
-  // U -= X C and G = U^T U of the result, one sweep (k <= 16, C fits one LDS chunk)
+  // U -= X C and G = U^T U of the result, one sweep (k <= 48, C fits one LDS chunk)
   int update_gram(int n, int l, const double* x, int k, const double* c_host, int ldc, double* u, double* g_host, int ldg) override
   {
-    if (k > 16 || l > 448 || l == 0) return Engine::update_gram(n, l, x, k, c_host, ldc, u, g_host, ldg);
+    if (k > 48 || l == 0 || (size_t)(l + 3) * 16 * ((k + 15) / 16) * sizeof(double) > (size_t)64 * 1024)
+      return Engine::update_gram(n, l, x, k, c_host, ldc, u, g_host, ldg);
     int stc = gemm_chunk(n, 0, l, x, k, c_host, ldc, u, 1, DLA_OP_GEMM, true);
     if (stc) return stc;
     stats.flops[DLA_OP_GRAM] += 2.0 * (double)n * k * k;
@@ -1348,10 +1378,19 @@ struct HipEngine : dla::Engine {
     return stage_to_device(pk.data(), sizeof(double) * cnt, d_cpk);
   }
 
-  template <typename ARGS>
+  template <int KT, typename ARGS>
   void launch_gemm_gram(const ARGS& a, int blocks, size_t lds, bool vec2, int mode)
   {
-#define GG(V, M) hipLaunchKernelGGL((gemm_kernel<1, V, M, ARGS, true>), dim3(blocks), dim3(256), lds, st, a)
+    // more than 64 KiB of dynamic LDS has to be enabled per kernel (gfx950 has 160 KiB per CU)
+#define GG(V, M)                                                                                              \
+    do {                                                                                                      \
+      auto kfn = gemm_kernel<KT, V, M, ARGS, true>;                                                           \
+      if (lds > (size_t)64 * 1024) {                                                                          \
+        static bool raised = false;                                                                           \
+        if (!raised) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; } \
+      }                                                                                                       \
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);                                           \
+    } while (0)
     if (vec2) { if (mode == 1) GG(2, 1); else if (mode == 2) GG(2, 2); else GG(2, 0); }
     else      { if (mode == 1) GG(1, 1); else if (mode == 2) GG(1, 2); else GG(1, 0); }
 #undef GG
@@ -1388,11 +1427,11 @@ struct HipEngine : dla::Engine {
     const long long ntiles = ((long long)n + wt - 1) / wt;
     // fused variant: + 4 wave tiles of (16*VEC rows) x 24 doubles, and >= 8 KiB for the final reduction
     const size_t lds_c = sizeof(double) * (size_t)kt * l4 * 16;
-    const size_t lds = fuse ? std::max(lds_c + sizeof(double) * 4 * (vec2 ? 32 : 16) * 24, (size_t)8192) : lds_c;
+    const size_t lds = fuse ? std::max(lds_c + sizeof(double) * 4 * (vec2 ? 32 : 16) * (16 * kt + 8), (size_t)8192) : lds_c;
     const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
     const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu * (tune[3] > 0 ? tune[3] : 1), (ntiles + 3) / 4));
     if (fuse) {
-      int stp = ensure_partial(sizeof(double) * (size_t)blocks * 256);
+      int stp = ensure_partial(sizeof(double) * (size_t)blocks * kt * kt * 256);
       if (stp) return stp;
       fused_blocks = blocks;
     }
@@ -1408,13 +1447,15 @@ struct HipEngine : dla::Engine {
       ai.x = a.x; ai.z = z; ai.n = n; ai.l = l; ai.l4 = l4; ai.k = k; ai.gpart = d_partial;
       for (int j = 0; j < k; ++j)
         for (int p = 0; p < l; ++p) ai.cin[p * 16 + j] = c_host[(size_t)(l0 + p) + (size_t)j * ldc];
-      if (fuse) launch_gemm_gram(ai, blocks, lds, vec2, mode);
+      if (fuse) launch_gemm_gram<1>(ai, blocks, lds, vec2, mode);
       else launch_gemm<1>(ai, blocks, lds, vec2, mode);
       HIPCHK(hipGetLastError());
       return DLA_OK;
     }
     if (fuse) {
-      launch_gemm_gram(a, blocks, lds, vec2, mode);
+      if (kt == 1) launch_gemm_gram<1>(a, blocks, lds, vec2, mode);
+      else if (kt == 2) launch_gemm_gram<2>(a, blocks, lds, vec2, mode);
+      else launch_gemm_gram<3>(a, blocks, lds, vec2, mode);
       HIPCHK(hipGetLastError());
       return DLA_OK;
     }

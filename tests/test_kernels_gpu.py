@@ -134,3 +134,20 @@ def test_gram_lower(ctx, oracle, rng, n, l):
     assert np.all(np.abs(got - want)[low] <= bound[low])
     up = ~low
     assert np.all((np.abs(got - want)[up] <= bound[up]) | (got[up] == 0.0))
+
+
+@pytest.mark.parametrize("n,m,k", [(3000, 40, 21), (2001, 111, 37), (4096, 100, 48), (1000, 26, 17)])
+def test_ortho_vs_x_wide_blocks_contiguous(ctx, oracle, rng, n, m, k):
+    """Blocks wider than 16 columns through the fused sweeps (TRMM+Gram, [X|U] sweep+Gram with 2-3 column tiles):
+    U is the block that follows X in one panel, as in the drivers."""
+    x = np.linalg.qr(rng.standard_normal((n, m)))[0]
+    u = rng.standard_normal((n, k)) + x[:, : min(m, k)] @ rng.standard_normal((min(m, k), k)) * 3
+    panel = ctx.panel(np.asfortranarray(np.hstack([x, u])))
+    ctx.ortho_vs_x(panel.col(0, m), panel.col(m, k))
+    got = panel.col(m, k).download()
+    want, _, st = oracle.ortho_vs_x(np.asfortranarray(x), np.asfortranarray(u))
+    assert st == 0
+    assert np.abs(got.T @ got - np.eye(k)).max() < 50 * EPS
+    assert np.abs(x.T @ got).max() < 50 * EPS
+    assert np.abs(got - want).max() < 1e-11
+    assert np.array_equal(panel.col(0, m).download(), np.asfortranarray(x))      # X untouched
