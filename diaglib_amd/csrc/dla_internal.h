@@ -82,6 +82,18 @@ struct Engine {
   std::string err;
 };
 
+// $DIAGLIB_AMD_HOSTTIME=1: wall time spent inside each C-ABI entry point (printed by dla_destroy)
+struct ApiTimer {
+  static bool on();
+  static void add(const char* name, double dt);
+  static void report();
+  static double now();
+  const char* name; double t0;
+  explicit ApiTimer(const char* n) : name(n), t0(on() ? now() : 0.0) {}
+  ~ApiTimer() { if (on()) add(name, now() - t0); }
+};
+#define DLA_T(name) dla::ApiTimer dla_api_timer_(name)
+
 // provided by the engine translation unit linked into the library
 Engine* make_engine(int device, std::string& err);
 int engine_unique_id(char id[128]);

@@ -16,6 +16,23 @@
 
 using dla::Engine;
 
+// ---- $DIAGLIB_AMD_HOSTTIME accounting
+#include <map>
+#include <string>
+#include <time.h>
+namespace dla {
+namespace { std::map<std::string, std::pair<double, long>>& api_tab() { static std::map<std::string, std::pair<double, long>> t; return t; } }
+bool ApiTimer::on() { static const bool v = std::getenv("DIAGLIB_AMD_HOSTTIME") != nullptr; return v; }
+double ApiTimer::now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+void ApiTimer::add(const char* name, double dt) { auto& e = api_tab()[name]; e.first += dt; e.second += 1; }
+void ApiTimer::report()
+{
+  if (!on()) return;
+  for (auto& kv : api_tab())
+    std::fprintf(stderr, "[dla] api %-22s %9.3f ms %7ld calls\n", kv.first.c_str(), kv.second.first * 1e3, kv.second.second);
+}
+}  // namespace dla
+
 namespace {
 
 const double kEps = DBL_EPSILON;           // epsilon(one)
@@ -68,6 +85,7 @@ int dla_create(dla_ctx** out, int device)
 int dla_destroy(dla_ctx* c)
 {
   if (!c) return DLA_OK;
+  dla::ApiTimer::report();
   if (c->stage_x) c->eng->host_free(c->stage_x);
   if (c->stage_y) c->eng->host_free(c->stage_y);
   delete c->eng;
@@ -187,41 +205,46 @@ int dla_set_shard(dla_ctx* c, long long n_global, long long row0)
 }
 
 // ------------------------------------------------------------------ memory
-int dla_alloc(dla_ctx* c, size_t bytes, void** dev) { return engfail(c, c->eng->alloc(bytes, dev)); }
-int dla_free(dla_ctx* c, void* dev) { return engfail(c, c->eng->free_(dev)); }
-int dla_zero(dla_ctx* c, void* dev, size_t bytes) { return engfail(c, c->eng->zero(dev, bytes)); }
-int dla_upload(dla_ctx* c, void* dev, const void* host, size_t bytes) { return engfail(c, c->eng->h2d(dev, host, bytes)); }
-int dla_download(dla_ctx* c, void* host, const void* dev, size_t bytes) { return engfail(c, c->eng->d2h(host, dev, bytes)); }
-int dla_copy(dla_ctx* c, void* dst, const void* src, size_t bytes) { return engfail(c, c->eng->d2d(dst, src, bytes)); }
-int dla_sync(dla_ctx* c) { return engfail(c, c->eng->sync()); }
+int dla_alloc(dla_ctx* c, size_t bytes, void** dev) { DLA_T("dla_alloc"); return engfail(c, c->eng->alloc(bytes, dev)); }
+int dla_free(dla_ctx* c, void* dev) { DLA_T("dla_free"); return engfail(c, c->eng->free_(dev)); }
+int dla_zero(dla_ctx* c, void* dev, size_t bytes) { DLA_T("dla_zero"); return engfail(c, c->eng->zero(dev, bytes)); }
+int dla_upload(dla_ctx* c, void* dev, const void* host, size_t bytes) { DLA_T("dla_upload"); return engfail(c, c->eng->h2d(dev, host, bytes)); }
+int dla_download(dla_ctx* c, void* host, const void* dev, size_t bytes) { DLA_T("dla_download"); return engfail(c, c->eng->d2h(host, dev, bytes)); }
+int dla_copy(dla_ctx* c, void* dst, const void* src, size_t bytes) { DLA_T("dla_copy"); return engfail(c, c->eng->d2d(dst, src, bytes)); }
+int dla_sync(dla_ctx* c) { DLA_T("dla_sync"); return engfail(c, c->eng->sync()); }
 
 // ------------------------------------------------------------------ block algebra
 int dla_gram(dla_ctx* c, int n, int l, const double* x, int k, const double* u, double* ch, int ldc)
 {
+  DLA_T("dla_gram");
   if (l <= 0 || k <= 0) return DLA_OK;
   return engfail(c, c->eng->gram(n, l, x, k, u, ch, ldc));
 }
 
 int dla_gram_lower(dla_ctx* c, int n, int l, const double* x, const double* u, double* ch, int ldc)
 {
+  DLA_T("dla_gram_lower");
   if (l <= 0) return DLA_OK;
   return engfail(c, c->eng->gram_lower(n, l, x, u, ch, ldc));
 }
 
 int dla_panel_gemm(dla_ctx* c, int n, int l, const double* x, int k, const double* ch, int ldc, double* z)
 {
+  DLA_T("dla_panel_gemm");
   if (k <= 0) return DLA_OK;
   return engfail(c, c->eng->gemm(n, l, x, k, ch, ldc, z, 0));
 }
 
 int dla_panel_update(dla_ctx* c, int n, int l, const double* x, int k, const double* ch, int ldc, double* u)
 {
+  DLA_T("dla_panel_update");
   if (k <= 0 || l <= 0) return DLA_OK;
   return engfail(c, c->eng->gemm(n, l, x, k, ch, ldc, u, 1));
 }
 
 int dla_trmm_linvt(dla_ctx* c, int n, int k, double* u, const double* linv, int ld)
 {
+  DLA_T("dla_trmm_linvt");
   // U <- U * Linv^T : W = Linv^T is upper triangular, W(p,j) = Linv(j,p) for p <= j
   std::vector<double> w((size_t)k * k, 0.0);
   for (int j = 0; j < k; ++j)
@@ -233,6 +256,7 @@ int dla_ritz_residual(dla_ctx* c, int n, int l, int m, const double* v, const do
                       const double* eig, int n_res, const int* skip, double* evec, double* r, double* avy,
                       double* rnorm)
 {
+  DLA_T("dla_ritz_residual");
   std::vector<double> sm((size_t)2 * (n_res > 0 ? n_res : 1), 0.0);
   int st = c->eng->ritz_residual(n, l, m, v, av, y, ldy, eig, n_res, skip, evec, r, avy, sm.data());
   if (st) return engfail(c, st);
@@ -247,11 +271,13 @@ int dla_ritz_residual(dla_ctx* c, int n, int l, int m, const double* v, const do
 
 int dla_axpy(dla_ctx* c, size_t len, double alpha, const double* x, double* y)
 {
+  DLA_T("dla_axpy");
   return engfail(c, c->eng->axpy(len, alpha, x, y));
 }
 
 int dla_nrm2(dla_ctx* c, size_t len, const double* x, double* out)
 {
+  DLA_T("dla_nrm2");
   double s = 0.0;
   int st = c->eng->sumsq(len, x, &s);
   if (st) return engfail(c, st);
@@ -352,6 +378,7 @@ static int ortho_cd_impl(dla_ctx* c, int n, int k, double* u, double* growth, in
 
 int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
 {
+  DLA_T("dla_ortho_cd");
   return ortho_cd_impl(c, n, k, u, growth, ok, nullptr);
 }
 
@@ -447,11 +474,13 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
 
 int dla_ortho_vs_x(dla_ctx* c, int n, int m, int k, const double* x, double* u)
 {
+  DLA_T("dla_ortho_vs_x");
   return ortho_vs_x_impl(c, n, m, k, x, x, u);
 }
 
 int dla_b_ortho_vs_x(dla_ctx* c, int n, int m, int k, const double* x, const double* bx, double* u)
 {
+  DLA_T("dla_b_ortho_vs_x");
   return ortho_vs_x_impl(c, n, m, k, x, bx, u);
 }
 
@@ -461,6 +490,7 @@ int dla_b_ortho_vs_x(dla_ctx* c, int n, int m, int k, const double* x, const dou
 // explicit inverse like ortho_cd does, which is the same linear map.
 int dla_b_ortho(dla_ctx* c, int n, int m, double* u, double* bu)
 {
+  DLA_T("dla_b_ortho");
   if (m <= 0) return DLA_OK;
   std::vector<double> metric((size_t)m * m);
   int st = c->eng->gram(n, m, u, m, bu, metric.data(), m);
@@ -475,6 +505,7 @@ int dla_b_ortho(dla_ctx* c, int n, int m, double* u, double* bu)
 // check_guess, diaglib.f90:3734-3786
 int dla_check_guess(dla_ctx* c, int n, int m, double* evec)
 {
+  DLA_T("dla_check_guess");
   double fac = 0.0, growth;
   int ok;
   int st = dla_nrm2(c, (size_t)n * m, evec, &fac);
@@ -503,6 +534,7 @@ int dla_check_guess(dla_ctx* c, int n, int m, double* evec)
 // summed over ranks here: the call runs with the communicator masked.
 int dla_get_coeffs(dla_ctx* c, int len_a, int len_u, int n_max, int n_act, const double* a_red, double* u_x, double* u_p)
 {
+  DLA_T("dla_get_coeffs");
   int off_x = n_max - n_act;
   for (int j = 0; j < n_max; ++j)
     for (int i = 0; i < len_u; ++i) u_x[(size_t)i + (size_t)j * len_u] = a_red[(size_t)i + (size_t)j * len_a];
@@ -545,6 +577,7 @@ static int ensure_stage(dla_ctx* c, size_t bytes)
 
 int dla_call_matvec(dla_ctx* c, dla_matvec_fn fn, int n, int m, const double* x, double* ax)
 {
+  DLA_T("dla_call_matvec");
   if (m <= 0) return DLA_OK;
   if (c->callbacks_on_device) {
     fn(&n, &m, x, ax);
@@ -561,6 +594,7 @@ int dla_call_matvec(dla_ctx* c, dla_matvec_fn fn, int n, int m, const double* x,
 
 int dla_call_precnd(dla_ctx* c, dla_precnd_fn fn, int n, int m, double fac, const double* x, double* px)
 {
+  DLA_T("dla_call_precnd");
   if (m <= 0) return DLA_OK;
   if (c->callbacks_on_device) {
     fn(&n, &m, &fac, x, px);

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <vector>
 #include "../../include/diaglib_amd.h"
+#include "dla_internal.h"
 
 namespace {
 
@@ -432,6 +433,7 @@ extern "C" {
 
 int dla_syev(char uplo, int n, double* a, int lda, double* w)
 {
+  DLA_T("dla_syev");
   if (n <= 0) return 0;
   if (lda < n) return -1;
   bool up = (uplo == 'u' || uplo == 'U');
@@ -465,6 +467,7 @@ int dla_syev(char uplo, int n, double* a, int lda, double* w)
 // callers use the first n_max eigenpairs only.
 int dla_syev_lowest(char uplo, int n, double* a, int lda, double* w, int m)
 {
+  DLA_T("dla_syev_lowest");
   if (n <= 0) return 0;
   if (lda < n) return -1;
   if (m > n) m = n;
@@ -492,6 +495,7 @@ int dla_syev_lowest(char uplo, int n, double* a, int lda, double* w, int m)
 
 int dla_potrf_lower(int m, double* a, int lda)
 {
+  DLA_T("dla_potrf_lower");
   for (int j = 0; j < m; ++j) {
     double dj = at(a, lda, j, j);
     for (int p = 0; p < j; ++p) dj -= at(a, lda, j, p) * at(a, lda, j, p);
@@ -510,6 +514,7 @@ int dla_potrf_lower(int m, double* a, int lda)
 
 int dla_trtri_lower(int m, double* a, int lda)
 {
+  DLA_T("dla_trtri_lower");
   for (int j = 0; j < m; ++j)
     if (at(a, lda, j, j) == 0.0) return j + 1;
   std::vector<double> x(m);
