@@ -1234,7 +1234,7 @@ struct HipEngine : dla::Engine {
       const bool same = (x == u) && (l == k);
       const int rs = (tlw * kt >= 6) ? 2 : 4;
       char kn[64];
-      std::snprintf(kn, sizeof kn, "gram_kernel<%d, %d, %d, %d, 0>", tlw, kt, vec2 ? 2 : 1, rs);
+      std::snprintf(kn, sizeof kn, "gram_kernel<%d, %d, %d, %d, 0, -1>", tlw, kt, vec2 ? 2 : 1, rs);
       Scope s(this, cls, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k, kn);
 #define GL(T, K) if (tlw == T && kt == K) launch_gram<T, K>(a, grid, vec2); else
       GL(1, 1) GL(2, 1) GL(3, 1) GL(4, 1) GL(6, 1) GL(8, 1) GL(12, 1)

@@ -142,64 +142,132 @@ int sym_eig(int n, std::vector<double>& s, std::vector<double>& d, std::vector<d
 // ---------------------------------------------------------------------------------------
 // Partial solver: the drivers only ever use the lowest n_max eigenpairs of the projected
 // matrix (reference diaglib.f90:1715-1721 uses a_copy(:,1:n_max), get_coeffs :3712 uses
-// a_red(:,1:n_max)).  Householder tridiagonalisation, all eigenvalues by implicit QL without
-// vectors, the m lowest eigenvectors by inverse iteration on the tridiagonal matrix with
+// a_red(:,1:n_max)).  Householder tridiagonalisation, the m lowest eigenvalues by bisection on
+// Sturm counts, their eigenvectors by inverse iteration on the tridiagonal matrix with
 // re-orthogonalisation inside clusters, back-transformation with the stored reflectors.
-// Cost 4/3 n^3 + O(m n^2) instead of ~9 n^3.
+// Cost 4/3 n^3 + O(m n^2) instead of ~9 n^3.  This runs on the critical path of every iteration
+// while the GPU waits, so the loops are laid out for the host's SIMD units.
 // ---------------------------------------------------------------------------------------
+typedef double v4 __attribute__((vector_size(32)));
+inline v4 ld4(const double* q) { v4 r; std::memcpy(&r, q, sizeof r); return r; }
+inline void st4(double* q, v4 r) { std::memcpy(q, &r, sizeof r); }
+inline v4 bc4(double x) { return (v4){x, x, x, x}; }
+inline double hsum4(v4 a) { return (a[0] + a[1]) + (a[2] + a[3]); }
+
 struct Tridiag {
   int n;
   std::vector<double> d, e;       // diagonal, sub-diagonal (e[i] couples i and i+1)
   std::vector<double> hv, hbeta;  // reflectors: row k of hv (entries k+1..n-1), beta_k
 };
 
+// One pass over the stored part of a row of the trailing matrix (upper triangle, row-major: row[0] is
+// the diagonal entry, row[j] couples this index with index + j).  All vectors are offset to this index.
+//   UPD: row[j] -= vi * w[j] + wi * v[j]                        (symmetric rank-2 update of step k)
+//   MV : returns sum_j row[j] * x[j]; pn[j] += row[j] * x[0], j >= 1   (both halves of A x for step k+1)
+template <bool UPD, bool MV>
+inline double row_pass(double* row, int len, double vi, double wi, const double* v, const double* w,
+                       const double* x, double* pn)
+{
+  double r0 = row[0];
+  if (UPD) { r0 -= vi * w[0] + wi * v[0]; row[0] = r0; }
+  double dot = 0.0;
+  const double x0 = MV ? x[0] : 0.0;
+  if (MV) dot = r0 * x0;
+  int j = 1;
+  v4 acc = bc4(0.0);
+  const v4 vvi = bc4(vi), vwi = bc4(wi), vx0 = bc4(x0);
+  for (; j + 4 <= len; j += 4) {
+    v4 r = ld4(row + j);
+    if (UPD) { r -= vvi * ld4(w + j) + vwi * ld4(v + j); st4(row + j, r); }
+    if (MV) { acc += r * ld4(x + j); st4(pn + j, ld4(pn + j) + r * vx0); }
+  }
+  double tail = 0.0;
+  for (; j < len; ++j) {
+    double r = row[j];
+    if (UPD) { r -= vi * w[j] + wi * v[j]; row[j] = r; }
+    if (MV) { tail += r * x[j]; pn[j] += r * x0; }
+  }
+  return dot + (hsum4(acc) + tail);
+}
+
+// Householder vector of x (length m): on exit v holds the vector, returns beta (0: nothing to annihilate)
+// and *sub = the new sub-diagonal entry.
+inline double make_reflector(const double* x, int m, double* v, double* sub)
+{
+  double scale = 0.0;
+  for (int i = 0; i < m; ++i) scale = std::max(scale, std::fabs(x[i]));
+  *sub = x[0];
+  if (scale == 0.0) return 0.0;
+  double rest = 0.0;
+  for (int i = 0; i < m; ++i) v[i] = x[i] / scale;
+  for (int i = 1; i < m; ++i) rest += v[i] * v[i];
+  if (rest == 0.0) return 0.0;
+  const double nrm = std::sqrt(v[0] * v[0] + rest);
+  const double alpha = (v[0] >= 0.0) ? -nrm : nrm;
+  v[0] -= alpha;
+  *sub = alpha * scale;
+  return 2.0 / (v[0] * v[0] + rest);
+}
+
+// s: symmetric n x n, row-major; only the upper triangle (j >= i) is read and updated.  The rank-2 update
+// of step k and the matrix-vector product of step k+1 share one pass over the trailing matrix.
 void tridiagonalize(int n, std::vector<double>& s, Tridiag& t)
 {
   t.n = n;
   t.d.assign(n, 0.0); t.e.assign(n, 0.0);
   t.hv.assign((size_t)n * n, 0.0); t.hbeta.assign(n, 0.0);
-  std::vector<double> v(n), p(n);
-  auto S = [&](int i, int j) -> double& { return s[(size_t)i * n + j]; };
-  for (int k = 0; k + 2 < n; ++k) {
-    const int m = n - k - 1;
-    double scale = 0.0;
-    for (int i = 0; i < m; ++i) scale = std::max(scale, std::fabs(S(k + 1 + i, k)));
-    if (scale == 0.0) continue;
-    double nrm = 0.0;
-    for (int i = 0; i < m; ++i) { v[i] = S(k + 1 + i, k) / scale; nrm += v[i] * v[i]; }
-    nrm = std::sqrt(nrm);
-    const double alpha = (v[0] >= 0.0) ? -nrm : nrm;
-    double rest = 0.0;
-    for (int i = 1; i < m; ++i) rest += v[i] * v[i];
-    if (rest == 0.0) continue;
-    v[0] -= alpha;
-    const double beta = 2.0 / (v[0] * v[0] + rest);
-    // p = beta * S22 v, accumulated column-wise (S22 is symmetric: row j == column j) so that the
-    // inner loop is an axpy the compiler vectorises without re-associating any sum
-    for (int i = 0; i < m; ++i) p[i] = 0.0;
-    for (int j = 0; j < m; ++j) {
-      const double* row = &s[(size_t)(k + 1 + j) * n + (k + 1)];
-      const double vj = v[j];
-      for (int i = 0; i < m; ++i) p[i] += row[i] * vj;
+  std::vector<double> vbuf[2], pbuf[2], w(n + 4, 0.0);
+  for (int q = 0; q < 2; ++q) { vbuf[q].assign(n + 4, 0.0); pbuf[q].assign(n + 4, 0.0); }
+  if (n >= 3) {
+    // step 0: reflector from row 0, plain product with the trailing matrix
+    double sub;
+    double beta = make_reflector(&s[1], n - 1, vbuf[0].data(), &sub);
+    double* p0 = pbuf[0].data();
+    if (beta != 0.0)
+      for (int i = 0; i < n - 1; ++i) {
+        double* row = &s[(size_t)(1 + i) * n + (1 + i)];
+        p0[i] += row_pass<false, true>(row, n - 1 - i, 0.0, 0.0, nullptr, nullptr, vbuf[0].data() + i, p0 + i);
+      }
+    for (int k = 0; k + 2 < n; ++k) {
+      const int m = n - k - 1;
+      double* v = vbuf[k & 1].data();
+      double* p = pbuf[k & 1].data();
+      double* vn = vbuf[(k + 1) & 1].data();
+      double* pn = pbuf[(k + 1) & 1].data();
+      t.hbeta[k] = beta;
+      t.e[k] = sub;
+      const bool upd = beta != 0.0;
+      if (upd) {
+        std::memcpy(&t.hv[(size_t)k * n + (k + 1)], v, sizeof(double) * m);
+        double pv = 0.0;
+        for (int i = 0; i < m; ++i) { p[i] *= beta; pv += p[i] * v[i]; }
+        const double kk = 0.5 * beta * pv;
+        for (int i = 0; i < m; ++i) w[i] = p[i] - kk * v[i];
+      }
+      // first row of the trailing matrix: update, then it defines the next reflector
+      double* row0 = &s[(size_t)(k + 1) * n + (k + 1)];
+      if (upd) row_pass<true, false>(row0, m, v[0], w[0], v, w.data(), nullptr, nullptr);
+      double betan = 0.0, subn = (m >= 2) ? row0[1] : 0.0;
+      const bool next = (k + 3 < n);
+      if (next) {
+        betan = make_reflector(row0 + 1, m - 1, vn, &subn);
+        for (int i = 0; i < m - 1; ++i) pn[i] = 0.0;
+      }
+      const bool mv = next && betan != 0.0;
+      for (int i = 1; i < m; ++i) {
+        double* row = &s[(size_t)(k + 1 + i) * n + (k + 1 + i)];
+        const int len = m - i;
+        if (upd && mv)       pn[i - 1] += row_pass<true, true>(row, len, v[i], w[i], v + i, w.data() + i, vn + i - 1, pn + i - 1);
+        else if (upd)        row_pass<true, false>(row, len, v[i], w[i], v + i, w.data() + i, nullptr, nullptr);
+        else if (mv)         pn[i - 1] += row_pass<false, true>(row, len, 0.0, 0.0, nullptr, nullptr, vn + i - 1, pn + i - 1);
+      }
+      beta = betan; sub = subn;
+      if (!next) { t.e[k + 1] = subn; }
     }
-    for (int i = 0; i < m; ++i) p[i] *= beta;
-    double pv = 0.0;
-    for (int i = 0; i < m; ++i) pv += p[i] * v[i];
-    const double kk = 0.5 * beta * pv;
-    for (int i = 0; i < m; ++i) p[i] -= kk * v[i];
-    for (int i = 0; i < m; ++i) {
-      double* row = &s[(size_t)(k + 1 + i) * n + (k + 1)];
-      const double vi = v[i], wi = p[i];
-      for (int j = 0; j < m; ++j) row[j] -= vi * p[j] + wi * v[j];
-    }
-    S(k + 1, k) = alpha * scale;
-    S(k, k + 1) = alpha * scale;
-    for (int i = 1; i < m; ++i) { S(k + 1 + i, k) = 0.0; S(k, k + 1 + i) = 0.0; }
-    t.hbeta[k] = beta;
-    std::memcpy(&t.hv[(size_t)k * n + (k + 1)], v.data(), sizeof(double) * m);
+  } else if (n == 2) {
+    t.e[0] = s[1];
   }
-  for (int i = 0; i < n; ++i) t.d[i] = S(i, i);
-  for (int i = 0; i + 1 < n; ++i) t.e[i] = S(i + 1, i);
+  for (int i = 0; i < n; ++i) t.d[i] = s[(size_t)i * n + i];
 }
 
 // implicit QL, eigenvalues only (d is overwritten, unsorted on exit); e is destroyed
@@ -240,96 +308,121 @@ int ql_values(int n, std::vector<double>& d, std::vector<double>& e)
   return 0;
 }
 
-// Solve (T - lam I) x = b in place (x holds b on entry) by Gaussian elimination with partial
-// pivoting on the tridiagonal matrix; tiny pivots are replaced by +-tiny (inverse iteration
-// only needs the direction).  d, e: diagonal / sub-diagonal of T.
-void tridiag_solve(int n, const std::vector<double>& d, const std::vector<double>& e, double lam, double tiny,
-                   std::vector<double>& x, std::vector<double>& a, std::vector<double>& b, std::vector<double>& c,
-                   std::vector<double>& l, std::vector<int>& piv)
-{
-  // a: diagonal of U, b: first super-diagonal of U, c: second super-diagonal of U, l: multipliers
-  for (int i = 0; i < n; ++i) { a[i] = d[i] - lam; b[i] = (i + 1 < n) ? e[i] : 0.0; c[i] = 0.0; }
-  for (int i = 0; i + 1 < n; ++i) {
-    const double sub = e[i];                 // T(i+1,i)
-    if (std::fabs(a[i]) >= std::fabs(sub)) {
-      piv[i] = 0;
-      if (a[i] == 0.0) a[i] = tiny;
-      const double mlt = sub / a[i];
-      l[i] = mlt;
-      a[i + 1] -= mlt * b[i];
-      // b[i+1] unchanged, c[i] = 0
-    } else {
-      piv[i] = 1;                            // swap rows i and i+1
-      const double mlt = a[i] / sub;
-      l[i] = mlt;
-      const double ai1 = a[i + 1], bi = b[i], bi1 = b[i + 1];
-      a[i] = sub; b[i] = ai1; c[i] = bi1;
-      a[i + 1] = bi - mlt * ai1;
-      b[i + 1] = -mlt * bi1;
+// (T - lam I) = P L U by Gaussian elimination with partial pivoting on the tridiagonal matrix; tiny pivots
+// are replaced by +-tiny (inverse iteration only needs the direction).  One factorisation serves all the
+// iterations of one eigenvector.
+struct TriLU {
+  std::vector<double> a, b, c, l;   // U: diagonal, first and second super-diagonal; multipliers
+  std::vector<int> piv;
+  explicit TriLU(int n) : a(n), b(n), c(n), l(n), piv(n) {}
+  void factor(int n, const std::vector<double>& d, const std::vector<double>& e, double lam, double tiny)
+  {
+    for (int i = 0; i < n; ++i) { a[i] = d[i] - lam; b[i] = (i + 1 < n) ? e[i] : 0.0; c[i] = 0.0; }
+    for (int i = 0; i + 1 < n; ++i) {
+      const double sub = e[i];                 // T(i+1,i)
+      if (std::fabs(a[i]) >= std::fabs(sub)) {
+        piv[i] = 0;
+        if (a[i] == 0.0) a[i] = tiny;
+        const double mlt = sub / a[i];
+        l[i] = mlt;
+        a[i + 1] -= mlt * b[i];
+      } else {
+        piv[i] = 1;                            // swap rows i and i+1
+        const double mlt = a[i] / sub;
+        l[i] = mlt;
+        const double ai1 = a[i + 1], bi = b[i], bi1 = b[i + 1];
+        a[i] = sub; b[i] = ai1; c[i] = bi1;
+        a[i + 1] = bi - mlt * ai1;
+        b[i + 1] = -mlt * bi1;
+      }
+    }
+    for (int i = 0; i < n; ++i) {
+      if (std::fabs(a[i]) < tiny) a[i] = (a[i] < 0.0 ? -tiny : tiny);
     }
   }
-  if (a[n - 1] == 0.0) a[n - 1] = tiny;
-  // forward: apply the row operations to the right-hand side
-  for (int i = 0; i + 1 < n; ++i) {
-    if (piv[i]) std::swap(x[i], x[i + 1]);
-    x[i + 1] -= l[i] * x[i];
+  void solve(int n, std::vector<double>& x) const
+  {
+    for (int i = 0; i + 1 < n; ++i) {
+      if (piv[i]) std::swap(x[i], x[i + 1]);
+      x[i + 1] -= l[i] * x[i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double t = x[i];
+      if (i + 1 < n) t -= b[i] * x[i + 1];
+      if (i + 2 < n) t -= c[i] * x[i + 2];
+      x[i] = t / a[i];
+    }
   }
-  // back substitution with the two super-diagonals
-  for (int i = n - 1; i >= 0; --i) {
-    double t = x[i];
-    if (i + 1 < n) t -= b[i] * x[i + 1];
-    if (i + 2 < n) t -= c[i] * x[i + 2];
-    double piv_a = a[i];
-    if (std::fabs(piv_a) < tiny) piv_a = (piv_a < 0.0 ? -tiny : tiny);
-    x[i] = t / piv_a;
-  }
-}
+};
 
 // The m lowest eigenvalues of the symmetric tridiagonal (d, e) by simultaneous bisection on Sturm
-// counts: count(x) = number of eigenvalues < x = number of negative pivots of T - x I.  All m
-// intervals advance together, 16 shifts per pass, so that the (latency-bound) pivot recurrences of
-// several SIMD vectors overlap.
-// Cost O(60 m n) against O(n^2) with a large constant for QL on all n values.
+// counts: count(x) = number of eigenvalues < x = number of sign changes in the sequence of leading
+// principal minors p_0 = 1, p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}.  The matrix is scaled to unit
+// norm and (p_i, p_{i-1}) are rescaled by a power of two every fourth step, so the division-free
+// recurrence neither overflows nor underflows; 16 shifts advance together (4 AVX2 vectors).
 void bisect_lowest(int n, const std::vector<double>& d, const std::vector<double>& e, int m, double onenrm,
                    std::vector<double>& w)
 {
   const double eps = 2.220446049250313e-16;
-  const double pivmin = std::max(1e-300, eps * eps * onenrm * onenrm * 1e-4);   // smallest pivot magnitude allowed
-  std::vector<double> e2(n > 0 ? n : 1, 0.0);
-  for (int i = 0; i + 1 < n; ++i) e2[i] = e[i] * e[i];
-  // Gershgorin bounds
-  double gl = d[0], gu = d[0];
+  const double inv = 1.0 / onenrm;
+  std::vector<double> ds(n), e2(n > 0 ? n : 1, 0.0);
+  for (int i = 0; i < n; ++i) ds[i] = d[i] * inv;
+  for (int i = 0; i + 1 < n; ++i) { const double es = e[i] * inv; e2[i] = es * es; }
+  // Gershgorin bounds (scaled)
+  double gl = ds[0], gu = ds[0];
   for (int i = 0; i < n; ++i) {
-    const double r = (i > 0 ? std::fabs(e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(e[i]) : 0.0);
-    gl = std::min(gl, d[i] - r);
-    gu = std::max(gu, d[i] + r);
+    const double r = (i > 0 ? std::fabs(e[i - 1]) : 0.0) * inv + (i + 1 < n ? std::fabs(e[i]) : 0.0) * inv;
+    gl = std::min(gl, ds[i] - r);
+    gu = std::max(gu, ds[i] + r);
   }
-  const double pad = 2.0 * eps * onenrm * n + 2.0 * pivmin;
+  const double pad = 4.0 * eps * n;
   gl -= pad; gu += pad;
-  constexpr int W = 16;   // 4 AVX2 vectors: four independent division chains in flight
+  constexpr int W = 16, NV = W / 4;
   const int mp = ((m + W - 1) / W) * W;
   std::vector<double> lo(mp, gl), hi(mp, gu), mid(mp, 0.0);
   std::vector<int> cnt(mp, 0);
+  const double BIG = 0x1p+300, SMALL = 0x1p-300, ZERO_REPL = 0x1p-900;
+  typedef long long v4i __attribute__((vector_size(32)));
   auto sturm = [&](const double* x, int* c) {   // counts for W shifts at once
-    double q[W];
-    int neg[W];
-    for (int s = 0; s < W; ++s) { q[s] = d[0] - x[s]; neg[s] = 0; }
-    for (int s = 0; s < W; ++s) {
-      if (std::fabs(q[s]) < pivmin) q[s] = -pivmin;
-      neg[s] += (q[s] < 0.0);
+    v4 xs[NV], p0[NV], p1[NV];
+    v4i neg[NV];
+    for (int q = 0; q < NV; ++q) {
+      xs[q] = ld4(x + 4 * q);
+      p0[q] = bc4(1.0);
+      p1[q] = bc4(ds[0]) - xs[q];
+      neg[q] = (v4i){0, 0, 0, 0};
     }
+    auto account = [&](int q) {
+      // an exact zero takes the sign opposite to its predecessor (it counts as a negative pivot)
+      v4i isz = (p1[q] == bc4(0.0));
+      v4 repl = (p0[q] < bc4(0.0)) ? bc4(ZERO_REPL) : bc4(-ZERO_REPL);
+      p1[q] = isz ? repl : p1[q];
+      v4i changed = ((p1[q] < bc4(0.0)) != (p0[q] < bc4(0.0)));   // all-ones (-1) where the sign changed
+      neg[q] -= changed;
+    };
+    for (int q = 0; q < NV; ++q) account(q);
     for (int i = 1; i < n; ++i) {
-      const double di = d[i], ei2 = e2[i - 1];
-      for (int s = 0; s < W; ++s) {
-        double t = di - x[s] - ei2 / q[s];
-        t = (std::fabs(t) < pivmin) ? -pivmin : t;
-        q[s] = t;
-        neg[s] += (t < 0.0);
+      const v4 di = bc4(ds[i]), ei2 = bc4(e2[i - 1]);
+      for (int q = 0; q < NV; ++q) {
+        const v4 t = (di - xs[q]) * p1[q] - ei2 * p0[q];
+        p0[q] = p1[q];
+        p1[q] = t;
+        account(q);
+      }
+      if ((i & 3) == 3) {
+        for (int q = 0; q < NV; ++q) {
+          v4 a1 = p1[q] < bc4(0.0) ? -p1[q] : p1[q];
+          v4 a0 = p0[q] < bc4(0.0) ? -p0[q] : p0[q];
+          v4 am = a1 > a0 ? a1 : a0;
+          v4 sc = am > bc4(BIG) ? bc4(SMALL) : (am < bc4(SMALL) ? bc4(BIG) : bc4(1.0));
+          p0[q] *= sc; p1[q] *= sc;
+        }
       }
     }
-    for (int s = 0; s < W; ++s) c[s] = neg[s];
+    for (int q = 0; q < NV; ++q)
+      for (int r = 0; r < 4; ++r) c[4 * q + r] = (int)neg[q][r];
   };
-  const double tol_abs = eps * onenrm;
+  const double tol_abs = eps;   // scaled units: eps * ||T||
   for (int it = 0; it < 120; ++it) {
     bool any = false;
     for (int j = 0; j < mp; ++j) {
@@ -344,7 +437,7 @@ void bisect_lowest(int n, const std::vector<double>& d, const std::vector<double
     }
   }
   w.resize(m);
-  for (int j = 0; j < m; ++j) w[j] = 0.5 * (lo[j] + hi[j]);
+  for (int j = 0; j < m; ++j) w[j] = 0.5 * (lo[j] + hi[j]) * onenrm;
   for (int j = 1; j < m; ++j) if (w[j] < w[j - 1]) w[j] = w[j - 1];   // keep the order monotone
 }
 
@@ -358,14 +451,19 @@ int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_
     double r = std::fabs(t.d[i]) + (i > 0 ? std::fabs(t.e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(t.e[i]) : 0.0);
     onenrm = std::max(onenrm, r);
   }
-  if (onenrm == 0.0) onenrm = 1.0;
+  if (onenrm == 0.0) {                       // the zero matrix: every vector is an eigenvector
+    w_all.assign(m, 0.0);
+    std::fill(zt.begin(), zt.end(), 0.0);
+    for (int j = 0; j < m; ++j) zt[(size_t)j * n + j] = 1.0;
+    return 0;
+  }
   bisect_lowest(n, t.d, t.e, m, onenrm, w_all);        // w_all[0..m-1]
   const double eps = 2.220446049250313e-16;
   const double ortol = 1.0e-3 * onenrm;     // cluster criterion (as LAPACK dstein)
   const double sep = 10.0 * eps * onenrm;   // minimal separation of the shifts inside a cluster
   const double tiny = eps * onenrm;
-  std::vector<double> x(n), a(n), b(n), c(n), l(n);
-  std::vector<int> piv(n);
+  std::vector<double> x(n);
+  TriLU lu(n);
   unsigned long long seed = 0x243F6A8885A308D3ULL;
   auto rnd = [&]() {   // deterministic start vectors
     seed = seed * 6364136223846793005ULL + 1442695040888963407ULL;
@@ -380,8 +478,9 @@ int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_
     lam_prev = lam;
     double* z = &zt[(size_t)j * n];
     for (int i = 0; i < n; ++i) x[i] = rnd();
+    lu.factor(n, t.d, t.e, lam, tiny);
     for (int it = 0; it < 8; ++it) {
-      tridiag_solve(n, t.d, t.e, lam, tiny, x, a, b, c, l, piv);
+      lu.solve(n, x);
       // re-orthogonalise against the earlier members of the cluster (modified Gram-Schmidt);
       // zt rows are still in tridiagonal coordinates here (back-transformation comes last)
       for (int q = cluster_start; q < j; ++q) {
@@ -411,19 +510,31 @@ int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_
     }
     std::memcpy(z, x.data(), sizeof(double) * n);
   }
-  // back-transformation: eigenvector of S = H_0 H_1 ... H_{n-3} z  (apply the last reflector first)
-  for (int j = 0; j < m; ++j) {
-    double* z = &zt[(size_t)j * n];
-    for (int k = n - 3; k >= 0; --k) {
-      const double beta = t.hbeta[k];
-      if (beta == 0.0) continue;
-      const double* vk = &t.hv[(size_t)k * n];
-      double acc = 0.0;
-      for (int r = k + 1; r < n; ++r) acc += vk[r] * z[r];
-      acc *= beta;
-      for (int r = k + 1; r < n; ++r) z[r] -= acc * vk[r];
+  // back-transformation: eigenvector of S = H_0 H_1 ... H_{n-3} z  (apply the last reflector first).
+  // All m vectors advance together: zz[r][j] = component r of vector j, so both loops run along j.
+  const int mp = (m + 3) & ~3;
+  std::vector<double> zz((size_t)n * mp, 0.0), acc(mp);
+  for (int j = 0; j < m; ++j)
+    for (int r = 0; r < n; ++r) zz[(size_t)r * mp + j] = zt[(size_t)j * n + r];
+  for (int k = n - 3; k >= 0; --k) {
+    const double beta = t.hbeta[k];
+    if (beta == 0.0) continue;
+    const double* vk = &t.hv[(size_t)k * n];
+    for (int j = 0; j < mp; ++j) acc[j] = 0.0;
+    for (int r = k + 1; r < n; ++r) {
+      const double vr = vk[r];
+      const double* zr = &zz[(size_t)r * mp];
+      for (int j = 0; j < mp; ++j) acc[j] += vr * zr[j];
+    }
+    for (int j = 0; j < mp; ++j) acc[j] *= beta;
+    for (int r = k + 1; r < n; ++r) {
+      const double vr = vk[r];
+      double* zr = &zz[(size_t)r * mp];
+      for (int j = 0; j < mp; ++j) zr[j] -= acc[j] * vr;
     }
   }
+  for (int j = 0; j < m; ++j)
+    for (int r = 0; r < n; ++r) zt[(size_t)j * n + r] = zz[(size_t)r * mp + j];
   return 0;
 }
 
