@@ -528,10 +528,88 @@ int dla_check_guess(dla_ctx* c, int n, int m, double* evec)
   return DLA_OK;
 }
 
+// Plain host loops for the host-size coefficient blocks of get_coeffs (column-major, ld = rows).  This is not
+// a device engine: it cannot be selected for a context, and everything that touches n-length panels is absent.
+namespace {
+struct CoeffAlgebra final : dla::Engine {
+  const char* name() const override { return "coeff-host"; }
+  void* stream() override { return nullptr; }
+  int alloc(size_t, void**) override { return DLA_ERR_ARG; }
+  int free_(void*) override { return DLA_ERR_ARG; }
+  int zero(void*, size_t) override { return DLA_ERR_ARG; }
+  int h2d(void*, const void*, size_t) override { return DLA_ERR_ARG; }
+  int d2h(void*, const void*, size_t) override { return DLA_ERR_ARG; }
+  int d2d(void*, const void*, size_t) override { return DLA_ERR_ARG; }
+  int sync() override { return DLA_OK; }
+  int gram(int n, int l, const double* x, int k, const double* u, double* ch, int ldc) override
+  {
+    for (int j = 0; j < k; ++j)
+      for (int i = 0; i < l; ++i) {
+        const double* xi = x + (size_t)i * n;
+        const double* uj = u + (size_t)j * n;
+        double acc = 0.0;
+        for (int r = 0; r < n; ++r) acc += xi[r] * uj[r];
+        ch[(size_t)i + (size_t)j * ldc] = acc;
+      }
+    return DLA_OK;
+  }
+  int gemm(int n, int l, const double* x, int k, const double* ch, int ldc, double* z, int mode) override
+  {
+    std::vector<double> col(n);
+    for (int j = 0; j < k; ++j) {
+      std::fill(col.begin(), col.end(), 0.0);
+      for (int i = 0; i < l; ++i) {
+        const double cij = ch[(size_t)i + (size_t)j * ldc];
+        const double* xi = x + (size_t)i * n;
+        for (int r = 0; r < n; ++r) col[r] += xi[r] * cij;
+      }
+      double* zj = z + (size_t)j * n;
+      if (mode == 0) for (int r = 0; r < n; ++r) zj[r] = col[r];
+      else if (mode == 1) for (int r = 0; r < n; ++r) zj[r] -= col[r];
+      else for (int r = 0; r < n; ++r) zj[r] += col[r];
+    }
+    return DLA_OK;
+  }
+  int trmm(int n, int k, double* u, const double* w, int ld) override
+  {
+    std::vector<double> out((size_t)n * k, 0.0);
+    for (int j = 0; j < k; ++j)
+      for (int i = 0; i < k; ++i) {
+        const double wij = w[(size_t)i + (size_t)j * ld];
+        if (wij == 0.0) continue;
+        const double* ui = u + (size_t)i * n;
+        double* oj = out.data() + (size_t)j * n;
+        for (int r = 0; r < n; ++r) oj[r] += ui[r] * wij;
+      }
+    std::memcpy(u, out.data(), sizeof(double) * (size_t)n * k);
+    return DLA_OK;
+  }
+  int ritz_residual(int, int, int, const double*, const double*, const double*, int, const double*, int, const int*,
+                    double*, double*, double*, double*) override { return DLA_ERR_ARG; }
+  int axpy(size_t len, double alpha, const double* x, double* y) override
+  {
+    for (size_t i = 0; i < len; ++i) y[i] += alpha * x[i];
+    return DLA_OK;
+  }
+  int sumsq(size_t len, const double* x, double* out) override
+  {
+    double acc = 0.0;
+    for (size_t i = 0; i < len; ++i) acc += x[i] * x[i];
+    *out = acc;
+    return DLA_OK;
+  }
+  int random_fill(int, int, double*, long long) override { return DLA_ERR_ARG; }
+  int synth_setup(long long, long long, int, int, double) override { return DLA_ERR_ARG; }
+  int synth_matvec(int, int, const double*, double*) override { return DLA_ERR_ARG; }
+  int synth_precnd(int, int, double, const double*, double*) override { return DLA_ERR_ARG; }
+  int host_alloc(size_t, void**) override { return DLA_ERR_ARG; }
+  int host_free(void*) override { return DLA_ERR_ARG; }
+  int comm_init(int, int, const char*) override { return DLA_ERR_ARG; }
+};
+}  // namespace
+
 // get_coeffs, diaglib.f90:3686-3732.  Host-size (len_u <= 3 n_max) problem: the same
-// ortho_vs_x runs on small device panels, so the numerics are those of the big sweeps.
-// The coefficient vectors are replicated on every rank, hence reductions must NOT be
-// summed over ranks here: the call runs with the communicator masked.
+// The coefficient vectors are replicated on every rank, hence nothing is reduced over ranks here.
 int dla_get_coeffs(dla_ctx* c, int len_a, int len_u, int n_max, int n_act, const double* a_red, double* u_x, double* u_p)
 {
   DLA_T("dla_get_coeffs");
@@ -542,20 +620,16 @@ int dla_get_coeffs(dla_ctx* c, int len_a, int len_u, int n_max, int n_act, const
     for (int i = 0; i < len_u; ++i) u_p[(size_t)i + (size_t)j * len_u] = u_x[(size_t)i + (size_t)(off_x + j) * len_u];
   for (int j = 0; j < n_act; ++j) u_p[(size_t)(off_x + j) + (size_t)j * len_u] -= 1.0;
   if (n_act <= 0) return DLA_OK;
-  void *dx = nullptr, *dp = nullptr;
-  size_t bx = sizeof(double) * (size_t)len_u * n_max, bp = sizeof(double) * (size_t)len_u * n_act;
-  int st = c->eng->alloc(bx, &dx);
-  if (st) return engfail(c, st);
-  st = c->eng->alloc(bp, &dp);
-  if (st) { c->eng->free_(dx); return engfail(c, st); }
-  c->eng->h2d(dx, u_x, bx);
-  c->eng->h2d(dp, u_p, bp);
-  c->eng->local_only = true;   // replicated data: local reductions only
-  st = dla_ortho_vs_x(c, len_u, n_max, n_act, (const double*)dx, (double*)dp);
-  c->eng->local_only = false;
-  if (st == DLA_OK) st = engfail(c, c->eng->d2h(u_p, dp, bp));
-  c->eng->free_(dx);
-  c->eng->free_(dp);
+  // u_x / u_p are len_u x n_max coefficient blocks (len_u <= 3 n_max rows, O(1) in n), identical on every
+  // rank: like the Cholesky factors and the projected eigenproblem they are host-size data, so the same
+  // ortho_vs_x control flow runs on them through the coefficient algebra below -- no launches, no reductions.
+  CoeffAlgebra small;
+  dla_ctx local;
+  local.eng = &small;
+  local.verbose_ortho = c->verbose_ortho;
+  int st = ortho_vs_x_impl(&local, len_u, n_max, n_act, u_x, u_x, u_p);
+  if (st) c->err = local.err.empty() ? small.err : local.err;
+  local.eng = nullptr;
   return st;
 }
 

@@ -788,7 +788,9 @@ contains
     logical,                              intent(inout) :: ok
     external                                            :: matvec, precnd, bvec
 !
-    type(c_ptr)    :: ctx, space, aspace, bspace, r, x_new, ax_new, bx_new, evd
+    type(c_ptr)    :: ctx, space, aspace, bspace, r, x_new, ax_new, bx_new, evd, xfin
+    type(c_ptr)    :: sp(2), asp(2), bsp(2)
+    integer        :: cur, nxt
     type(c_funptr) :: mv, pc, bv
     integer        :: it, i_eig, n_act, ind_x, ind_w, ind_p, len_a, len_u, n_mv
     logical        :: evec_dev
@@ -803,20 +805,26 @@ contains
     pc  = c_funloc(precnd)
     bv  = c_funloc(bvec)
     evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
+    bsp    = c_null_ptr
     bspace = c_null_ptr
     bx_new = c_null_ptr
 !
+!   The reference keeps one basis [X P W] per panel and copies the new X (x_new, ax_new, bx_new) and the new
+!   P (via its evec scratch) into it every iteration (:495-514).  Here every panel exists twice: an iteration
+!   reads the basis from one copy and writes the new X and P blocks straight into the other, then the two
+!   swap roles -- the four (six) block copies per iteration become none.
+!
     len_a = 3*n_max
-    call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), space),  'allocation of space')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), aspace), 'allocation of aspace')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), r),      'allocation of r')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), x_new),  'allocation of x_new')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), ax_new), 'allocation of ax_new')
-    if (gen_eig) then
+    do cur = 1, 2
+      call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), sp(cur)),  'allocation of space')
+      call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), asp(cur)), 'allocation of aspace')
 !     (the reference allocates bspace/bx_new also for the standard problem, :259,270; here only when used)
-      call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), bspace), 'allocation of bspace')
-      call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), bx_new), 'allocation of bx_new')
-    end if
+      if (gen_eig) call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), bsp(cur)), 'allocation of bspace')
+    end do
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), r), 'allocation of r')
+    cur = 1
+    nxt = 2
+    call select_panels()
     if (evec_dev) then
       evd = c_loc(evec)
     else
@@ -841,9 +849,8 @@ contains
 !   generalised problem: B times the guess, then B-orthonormalise it (reference :299-302)
 !
     if (gen_eig) then
-      call chk(ctx, dla_call_matvec(ctx, bv, n, n_max, evd, bx_new), 'bvec')
-      call chk(ctx, dla_b_ortho(ctx, n, n_max, evd, bx_new), 'b_ortho')
-      call chk(ctx, dla_copy(ctx, bspace, bx_new, nbytes(n,n_max)), 'copy')
+      call chk(ctx, dla_call_matvec(ctx, bv, n, n_max, evd, bspace), 'bvec')
+      call chk(ctx, dla_b_ortho(ctx, n, n_max, evd, bspace), 'b_ortho')
     end if
 !
 !   first Rayleigh-Ritz step on the guess (reference :306-325)
@@ -870,13 +877,12 @@ contains
       call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, bspace, aspace, a_red, len_a, eig, n_max, skip, &
                                       bx_new, r, ax_new, r_norm), 'ritz/residual')
       call chk(ctx, dla_panel_gemm(ctx, n, n_max, space, n_max, a_red, len_a, x_new), 'ritz vectors')
-      call chk(ctx, dla_copy(ctx, bspace, bx_new, nbytes(n,n_max)), 'copy')
     else
       call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, space, aspace, a_red, len_a, eig, n_max, skip, &
                                       x_new, r, ax_new, r_norm), 'ritz/residual')
     end if
-    call chk(ctx, dla_copy(ctx, space,  x_new,  nbytes(n,n_max)), 'copy')
-    call chk(ctx, dla_copy(ctx, aspace, ax_new, nbytes(n,n_max)), 'copy')
+    xfin = x_new
+    call swap_panels()
 !
 !   first block of preconditioned residuals (:350-367)
 !
@@ -948,6 +954,7 @@ contains
         call chk(ctx, dla_ritz_residual(ctx, n, len_u, n_max, space, aspace, a_red, len_a, eig, n_max, skip, &
                                         x_new, r, ax_new, r_norm), 'ritz/residual')
       end if
+      xfin = x_new
 !
 !     lock the leading converged roots (:446-455)
 !
@@ -980,31 +987,15 @@ contains
 !
       allocate (u_x(len_u,n_max), u_p(len_u,max(n_act,1)))
       call chk(ctx, dla_get_coeffs(ctx, len_a, len_u, n_max, n_act, a_red, u_x, u_p), 'get_coeffs')
-!     The reference forms each product in the evec scratch and copies it into the P block (:495-503).
-!     dla_panel_gemm may write a column block of its own input panel (every row tile is read completely
-!     before it is stored, include/diaglib_amd.h), so the products go straight into place when the block
-!     fits one output pass (n_act <= 48); wider blocks keep the scratch + copy.
-      if (n_act.le.48) then
-        call chk(ctx, dla_panel_gemm(ctx, n, len_u, space,  n_act, u_p, len_u, colp(space,n,ind_p)), 'p block')
-        call chk(ctx, dla_panel_gemm(ctx, n, len_u, aspace, n_act, u_p, len_u, colp(aspace,n,ind_p)), 'ap block')
-        if (gen_eig) call chk(ctx, dla_panel_gemm(ctx, n, len_u, bspace, n_act, u_p, len_u, colp(bspace,n,ind_p)), 'bp block')
-      else
-        call chk(ctx, dla_panel_gemm(ctx, n, len_u, space,  n_act, u_p, len_u, evd), 'p block')
-        call chk(ctx, dla_copy(ctx, colp(space,n,ind_p), evd, nbytes(n,n_act)), 'copy')
-        call chk(ctx, dla_panel_gemm(ctx, n, len_u, aspace, n_act, u_p, len_u, evd), 'ap block')
-        call chk(ctx, dla_copy(ctx, colp(aspace,n,ind_p), evd, nbytes(n,n_act)), 'copy')
-        if (gen_eig) then
-          call chk(ctx, dla_panel_gemm(ctx, n, len_u, bspace, n_act, u_p, len_u, evd), 'bp block')
-          call chk(ctx, dla_copy(ctx, colp(bspace,n,ind_p), evd, nbytes(n,n_act)), 'copy')
-        end if
-      end if
+!     P = S u_p, AP = AS u_p [, BP = BS u_p] (:495-503) go straight into the P block of the other copy
+      call chk(ctx, dla_panel_gemm(ctx, n, len_u, space,  n_act, u_p, len_u, colp(sp(nxt),n,ind_p)), 'p block')
+      call chk(ctx, dla_panel_gemm(ctx, n, len_u, aspace, n_act, u_p, len_u, colp(asp(nxt),n,ind_p)), 'ap block')
+      if (gen_eig) call chk(ctx, dla_panel_gemm(ctx, n, len_u, bspace, n_act, u_p, len_u, colp(bsp(nxt),n,ind_p)), 'bp block')
       deallocate (u_x, u_p)
 !
-!     x_new, ax_new become the X block (:510-511)
+!     x_new, ax_new [, bx_new] already are the X block of the other copy (:510-511): it becomes the basis
 !
-      call chk(ctx, dla_copy(ctx, space,  x_new,  nbytes(n,n_max)), 'copy')
-      call chk(ctx, dla_copy(ctx, aspace, ax_new, nbytes(n,n_max)), 'copy')
-      if (gen_eig) call chk(ctx, dla_copy(ctx, bspace, bx_new, nbytes(n,n_max)), 'copy')
+      call swap_panels()
 !
 !     new W block: preconditioned active residuals, orthogonalised against [X P] (:518-528)
 !
@@ -1028,7 +1019,7 @@ contains
 !   the current Ritz vectors go back in evec (the reference does this on convergence, :466;
 !   on a non-converged exit it leaves its P-block scratch there -- we return x_new in both cases)
 !
-    call chk(ctx, dla_copy(ctx, evd, x_new, nbytes(n,n_max)), 'copy')
+    call chk(ctx, dla_copy(ctx, evd, xfin, nbytes(n,n_max)), 'copy')
 !
     1000 format(t3,'timings for lobpcg (cpu/wall):   ',/, &
                 t3,'  matrix-vector multiplications: ',2f12.4,/, &
@@ -1042,17 +1033,34 @@ contains
       call chk(ctx, dla_download(ctx, c_loc(evec), evd, nbytes(n,n_max)), 'download of evec')
       call chk(ctx, dla_free(ctx, evd), 'free')
     end if
-    call chk(ctx, dla_free(ctx, space), 'free')
-    call chk(ctx, dla_free(ctx, aspace), 'free')
+    do cur = 1, 2
+      call chk(ctx, dla_free(ctx, sp(cur)), 'free')
+      call chk(ctx, dla_free(ctx, asp(cur)), 'free')
+      if (gen_eig) call chk(ctx, dla_free(ctx, bsp(cur)), 'free')
+    end do
     call chk(ctx, dla_free(ctx, r), 'free')
-    call chk(ctx, dla_free(ctx, x_new), 'free')
-    call chk(ctx, dla_free(ctx, ax_new), 'free')
-    if (gen_eig) then
-      call chk(ctx, dla_free(ctx, bspace), 'free')
-      call chk(ctx, dla_free(ctx, bx_new), 'free')
-    end if
     deallocate (a_red, e_red, done, skip, r_norm)
     return
+!
+  contains
+!
+    subroutine select_panels()
+!     the basis is read from copy cur; the new X block (x_new, ax_new, bx_new) is written into copy nxt
+      space  = sp(cur)
+      aspace = asp(cur)
+      bspace = bsp(cur)
+      x_new  = sp(nxt)
+      ax_new = asp(nxt)
+      bx_new = bsp(nxt)
+    end subroutine select_panels
+!
+    subroutine swap_panels()
+      integer :: tmp
+      tmp = cur
+      cur = nxt
+      nxt = tmp
+      call select_panels()
+    end subroutine swap_panels
   end subroutine lobpcg_driver
 !
 ! ---------------------------------------------------------------------------------------
