@@ -38,7 +38,8 @@ EXPORTS = [
     "dla_call_matvec", "dla_call_precnd",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
     "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd",
-    "dla_davidson_driver", "dla_gen_david_driver", "dla_lobpcg_driver", "dla_last_solve_info", "dla_set_solve_info",
+    "dla_davidson_driver", "dla_gen_david_driver", "dla_lobpcg_driver", "dla_caslr_eff_driver", "dla_call_lrprec",
+    "dla_last_solve_info", "dla_set_solve_info",
 ]
 
 
@@ -106,6 +107,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_synth_setup": (i, [vp, C.c_longlong, C.c_longlong, i, i, d]),
         "dla_davidson_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, c_ip]),
         "dla_lobpcg_driver": (None, [i, i, i, i, i, i, d, d, vp, vp, vp, vp, vp, c_ip]),
+        "dla_caslr_eff_driver": (None, [i, i, i, i, i, d, i, vp, vp, vp, vp, vp, vp, vp, c_ip]),
+        "dla_call_lrprec": (i, [vp, vp, i, i, d, vp, vp, vp, vp]),
         "dla_gen_david_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, vp, c_ip]),
         "dla_last_solve_info": (None, [c_ip, c_ip, c_ip]),
     }
@@ -401,6 +404,42 @@ class Context:
         self.lib.dla_lobpcg_driver(int(verbose), 0 if bvec is None else 1, n, n_targ, n_max, max_iter, tol, shift, mv, pc, bv,
                                    eig.ctypes.data, ev_ptr, C.byref(ok))
         return eig, out, bool(ok.value), self.last_solve_info()
+
+    def caslr_eff_driver(self, n: int, n_targ: int, n_max: int, max_iter: int, tol: float, max_dav: int,
+                         apbmul: Callback, ambmul: Callback, spdmul: Callback, smdmul: Callback, lrprec: Callback,
+                         evec, verbose: bool = False):
+        """linear-response driver (reference diaglib.f90:1024-1481); evec is 2n x n_max; lrprec as an address or a
+        Python callable (fac, xp, xm) -> (yp, ym)"""
+        f1, f2, f3, f4 = (self._wrap_mv(f) for f in (apbmul, ambmul, spdmul, smdmul))
+        f5 = self._wrap_lrpc(lrprec)
+        eig = np.zeros(n_max); ok = C.c_int(0)
+        if isinstance(evec, DevPanel):
+            self.set_option(OPT_EVEC_ON_DEVICE, 1)
+            ev_ptr, out = evec.ptr, evec
+        else:
+            self.set_option(OPT_EVEC_ON_DEVICE, 0)
+            out = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
+            assert out.shape == (2 * n, n_max)
+            ev_ptr = out.ctypes.data
+        self.lib.dla_caslr_eff_driver(int(verbose), n, n_targ, n_max, max_iter, tol, max_dav, f1, f2, f3, f4, f5,
+                                      eig.ctypes.data, ev_ptr, C.byref(ok))
+        return eig, out, bool(ok.value), self.last_solve_info()
+
+    def _wrap_lrpc(self, f: Callback) -> int:
+        if isinstance(f, int):
+            return f
+
+        def tramp(pn, pm, pf, pxp, pxm, pyp, pym):
+            n, m = pn[0], pm[0]
+            xp = np.ctypeslib.as_array(pxp, (m, n)).T
+            xm = np.ctypeslib.as_array(pxm, (m, n)).T
+            yp, ym = f(pf[0], xp, xm)
+            np.ctypeslib.as_array(pyp, (m, n)).T[:, :] = yp
+            np.ctypeslib.as_array(pym, (m, n)).T[:, :] = ym
+
+        cb = C.CFUNCTYPE(None, c_ip, c_ip, c_dp, c_dp, c_dp, c_dp, c_dp)(tramp)
+        self._keep.append(cb)
+        return C.cast(cb, C.c_void_p).value
 
     def last_solve_info(self) -> dict:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)

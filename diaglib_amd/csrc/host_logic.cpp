@@ -683,6 +683,31 @@ int dla_call_precnd(dla_ctx* c, dla_precnd_fn fn, int n, int m, double fac, cons
   return engfail(c, c->eng->h2d(px, c->stage_y, bytes));
 }
 
+// linear-response preconditioner lrprec(n,m,fac,xp,xm,yp,ym) (reference diaglib.f90:1317, caller main.f90:257-281):
+// two inputs, two outputs, one scalar by reference
+int dla_call_lrprec(dla_ctx* c, dla_lrprec_fn fn, int n, int m, double fac, const double* xp, const double* xm,
+                    double* yp, double* ym)
+{
+  DLA_T("dla_call_lrprec");
+  if (m <= 0) return DLA_OK;
+  if (c->callbacks_on_device) {
+    fn(&n, &m, &fac, xp, xm, yp, ym);
+    return DLA_OK;
+  }
+  const size_t bytes = sizeof(double) * (size_t)n * m;
+  int st = ensure_stage(c, 2 * bytes);
+  if (st) return st;
+  double* hx = c->stage_x;
+  double* hy = c->stage_y;
+  st = c->eng->d2h(hx, xp, bytes);
+  if (!st) st = c->eng->d2h(hx + (size_t)n * m, xm, bytes);
+  if (st) return engfail(c, st);
+  fn(&n, &m, &fac, hx, hx + (size_t)n * m, hy, hy + (size_t)n * m);
+  st = c->eng->h2d(yp, hy, bytes);
+  if (!st) st = c->eng->h2d(ym, hy + (size_t)n * m, bytes);
+  return engfail(c, st);
+}
+
 // ------------------------------------------------------------------ solve report
 static int g_info[3] = {0, 0, 0};
 void dla_set_solve_info(int iters, int matvec_cols, int restarts) { g_info[0] = iters; g_info[1] = matvec_cols; g_info[2] = restarts; }

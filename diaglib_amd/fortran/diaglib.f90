@@ -16,8 +16,9 @@
 !
 ! The generalised problem (metric B through a bvec callback) is served by gen_david_driver and by
 ! lobpcg_driver with gen_eig=.true. (reference diaglib.f90:1855-2250, 299-302/357-364/523-526).
-! Not provided (out of scope for this path, SURVEY.md 2 rows 4-5): caslr_driver, caslr_eff_driver,
-! nonsym_driver.
+! The linear-response problem is served by caslr_eff_driver (reference diaglib.f90:1024-1481), built from the
+! same device operations.  Not provided (SURVEY.md 2 rows 4-5): caslr_driver (the older 2n-dimensional
+! formulation of the same problem) and nonsym_driver.
 !
 module diaglib
   use real_precision
@@ -26,6 +27,7 @@ module diaglib
   private
 !
   public :: lobpcg_driver, davidson_driver, gen_david_driver, ortho, b_ortho, ortho_cd, ortho_vs_x, b_ortho_vs_x
+  public :: caslr_eff_driver
   public :: diaglib_amd_config
 !
   real(dp), parameter :: zero = 0.0_dp, one = 1.0_dp, ten = 10.0_dp
@@ -183,6 +185,14 @@ module diaglib
     function dla_call_precnd(ctx,fn,n,m,fac,x,px) bind(C,name='dla_call_precnd') result(st)
       import :: c_ptr, c_funptr, c_int, c_double
       type(c_ptr), value :: ctx, x, px
+      type(c_funptr), value :: fn
+      integer(c_int), value :: n, m
+      real(c_double), value :: fac
+      integer(c_int) :: st
+    end function
+    function dla_call_lrprec(ctx,fn,n,m,fac,xp,xm,yp,ym) bind(C,name='dla_call_lrprec') result(st)
+      import :: c_ptr, c_funptr, c_int, c_double
+      type(c_ptr), value :: ctx, xp, xm, yp, ym
       type(c_funptr), value :: fn
       integer(c_int), value :: n, m
       real(c_double), value :: fac
@@ -1147,5 +1157,341 @@ contains
     call chk(ctx, dla_free(ctx, bd), 'free')
     call chk(ctx, dla_free(ctx, ud), 'free')
   end subroutine b_ortho_vs_x
+!
+! ---------------------------------------------------------------------------------------
+! caslr_eff_driver: linear-response generalised eigenproblem
+!
+!   / A  B \ / Y \     /  S  D \ / Y \
+!   |      | |   | = w |       | |   |     (reference diaglib.f90:1024-1481)
+!   \ B  A / \ Z /     \ -D -S / \ Z /
+!
+! solved in the symmetric/antisymmetric combinations b+ = Y+Z, b- = Y-Z with the Casida matrix as
+! the metric: the expansion spaces vp, vm are (A+B)- and (A-B)-orthonormal, the reduced problem is
+! s^T s u+ = (1/w)^2 u+ with s = vm^T (S+D) vp, and u- = w s u+ (reference :1052-1060).
+! Device-resident: vp, vm, their images under (A+B), (A-B), (S-D), (S+D), and the residuals.
+! Deviations from the reference's operation order, none of which changes a result beyond rounding:
+!   - s is extended by its new block row and block column instead of being recomputed (:1289);
+!   - the Ritz vectors (:1324-1333) are formed when they are needed (convergence, restart, exit),
+!     not in every iteration.
+! ---------------------------------------------------------------------------------------
+  subroutine caslr_eff_driver(verbose,n,n2,n_targ,n_max,max_iter,tol,max_dav, &
+                              apbmul,ambmul,spdmul,smdmul,lrprec,eig,evec,ok)
+    logical,                               intent(in)    :: verbose
+    integer,                               intent(in)    :: n, n2, n_targ, n_max
+    integer,                               intent(in)    :: max_iter, max_dav
+    real(dp),                              intent(in)    :: tol
+    real(dp), dimension(n_max),            intent(inout) :: eig
+    real(dp), dimension(n2,n_max), target, intent(inout) :: evec
+    logical,                               intent(inout) :: ok
+    external                                             :: apbmul, ambmul, spdmul, smdmul, lrprec
+!
+    type(c_ptr)    :: ctx, vp, vm, lvp, lvm, bvp, bvm, rp, rm, bp, bm, tp, tm, evd
+    type(c_funptr) :: f_apb, f_amb, f_spd, f_smd, f_prec
+    integer        :: dim_dav, lda, n_act, ind, i_beg, m_dim, ldu, n_frozen, it, i_eig, j, n_mv, n_restarts
+    logical        :: evec_dev, have_evec
+    real(dp)       :: tol_rms, tol_max, sqrt2
+    logical,        allocatable :: done(:)
+    integer(c_int), allocatable :: skip(:)
+    real(dp),       allocatable :: smat(:,:), s_copy(:,:), e_red(:), up(:,:), um(:,:), ident(:,:)
+    real(dp),       allocatable :: r_norm(:,:), rn_p(:,:), rn_m(:,:)
+    integer(c_int) :: info
+!
+    ctx    = dla_default_ctx()
+    f_apb  = c_funloc(apbmul)
+    f_amb  = c_funloc(ambmul)
+    f_spd  = c_funloc(spdmul)
+    f_smd  = c_funloc(smdmul)
+    f_prec = c_funloc(lrprec)
+    evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
+!
+    dim_dav = max(min_dav,max_dav)
+    lda     = dim_dav*n_max
+    sqrt2   = sqrt(2.0_dp)
+!
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), vp),  'allocation of vp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), vm),  'allocation of vm')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), lvp), 'allocation of lvp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), lvm), 'allocation of lvm')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), bvp), 'allocation of bvp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), bvm), 'allocation of bvm')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), rp), 'allocation of rp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), rm), 'allocation of rm')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), bp), 'allocation of bp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), bm), 'allocation of bm')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), tp), 'allocation of tp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), tm), 'allocation of tm')
+    if (evec_dev) then
+      evd = c_loc(evec)
+    else
+      call chk(ctx, dla_alloc(ctx, nbytes(n2,n_max), evd), 'allocation of evec')
+      call chk(ctx, dla_upload(ctx, evd, c_loc(evec), nbytes(n2,n_max)), 'upload of the guess')
+    end if
+    allocate (done(n_max), skip(n_max), r_norm(2,n_max), rn_p(2,n_max), rn_m(2,n_max))
+    allocate (smat(lda,lda), s_copy(lda,lda), e_red(lda), up(lda,n_max), um(lda,n_max), ident(n_max,n_max))
+!
+    tol_rms = tol
+    tol_max = ten * tol
+    t_diag  = zero
+    t_ortho = zero
+    t_mv    = zero
+    t_tot   = zero
+    smat    = zero
+    r_norm  = zero
+    rn_p    = zero
+    rn_m    = zero
+    ident   = zero
+    do j = 1, n_max
+      ident(j,j) = one
+    end do
+    ok      = .false.
+    done    = .false.
+    n_mv    = 0
+    n_restarts = 0
+!
+    call get_time(t_tot)
+!
+!   the guess in the plus/minus combinations, orthonormal in the metric (reference :1249-1259)
+!
+    call split_evec()
+    call new_metric_blocks(1, n_max)
+!
+    n_act = n_max
+    ind   = 1
+    i_beg = 1
+    m_dim = 1
+    ldu   = 0
+    n_frozen = 0
+    have_evec = .false.
+!
+    1030 format(t5,'Davidson-Liu iterations (tol=',d10.2,'):',/, &
+                t5,'------------------------------------------------------------------',/, &
+                t7,'  iter  root              eigenvalue','         rms         max ok',/, &
+                t5,'------------------------------------------------------------------')
+    1040 format(t9,i4,2x,i4,f24.12,2d12.4,l3)
+    if (verbose) write(6,1030) tol
+!
+    do it = 1, max_iter
+      ldu = ldu + n_act
+      have_evec = .false.
+!
+!     (S+D) times the new vp block, (S-D) times the new vm block (reference :1281-1282)
+!
+      call get_time(t1)
+      call chk(ctx, dla_call_matvec(ctx, f_spd, n, n_act, colp(vp,n,i_beg), colp(bvm,n,i_beg)), 'spdmul')
+      call chk(ctx, dla_call_matvec(ctx, f_smd, n, n_act, colp(vm,n,i_beg), colp(bvp,n,i_beg)), 'smdmul')
+      call get_time(t2)
+      t_mv = t_mv + t2 - t1
+      n_mv = n_mv + 2*n_act
+!
+!     s = vm^T bvm (reference :1289): the new block column and the new block row
+!
+      call chk(ctx, dla_gram(ctx, n, ldu, vm, n_act, colp(bvm,n,i_beg), smat(1,i_beg), lda), 'reduced matrix')
+      if (i_beg.gt.1) call chk(ctx, dla_gram(ctx, n, n_act, colp(vm,n,i_beg), i_beg-1, bvm, smat(i_beg,1), lda), &
+                               'reduced matrix')
+!
+!     s^T s and its largest eigenpairs (reference :1293-1311): the lowest ones of -s^T s
+!
+      s_copy(1:ldu,1:ldu) = -matmul(transpose(smat(1:ldu,1:ldu)), smat(1:ldu,1:ldu))
+      call get_time(t1)
+      info = dla_syev_lowest('u', ldu, s_copy, lda, e_red, n_max)
+      call get_time(t2)
+      t_diag = t_diag + t2 - t1
+      if (info.ne.0) then
+        write(6,'(t3,a,i6)') 'dsyev failed. info = ',info
+        stop
+      end if
+      do i_eig = 1, n_max
+        eig(i_eig)      = sqrt(-e_red(i_eig))
+        up(1:ldu,i_eig) = s_copy(1:ldu,i_eig)
+      end do
+!
+!     u- = s u+ / eig (reference :1315-1318)
+!
+      um(1:ldu,:) = matmul(smat(1:ldu,1:ldu), up(1:ldu,:))
+      do i_eig = 1, n_max
+        um(1:ldu,i_eig) = um(1:ldu,i_eig)/eig(i_eig)
+      end do
+!
+!     residuals rp = bvp u- - eig lvp u+, rm = bvm u+ - eig lvm u- and their norms (reference :1337-1353)
+!
+      do i_eig = 1, n_max
+        skip(i_eig) = merge(1_c_int, 0_c_int, done(i_eig))
+      end do
+      call chk(ctx, dla_panel_gemm(ctx, n, ldu, lvp, n_max, up, lda, bp), 'bp')
+      call chk(ctx, dla_panel_gemm(ctx, n, ldu, bvp, n_max, um, lda, tp), 'rp')
+      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, bp, tp, ident, n_max, eig, n_targ, skip, &
+                                      tm, rp, c_null_ptr, rn_p), 'residual')
+      call chk(ctx, dla_panel_gemm(ctx, n, ldu, lvm, n_max, um, lda, bm), 'bm')
+      call chk(ctx, dla_panel_gemm(ctx, n, ldu, bvm, n_max, up, lda, tp), 'rm')
+      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, bm, tp, ident, n_max, eig, n_targ, skip, &
+                                      tm, rm, c_null_ptr, rn_m), 'residual')
+      do i_eig = 1, n_targ
+        if (done(i_eig)) cycle
+        r_norm(1,i_eig) = (rn_p(1,i_eig) + rn_m(1,i_eig))/(eig(i_eig)*sqrt2)
+        r_norm(2,i_eig) = (rn_p(2,i_eig) + rn_m(2,i_eig))/(sqrt2*eig(i_eig))
+      end do
+!
+!     lock the leading converged roots (reference :1358-1367)
+!
+      do i_eig = 1, n_targ
+        if (done(i_eig)) cycle
+        done(i_eig) = r_norm(1,i_eig).lt.tol_rms .and. r_norm(2,i_eig).lt.tol_max .and. it.gt.1
+        if (.not.done(i_eig)) then
+          done(i_eig+1:n_max) = .false.
+          exit
+        end if
+      end do
+!
+      if (verbose) then
+        do i_eig = 1, n_targ
+          write(6,1040) it, i_eig, one/eig(i_eig), r_norm(:,i_eig), done(i_eig)
+        end do
+        write(6,*)
+      end if
+!
+      if (all(done(1:n_targ))) then
+        ok = .true.
+        call merge_evec()
+        do i_eig = 1, n_targ
+          eig(i_eig) = one/eig(i_eig)
+        end do
+        exit
+      end if
+!
+      if (m_dim .lt. dim_dav) then
+!
+!       expand both spaces with the preconditioned residuals (reference :1397-1424)
+!
+        m_dim = m_dim + 1
+        i_beg = i_beg + n_act
+        n_act = n_max
+        n_frozen = 0
+        do i_eig = 1, n_targ
+          if (done(i_eig)) then
+            n_act = n_act - 1
+            n_frozen = n_frozen + 1
+          else
+            exit
+          end if
+        end do
+        ind = n_max - n_act + 1
+        call chk(ctx, dla_call_lrprec(ctx, f_prec, n, n_act, eig(ind), colp(rp,n,ind), colp(rm,n,ind), &
+                                      colp(vp,n,i_beg), colp(vm,n,i_beg)), 'lrprec')
+        call get_time(t1)
+        call chk(ctx, dla_b_ortho_vs_x(ctx, n, ldu, n_act, vp, lvp, colp(vp,n,i_beg)), 'b_ortho_vs_x')
+        call chk(ctx, dla_b_ortho_vs_x(ctx, n, ldu, n_act, vm, lvm, colp(vm,n,i_beg)), 'b_ortho_vs_x')
+        call new_metric_blocks(i_beg, n_act)
+        call get_time(t2)
+        t_ortho = t_ortho + t2 - t1
+      else
+!
+!       restart from the current Ritz vectors (reference :1426-1463)
+!
+        if (verbose) write(6,'(t7,a)') 'Restarting davidson.'
+        n_restarts = n_restarts + 1
+        call merge_evec()
+        ldu   = 0
+        i_beg = 1
+        m_dim = 1
+        n_act = n_max
+        call split_evec()
+        call new_metric_blocks(1, n_max)
+        smat = zero
+      end if
+      if (verbose) write(6,1050) n_targ, n_act, n_frozen
+    end do
+!
+!   evec holds the current approximation on every exit, like the reference (:1330-1333)
+!
+    if (.not.have_evec) call merge_evec()
+    call get_time(t2)
+    t_tot = t2 - t_tot
+    call dla_set_solve_info(int(min(it,max_iter),c_int), int(n_mv,c_int), int(n_restarts,c_int))
+!
+    1000 format(t3,'timings for caslr_eff (cpu/wall):   ',/, &
+                t3,'  matrix-vector multiplications: ',2f12.4,/, &
+                t3,'  diagonalization:               ',2f12.4,/, &
+                t3,'  orthogonalization:             ',2f12.4,/, &
+                t3,'                                 ',24('='),/,  &
+                t3,'  total:                         ',2f12.4)
+    if (verbose) write(6,1000) t_mv, t_diag, t_ortho, t_tot
+!
+    if (.not.evec_dev) then
+      call chk(ctx, dla_download(ctx, c_loc(evec), evd, nbytes(n2,n_max)), 'download of evec')
+      call chk(ctx, dla_free(ctx, evd), 'free')
+    end if
+    call chk(ctx, dla_free(ctx, vp), 'free')
+    call chk(ctx, dla_free(ctx, vm), 'free')
+    call chk(ctx, dla_free(ctx, lvp), 'free')
+    call chk(ctx, dla_free(ctx, lvm), 'free')
+    call chk(ctx, dla_free(ctx, bvp), 'free')
+    call chk(ctx, dla_free(ctx, bvm), 'free')
+    call chk(ctx, dla_free(ctx, rp), 'free')
+    call chk(ctx, dla_free(ctx, rm), 'free')
+    call chk(ctx, dla_free(ctx, bp), 'free')
+    call chk(ctx, dla_free(ctx, bm), 'free')
+    call chk(ctx, dla_free(ctx, tp), 'free')
+    call chk(ctx, dla_free(ctx, tm), 'free')
+    deallocate (done, skip, r_norm, rn_p, rn_m, smat, s_copy, e_red, up, um, ident)
+!
+    1050 format(t5,'----------------------------------------',/,&
+                t7,'# target vectors:    ',i4,/,&
+                t7,'# new vectors added: ',i4,/,&
+                t7,'# converged vectors: ',i4,/,&
+                t5,'----------------------------------------')
+    return
+!
+  contains
+!
+!   device address of the upper (half = 0) or lower (half = 1) n rows of column j of the n2 x n_max block
+!
+    function halfp(j, half) result(p)
+      integer, intent(in) :: j, half
+      type(c_ptr)         :: p
+      integer(c_intptr_t) :: a
+      a = transfer(evd, a) + 8_c_intptr_t * (int(n2,c_intptr_t) * int(j-1,c_intptr_t) + int(half*n,c_intptr_t))
+      p = transfer(a, p)
+    end function halfp
+!
+!   vp = Y + Z, vm = Y - Z for the n_max columns of evec (reference :1249-1252, 1443-1446)
+!
+    subroutine split_evec()
+      integer :: jj
+      do jj = 1, n_max
+        call chk(ctx, dla_copy(ctx, colp(vp,n,jj), halfp(jj,0), nbytes(n,1)), 'copy')
+        call chk(ctx, dla_axpy(ctx, int(n,c_size_t), one, halfp(jj,1), colp(vp,n,jj)), 'axpy')
+        call chk(ctx, dla_copy(ctx, colp(vm,n,jj), halfp(jj,0), nbytes(n,1)), 'copy')
+        call chk(ctx, dla_axpy(ctx, int(n,c_size_t), -one, halfp(jj,1), colp(vm,n,jj)), 'axpy')
+      end do
+    end subroutine split_evec
+!
+!   Ritz vectors in the plus/minus combinations, eigp = vp u+, eigm = vm u- (reference :1324-1325; bp, bm
+!   are free here and hold them), then Y = eigp + eigm, Z = eigp - eigm (:1330-1333)
+!
+    subroutine merge_evec()
+      integer :: jj
+      call chk(ctx, dla_panel_gemm(ctx, n, ldu, vp, n_max, up, lda, bp), 'ritz vectors')
+      call chk(ctx, dla_panel_gemm(ctx, n, ldu, vm, n_max, um, lda, bm), 'ritz vectors')
+      do jj = 1, n_max
+        call chk(ctx, dla_copy(ctx, halfp(jj,0), colp(bp,n,jj), nbytes(n,1)), 'copy')
+        call chk(ctx, dla_axpy(ctx, int(n,c_size_t), one, colp(bm,n,jj), halfp(jj,0)), 'axpy')
+        call chk(ctx, dla_copy(ctx, halfp(jj,1), colp(bp,n,jj), nbytes(n,1)), 'copy')
+        call chk(ctx, dla_axpy(ctx, int(n,c_size_t), -one, colp(bm,n,jj), halfp(jj,1)), 'axpy')
+      end do
+      have_evec = .true.
+    end subroutine merge_evec
+!
+!   (A+B) vp and (A-B) vm for a new block, which is then made orthonormal in its metric
+!   (reference :1256-1259, 1420-1424)
+!
+    subroutine new_metric_blocks(c0, k)
+      integer, intent(in) :: c0, k
+      call chk(ctx, dla_call_matvec(ctx, f_apb, n, k, colp(vp,n,c0), colp(lvp,n,c0)), 'apbmul')
+      call chk(ctx, dla_b_ortho(ctx, n, k, colp(vp,n,c0), colp(lvp,n,c0)), 'b_ortho')
+      call chk(ctx, dla_call_matvec(ctx, f_amb, n, k, colp(vm,n,c0), colp(lvm,n,c0)), 'ambmul')
+      call chk(ctx, dla_b_ortho(ctx, n, k, colp(vm,n,c0), colp(lvm,n,c0)), 'b_ortho')
+      n_mv = n_mv + 2*k
+    end subroutine new_metric_blocks
+  end subroutine caslr_eff_driver
 !
 end module diaglib

@@ -6,7 +6,7 @@
 !
 module diaglib_cbind
   use iso_c_binding
-  use diaglib, only : davidson_driver, lobpcg_driver, gen_david_driver
+  use diaglib, only : davidson_driver, lobpcg_driver, gen_david_driver, caslr_eff_driver
   implicit none
 !
   abstract interface
@@ -21,6 +21,12 @@ module diaglib_cbind
       real(c_double) :: fac
       real(c_double) :: x(*), px(*)
     end subroutine pc_iface
+    subroutine lrpc_iface(n,m,fac,xp,xm,yp,ym) bind(C)
+      import :: c_int, c_double
+      integer(c_int) :: n, m
+      real(c_double) :: fac
+      real(c_double) :: xp(*), xm(*), yp(*), ym(*)
+    end subroutine lrpc_iface
   end interface
 !
 contains
@@ -77,5 +83,25 @@ contains
     call lobpcg_driver(verbose.ne.0,gen_eig.ne.0,n,n_targ,n_max,max_iter,tol,shift,mv,pc,bv,eig,evec,lok)
     ok = merge(1_c_int, 0_c_int, lok)
   end subroutine dla_lobpcg_driver
+!
+  subroutine dla_caslr_eff_driver(verbose,n,n_targ,n_max,max_iter,tol,max_dav, &
+                                  apbmul,ambmul,spdmul,smdmul,lrprec,eig,evec,ok) bind(C,name='dla_caslr_eff_driver')
+    integer(c_int), value :: verbose, n, n_targ, n_max, max_iter, max_dav
+    real(c_double), value :: tol
+    type(c_funptr), value :: apbmul, ambmul, spdmul, smdmul, lrprec
+    real(c_double)        :: eig(n_max), evec(2*n,n_max)
+    integer(c_int)        :: ok
+    procedure(mv_iface),   pointer :: f1, f2, f3, f4
+    procedure(lrpc_iface), pointer :: f5
+    logical :: lok
+    call c_f_procpointer(apbmul, f1)
+    call c_f_procpointer(ambmul, f2)
+    call c_f_procpointer(spdmul, f3)
+    call c_f_procpointer(smdmul, f4)
+    call c_f_procpointer(lrprec, f5)
+    lok = .false.
+    call caslr_eff_driver(verbose.ne.0,n,2*n,n_targ,n_max,max_iter,tol,max_dav,f1,f2,f3,f4,f5,eig,evec,lok)
+    ok = merge(1_c_int, 0_c_int, lok)
+  end subroutine dla_caslr_eff_driver
 !
 end module diaglib_cbind

@@ -47,6 +47,9 @@ enum {
 /* reference callback shapes, README.md:34-35 (F77 ABI: everything by reference) */
 typedef void (*dla_matvec_fn)(const int* n, const int* m, const double* x, double* ax);
 typedef void (*dla_precnd_fn)(const int* n, const int* m, const double* fac, const double* x, double* px);
+/* linear-response preconditioner lrprec(n,m,fac,xp,xm,yp,ym): reference diaglib.f90:1317, callers main.f90:234-281 */
+typedef void (*dla_lrprec_fn)(const int* n, const int* m, const double* fac, const double* xp, const double* xm,
+                              double* yp, double* ym);
 
 /* options for dla_set_option */
 enum {
@@ -173,6 +176,9 @@ int  dla_get_coeffs(dla_ctx* ctx, int len_a, int len_u, int n_max, int n_act, co
  * (diaglib.f90:1685,1786, 309,352,394,518).  Host-callback mode stages through pinned memory. */
 int  dla_call_matvec(dla_ctx* ctx, dla_matvec_fn fn, int n, int m, const double* x_dev, double* ax_dev);
 int  dla_call_precnd(dla_ctx* ctx, dla_precnd_fn fn, int n, int m, double fac, const double* x_dev, double* px_dev);
+/* call lrprec(n,m,fac,xp,xm,yp,ym) (diaglib.f90:1317) on two device blocks, staging through pinned memory in host mode */
+int  dla_call_lrprec(dla_ctx* ctx, dla_lrprec_fn fn, int n, int m, double fac, const double* xp_dev, const double* xm_dev,
+                     double* yp_dev, double* ym_dev);
 
 /* ---------------------------------------------------------------- small dense, host (LAPACK in the reference) */
 int    dla_syev(char uplo, int n, double* a, int lda, double* w);   /* dsyev('v',uplo): :315,406,1708 */
@@ -202,6 +208,11 @@ void dla_gen_david_driver(int verbose, int n, int n_targ, int n_max, int max_ite
 void dla_lobpcg_driver(int verbose, int gen_eig, int n, int n_targ, int n_max, int max_iter, double tol,
                        double shift, dla_matvec_fn matvec, dla_precnd_fn precnd, dla_matvec_fn bvec,
                        double* eig, double* evec, int* ok);
+/* linear-response problem (A B; B A)(Y Z) = w (S D; -D -S)(Y Z): reference diaglib.f90:1024-1481 (caslr_eff_driver).
+ * evec is 2n x n_max (Y on top of Z); the four operators have the matvec shape and apply A+B, A-B, S+D, S-D. */
+void dla_caslr_eff_driver(int verbose, int n, int n_targ, int n_max, int max_iter, double tol, int max_dav,
+                          dla_matvec_fn apbmul, dla_matvec_fn ambmul, dla_matvec_fn spdmul, dla_matvec_fn smdmul,
+                          dla_lrprec_fn lrprec, double* eig, double* evec, int* ok);
 /* iteration report of the last driver call (iterations, matvec columns, restarts) */
 void dla_last_solve_info(int* iters, int* matvec_cols, int* restarts);
 void dla_set_solve_info(int iters, int matvec_cols, int restarts);   /* used by the Fortran drivers */

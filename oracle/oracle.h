@@ -97,6 +97,17 @@ void orc_metric_setup(int n);
 void orc_metric_matvec(const int* n, const int* m, const double* x, double* sx);
 const double* orc_metric(void);
 
+/* ---- linear-response test problem (roles of main.f90:528-600, portable generator) ---- */
+typedef void (*orc_lrprec_t)(const int* n, const int* m, const double* fac, const double* xp, const double* xm,
+                             double* yp, double* ym);
+void orc_lr_setup(int n);
+void orc_lr_apb(const int* n, const int* m, const double* x, double* y);   /* (A+B) x */
+void orc_lr_amb(const int* n, const int* m, const double* x, double* y);   /* (A-B) x */
+void orc_lr_spd(const int* n, const int* m, const double* x, double* y);   /* (S+D) x */
+void orc_lr_smd(const int* n, const int* m, const double* x, double* y);   /* (S-D) x */
+void orc_lr_prec(const int* n, const int* m, const double* fac, const double* xp, const double* xm, double* yp, double* ym);
+const double* orc_lr_matrix(int which);                                     /* 0 A+B, 1 A-B, 2 S+D, 3 S-D; column-major */
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,76 @@ void orc_metric_matvec(const int* pn, const int* pm, const double* x, double* sx
   }
 }
 
+/* ---------------- linear-response test problem (same roles as main.f90:528-600) ----------------
+ * A+B: diag 5+i, off-diagonal 0.2/(i+j);  A-B: diag 2+i;  S = I + (0.5/8) G G^T (the metric above, seed 5);
+ * D antisymmetric, D(i,j) = 0.05 (u01(7,i,j) - u01(7,j,i)) for i < j.  The reference harness draws S and D
+ * with the compiler's random_number; here they come from the portable generator so that every
+ * implementation sees the same matrices.  Preconditioner: main.f90:257-281 (lrprec_2). */
+static int     g_ln = 0;
+static double *g_apb = NULL, *g_amb = NULL, *g_spd = NULL, *g_smd = NULL, *g_adiag = NULL, *g_sdiag = NULL;
+
+void orc_lr_setup(int n)
+{
+  free(g_apb); free(g_amb); free(g_spd); free(g_smd); free(g_adiag); free(g_sdiag);
+  g_ln = n;
+  size_t nn = (size_t)n * n;
+  g_apb = (double*)calloc(nn, sizeof(double)); g_amb = (double*)calloc(nn, sizeof(double));
+  g_spd = (double*)calloc(nn, sizeof(double)); g_smd = (double*)calloc(nn, sizeof(double));
+  g_adiag = (double*)malloc(sizeof(double) * n); g_sdiag = (double*)malloc(sizeof(double) * n);
+  const int kw = 8;
+  double* g = (double*)malloc(sizeof(double) * (size_t)n * kw);
+  for (int j = 0; j < kw; ++j)
+    for (int i = 0; i < n; ++i) g[(size_t)j * n + i] = orc_u01(5ULL, (unsigned long long)(i + 1), (unsigned long long)(j + 1)) - 0.5;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      size_t p = (size_t)j * n + i;
+      int fi = i + 1, fj = j + 1;
+      g_apb[p] = (i == j) ? 5.0 + fi : 0.2 / (double)(fi + fj);
+      g_amb[p] = (i == j) ? 2.0 + fi : 0.0;
+      double sg = 0.0;
+      for (int q = 0; q < kw; ++q) sg += g[(size_t)q * n + i] * g[(size_t)q * n + j];
+      sg = (0.5 / kw) * sg + (i == j ? 1.0 : 0.0);
+      double dl = 0.0;
+      if (i < j) dl = 0.05 * (orc_u01(7ULL, fi, fj) - orc_u01(7ULL, fj, fi));
+      if (i > j) dl = -0.05 * (orc_u01(7ULL, fj, fi) - orc_u01(7ULL, fi, fj));
+      g_spd[p] = sg + dl;
+      g_smd[p] = sg - dl;
+      if (i == j) { g_adiag[i] = 0.5 * (g_apb[p] + g_amb[p]); g_sdiag[i] = sg; }
+    }
+  free(g);
+}
+
+static void lr_apply(const double* mat, int n, int m, const double* x, double* y)
+{
+  /* y = mat x, column by column like main.f90:173-232 (matmul); mat is column-major */
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i)
+    for (int c = 0; c < m; ++c) {
+      const double* xc = x + (size_t)c * n;
+      double s = 0.0;
+      for (int j = 0; j < n; ++j) s += mat[(size_t)j * n + i] * xc[j];
+      y[(size_t)c * n + i] = s;
+    }
+}
+void orc_lr_apb(const int* n, const int* m, const double* x, double* y) { lr_apply(g_apb, *n, *m, x, y); }
+void orc_lr_amb(const int* n, const int* m, const double* x, double* y) { lr_apply(g_amb, *n, *m, x, y); }
+void orc_lr_spd(const int* n, const int* m, const double* x, double* y) { lr_apply(g_spd, *n, *m, x, y); }
+void orc_lr_smd(const int* n, const int* m, const double* x, double* y) { lr_apply(g_smd, *n, *m, x, y); }
+const double* orc_lr_matrix(int which) { return which == 0 ? g_apb : which == 1 ? g_amb : which == 2 ? g_spd : g_smd; }
+
+void orc_lr_prec(const int* pn, const int* pm, const double* pfac, const double* xp, const double* xm, double* yp, double* ym)
+{
+  const int n = *pn, m = *pm;
+  const double fac = *pfac;
+  for (int c = 0; c < m; ++c)
+    for (int i = 0; i < n; ++i) {
+      const size_t p = (size_t)c * n + i;
+      const double den = 1.0 / (fac * fac * g_adiag[i] * g_adiag[i] - g_sdiag[i] * g_sdiag[i]);
+      yp[p] = den * (fac * g_adiag[i] * xp[p] + g_sdiag[i] * xm[p]);
+      ym[p] = den * (fac * g_adiag[i] * xm[p] + g_sdiag[i] * xp[p]);
+    }
+}
+
 /* ---------------- synthetic matrix-free ---------------- */
 static long long g_row0 = 0;
 static int       g_nl = 0, g_rw = 0;

@@ -178,6 +178,12 @@ class Oracle:
         self.lib.orc_metric_setup(n)
         return np.ctypeslib.as_array(self.lib.orc_metric(), (n, n)).copy(order="F")
 
+    def lr_setup(self, n):
+        """linear-response test problem; returns the dense matrices (A+B, A-B, S+D, S-D)"""
+        self.lib.orc_lr_setup(n)
+        self.lib.orc_lr_matrix.restype = c_dp
+        return tuple(np.ctypeslib.as_array(self.lib.orc_lr_matrix(w), (n, n)).T.copy(order="F") for w in range(4))
+
     def synth_setup(self, n_global, row0, n_local, rank_w=4, sigma=0.5):
         self.lib.orc_synth_setup(n_global, row0, n_local, rank_w, sigma)
         self._synth = (n_local, rank_w)
@@ -326,6 +332,16 @@ class Reference:
         evec = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
         eig = np.zeros(n_max); ok = C.c_int(0)
         self.lib.ref_gen_david(int(verbose), n, n_targ, n_max, max_iter, tol, max_dav, shift, matvec, precnd, bvec,
+                               _p(eig), _p(evec), C.byref(ok))
+        return eig, evec, bool(ok.value)
+
+    def caslr_eff(self, n, n_targ, n_max, max_iter, tol, max_dav, apb, amb, spd, smd, lrprec, evec, verbose=False):
+        """reference caslr_eff_driver (diaglib.f90:1024-1481); evec is 2n x n_max"""
+        evec = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
+        assert evec.shape == (2 * n, n_max)
+        eig = np.zeros(n_max); ok = C.c_int(0)
+        self.lib.ref_caslr_eff.argtypes = [C.c_int] * 5 + [C.c_double, C.c_int] + [C.c_void_p] * 5 + [c_dp, c_dp, c_ip]
+        self.lib.ref_caslr_eff(int(verbose), n, n_targ, n_max, max_iter, tol, max_dav, apb, amb, spd, smd, lrprec,
                                _p(eig), _p(evec), C.byref(ok))
         return eig, evec, bool(ok.value)
 

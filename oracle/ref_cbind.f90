@@ -13,7 +13,7 @@
 module ref_cbind
   use iso_c_binding
   use diaglib, only : davidson_driver, lobpcg_driver, gen_david_driver, ortho_cd, ortho_vs_x, &
-                      b_ortho, b_ortho_vs_x
+                      b_ortho, b_ortho_vs_x, caslr_eff_driver
   implicit none
 !
   abstract interface
@@ -28,9 +28,37 @@ module ref_cbind
       real(c_double) :: fac
       real(c_double) :: x(*), px(*)
     end subroutine pc_iface
+    subroutine lrpc_iface(n,m,fac,xp,xm,yp,ym) bind(C)
+      import :: c_int, c_double
+      integer(c_int) :: n, m
+      real(c_double) :: fac
+      real(c_double) :: xp(*), xm(*), yp(*), ym(*)
+    end subroutine lrpc_iface
   end interface
 !
 contains
+!
+  subroutine ref_caslr_eff(verbose,n,n_targ,n_max,max_iter,tol,max_dav, &
+                           apbmul,ambmul,spdmul,smdmul,lrprec,eig,evec,ok) bind(C,name='ref_caslr_eff')
+    integer(c_int), value :: verbose, n, n_targ, n_max, max_iter, max_dav
+    real(c_double), value :: tol
+    type(c_funptr), value :: apbmul, ambmul, spdmul, smdmul, lrprec
+    real(c_double)        :: eig(n_max), evec(2*n,n_max)
+    integer(c_int)        :: ok
+    procedure(mv_iface),   pointer :: f1, f2, f3, f4
+    procedure(lrpc_iface), pointer :: f5
+    logical :: lok, lverb
+    call c_f_procpointer(apbmul, f1)
+    call c_f_procpointer(ambmul, f2)
+    call c_f_procpointer(spdmul, f3)
+    call c_f_procpointer(smdmul, f4)
+    call c_f_procpointer(lrprec, f5)
+    lok = .false.
+    lverb = verbose .ne. 0
+    call caslr_eff_driver(lverb,n,2*n,n_targ,n_max,max_iter,tol,max_dav,f1,f2,f3,f4,f5,eig,evec,lok)
+    ok = 0
+    if (lok) ok = 1
+  end subroutine ref_caslr_eff
 !
   subroutine ref_davidson(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift, &
                           matvec,precnd,eig,evec,ok) bind(C,name='ref_davidson')
