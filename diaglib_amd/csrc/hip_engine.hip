@@ -223,6 +223,129 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
     }
 }
 
+// Same product with full-line loads: every lane loads 16 B of a 128-byte column segment (8 lanes per column,
+// 8 columns per instruction), non-temporal, and the 16-row tile is staged through a wave-private LDS image
+// [column][18] from which the MFMA fragments (lane (c, g): row 4s+g of column c) are read.  No block-level
+// synchronisation inside the sweep; the next tile's loads are in flight while the current one is multiplied.
+// Even n only (16-byte row pairs).
+template <int TLW, int KT, int NT = 1, int R = 16>
+__global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
+{
+  // R rows per wave tile (16 or 32): R/2 lanes cover one column segment, 128/R columns per load instruction
+  constexpr int RS = R + 2;                // doubles per staged column (+2 keeps 16-byte alignment)
+  constexpr int LPC = R / 2;               // lanes per column
+  constexpr int CPI = 64 / LPC;            // columns per load instruction
+  constexpr int NC = 16 * (TLW + KT);      // staged columns: the pass's X tiles, then its U tiles
+  constexpr int NI = NC / CPI;             // load instructions per tile
+  extern __shared__ __attribute__((aligned(16))) double glds[];   // [4][NC][RS]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* my = glds + (size_t)wave * NC * RS;
+  const int c = lane & 15, g = lane >> 4;
+  const int li = lane % LPC, lc = lane / LPC;
+  const int xg = blockIdx.y % a.passes_x, ug = blockIdx.y / a.passes_x;
+  const long long n = a.n;
+
+  // staged column j*CPI + lc of this lane -> panel column (clamped: garbage only reaches unused rows/columns of D)
+  const double* cp[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int sc = CPI * j + lc;
+    if (sc < 16 * TLW) {
+      int col = xg * TLW * 16 + sc;
+      col = col < a.l ? col : a.l - 1;
+      cp[j] = a.x + (size_t)col * (size_t)n + 2 * li;
+    } else {
+      int col = ug * KT * 16 + (sc - 16 * TLW);
+      col = col < a.k ? col : a.k - 1;
+      cp[j] = a.u + (size_t)col * (size_t)n + 2 * li;
+    }
+  }
+  v4d acc[TLW][KT];
+  bool want[TLW][KT];
+  bool any_want = false;
+#pragma unroll
+  for (int t = 0; t < TLW; ++t)
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+      acc[t][q] = (v4d){0.0, 0.0, 0.0, 0.0};
+      want[t][q] = !a.lower || (xg * TLW + t >= ug * KT + q);
+      any_want = any_want || want[t][q];
+    }
+  typedef VecOf<2>::type vec_t;
+  vec_t stg[NI];
+  auto load_tile = [&](long long tile) {
+    const long long r0 = tile * R;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) stg[j] = pload<2, NT>(cp[j] + r0);
+  };
+  auto stage_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) *(vec_t*)(my + (size_t)(CPI * j + lc) * RS + 2 * li) = stg[j];
+  };
+  auto mfma_tile = [&]() {
+#pragma unroll
+    for (int s4 = 0; s4 < R / 4; ++s4) {
+      double uf[KT];
+#pragma unroll
+      for (int q = 0; q < KT; ++q) uf[q] = my[(size_t)(16 * TLW + 16 * q + c) * RS + 4 * s4 + g];
+#pragma unroll
+      for (int t = 0; t < TLW; ++t) {
+        const double xf = my[(size_t)(16 * t + c) * RS + 4 * s4 + g];
+#pragma unroll
+        for (int q = 0; q < KT; ++q)
+          if (want[t][q]) acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf, uf[q], acc[t][q], 0, 0, 0);
+      }
+    }
+  };
+  const long long nfull = n / R;
+  const long long stride = (long long)gridDim.x * 4;
+  long long tile = (long long)blockIdx.x * 4 + wave;
+  if (!any_want) tile = (1LL << 62);
+  if (tile < nfull) {
+    load_tile(tile);
+    for (;;) {
+      stage_tile();
+      __builtin_amdgcn_wave_barrier();
+      const long long next = tile + stride;
+      if (next < nfull) load_tile(next);
+      mfma_tile();
+      __builtin_amdgcn_wave_barrier();
+      tile = next;
+      if (next >= nfull) break;
+    }
+  }
+  if (tile == nfull && nfull * R < n) {
+    // tail tile: rows >= n contribute zero (n even: a 16-byte row pair is all-in or all-out)
+    const long long r0 = nfull * R;
+    const bool ok = r0 + 2 * li < n;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      stg[j] = vzero<2>();
+      if (ok) stg[j] = *(const vec_t*)(cp[j] + r0);
+    }
+    stage_tile();
+    __builtin_amdgcn_wave_barrier();
+    mfma_tile();
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // deterministic in-block reduction over the 4 waves, one slot at a time (the staging area is free now)
+  __syncthreads();
+  double* red = glds;   // [4][256]
+  double* pout = a.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(TLW * KT) * 256;
+#pragma unroll
+  for (int t = 0; t < TLW; ++t)
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = acc[t][q][r];
+      __syncthreads();
+      double sum = ((red[threadIdx.x] + red[256 + threadIdx.x]) + red[512 + threadIdx.x]) + red[768 + threadIdx.x];
+      pout[(size_t)(t * KT + q) * 256 + threadIdx.x] = sum;
+      __syncthreads();
+    }
+}
+
 // second stage: sum the block partials in a fixed order and scatter into column-major C (ld = l).
 // One launch, two levels: block (ps, grp) sums its share of the partials into lvl2[ps][grp]; the
 // block that draws the last ticket for ps adds the `groups` level-2 rows in index order (so the
@@ -1188,13 +1311,42 @@ struct HipEngine : dla::Engine {
   }
 
   // ---- Gram
+  template <int TLW, int KT, int R>
+  int launch_gram_lds(const GramArgs& a, dim3 grid)
+  {
+    auto kfn = gram_lds_kernel<TLW, KT, 1, R>;
+    const size_t lds = sizeof(double) * 4 * 16 * (TLW + KT) * (R + 2);
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    return DLA_OK;
+  }
+  // tile rows of the LDS-staged kernel: 32 for narrow passes (few loads per tile otherwise) and for 3-tile U blocks,
+  // 16 elsewhere (A/B at n = 2e6, tools/tune_gram.py)
+  static int lds_rows(int tlw, int kt) { return (tlw <= 2 || kt == 3) ? 32 : 16; }
+  bool use_lds_gram(bool vec2, int tlw, int kt) const { return vec2 && kt <= 3 && tune[5] != 2; }
   template <int TLW, int KT>
   int launch_gram(const GramArgs& a, dim3 grid, bool vec2)
   {
-    constexpr int RS = (TLW * KT >= 6) ? 2 : 4;
-    if (vec2) hipLaunchKernelGGL((gram_kernel<TLW, KT, 2, RS>), grid, dim3(256), 0, st, a);
-    else      hipLaunchKernelGGL((gram_kernel<TLW, KT, 1, RS>), grid, dim3(256), 0, st, a);
-    return DLA_OK;
+    if constexpr (KT <= 3) {
+      if (use_lds_gram(vec2, TLW, KT)) {
+        constexpr bool can32 = sizeof(double) * 4 * 16 * (TLW + KT) * 34 <= 150 * 1024;
+        if constexpr (can32) { if (lds_rows(TLW, KT) == 32) return launch_gram_lds<TLW, KT, 32>(a, grid); }
+        return launch_gram_lds<TLW, KT, 16>(a, grid);
+      }
+    }
+    if constexpr (TLW == 5 || TLW == 7 || TLW == 10 || (TLW == 12 && KT > 1)) {
+      err = "gram: width without a direct-load instance";
+      return DLA_ERR_RUNTIME;
+    } else {
+      constexpr int RS = (TLW * KT >= 6) ? 2 : 4;
+      if (vec2) hipLaunchKernelGGL((gram_kernel<TLW, KT, 2, RS>), grid, dim3(256), 0, st, a);
+      else      hipLaunchKernelGGL((gram_kernel<TLW, KT, 1, RS>), grid, dim3(256), 0, st, a);
+      return DLA_OK;
+    }
   }
 
   // result stays on the device in d_small (l x k, ld = l), reduced over ranks
@@ -1205,18 +1357,24 @@ struct HipEngine : dla::Engine {
     int kt = std::min(tu, 4);
     const int passes_u = (tu + kt - 1) / kt;
     kt = (tu + passes_u - 1) / passes_u;
-    static const int maxtl[5] = {0, 8, 6, 4, 3};   // wider passes lose the register prefetch stage (measured)
-    const int passes_x = (tx + maxtl[kt] - 1) / maxtl[kt];
+    const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)u) % 16 == 0);
+    const bool ldsk = use_lds_gram(vec2, 0, kt);
+    // widest pass: the direct-load kernel loses its register prefetch stage beyond 8 tiles (measured); the LDS-staged
+    // one keeps all of X's columns of up to 12 tiles in one pass, so U is read once for L <= 192
+    static const int maxtl[5] = {0, 8, 6, 4, 3};
+    const int mt = (ldsk && kt == 1) ? 12 : maxtl[kt];
+    const int passes_x = (tx + mt - 1) / mt;
     int tlw = (tx + passes_x - 1) / passes_x;
     // round up to an instantiated width
     static const int avail1[] = {1, 2, 3, 4, 6, 8, 12};
-    if (kt == 1) { for (int v : avail1) if (v >= tlw) { tlw = v; break; } }
+    static const int avail1l[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
+    if (kt == 1 && ldsk) { for (int v : avail1l) if (v >= tlw) { tlw = v; break; } }
+    else if (kt == 1) { for (int v : avail1) if (v >= tlw) { tlw = v; break; } }
     else if (kt == 2) { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : tlw <= 4 ? 4 : 6; }
     else if (kt == 3) { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : 4; }
     else { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : 3; }
     const int px = (tx + tlw - 1) / tlw;
     const int passes = px * passes_u;
-    const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)u) % 16 == 0);
     const int ch = vec2 ? 32 : 16;
     long long nchunks = ((long long)n + ch - 1) / ch;
     long long want = (nchunks + 4 * 4 - 1) / (4 * 4);   // >= 4 chunks per wave
@@ -1234,10 +1392,14 @@ struct HipEngine : dla::Engine {
       const bool same = (x == u) && (l == k);
       const int rs = (tlw * kt >= 6) ? 2 : 4;
       char kn[64];
-      std::snprintf(kn, sizeof kn, "gram_kernel<%d, %d, %d, %d, 0, -1>", tlw, kt, vec2 ? 2 : 1, rs);
+      if (use_lds_gram(vec2, tlw, kt)) {
+        const bool can32 = sizeof(double) * 4 * 16 * (tlw + kt) * 34 <= 150 * 1024;
+        std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d>", tlw, kt, (can32 && lds_rows(tlw, kt) == 32) ? 32 : 16);
+      }
+      else std::snprintf(kn, sizeof kn, "gram_kernel<%d, %d, %d, %d, 0, -1>", tlw, kt, vec2 ? 2 : 1, rs);
       Scope s(this, cls, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k, kn);
-#define GL(T, K) if (tlw == T && kt == K) launch_gram<T, K>(a, grid, vec2); else
-      GL(1, 1) GL(2, 1) GL(3, 1) GL(4, 1) GL(6, 1) GL(8, 1) GL(12, 1)
+#define GL(T, K) if (tlw == T && kt == K) { int r_ = launch_gram<T, K>(a, grid, vec2); if (r_) return r_; } else
+      GL(1, 1) GL(2, 1) GL(3, 1) GL(4, 1) GL(5, 1) GL(6, 1) GL(7, 1) GL(8, 1) GL(10, 1) GL(12, 1)
       GL(1, 2) GL(2, 2) GL(4, 2) GL(6, 2)
       GL(1, 3) GL(2, 3) GL(4, 3)
       GL(1, 4) GL(2, 4) GL(3, 4)
