@@ -458,7 +458,7 @@ __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return
 // column steps are processed PIPE at a time through a two-stage register pipeline -- the loads of the next
 // stage are in flight while the MFMAs of the current one issue.  For KT == 1 occupancy hides the latency
 // better than registers do (A/B: batching there costs 5-10 %).
-template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1), int PIPE = (KT >= 2 ? 2 : 0)>
+template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1), int PIPE = (KT >= 2 ? 2 : 0), int ZPAD = 9>
 __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 {
 
@@ -479,9 +479,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
   const int i = lane & 15, g = lane >> 4;
   const long long ntiles = (n + WT - 1) / WT;
   const int nsteps = l4 / 4;
-  // LDS row stride of the transpose tile (doubles): 16*KT + 8 keeps rows two apart 32 banks apart, which makes
-  // the 64-bit fragment reads conflict-free (cdna_hip_programming.md section 2)
-  constexpr int ZS = 16 * KT + 8;
+  // LDS row stride of the transpose tile (doubles).  The fragment reads run along a row (16 lanes, 128 contiguous
+  // bytes) and are conflict-free for any stride; the tile WRITES put the 16 lanes of a group on rows 2i+e of one
+  // column, i.e. 2*ZS doubles apart: with an even ZS/4 all of them fall on one bank (16-way conflict, measured as
+  // 25 % LDS-issue stall in the 13-column TRMM+Gram sweep), ZS = 16*KT + 9 leaves a 2-way conflict.
+  constexpr int ZS = 16 * KT + ZPAD;
   double* zs = cs + (size_t)KT * l4 * 16 + (size_t)wave * RG * ZS;   // [RG rows][ZS] per wave (GRAM only)
   v4d gacc[KT][KT];                                        // tile (qa, qb) of Z^T Z, qa >= qb only
 #pragma unroll
@@ -1327,12 +1329,15 @@ struct HipEngine : dla::Engine {
   // tile rows of the LDS-staged kernel: 32 for narrow passes (few loads per tile otherwise) and for 3-tile U blocks,
   // 16 elsewhere (A/B at n = 2e6, tools/tune_gram.py)
   static int lds_rows(int tlw, int kt) { return (tlw <= 2 || kt == 3) ? 32 : 16; }
-  bool use_lds_gram(bool vec2, int tlw, int kt) const { return vec2 && kt <= 3 && tune[5] != 2; }
+  // (a pass narrower than one tile, e.g. the 4-column W^T x of the benchmark operator, would stage mostly
+  // duplicates of its last column: it keeps the direct-load kernel)
+  bool use_lds_gram(bool vec2, int l, int kt) const { return vec2 && kt <= 3 && l > 8 && tune[5] != 2; }
+  bool cur_lds = false;   // decision of the Gram being launched
   template <int TLW, int KT>
   int launch_gram(const GramArgs& a, dim3 grid, bool vec2)
   {
     if constexpr (KT <= 3) {
-      if (use_lds_gram(vec2, TLW, KT)) {
+      if (cur_lds) {
         constexpr bool can32 = sizeof(double) * 4 * 16 * (TLW + KT) * 34 <= 150 * 1024;
         if constexpr (can32) { if (lds_rows(TLW, KT) == 32) return launch_gram_lds<TLW, KT, 32>(a, grid); }
         return launch_gram_lds<TLW, KT, 16>(a, grid);
@@ -1358,7 +1363,7 @@ struct HipEngine : dla::Engine {
     const int passes_u = (tu + kt - 1) / kt;
     kt = (tu + passes_u - 1) / passes_u;
     const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)u) % 16 == 0);
-    const bool ldsk = use_lds_gram(vec2, 0, kt);
+    const bool ldsk = cur_lds = use_lds_gram(vec2, l, kt);
     // widest pass: the direct-load kernel loses its register prefetch stage beyond 8 tiles (measured); the LDS-staged
     // one keeps all of X's columns of up to 12 tiles in one pass, so U is read once for L <= 192
     static const int maxtl[5] = {0, 8, 6, 4, 3};
@@ -1392,7 +1397,7 @@ struct HipEngine : dla::Engine {
       const bool same = (x == u) && (l == k);
       const int rs = (tlw * kt >= 6) ? 2 : 4;
       char kn[64];
-      if (use_lds_gram(vec2, tlw, kt)) {
+      if (cur_lds) {
         const bool can32 = sizeof(double) * 4 * 16 * (tlw + kt) * 34 <= 150 * 1024;
         std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d>", tlw, kt, (can32 && lds_rows(tlw, kt) == 32) ? 32 : 16);
       }
@@ -1553,9 +1558,32 @@ struct HipEngine : dla::Engine {
       }                                                                                                       \
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);                                           \
     } while (0)
+#define GGP(M, P)                                                                                             \
+    do {                                                                                                      \
+      auto kfn = gemm_kernel<KT, 2, M, ARGS, true, 1, P>;                                                     \
+      if (lds > (size_t)64 * 1024) {                                                                          \
+        static bool raised = false;                                                                           \
+        if (!raised) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; } \
+      }                                                                                                       \
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);                                           \
+    } while (0)
+    if constexpr (KT == 1) {
+      if (vec2 && (mode == 0 || mode == 1) && (tune[7] == 4 || tune[7] == 8)) {
+        if (tune[7] == 4) { if (mode == 0) GGP(0, 4); else GGP(1, 4); }
+        else              { if (mode == 0) GGP(0, 8); else GGP(1, 8); }
+        return;
+      }
+    }
+    if constexpr (KT == 1) {
+      if (vec2 && mode == 2 && tune[6] == 1) {   // A/B: the old transpose-tile stride
+        hipLaunchKernelGGL((gemm_kernel<1, 2, 2, ARGS, true, 0, 0, 8>), dim3(blocks), dim3(256), lds, st, a);
+        return;
+      }
+    }
     if (vec2) { if (mode == 1) GG(2, 1); else if (mode == 2) GG(2, 2); else GG(2, 0); }
     else      { if (mode == 1) GG(1, 1); else if (mode == 2) GG(1, 2); else GG(1, 0); }
 #undef GG
+#undef GGP
   }
 
   template <int KT, typename ARGS>
@@ -1589,7 +1617,7 @@ struct HipEngine : dla::Engine {
     const long long ntiles = ((long long)n + wt - 1) / wt;
     // fused variant: + 4 wave tiles of (16*VEC rows) x 24 doubles, and >= 8 KiB for the final reduction
     const size_t lds_c = sizeof(double) * (size_t)kt * l4 * 16;
-    const size_t lds = fuse ? std::max(lds_c + sizeof(double) * 4 * (vec2 ? 32 : 16) * (16 * kt + 8), (size_t)8192) : lds_c;
+    const size_t lds = fuse ? std::max(lds_c + sizeof(double) * 4 * (vec2 ? 32 : 16) * (16 * kt + 9), (size_t)8192) : lds_c;
     const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
     const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu * (tune[3] > 0 ? tune[3] : 1), (ntiles + 3) / 4));
     if (fuse) {
@@ -1602,7 +1630,8 @@ struct HipEngine : dla::Engine {
     const double rd = (mode == 0) ? 8.0 * n * (double)l : (mode == 2 ? 8.0 * n * (double)k : 8.0 * n * (double)(l + k));
     char kn[96];
     std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, %d, %d>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
-                  fuse ? "true" : "false", mode == 2 ? 0 : 1, kt >= 2 ? 2 : 0);
+                  fuse ? "true" : "false", mode == 2 ? 0 : 1,
+                  kt >= 2 ? 2 : ((fuse && kt == 1 && vec2 && !inl && mode <= 1 && (tune[7] == 4 || tune[7] == 8)) ? tune[7] : 0));
     Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k, kn);
     if (inl) {
       GemmArgsInl ai{};

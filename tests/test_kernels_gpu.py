@@ -31,6 +31,25 @@ def test_gram(ctx, oracle, rng, n, l, k):
     assert np.all(np.abs(got - want) <= _bound(np.abs(x), np.abs(u), n))
 
 
+@pytest.mark.parametrize("n", [2, 6, 14, 16, 18, 30, 32, 34, 46, 62, 64, 66, 1000, 4110])
+@pytest.mark.parametrize("l,k", [(4, 13), (13, 13), (26, 13), (65, 13), (104, 13), (143, 13), (191, 13), (208, 13), (100, 21), (60, 37)])
+def test_gram_even_n_tails(ctx, oracle, rng, n, l, k):
+    """Even n takes the LDS-staged kernel (16- or 32-row wave tiles): every tail residue, fewer rows than one tile,
+    one pass of up to 12 column tiles and two passes."""
+    x = np.asfortranarray(rng.standard_normal((n, l)))
+    u = np.asfortranarray(rng.standard_normal((n, k)))
+    # guard columns on both sides: a kernel that runs past a column's end would pick these up
+    xp = ctx.panel(np.asfortranarray(np.hstack([np.full((n, 1), 1e30), x, np.full((n, 1), 1e30)])))
+    up = ctx.panel(np.asfortranarray(np.hstack([np.full((n, 1), 1e30), u, np.full((n, 1), 1e30)])))
+    got = ctx.gram(xp.col(1, l), up.col(1, k))
+    want = oracle.gemm_tn(x, u)
+    assert np.all(np.abs(got - want) <= _bound(np.abs(x), np.abs(u), n))
+    if l == k:
+        got2 = ctx.gram_lower(xp.col(1, l), up.col(1, k))
+        low = np.tril(np.ones((l, l), bool))
+        assert np.all(np.abs(got2 - want)[low] <= _bound(np.abs(x), np.abs(u), n)[low])
+
+
 def test_gram_self_and_column_views(ctx, oracle, rng):
     n, lda, k = 2000, 60, 13
     big = np.asfortranarray(rng.standard_normal((n, lda)))

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""A/B of the column-step pipeline depth of the fused projection sweep (knob 7: 0 = none, 4, 8) on real
+ortho_vs_x calls, one process.   python tools/tune_fused.py [n] [rounds]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from diaglib_amd import capi  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+ctx = capi.Context()
+ctx.set_option(capi.OPT_PROFILE, 1)
+TUNE0 = 100
+k = 13
+for L in (26, 65, 117):
+    panel = ctx.panel(n, L + k)
+    ctx.random_fill(panel)
+    for j in range(0, L, 13):                      # orthonormal X, block by block
+        if j:
+            ctx.ortho_vs_x(panel.col(0, j), panel.col(j, min(13, L - j)))
+        else:
+            ctx.ortho_cd(panel.col(0, 13))
+    keep = ctx.panel(n, k); ctx.random_fill(keep)
+    res = {}
+    for _ in range(rounds):
+        for v in (0, 4, 8):
+            ctx.set_option(TUNE0 + 7, v)
+            ctx.lib.dla_copy(ctx.h, panel.col(L, k).ptr, keep.ptr, 8 * n * k)
+            ctx.reset_stats()
+            ctx.ortho_vs_x(panel.col(0, L), panel.col(L, k))
+            for name, st in ctx.kernel_stats().items():
+                if name.startswith("gemm_kernel<1, 2, 0, GemmArgs, true") or name.startswith("gemm_kernel<1, 2, 1, GemmArgs, true"):
+                    res.setdefault(v, []).append(st["alg_bytes"] / st["ms"] / 1e6)
+    ctx.set_option(TUNE0 + 7, 0)
+    print(f"L={L:4d}  " + "  ".join(f"pipe {v}: med {np.median(res[v]):7.1f} GB/s" for v in sorted(res)), flush=True)
