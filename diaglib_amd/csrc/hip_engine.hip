@@ -941,15 +941,33 @@ __global__ __launch_bounds__(256) void synth_apply_kernel(long long row0, int n,
   }
 }
 
+// one thread keeps VEC rows of the diagonal in registers and walks the m columns (the diagonal is read once,
+// no index arithmetic per element); panel accesses are non-temporal
+template <int VEC>
 __global__ void synth_precnd_kernel(int n, int m, double fac, const double* __restrict__ diag,
                                     const double* __restrict__ x, double* __restrict__ px)
 {
-  const size_t total = (size_t)n * m;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  typedef typename VecOf<VEC>::type vec_t;
+  const size_t nv = (size_t)n / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; idx < total; idx += stride) {
-    const double den = diag[idx % n] + fac;
-    px[idx] = (fabs(den) > 1.0e-5) ? x[idx] / den : x[idx];   // mprec, main.f90:161-169
+  for (size_t iv = (size_t)blockIdx.x * blockDim.x + threadIdx.x; iv < nv; iv += stride) {
+    const size_t i = iv * VEC;
+    const vec_t dg = *(const vec_t*)(diag + i);
+    double inv[VEC];
+    bool use[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const double den = vget<VEC>(dg, e) + fac;
+      use[e] = fabs(den) > 1.0e-5;                          // mprec, main.f90:161-169
+      inv[e] = den;
+    }
+    for (int c = 0; c < m; ++c) {
+      const vec_t xv = pload<VEC, 1>(x + (size_t)c * n + i);
+      double o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = use[e] ? vget<VEC>(xv, e) / inv[e] : vget<VEC>(xv, e);
+      pstore<VEC, 2>(px + (size_t)c * n + i, vmake<VEC>(o[0], o[VEC - 1]));
+    }
   }
 }
 
@@ -1855,9 +1873,11 @@ struct HipEngine : dla::Engine {
   {
     if (n != syn_n) { err = "synth_precnd: n differs from setup"; return DLA_ERR_ARG; }
     Scope s(this, DLA_OP_PRECND, 8.0 * n * (2.0 * m + 1.0), (double)n * m);
-    const size_t total = (size_t)n * m;
-    const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 8, (total + 255) / 256));
-    hipLaunchKernelGGL(synth_precnd_kernel, dim3(blocks), dim3(256), 0, st, n, m, fac, d_diag, x, px);
+    const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)px) % 16 == 0);
+    const size_t nv = (size_t)n / (vec2 ? 2 : 1);
+    const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 8, (nv + 255) / 256));
+    if (vec2) hipLaunchKernelGGL(synth_precnd_kernel<2>, dim3(blocks), dim3(256), 0, st, n, m, fac, d_diag, x, px);
+    else      hipLaunchKernelGGL(synth_precnd_kernel<1>, dim3(blocks), dim3(256), 0, st, n, m, fac, d_diag, x, px);
     HIPCHK(hipGetLastError());
     return DLA_OK;
   }
