@@ -3,7 +3,9 @@
 
 Workload (BASELINE.json metric / SURVEY.md 8d): block Davidson-Liu on the matrix-free dense
 symmetric operator A = diag(i+1) + 0.5 W W^T (rank 4), n = 2e6 rows, 8 wanted roots, block
-n_max = 13, max_dav = 20, unit-vector guess, device-resident callbacks and eigenvector block.
+n_max = 13, max_dav = 20, unit-vector guess, device-resident callbacks and eigenvector block.  Tolerance
+2e-13 in the reference's sense (rms < tol and max < 10 tol): the loosest one for which rms * sqrt(n) / |lambda_min|
+guarantees the north star's ||A x - lambda x||_2 / |lambda| <= 1e-10 (measured: 2-3e-12).
 One "step" = one complete solve (guess -> converged eigenpairs).  With --gpus N the n rows are
 sharded row-wise over N ranks (strong scaling, as the metric is quoted: same n on 1/2/4/8 GPUs);
 the only cross-rank traffic is the RCCL all-reduce of the small m x m products.
@@ -83,7 +85,7 @@ def main() -> None:
     ap.add_argument("--n", type=int, default=2_000_000)
     ap.add_argument("--roots", type=int, default=8)
     ap.add_argument("--solver", default="davidson", choices=["davidson", "lobpcg"])
-    ap.add_argument("--tol", type=float, default=1e-13)
+    ap.add_argument("--tol", type=float, default=2e-13)
     ap.add_argument("--max-dav", type=int, default=20)
     ap.add_argument("--event-steps", type=int, default=1,
                     help="timed steps during which per-kernel HIP events are recorded (roofline figures)")

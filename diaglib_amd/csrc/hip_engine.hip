@@ -480,11 +480,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
   const long long ntiles = (n + WT - 1) / WT;
   const int nsteps = l4 / 4;
   // LDS row stride of the transpose tile (doubles).  The fragment reads run along a row (16 lanes, 128 contiguous
-  // bytes) and are conflict-free for any stride; the tile WRITES put the 16 lanes of a group on rows 2i+e of one
-  // column, i.e. 2*ZS doubles apart: with an even ZS/4 all of them fall on one bank (16-way conflict, measured as
-  // 25 % LDS-issue stall in the 13-column TRMM+Gram sweep), ZS = 16*KT + 9 leaves a 2-way conflict.
+  // bytes) and are conflict-free for any stride; the tile WRITES put the 16 lanes of a group on 16 rows of one
+  // column, ZS doubles apart: an odd ZS spreads them over all banks.  (The first version used 16*KT + 8 with rows
+  // 2 apart: all 16 lanes on one bank, measured as 25 % LDS-issue stall in the 13-column TRMM+Gram sweep.)
   constexpr int ZS = 16 * KT + ZPAD;
-  double* zs = cs + (size_t)KT * l4 * 16 + (size_t)wave * RG * ZS;   // [RG rows][ZS] per wave (GRAM only)
+  double* zs = cs + (size_t)KT * l4 * 16 + (size_t)wave * 16 * ZS;   // [16 rows][ZS] per wave (GRAM only)
   v4d gacc[KT][KT];                                        // tile (qa, qb) of Z^T Z, qa >= qb only
 #pragma unroll
   for (int qa = 0; qa < KT; ++qa)
@@ -578,6 +578,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       if (!GRAM && !rok[rt]) continue;
+      vec_t vkeep[KT][4];
 #pragma unroll
       for (int q = 0; q < KT; ++q)
 #pragma unroll
@@ -592,27 +593,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
             if constexpr (MODE == 3) { vec_t old = *(const vec_t*)zp; v = old + v; }
             pstore<VEC, NT>(zp, v);
           }
-          if constexpr (GRAM) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) zs[(VEC * i + e) * ZS + j] = vget<VEC>(v, e);
-          }
+          vkeep[q][reg] = v;
         }
       if constexpr (GRAM) {
-        __builtin_amdgcn_wave_barrier();
+        // 16 stored rows at a time (row e of every lane's pair) go through the wave-private tile: lane (i, g)
+        // writes Z[row i][16q + g + 4 reg], lane (c, g) reads Z[row 4 s4 + g][16q + c] as MFMA operands
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
+        for (int e = 0; e < VEC; ++e) {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
+          for (int q = 0; q < KT; ++q)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) zs[i * ZS + 16 * q + g + 4 * reg] = vget<VEC>(vkeep[q][reg], e);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
             double zv[KT];
 #pragma unroll
-            for (int q = 0; q < KT; ++q) zv[q] = zs[(4 * VEC * s4 + VEC * g + e) * ZS + 16 * q + i];
+            for (int q = 0; q < KT; ++q) zv[q] = zs[(4 * s4 + g) * ZS + 16 * q + i];
 #pragma unroll
             for (int qa = 0; qa < KT; ++qa)
 #pragma unroll
               for (int qb = 0; qb <= qa; ++qb)
                 gacc[qa][qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[qa], zv[qb], gacc[qa][qb], 0, 0, 0);
           }
-        __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_wave_barrier();
+        }
       }
     }
   }
@@ -1635,9 +1640,10 @@ struct HipEngine : dla::Engine {
     const long long ntiles = ((long long)n + wt - 1) / wt;
     // fused variant: + 4 wave tiles of (16*VEC rows) x 24 doubles, and >= 8 KiB for the final reduction
     const size_t lds_c = sizeof(double) * (size_t)kt * l4 * 16;
-    const size_t lds = fuse ? std::max(lds_c + sizeof(double) * 4 * (vec2 ? 32 : 16) * (16 * kt + 9), (size_t)8192) : lds_c;
-    const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
-    const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu * (tune[3] > 0 ? tune[3] : 1), (ntiles + 3) / 4));
+    const size_t lds = fuse ? std::max(lds_c + sizeof(double) * 4 * 16 * (16 * kt + 9), (size_t)8192) : lds_c;
+    int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
+    if (tune[3] > 0) per_cu = (int)std::max((size_t)1, std::min((size_t)tune[3], (size_t)(156 * 1024) / std::max(lds, (size_t)4096)));
+    const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu, (ntiles + 3) / 4));
     if (fuse) {
       int stp = ensure_partial(sizeof(double) * (size_t)blocks * kt * kt * 256);
       if (stp) return stp;
@@ -1647,7 +1653,7 @@ struct HipEngine : dla::Engine {
     a.x = x + (size_t)l0 * n; a.cpk = d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k; a.gpart = d_partial;
     const double rd = (mode == 0) ? 8.0 * n * (double)l : (mode == 2 ? 8.0 * n * (double)k : 8.0 * n * (double)(l + k));
     char kn[96];
-    std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, %d, %d>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
+    std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, %d, %d, 9>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
                   fuse ? "true" : "false", mode == 2 ? 0 : 1,
                   kt >= 2 ? 2 : ((fuse && kt == 1 && vec2 && !inl && mode <= 1 && (tune[7] == 4 || tune[7] == 8)) ? tune[7] : 0));
     Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k, kn);

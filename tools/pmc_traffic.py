@@ -14,7 +14,7 @@ import re
 import sys
 from collections import defaultdict
 
-CLASS = [("gram_kernel", "gram"), ("gram_reduce", "gram"), ("ritz_kernel", "ritz"), ("ritz_reduce", "ritz")]
+CLASS = [("gram_kernel", "gram"), ("gram_lds_kernel", "gram"), ("gram_reduce", "gram"), ("ritz_kernel", "ritz"), ("ritz_reduce", "ritz")]
 
 
 def klass(name, grid):
@@ -37,7 +37,7 @@ def load(path, counter):
         if "synth_apply_kernel" in r["Kernel_Name"]:
             j, seen = i - 1, 0
             while j >= 0 and seen < 2:
-                if "gram_kernel" in rows[j]["Kernel_Name"] or "gram_reduce" in rows[j]["Kernel_Name"]:
+                if "gram_kernel" in rows[j]["Kernel_Name"] or "gram_lds_kernel" in rows[j]["Kernel_Name"] or "gram_reduce" in rows[j]["Kernel_Name"]:
                     cls[j] = "matvec"; seen += 1
                 j -= 1
     per = defaultdict(lambda: [0.0, 0])
@@ -49,7 +49,7 @@ def load(path, counter):
             per[c][1] += 1
         if c != "matvec":
             # per kernel symbol as well (name as bench.py reports it)
-            m = re.search(r"((gram|gemm|ritz)_kernel<[^>]*>)", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
+            m = re.search(r"((gram_lds|gram|gemm|ritz)_kernel<[^>]*>)", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
             if m:
                 per[m.group(1)][0] += float(r["Counter_Value"])
                 per[m.group(1)][1] += 1
