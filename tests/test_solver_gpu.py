@@ -336,3 +336,61 @@ def test_davidson_restarts_with_device_callbacks(ctx, oracle, rng):
     x = ev.download()[:, :t]
     assert np.abs(x.T @ x - np.eye(t)).max() < 1e-12
     _cmp_vecs(ev.download(), vo, t, 1e-6)
+
+
+@pytest.mark.parametrize("solver", ["davidson", "lobpcg"])
+@pytest.mark.parametrize("n_targ,n_max", [(1, 1), (3, 3), (1, 6)])
+def test_driver_block_edge_cases(ctx, oracle, solver, n_targ, n_max):
+    """No guard vectors (n_max == n_targ), a single vector, one wanted root in a wide block: reference dense
+    matrix, unit-vector guess, against the oracle."""
+    n = 800
+    oracle.dense_setup(n)
+    mv, pc = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd")
+    g = np.zeros((n, n_max), order="F"); g[np.arange(n_max), np.arange(n_max)] = 1.0
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+    if solver == "davidson":
+        eig, v, ok, info = ctx.davidson_driver(n, n_targ, n_max, 200, 1e-9, 20, 0.0, mv, pc, g)
+        eo, vo, oko, tr = oracle.davidson(n, n_targ, n_max, 200, 1e-9, 20, 0.0, mv, pc, g)
+    else:
+        eig, v, ok, info = ctx.lobpcg_driver(n, n_targ, n_max, 200, 1e-9, 0.0, mv, pc, g)
+        eo, vo, oko, tr = oracle.lobpcg(n, n_targ, n_max, 200, 1e-9, 0.0, mv, pc, g)
+    assert ok and oko
+    _cmp_trace(info, tr, eig, eo, n_targ, exact=False)
+    _cmp_vecs(v, vo, n_targ, 1e-6)
+
+
+@pytest.mark.parametrize("solver", ["davidson", "lobpcg"])
+def test_driver_gives_up_at_max_iter_like_the_reference(ctx, oracle, solver):
+    """max_iter too small: ok = false, eig/evec hold the current Ritz pairs (SURVEY 8b ownership row)."""
+    n, n_targ, n_max = 1000, 4, 8
+    oracle.dense_setup(n)
+    mv, pc = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd")
+    g = np.asfortranarray(np.random.default_rng(4).random((n, n_max)) - 0.5)
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+    if solver == "davidson":
+        eig, v, ok, info = ctx.davidson_driver(n, n_targ, n_max, 4, 1e-10, 20, 0.0, mv, pc, g)
+        eo, vo, oko, tr = oracle.davidson(n, n_targ, n_max, 4, 1e-10, 20, 0.0, mv, pc, g)
+    else:
+        eig, v, ok, info = ctx.lobpcg_driver(n, n_targ, n_max, 4, 1e-10, 0.0, mv, pc, g)
+        eo, vo, oko, tr = oracle.lobpcg(n, n_targ, n_max, 4, 1e-10, 0.0, mv, pc, g)
+    assert not ok and not oko
+    assert info["iters"] == 4
+    assert np.allclose(eig[:n_targ], eo[:n_targ], rtol=1e-9, atol=0)
+    # the returned vectors are the current Ritz vectors: Rayleigh quotients reproduce eig
+    idx = np.arange(1, n + 1, dtype=np.float64)
+    a = 1.0 / (idx[:, None] + idx[None, :]); np.fill_diagonal(a, idx + 1.0)
+    rq = np.einsum("ij,ij->j", v[:, :n_targ], a @ v[:, :n_targ]) / np.einsum("ij,ij->j", v[:, :n_targ], v[:, :n_targ])
+    assert np.allclose(rq, eig[:n_targ], rtol=1e-9)
+
+
+def test_loose_tolerance_still_takes_two_iterations(ctx, oracle):
+    """done(i) can only be set when it > 1 (diaglib.f90:1741): an already converged guess costs two iterations."""
+    n, n_targ, n_max = 600, 2, 4
+    oracle.dense_setup(n)
+    mv, pc = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd")
+    g = np.zeros((n, n_max), order="F"); g[np.arange(n_max), np.arange(n_max)] = 1.0
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+    eig, v, ok, info = ctx.davidson_driver(n, n_targ, n_max, 50, 1.0e3, 20, 0.0, mv, pc, g)
+    eo, vo, oko, tr = oracle.davidson(n, n_targ, n_max, 50, 1.0e3, 20, 0.0, mv, pc, g)
+    assert ok and oko and info["iters"] == 2 and tr.iters == 2
+    assert np.allclose(eig[:n_targ], eo[:n_targ], rtol=1e-12)
