@@ -92,7 +92,9 @@ struct ApiTimer {
   explicit ApiTimer(const char* n) : name(n), t0(on() ? now() : 0.0) {}
   ~ApiTimer() { if (on()) add(name, now() - t0); }
 };
-#define DLA_T(name) dla::ApiTimer dla_api_timer_(name)
+#define DLA_CAT2(a, b) a##b
+#define DLA_CAT(a, b) DLA_CAT2(a, b)
+#define DLA_T(name) dla::ApiTimer DLA_CAT(dla_api_timer_, __LINE__)(name)
 
 // provided by the engine translation unit linked into the library
 Engine* make_engine(int device, std::string& err);

@@ -660,9 +660,10 @@ int dla_call_matvec(dla_ctx* c, dla_matvec_fn fn, int n, int m, const double* x,
   size_t bytes = sizeof(double) * (size_t)n * m;
   int st = ensure_stage(c, bytes);
   if (st) return st;
-  st = c->eng->d2h(c->stage_x, x, bytes);
+  { DLA_T("  stage d2h"); st = c->eng->d2h(c->stage_x, x, bytes); }
   if (st) return engfail(c, st);
-  fn(&n, &m, c->stage_x, c->stage_y);
+  { DLA_T("  user matvec"); fn(&n, &m, c->stage_x, c->stage_y); }
+  DLA_T("  stage h2d");
   return engfail(c, c->eng->h2d(ax, c->stage_y, bytes));
 }
 
@@ -677,9 +678,10 @@ int dla_call_precnd(dla_ctx* c, dla_precnd_fn fn, int n, int m, double fac, cons
   size_t bytes = sizeof(double) * (size_t)n * m;
   int st = ensure_stage(c, bytes);
   if (st) return st;
-  st = c->eng->d2h(c->stage_x, x, bytes);
+  { DLA_T("  stage d2h"); st = c->eng->d2h(c->stage_x, x, bytes); }
   if (st) return engfail(c, st);
-  fn(&n, &m, &fac, c->stage_x, c->stage_y);
+  { DLA_T("  user precnd"); fn(&n, &m, &fac, c->stage_x, c->stage_y); }
+  DLA_T("  stage h2d");
   return engfail(c, c->eng->h2d(px, c->stage_y, bytes));
 }
 

@@ -43,3 +43,6 @@ print(f"device callbacks + device evec: {dt_dev * 1e3:8.1f} ms per solve, {info2
 print("eigenvalue difference", np.abs(eig[:t] - eig2[:t]).max())
 blk = 8.0 * n * m
 print(f"PCIe volume per solve (host mode): {(2 * info['matvec_cols'] / m + 2 * info['iters']) * blk / 1e9:.2f} GB")
+if os.environ.get("DIAGLIB_AMD_HOSTTIME"):
+    ev.free()
+    ctx.lib.dla_destroy(ctx.h)       # prints the per-entry-point wall times
