@@ -48,6 +48,14 @@ template <int V, int NT> __device__ __forceinline__ typename VecOf<V>::type ploa
   if constexpr (NT & 1) return __builtin_nontemporal_load((const vt*)p);
   else return *(const vt*)p;
 }
+// LDS images are written as 16-byte pairs and read back as single doubles by other lanes: both sides go through
+// may_alias types so that type-based alias analysis cannot reorder them against each other
+typedef double __attribute__((may_alias)) lds_f64;
+typedef v2d __attribute__((may_alias)) lds_v2f64;
+__device__ __forceinline__ void lds_store2(double* p, v2d v) { *(lds_v2f64*)p = v; }
+__device__ __forceinline__ void lds_store1(double* p, double v) { *(lds_f64*)p = v; }
+__device__ __forceinline__ double lds_load1(const double* p) { return *(const lds_f64*)p; }
+
 template <int V, int NT> __device__ __forceinline__ void pstore(double* p, typename VecOf<V>::type v)
 {
   typedef typename VecOf<V>::type vt;
@@ -280,17 +288,17 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   };
   auto stage_tile = [&]() {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) *(vec_t*)(my + (size_t)(CPI * j + lc) * RS + 2 * li) = stg[j];
+    for (int j = 0; j < NI; ++j) lds_store2(my + (size_t)(CPI * j + lc) * RS + 2 * li, stg[j]);
   };
   auto mfma_tile = [&]() {
 #pragma unroll
     for (int s4 = 0; s4 < R / 4; ++s4) {
       double uf[KT];
 #pragma unroll
-      for (int q = 0; q < KT; ++q) uf[q] = my[(size_t)(16 * TLW + 16 * q + c) * RS + 4 * s4 + g];
+      for (int q = 0; q < KT; ++q) uf[q] = lds_load1(my + (size_t)(16 * TLW + 16 * q + c) * RS + 4 * s4 + g);
 #pragma unroll
       for (int t = 0; t < TLW; ++t) {
-        const double xf = my[(size_t)(16 * t + c) * RS + 4 * s4 + g];
+        const double xf = lds_load1(my + (size_t)(16 * t + c) * RS + 4 * s4 + g);
 #pragma unroll
         for (int q = 0; q < KT; ++q)
           if (want[t][q]) acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf, uf[q], acc[t][q], 0, 0, 0);

@@ -29,17 +29,21 @@ for L in (26, 65, 117):
             ctx.ortho_cd(panel.col(0, 13))
     keep = ctx.panel(n, k); ctx.random_fill(keep)
     res = {}
+    outs = {}
     for _ in range(rounds):
         for v in values:
             ctx.set_option(TUNE0 + knob, v)
             ctx.lib.dla_copy(ctx.h, panel.col(L, k).ptr, keep.ptr, 8 * n * k)
             ctx.reset_stats()
             ctx.ortho_vs_x(panel.col(0, L), panel.col(L, k))
+            outs[v] = panel.col(L, k).download()
             for name, st in ctx.kernel_stats().items():
-                if name.startswith("gemm_kernel<1, 2, 0, GemmArgs, true") or name.startswith("gemm_kernel<1, 2, 1, GemmArgs, true"):
+                if name.startswith(("gemm_kernel<1, 2, 0, GemmArgs, true", "gemm_kernel<1, 2, 1, GemmArgs, true",
+                                    "gemm_lds_kernel<1, 0, true", "gemm_lds_kernel<1, 1, true")):
                     res.setdefault(("proj", v), []).append(st["alg_bytes"] / st["ms"] / 1e6)
                 if name.startswith("gemm_kernel<1, 2, 2, GemmArgsInl, true"):
                     res.setdefault(("trmm", v), []).append(st["alg_bytes"] / st["ms"] / 1e6)
     ctx.set_option(TUNE0 + knob, 0)
+    print(f"L={L:4d} max |U(v) - U(v0)| =", [float(np.abs(outs[v] - outs[values[0]]).max()) for v in values])
     for what in ("proj", "trmm"):
         print(f"L={L:4d} {what}  " + "  ".join(f"knob{knob}={v}: med {np.median(res[(what, v)]):7.1f} GB/s" for v in values), flush=True)
