@@ -7,7 +7,8 @@
 // the kernels use 16-byte (double2) accesses (VEC=2); odd n falls back to 8-byte accesses (VEC=1).
 //
 // Kernels and what bounds them (all HBM-bound; arithmetic intensity k/4 flop/B):
-//   gram_kernel        C = X^T U          reads 8n(l+k) B     -- MFMA contracts over rows
+//   gram_lds_kernel    C = X^T U          reads 8n(l+k) B     -- MFMA contracts over rows; full-line loads staged
+//                      through wave-private LDS (even n); gram_kernel = direct fragment loads (odd n, tiny passes)
 //   gemm_kernel        Z = XC, Z -= XC    reads 8n(l[+k]) B, writes 8nk B
 //                      (also U <- U W in place for the Cholesky-QR triangular update)
 //   ritz_kernel        evec = V Y, r = AV Y - theta evec, ||r||, max|r| in one sweep over V, AV
