@@ -1375,7 +1375,7 @@ struct HipEngine : dla::Engine {
         return launch_gram_lds<TLW, KT, 16>(a, grid);
       }
     }
-    if constexpr (TLW == 5 || TLW == 7 || TLW == 10 || (TLW == 12 && KT > 1)) {
+    if constexpr (TLW == 5 || TLW == 7 || TLW == 10 || (TLW == 12 && KT > 1) || (TLW == 3 && KT >= 2 && KT <= 3)) {
       err = "gram: width without a direct-load instance";
       return DLA_ERR_RUNTIME;
     } else {
@@ -1407,6 +1407,8 @@ struct HipEngine : dla::Engine {
     static const int avail1l[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
     if (kt == 1 && ldsk) { for (int v : avail1l) if (v >= tlw) { tlw = v; break; } }
     else if (kt == 1) { for (int v : avail1) if (v >= tlw) { tlw = v; break; } }
+    else if (kt == 2 && ldsk) { tlw = std::min(tlw, 6); }                       // 1..6 all instantiated
+    else if (kt == 3 && ldsk) { tlw = std::min(tlw, 4); }                       // 1..4
     else if (kt == 2) { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : tlw <= 4 ? 4 : 6; }
     else if (kt == 3) { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : 4; }
     else { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : 3; }
@@ -1437,8 +1439,8 @@ struct HipEngine : dla::Engine {
       Scope s(this, cls, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k, kn);
 #define GL(T, K) if (tlw == T && kt == K) { int r_ = launch_gram<T, K>(a, grid, vec2); if (r_) return r_; } else
       GL(1, 1) GL(2, 1) GL(3, 1) GL(4, 1) GL(5, 1) GL(6, 1) GL(7, 1) GL(8, 1) GL(10, 1) GL(12, 1)
-      GL(1, 2) GL(2, 2) GL(4, 2) GL(6, 2)
-      GL(1, 3) GL(2, 3) GL(4, 3)
+      GL(1, 2) GL(2, 2) GL(3, 2) GL(4, 2) GL(5, 2) GL(6, 2)
+      GL(1, 3) GL(2, 3) GL(3, 3) GL(4, 3)
       GL(1, 4) GL(2, 4) GL(3, 4)
       { err = "gram: no kernel instance"; return DLA_ERR_RUNTIME; }
 #undef GL
