@@ -328,15 +328,39 @@ class Context:
         self._chk(self.lib.dla_call_matvec(self.h, fn_address("dla_synth_matvec"), x.n, x.m, x.ptr, ax.ptr))
 
     # ---- callbacks
+    # A Python callable receives numpy views of the HOST blocks by default.  With OPT_CALLBACKS_ON_DEVICE = 1 it
+    # receives torch tensors that alias the DEVICE blocks (zero copy, n x m, column-major strides), so an operator
+    # written with torch (dense, torch.sparse, custom kernels) stays in HBM.  The engine's stream is drained before
+    # the call and torch's after it; the result is written into the output block.
+    def _device_callbacks(self) -> bool:
+        return self.lib.dla_get_option(self.h, OPT_CALLBACKS_ON_DEVICE) == 1
+
+    @staticmethod
+    def _dev_tensor(ptr, n: int, m: int):
+        import torch
+
+        class _Block:                      # column-major n x m block as an (m, n) row-major array
+            __cuda_array_interface__ = {"shape": (m, n), "typestr": "<f8", "data": (C.cast(ptr, C.c_void_p).value, False),
+                                        "version": 3, "strides": None}
+        return torch.as_tensor(_Block(), device="cuda").T
+
     def _wrap_mv(self, f: Callback) -> int:
         if isinstance(f, int):
             return f
+        if self._device_callbacks():
+            import torch
 
-        def tramp(pn, pm, px, pax):
-            n, m = pn[0], pm[0]
-            x = np.ctypeslib.as_array(px, (m, n)).T
-            ax = np.ctypeslib.as_array(pax, (m, n)).T
-            ax[:, :] = f(x)
+            def tramp(pn, pm, px, pax):
+                n, m = pn[0], pm[0]
+                self.sync()
+                self._dev_tensor(pax, n, m).copy_(f(self._dev_tensor(px, n, m)))
+                torch.cuda.synchronize()
+        else:
+            def tramp(pn, pm, px, pax):
+                n, m = pn[0], pm[0]
+                x = np.ctypeslib.as_array(px, (m, n)).T
+                ax = np.ctypeslib.as_array(pax, (m, n)).T
+                ax[:, :] = f(x)
 
         cb = MATVEC_T(tramp)
         self._keep.append(cb)
@@ -345,12 +369,20 @@ class Context:
     def _wrap_pc(self, f: Callback) -> int:
         if isinstance(f, int):
             return f
+        if self._device_callbacks():
+            import torch
 
-        def tramp(pn, pm, pf, px, ppx):
-            n, m = pn[0], pm[0]
-            x = np.ctypeslib.as_array(px, (m, n)).T
-            y = np.ctypeslib.as_array(ppx, (m, n)).T
-            y[:, :] = f(pf[0], x)
+            def tramp(pn, pm, pf, px, ppx):
+                n, m = pn[0], pm[0]
+                self.sync()
+                self._dev_tensor(ppx, n, m).copy_(f(pf[0], self._dev_tensor(px, n, m)))
+                torch.cuda.synchronize()
+        else:
+            def tramp(pn, pm, pf, px, ppx):
+                n, m = pn[0], pm[0]
+                x = np.ctypeslib.as_array(px, (m, n)).T
+                y = np.ctypeslib.as_array(ppx, (m, n)).T
+                y[:, :] = f(pf[0], x)
 
         cb = PRECND_T(tramp)
         self._keep.append(cb)
