@@ -43,3 +43,9 @@ def test_fortran_caller_drop_in(tmp_path, ctx):
     dav_cols = int(re.search(r"DAVIDSON ok/matvec columns:\s+T\s+(\d+)", out).group(1))
     assert lob_cols == 45 and dav_cols == 45, (lob_cols, dav_cols)
     assert abs(float(re.search(r"\|x1\|:\s+([0-9.]+)", out).group(1)) - 1.0) < 1e-9
+    # linear response through the module's caslr_eff_driver: converged, ascending positive roots, and the caller's own
+    # residual of the 2n-dimensional pencil (computed in Fortran from Y and Z) at the tolerance level
+    assert re.search(r"CASLR_EFF ok:\s+T", out), out
+    lr = [float(v) for v in re.search(r"CASLR_EFF eig:(.*)", out).group(1).split()]
+    assert all(b > a > 0 for a, b in zip(lr, lr[1:])), lr
+    assert float(re.search(r"CASLR_EFF max residual:\s+([0-9.Ee+-]+)", out).group(1)) < 1e-6
