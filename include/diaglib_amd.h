@@ -59,7 +59,8 @@ enum {
                                       1: evec is a device address (guess in, Ritz vectors out), eig stays host  */
   DLA_OPT_PROFILE = 3,             /* 1: bracket every kernel launch with HIP events (dla_get_stats)          */
   DLA_OPT_VERBOSE_ORTHO = 4,       /* 1: print ortho_cd/ortho_vs_x pass counts                                 */
-  DLA_OPT_TUNE0 = 100              /* 100..107: kernel-shape experiment knobs (tools/kernel_bench.py); 0 = default */
+  DLA_OPT_TUNE0 = 100              /* 100..107: kernel-shape experiment knobs for the interleaved A/B tools
+                                      (tools/tune_*.py, tools/kernel_bench.py); 0 = the shipped default          */
 };
 
 /* op classes for statistics */
