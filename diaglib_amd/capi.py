@@ -38,7 +38,7 @@ EXPORTS = [
     "dla_call_matvec", "dla_call_precnd",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
     "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd",
-    "dla_davidson_driver", "dla_gen_david_driver", "dla_lobpcg_driver", "dla_caslr_eff_driver", "dla_call_lrprec",
+    "dla_davidson_driver", "dla_gen_david_driver", "dla_lobpcg_driver", "dla_caslr_eff_driver", "dla_caslr_driver", "dla_call_lrprec",
     "dla_last_solve_info", "dla_set_solve_info",
 ]
 
@@ -108,6 +108,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_davidson_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, c_ip]),
         "dla_lobpcg_driver": (None, [i, i, i, i, i, i, d, d, vp, vp, vp, vp, vp, c_ip]),
         "dla_caslr_eff_driver": (None, [i, i, i, i, i, d, i, vp, vp, vp, vp, vp, vp, vp, c_ip]),
+        "dla_caslr_driver": (None, [i, i, i, i, i, d, i, vp, vp, vp, vp, vp, vp, vp, c_ip]),
         "dla_call_lrprec": (i, [vp, vp, i, i, d, vp, vp, vp, vp]),
         "dla_gen_david_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, vp, c_ip]),
         "dla_last_solve_info": (None, [c_ip, c_ip, c_ip]),
@@ -437,9 +438,13 @@ class Context:
                                    eig.ctypes.data, ev_ptr, C.byref(ok))
         return eig, out, bool(ok.value), self.last_solve_info()
 
+    def caslr_driver(self, *args, **kw):
+        """traditional linear-response driver (reference diaglib.f90:558-1022); arguments as caslr_eff_driver"""
+        return self.caslr_eff_driver(*args, _entry="dla_caslr_driver", **kw)
+
     def caslr_eff_driver(self, n: int, n_targ: int, n_max: int, max_iter: int, tol: float, max_dav: int,
                          apbmul: Callback, ambmul: Callback, spdmul: Callback, smdmul: Callback, lrprec: Callback,
-                         evec, verbose: bool = False):
+                         evec, verbose: bool = False, _entry: str = "dla_caslr_eff_driver"):
         """linear-response driver (reference diaglib.f90:1024-1481); evec is 2n x n_max; lrprec as an address or a
         Python callable (fac, xp, xm) -> (yp, ym)"""
         f1, f2, f3, f4 = (self._wrap_mv(f) for f in (apbmul, ambmul, spdmul, smdmul))
@@ -453,8 +458,8 @@ class Context:
             out = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
             assert out.shape == (2 * n, n_max)
             ev_ptr = out.ctypes.data
-        self.lib.dla_caslr_eff_driver(int(verbose), n, n_targ, n_max, max_iter, tol, max_dav, f1, f2, f3, f4, f5,
-                                      eig.ctypes.data, ev_ptr, C.byref(ok))
+        getattr(self.lib, _entry)(int(verbose), n, n_targ, n_max, max_iter, tol, max_dav, f1, f2, f3, f4, f5,
+                                  eig.ctypes.data, ev_ptr, C.byref(ok))
         return eig, out, bool(ok.value), self.last_solve_info()
 
     def _wrap_lrpc(self, f: Callback) -> int:

@@ -16,9 +16,10 @@
 !
 ! The generalised problem (metric B through a bvec callback) is served by gen_david_driver and by
 ! lobpcg_driver with gen_eig=.true. (reference diaglib.f90:1855-2250, 299-302/357-364/523-526).
-! The linear-response problem is served by caslr_eff_driver (reference diaglib.f90:1024-1481), built from the
-! same device operations.  Not provided (SURVEY.md 2 rows 4-5): caslr_driver (the older 2n-dimensional
-! formulation of the same problem) and nonsym_driver.
+! The linear-response problem is served by caslr_eff_driver (reference diaglib.f90:1024-1481) and caslr_driver
+! (:558-1022, its default algorithm i_alg = 0), built from the same device operations.  Not provided (SURVEY.md 2
+! row 5): nonsym_driver, and the Helmich-Paris variant of caslr_driver (i_alg = 1, a switch of the reference
+! harness' module utils).
 !
 module diaglib
   use real_precision
@@ -27,7 +28,7 @@ module diaglib
   private
 !
   public :: lobpcg_driver, davidson_driver, gen_david_driver, ortho, b_ortho, ortho_cd, ortho_vs_x, b_ortho_vs_x
-  public :: caslr_eff_driver
+  public :: caslr_eff_driver, caslr_driver
   public :: diaglib_amd_config
 !
   real(dp), parameter :: zero = 0.0_dp, one = 1.0_dp, ten = 10.0_dp
@@ -197,6 +198,18 @@ module diaglib
       integer(c_int), value :: n, m
       real(c_double), value :: fac
       integer(c_int) :: st
+    end function
+    function dla_potrf_lower(m,a,lda) bind(C,name='dla_potrf_lower') result(info)
+      import :: c_int, c_double
+      integer(c_int), value :: m, lda
+      real(c_double) :: a(*)
+      integer(c_int) :: info
+    end function
+    function dla_trtri_lower(m,a,lda) bind(C,name='dla_trtri_lower') result(info)
+      import :: c_int, c_double
+      integer(c_int), value :: m, lda
+      real(c_double) :: a(*)
+      integer(c_int) :: info
     end function
     function dla_syev_lowest(uplo,n,a,lda,w,m) bind(C,name='dla_syev_lowest') result(info)
       import :: c_char, c_int, c_double
@@ -1493,5 +1506,366 @@ contains
       n_mv = n_mv + 2*k
     end subroutine new_metric_blocks
   end subroutine caslr_eff_driver
+!
+! ---------------------------------------------------------------------------------------
+! caslr_driver: the traditional solver of the same linear-response problem (reference
+! diaglib.f90:558-1022, its default algorithm i_alg = 0).  vp, vm are Euclidean-orthonormal
+! (ortho_cd / ortho_vs_x); the reduced problem is the 2 ldu-dimensional generalised one
+!
+!     /  0   s^T \ / u+ \   1  / E+  0  \ / u+ \          E+ = vp^T (A+B) vp,  E- = vm^T (A-B) vm,
+!     |          | |    | = -  |        | |    |          s  = vm^T (S+D) vp
+!     \  s    0  / \ u- /   w  \ 0   E- / \ u- /
+!
+! (dsygv itype 1 at :783).  Here the block-diagonal metric is factored blockwise, E+ = L+ L+^T, E- = L- L-^T,
+! which turns the pencil into the symmetric matrix (0 M^T; M 0), M = L-^-1 s L+^-T, whose largest eigenpairs come
+! from the partial solver; u = L^-T y has the dsygv normalisation u^T diag(E+,E-) u = 1.  As in caslr_eff_driver
+! the reduced matrices grow by their new block rows/columns (:754-756 recompute them), and the Ritz vectors
+! (:862-868) are formed at convergence, restart and exit.
+! ---------------------------------------------------------------------------------------
+  subroutine caslr_driver(verbose,n,n2,n_targ,n_max,max_iter,tol,max_dav, &
+                          apbmul,ambmul,spdmul,smdmul,lrprec,eig,evec,ok)
+    logical,                               intent(in)    :: verbose
+    integer,                               intent(in)    :: n, n2, n_targ, n_max
+    integer,                               intent(in)    :: max_iter, max_dav
+    real(dp),                              intent(in)    :: tol
+    real(dp), dimension(n_max),            intent(inout) :: eig
+    real(dp), dimension(n2,n_max), target, intent(inout) :: evec
+    logical,                               intent(inout) :: ok
+    external                                             :: apbmul, ambmul, spdmul, smdmul, lrprec
+!
+    type(c_ptr)    :: ctx, vp, vm, lvp, lvm, bvp, bvm, rp, rm, bp, bm, tp, tm, evd
+    type(c_funptr) :: f_apb, f_amb, f_spd, f_smd, f_prec
+    integer        :: dim_dav, lda, n_act, ind, i_beg, m_dim, ldu, n_frozen, it, i_eig, j, n_mv, n_restarts
+    logical        :: evec_dev, have_evec
+    real(dp)       :: tol_rms, tol_max, growth
+    logical,        allocatable :: done(:)
+    integer(c_int), allocatable :: skip(:)
+    real(dp),       allocatable :: epmat(:,:), emmat(:,:), smat(:,:), up(:,:), um(:,:), ident(:,:)
+    real(dp),       allocatable :: r_norm(:,:), rn_p(:,:), rn_m(:,:)
+    integer(c_int) :: okc
+!
+    ctx    = dla_default_ctx()
+    f_apb  = c_funloc(apbmul)
+    f_amb  = c_funloc(ambmul)
+    f_spd  = c_funloc(spdmul)
+    f_smd  = c_funloc(smdmul)
+    f_prec = c_funloc(lrprec)
+    evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
+!
+    dim_dav = max(min_dav,max_dav)
+    lda     = dim_dav*n_max
+!
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), vp),  'allocation of vp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), vm),  'allocation of vm')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), lvp), 'allocation of lvp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), lvm), 'allocation of lvm')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), bvp), 'allocation of bvp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), bvm), 'allocation of bvm')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), rp), 'allocation of rp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), rm), 'allocation of rm')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), bp), 'allocation of bp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), bm), 'allocation of bm')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), tp), 'allocation of tp')
+    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), tm), 'allocation of tm')
+    if (evec_dev) then
+      evd = c_loc(evec)
+    else
+      call chk(ctx, dla_alloc(ctx, nbytes(n2,n_max), evd), 'allocation of evec')
+      call chk(ctx, dla_upload(ctx, evd, c_loc(evec), nbytes(n2,n_max)), 'upload of the guess')
+    end if
+    allocate (done(n_max), skip(n_max), r_norm(2,n_max), rn_p(2,n_max), rn_m(2,n_max))
+    allocate (epmat(lda,lda), emmat(lda,lda), smat(lda,lda), up(lda,n_max), um(lda,n_max), ident(n_max,n_max))
+!
+    tol_rms = tol
+    tol_max = ten * tol
+    t_diag  = zero
+    t_ortho = zero
+    t_mv    = zero
+    t_tot   = zero
+    epmat   = zero
+    emmat   = zero
+    smat    = zero
+    r_norm  = zero
+    rn_p    = zero
+    rn_m    = zero
+    ident   = zero
+    do j = 1, n_max
+      ident(j,j) = one
+    end do
+    ok      = .false.
+    done    = .false.
+    n_mv    = 0
+    n_restarts = 0
+!
+    call get_time(t_tot)
+!
+!   the guess in the plus/minus combinations, orthonormalised (reference :709-716)
+!
+    call lr_split_evec(ctx, n, n2, n_max, evd, vp, vm)
+    call chk(ctx, dla_ortho_cd(ctx, n, n_max, vp, growth, okc), 'ortho_cd')
+    call chk(ctx, dla_ortho_cd(ctx, n, n_max, vm, growth, okc), 'ortho_cd')
+!
+    n_act = n_max
+    ind   = 1
+    i_beg = 1
+    m_dim = 1
+    ldu   = 0
+    n_frozen = 0
+    have_evec = .false.
+!
+    1030 format(t5,'Davidson-Liu iterations (tol=',d10.2,'):',/, &
+                t5,'------------------------------------------------------------------',/, &
+                t7,'  iter  root              eigenvalue','         rms         max ok',/, &
+                t5,'------------------------------------------------------------------')
+    1040 format(t9,i4,2x,i4,f24.12,2d12.4,l3)
+    if (verbose) write(6,1030) tol
+!
+    do it = 1, max_iter
+      ldu = ldu + n_act
+      have_evec = .false.
+!
+!     the four products on the new blocks (reference :743-746)
+!
+      call get_time(t1)
+      call chk(ctx, dla_call_matvec(ctx, f_apb, n, n_act, colp(vp,n,i_beg), colp(lvp,n,i_beg)), 'apbmul')
+      call chk(ctx, dla_call_matvec(ctx, f_amb, n, n_act, colp(vm,n,i_beg), colp(lvm,n,i_beg)), 'ambmul')
+      call chk(ctx, dla_call_matvec(ctx, f_spd, n, n_act, colp(vp,n,i_beg), colp(bvm,n,i_beg)), 'spdmul')
+      call chk(ctx, dla_call_matvec(ctx, f_smd, n, n_act, colp(vm,n,i_beg), colp(bvp,n,i_beg)), 'smdmul')
+      call get_time(t2)
+      t_mv = t_mv + t2 - t1
+      n_mv = n_mv + 4*n_act
+!
+!     reduced matrices (reference :754-756): new block columns, and for the non-symmetric s also the new block row
+!
+      call chk(ctx, dla_gram(ctx, n, ldu, vp, n_act, colp(lvp,n,i_beg), epmat(1,i_beg), lda), 'reduced matrix')
+      call chk(ctx, dla_gram(ctx, n, ldu, vm, n_act, colp(lvm,n,i_beg), emmat(1,i_beg), lda), 'reduced matrix')
+      call chk(ctx, dla_gram(ctx, n, ldu, vm, n_act, colp(bvm,n,i_beg), smat(1,i_beg), lda), 'reduced matrix')
+      if (i_beg.gt.1) then
+        epmat(i_beg:ldu,1:i_beg-1) = transpose(epmat(1:i_beg-1,i_beg:ldu))
+        emmat(i_beg:ldu,1:i_beg-1) = transpose(emmat(1:i_beg-1,i_beg:ldu))
+        call chk(ctx, dla_gram(ctx, n, n_act, colp(vm,n,i_beg), i_beg-1, bvm, smat(i_beg,1), lda), 'reduced matrix')
+      end if
+!
+!     largest eigenpairs of the reduced pencil (reference :775-800)
+!
+      call get_time(t1)
+      call lr_reduced_pairs(ldu, lda, n_max, epmat, emmat, smat, eig, up, um)
+      call get_time(t2)
+      t_diag = t_diag + t2 - t1
+!
+!     residuals rp = lvp u+ - eig bvp u-, rm = lvm u- - eig bvm u+ and their norms (reference :872-889)
+!
+      do i_eig = 1, n_max
+        skip(i_eig) = merge(1_c_int, 0_c_int, done(i_eig))
+      end do
+      call chk(ctx, dla_panel_gemm(ctx, n, ldu, bvp, n_max, um, lda, bp), 'bp')
+      call chk(ctx, dla_panel_gemm(ctx, n, ldu, lvp, n_max, up, lda, tp), 'rp')
+      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, bp, tp, ident, n_max, eig, n_targ, skip, &
+                                      tm, rp, c_null_ptr, rn_p), 'residual')
+      call chk(ctx, dla_panel_gemm(ctx, n, ldu, bvm, n_max, up, lda, bm), 'bm')
+      call chk(ctx, dla_panel_gemm(ctx, n, ldu, lvm, n_max, um, lda, tp), 'rm')
+      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, bm, tp, ident, n_max, eig, n_targ, skip, &
+                                      tm, rm, c_null_ptr, rn_m), 'residual')
+      do i_eig = 1, n_targ
+        if (done(i_eig)) cycle
+        r_norm(1,i_eig) = rn_p(1,i_eig) + rn_m(1,i_eig)
+        r_norm(2,i_eig) = rn_p(2,i_eig) + rn_m(2,i_eig)
+      end do
+!
+!     lock the leading converged roots (reference :894-903)
+!
+      do i_eig = 1, n_targ
+        if (done(i_eig)) cycle
+        done(i_eig) = r_norm(1,i_eig).lt.tol_rms .and. r_norm(2,i_eig).lt.tol_max .and. it.gt.1
+        if (.not.done(i_eig)) then
+          done(i_eig+1:n_max) = .false.
+          exit
+        end if
+      end do
+!
+      if (verbose) then
+        do i_eig = 1, n_targ
+          write(6,1040) it, i_eig, eig(i_eig), r_norm(:,i_eig), done(i_eig)
+        end do
+        write(6,*)
+      end if
+!
+      if (all(done(1:n_targ))) then
+        ok = .true.
+        exit
+      end if
+!
+      if (m_dim .lt. dim_dav) then
+!
+!       expand both spaces with the preconditioned residuals (reference :928-955)
+!
+        m_dim = m_dim + 1
+        i_beg = i_beg + n_act
+        n_act = n_max
+        n_frozen = 0
+        do i_eig = 1, n_targ
+          if (done(i_eig)) then
+            n_act = n_act - 1
+            n_frozen = n_frozen + 1
+          else
+            exit
+          end if
+        end do
+        ind = n_max - n_act + 1
+        call chk(ctx, dla_call_lrprec(ctx, f_prec, n, n_act, eig(ind), colp(rp,n,ind), colp(rm,n,ind), &
+                                      colp(vp,n,i_beg), colp(vm,n,i_beg)), 'lrprec')
+        call get_time(t1)
+        call chk(ctx, dla_ortho_vs_x(ctx, n, ldu, n_act, vp, colp(vp,n,i_beg)), 'ortho_vs_x')
+        call chk(ctx, dla_ortho_vs_x(ctx, n, ldu, n_act, vm, colp(vm,n,i_beg)), 'ortho_vs_x')
+        call get_time(t2)
+        t_ortho = t_ortho + t2 - t1
+      else
+!
+!       restart from the current Ritz vectors (reference :957-991)
+!
+        if (verbose) write(6,'(t7,a)') 'Restarting davidson.'
+        n_restarts = n_restarts + 1
+        call lr_merge_evec(ctx, n, n2, n_max, ldu, lda, vp, vm, up, um, bp, bm, evd)
+        ldu   = 0
+        i_beg = 1
+        m_dim = 1
+        n_act = n_max
+        call lr_split_evec(ctx, n, n2, n_max, evd, vp, vm)
+        call chk(ctx, dla_ortho_cd(ctx, n, n_max, vp, growth, okc), 'ortho_cd')
+        call chk(ctx, dla_ortho_cd(ctx, n, n_max, vm, growth, okc), 'ortho_cd')
+        epmat = zero
+        emmat = zero
+        smat  = zero
+      end if
+      if (verbose) write(6,1050) n_targ, n_act, n_frozen
+    end do
+!
+!   evec holds the current approximation on every exit, like the reference (:865-868)
+!
+    if (ldu.gt.0) call lr_merge_evec(ctx, n, n2, n_max, ldu, lda, vp, vm, up, um, bp, bm, evd)
+    call get_time(t2)
+    t_tot = t2 - t_tot
+    call dla_set_solve_info(int(min(it,max_iter),c_int), int(n_mv,c_int), int(n_restarts,c_int))
+!
+    1000 format(t3,'timings for caslr (cpu/wall):   ',/, &
+                t3,'  matrix-vector multiplications: ',2f12.4,/, &
+                t3,'  diagonalization:               ',2f12.4,/, &
+                t3,'  orthogonalization:             ',2f12.4,/, &
+                t3,'                                 ',24('='),/,  &
+                t3,'  total:                         ',2f12.4)
+    if (verbose) write(6,1000) t_mv, t_diag, t_ortho, t_tot
+!
+    if (.not.evec_dev) then
+      call chk(ctx, dla_download(ctx, c_loc(evec), evd, nbytes(n2,n_max)), 'download of evec')
+      call chk(ctx, dla_free(ctx, evd), 'free')
+    end if
+    call chk(ctx, dla_free(ctx, vp), 'free')
+    call chk(ctx, dla_free(ctx, vm), 'free')
+    call chk(ctx, dla_free(ctx, lvp), 'free')
+    call chk(ctx, dla_free(ctx, lvm), 'free')
+    call chk(ctx, dla_free(ctx, bvp), 'free')
+    call chk(ctx, dla_free(ctx, bvm), 'free')
+    call chk(ctx, dla_free(ctx, rp), 'free')
+    call chk(ctx, dla_free(ctx, rm), 'free')
+    call chk(ctx, dla_free(ctx, bp), 'free')
+    call chk(ctx, dla_free(ctx, bm), 'free')
+    call chk(ctx, dla_free(ctx, tp), 'free')
+    call chk(ctx, dla_free(ctx, tm), 'free')
+    deallocate (done, skip, r_norm, rn_p, rn_m, epmat, emmat, smat, up, um, ident)
+!
+    1050 format(t5,'----------------------------------------',/,&
+                t7,'# target vectors:    ',i4,/,&
+                t7,'# new vectors added: ',i4,/,&
+                t7,'# converged vectors: ',i4,/,&
+                t5,'----------------------------------------')
+    return
+  end subroutine caslr_driver
+!
+! the n_max largest eigenpairs of (0 s^T; s 0) u = (1/w) diag(E+,E-) u (dsygv itype 1, reference :783):
+! eig = w, up/um = the two halves of u, normalised u^T diag(E+,E-) u = 1
+!
+  subroutine lr_reduced_pairs(ldu, lda, n_max, epmat, emmat, smat, eig, up, um)
+    integer,  intent(in)    :: ldu, lda, n_max
+    real(dp), intent(in)    :: epmat(lda,lda), emmat(lda,lda), smat(lda,lda)
+    real(dp), intent(inout) :: eig(n_max), up(lda,n_max), um(lda,n_max)
+    real(dp), allocatable   :: lp(:,:), lm(:,:), mm(:,:), cc(:,:), w(:)
+    integer                 :: i, j, l2
+    integer(c_int)          :: info
+    l2 = 2*ldu
+    allocate (lp(ldu,ldu), lm(ldu,ldu), mm(ldu,ldu), cc(l2,l2), w(l2))
+    lp = epmat(1:ldu,1:ldu)
+    lm = emmat(1:ldu,1:ldu)
+    info = dla_potrf_lower(ldu, lp, ldu)
+    if (info.eq.0) info = dla_potrf_lower(ldu, lm, ldu)
+    if (info.ne.0) then
+      write(6,'(t3,a)') 'DSYGV failed in caslr_driver'
+      stop
+    end if
+    do j = 2, ldu
+      lp(1:j-1,j) = zero
+      lm(1:j-1,j) = zero
+    end do
+    info = dla_trtri_lower(ldu, lp, ldu)
+    info = dla_trtri_lower(ldu, lm, ldu)
+!   M = L-^-1 s L+^-T
+    mm = matmul(lm, matmul(smat(1:ldu,1:ldu), transpose(lp)))
+    cc = zero
+    cc(ldu+1:l2,1:ldu) = -mm
+    cc(1:ldu,ldu+1:l2) = -transpose(mm)
+    info = dla_syev_lowest('l', l2, cc, l2, w, n_max)
+    if (info.ne.0) then
+      write(6,'(t3,a,i6)') 'dsyev failed. info = ',info
+      stop
+    end if
+    do i = 1, n_max
+      eig(i)      = -one/w(i)
+      up(1:ldu,i) = matmul(transpose(lp), cc(1:ldu,i))
+      um(1:ldu,i) = matmul(transpose(lm), cc(ldu+1:l2,i))
+    end do
+    deallocate (lp, lm, mm, cc, w)
+  end subroutine lr_reduced_pairs
+!
+! vp = Y + Z, vm = Y - Z for the n_max columns of the 2n x n_max block evd (reference :709-712, 1249-1252)
+!
+  subroutine lr_split_evec(ctx, n, n2, n_max, evd, vp, vm)
+    type(c_ptr), intent(in) :: ctx, evd, vp, vm
+    integer,     intent(in) :: n, n2, n_max
+    integer :: jj
+    do jj = 1, n_max
+      call chk(ctx, dla_copy(ctx, colp(vp,n,jj), lr_halfp(evd,n,n2,jj,0), nbytes(n,1)), 'copy')
+      call chk(ctx, dla_axpy(ctx, int(n,c_size_t), one, lr_halfp(evd,n,n2,jj,1), colp(vp,n,jj)), 'axpy')
+      call chk(ctx, dla_copy(ctx, colp(vm,n,jj), lr_halfp(evd,n,n2,jj,0), nbytes(n,1)), 'copy')
+      call chk(ctx, dla_axpy(ctx, int(n,c_size_t), -one, lr_halfp(evd,n,n2,jj,1), colp(vm,n,jj)), 'axpy')
+    end do
+  end subroutine lr_split_evec
+!
+! Ritz vectors eigp = vp u+, eigm = vm u- (in the scratch blocks bp, bm), then Y = eigp + eigm, Z = eigp - eigm
+! (reference :862-868, 1324-1333)
+!
+  subroutine lr_merge_evec(ctx, n, n2, n_max, ldu, lda, vp, vm, up, um, bp, bm, evd)
+    type(c_ptr), intent(in) :: ctx, vp, vm, bp, bm, evd
+    integer,     intent(in) :: n, n2, n_max, ldu, lda
+    real(dp),    intent(in) :: up(lda,n_max), um(lda,n_max)
+    integer :: jj
+    call chk(ctx, dla_panel_gemm(ctx, n, ldu, vp, n_max, up, lda, bp), 'ritz vectors')
+    call chk(ctx, dla_panel_gemm(ctx, n, ldu, vm, n_max, um, lda, bm), 'ritz vectors')
+    do jj = 1, n_max
+      call chk(ctx, dla_copy(ctx, lr_halfp(evd,n,n2,jj,0), colp(bp,n,jj), nbytes(n,1)), 'copy')
+      call chk(ctx, dla_axpy(ctx, int(n,c_size_t), one, colp(bm,n,jj), lr_halfp(evd,n,n2,jj,0)), 'axpy')
+      call chk(ctx, dla_copy(ctx, lr_halfp(evd,n,n2,jj,1), colp(bp,n,jj), nbytes(n,1)), 'copy')
+      call chk(ctx, dla_axpy(ctx, int(n,c_size_t), -one, colp(bm,n,jj), lr_halfp(evd,n,n2,jj,1)), 'axpy')
+    end do
+  end subroutine lr_merge_evec
+!
+! device address of the upper (half = 0) or lower (half = 1) n rows of column j of a 2n x m block
+!
+  function lr_halfp(evd, n, n2, j, half) result(p)
+    type(c_ptr), intent(in) :: evd
+    integer,     intent(in) :: n, n2, j, half
+    type(c_ptr)             :: p
+    integer(c_intptr_t)     :: a
+    a = transfer(evd, a) + 8_c_intptr_t * (int(n2,c_intptr_t) * int(j-1,c_intptr_t) + int(half*n,c_intptr_t))
+    p = transfer(a, p)
+  end function lr_halfp
 !
 end module diaglib

@@ -6,7 +6,7 @@
 !
 module diaglib_cbind
   use iso_c_binding
-  use diaglib, only : davidson_driver, lobpcg_driver, gen_david_driver, caslr_eff_driver
+  use diaglib, only : davidson_driver, lobpcg_driver, gen_david_driver, caslr_eff_driver, caslr_driver
   implicit none
 !
   abstract interface
@@ -103,5 +103,25 @@ contains
     call caslr_eff_driver(verbose.ne.0,n,2*n,n_targ,n_max,max_iter,tol,max_dav,f1,f2,f3,f4,f5,eig,evec,lok)
     ok = merge(1_c_int, 0_c_int, lok)
   end subroutine dla_caslr_eff_driver
+!
+  subroutine dla_caslr_driver(verbose,n,n_targ,n_max,max_iter,tol,max_dav, &
+                              apbmul,ambmul,spdmul,smdmul,lrprec,eig,evec,ok) bind(C,name='dla_caslr_driver')
+    integer(c_int), value :: verbose, n, n_targ, n_max, max_iter, max_dav
+    real(c_double), value :: tol
+    type(c_funptr), value :: apbmul, ambmul, spdmul, smdmul, lrprec
+    real(c_double)        :: eig(n_max), evec(2*n,n_max)
+    integer(c_int)        :: ok
+    procedure(mv_iface),   pointer :: f1, f2, f3, f4
+    procedure(lrpc_iface), pointer :: f5
+    logical :: lok
+    call c_f_procpointer(apbmul, f1)
+    call c_f_procpointer(ambmul, f2)
+    call c_f_procpointer(spdmul, f3)
+    call c_f_procpointer(smdmul, f4)
+    call c_f_procpointer(lrprec, f5)
+    lok = .false.
+    call caslr_driver(verbose.ne.0,n,2*n,n_targ,n_max,max_iter,tol,max_dav,f1,f2,f3,f4,f5,eig,evec,lok)
+    ok = merge(1_c_int, 0_c_int, lok)
+  end subroutine dla_caslr_driver
 !
 end module diaglib_cbind

@@ -214,6 +214,10 @@ void dla_lobpcg_driver(int verbose, int gen_eig, int n, int n_targ, int n_max, i
 void dla_caslr_eff_driver(int verbose, int n, int n_targ, int n_max, int max_iter, double tol, int max_dav,
                           dla_matvec_fn apbmul, dla_matvec_fn ambmul, dla_matvec_fn spdmul, dla_matvec_fn smdmul,
                           dla_lrprec_fn lrprec, double* eig, double* evec, int* ok);
+/* same problem, traditional solver: reference diaglib.f90:558-1022 (caslr_driver, its default algorithm i_alg = 0) */
+void dla_caslr_driver(int verbose, int n, int n_targ, int n_max, int max_iter, double tol, int max_dav,
+                      dla_matvec_fn apbmul, dla_matvec_fn ambmul, dla_matvec_fn spdmul, dla_matvec_fn smdmul,
+                      dla_lrprec_fn lrprec, double* eig, double* evec, int* ok);
 /* iteration report of the last driver call (iterations, matvec columns, restarts) */
 void dla_last_solve_info(int* iters, int* matvec_cols, int* restarts);
 void dla_set_solve_info(int iters, int matvec_cols, int restarts);   /* used by the Fortran drivers */

@@ -106,6 +106,7 @@ void orc_lr_amb(const int* n, const int* m, const double* x, double* y);   /* (A
 void orc_lr_spd(const int* n, const int* m, const double* x, double* y);   /* (S+D) x */
 void orc_lr_smd(const int* n, const int* m, const double* x, double* y);   /* (S-D) x */
 void orc_lr_prec(const int* n, const int* m, const double* fac, const double* xp, const double* xm, double* yp, double* ym);
+void orc_lr_prec1(const int* n, const int* m, const double* fac, const double* xp, const double* xm, double* yp, double* ym);
 const double* orc_lr_matrix(int which);                                     /* 0 A+B, 1 A-B, 2 S+D, 3 S-D; column-major */
 
 #ifdef __cplusplus

@@ -173,6 +173,20 @@ void orc_lr_prec(const int* pn, const int* pm, const double* pfac, const double*
     }
 }
 
+/* main.f90:234-255 (lrprec_1, used by the harness with caslr_driver) */
+void orc_lr_prec1(const int* pn, const int* pm, const double* pfac, const double* xp, const double* xm, double* yp, double* ym)
+{
+  const int n = *pn, m = *pm;
+  const double fac = *pfac;
+  for (int c = 0; c < m; ++c)
+    for (int i = 0; i < n; ++i) {
+      const size_t p = (size_t)c * n + i;
+      const double den = -1.0 / (g_adiag[i] * g_adiag[i] - fac * fac * g_sdiag[i] * g_sdiag[i]);
+      yp[p] = den * (g_adiag[i] * xp[p] + fac * g_sdiag[i] * xm[p]);
+      ym[p] = den * (g_adiag[i] * xm[p] + fac * g_sdiag[i] * xp[p]);
+    }
+}
+
 /* ---------------- synthetic matrix-free ---------------- */
 static long long g_row0 = 0;
 static int       g_nl = 0, g_rw = 0;

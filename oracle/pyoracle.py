@@ -335,6 +335,15 @@ class Reference:
                                _p(eig), _p(evec), C.byref(ok))
         return eig, evec, bool(ok.value)
 
+    def caslr(self, n, n_targ, n_max, max_iter, tol, max_dav, apb, amb, spd, smd, lrprec, evec, verbose=False):
+        """reference caslr_driver (diaglib.f90:558-1022, i_alg = 0); evec is 2n x n_max"""
+        evec = np.asfortranarray(evec, dtype=np.float64).copy(order="F")
+        eig = np.zeros(n_max); ok = C.c_int(0)
+        self.lib.ref_caslr.argtypes = [C.c_int] * 5 + [C.c_double, C.c_int] + [C.c_void_p] * 5 + [c_dp, c_dp, c_ip]
+        self.lib.ref_caslr(int(verbose), n, n_targ, n_max, max_iter, tol, max_dav, apb, amb, spd, smd, lrprec,
+                           _p(eig), _p(evec), C.byref(ok))
+        return eig, evec, bool(ok.value)
+
     def caslr_eff(self, n, n_targ, n_max, max_iter, tol, max_dav, apb, amb, spd, smd, lrprec, evec, verbose=False):
         """reference caslr_eff_driver (diaglib.f90:1024-1481); evec is 2n x n_max"""
         evec = np.asfortranarray(evec, dtype=np.float64).copy(order="F")

@@ -13,7 +13,7 @@
 module ref_cbind
   use iso_c_binding
   use diaglib, only : davidson_driver, lobpcg_driver, gen_david_driver, ortho_cd, ortho_vs_x, &
-                      b_ortho, b_ortho_vs_x, caslr_eff_driver
+                      b_ortho, b_ortho_vs_x, caslr_eff_driver, caslr_driver
   implicit none
 !
   abstract interface
@@ -37,6 +37,28 @@ module ref_cbind
   end interface
 !
 contains
+!
+  subroutine ref_caslr(verbose,n,n_targ,n_max,max_iter,tol,max_dav, &
+                       apbmul,ambmul,spdmul,smdmul,lrprec,eig,evec,ok) bind(C,name='ref_caslr')
+    integer(c_int), value :: verbose, n, n_targ, n_max, max_iter, max_dav
+    real(c_double), value :: tol
+    type(c_funptr), value :: apbmul, ambmul, spdmul, smdmul, lrprec
+    real(c_double)        :: eig(n_max), evec(2*n,n_max)
+    integer(c_int)        :: ok
+    procedure(mv_iface),   pointer :: f1, f2, f3, f4
+    procedure(lrpc_iface), pointer :: f5
+    logical :: lok, lverb
+    call c_f_procpointer(apbmul, f1)
+    call c_f_procpointer(ambmul, f2)
+    call c_f_procpointer(spdmul, f3)
+    call c_f_procpointer(smdmul, f4)
+    call c_f_procpointer(lrprec, f5)
+    lok = .false.
+    lverb = verbose .ne. 0
+    call caslr_driver(lverb,n,2*n,n_targ,n_max,max_iter,tol,max_dav,f1,f2,f3,f4,f5,eig,evec,lok)
+    ok = 0
+    if (lok) ok = 1
+  end subroutine ref_caslr
 !
   subroutine ref_caslr_eff(verbose,n,n_targ,n_max,max_iter,tol,max_dav, &
                            apbmul,ambmul,spdmul,smdmul,lrprec,eig,evec,ok) bind(C,name='ref_caslr_eff')

@@ -27,6 +27,9 @@ CASES = [
     dict(name="lr_n300_unit", n=300, n_targ=4, n_max=8, max_iter=100, tol=1e-8, max_dav=20, guess="unit", seed=0),
     dict(name="lr_n300_rand", n=300, n_targ=4, n_max=8, max_iter=200, tol=1e-11, max_dav=10, guess="rand", seed=3),
     dict(name="lr_n500_rand", n=500, n_targ=6, n_max=11, max_iter=200, tol=1e-9, max_dav=20, guess="rand", seed=8),
+    # the traditional driver (caslr_driver, i_alg = 0) with the harness' preconditioner for it (lrprec_1)
+    dict(name="lrt_n300_unit", driver="caslr", n=300, n_targ=4, n_max=8, max_iter=100, tol=1e-8, max_dav=20, guess="unit", seed=0),
+    dict(name="lrt_n300_rand", driver="caslr", n=300, n_targ=4, n_max=8, max_iter=300, tol=1e-10, max_dav=10, guess="rand", seed=3),
 ]
 
 CHILD = r"""
@@ -37,9 +40,11 @@ spec = json.loads(%r)
 o = Oracle(); r = Reference()
 n = spec['n']
 o.lr_setup(n)
-fn = [o.fn(k) for k in ("orc_lr_apb", "orc_lr_amb", "orc_lr_spd", "orc_lr_smd", "orc_lr_prec")]
+trad = spec.get('driver') == 'caslr'
+fn = [o.fn(k) for k in ("orc_lr_apb", "orc_lr_amb", "orc_lr_spd", "orc_lr_smd", "orc_lr_prec1" if trad else "orc_lr_prec")]
 g = np.load(spec['guess_file'])
-e, v, ok = r.caslr_eff(n, spec['n_targ'], spec['n_max'], spec['max_iter'], spec['tol'], spec['max_dav'], *fn, g, verbose=True)
+solve = r.caslr if trad else r.caslr_eff
+e, v, ok = solve(n, spec['n_targ'], spec['n_max'], spec['max_iter'], spec['tol'], spec['max_dav'], *fn, g, verbose=True)
 sys.stdout.flush()
 np.savez(spec['out'], eig=e, evec=v[:, :spec['n_targ']], ok=ok)
 """

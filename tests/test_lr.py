@@ -1,4 +1,4 @@
-"""Linear-response driver caslr_eff_driver (reference diaglib.f90:1024-1481) against the fixtures the
+"""Linear-response drivers caslr_eff_driver (reference diaglib.f90:1024-1481) and caslr_driver (:558-1022) against the fixtures the
 unmodified reference produced (tests/golden/make_golden_lr.py).
 
 CPU: the product's Fortran driver + host logic on the host-memory test engine (tests/hostsim.py), in a
@@ -14,7 +14,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIX = os.path.join(ROOT, "tests", "golden", "reference_lr_fixtures.npz")
-CASES = ["lr_n300_unit", "lr_n300_rand", "lr_n500_rand"]
+CASES = ["lr_n300_unit", "lr_n300_rand", "lr_n500_rand", "lrt_n300_unit", "lrt_n300_rand"]
 
 WORKER = r"""
 import os, sys, json
@@ -30,12 +30,14 @@ spec = json.loads({spec!r})
 o = Oracle()
 n, t, m = spec["n"], spec["n_targ"], spec["n_max"]
 o.lr_setup(n)
-fn = [o.fn(k) for k in ("orc_lr_apb", "orc_lr_amb", "orc_lr_spd", "orc_lr_smd", "orc_lr_prec")]
+trad = spec.get("driver") == "caslr"
+fn = [o.fn(k) for k in ("orc_lr_apb", "orc_lr_amb", "orc_lr_spd", "orc_lr_smd", "orc_lr_prec1" if trad else "orc_lr_prec")]
 g = np.load(spec["guess_file"])
 ctx = capi.Context()
 assert ctx.backend.startswith("hostsim" if {hostsim!r} else "hip:"), ctx.backend
 ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
-eig, vec, ok, info = ctx.caslr_eff_driver(n, t, m, spec["max_iter"], spec["tol"], spec["max_dav"], *fn, g)
+solve = ctx.caslr_driver if trad else ctx.caslr_eff_driver
+eig, vec, ok, info = solve(n, t, m, spec["max_iter"], spec["tol"], spec["max_dav"], *fn, g)
 np.savez(spec["out"], eig=eig, vec=vec, ok=ok, iters=info["iters"], restarts=info["restarts"])
 """
 
