@@ -1258,10 +1258,20 @@ struct HipEngine : dla::Engine {
   hipEvent_t ev_wait = nullptr;
   int wait_stream()
   {
-    if (!ev_wait) HIPCHK(hipEventCreateWithFlags(&ev_wait, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ev_wait, st));
     const double t0 = now();
     hipError_t q;
+    if (tune[6] == 2) {                      // A/B: poll the stream itself, no event packet
+      while ((q = hipStreamQuery(st)) == hipErrorNotReady) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      t_sync += now() - t0; n_sync++;
+      if (q != hipSuccess) { err = std::string("hipStreamQuery: ") + hipGetErrorString(q); return DLA_ERR_RUNTIME; }
+      return DLA_OK;
+    }
+    if (!ev_wait) HIPCHK(hipEventCreateWithFlags(&ev_wait, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev_wait, st));
     while ((q = hipEventQuery(ev_wait)) == hipErrorNotReady) {
 #if defined(__x86_64__)
       __builtin_ia32_pause();
