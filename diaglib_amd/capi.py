@@ -31,7 +31,7 @@ EXPORTS = [
     "dla_create", "dla_destroy", "dla_default_ctx", "dla_set_option", "dla_get_option", "dla_last_error",
     "dla_backend_name", "dla_get_stats", "dla_reset_stats", "dla_get_kernel_stats", "dla_stream",
     "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_set_allreduce_hook", "dla_set_shard",
-    "dla_alloc", "dla_free", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
+    "dla_alloc", "dla_free", "dla_trim", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
     "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_ritz_residual", "dla_axpy",
     "dla_nrm2", "dla_random_fill",
     "dla_ortho_cd", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
@@ -78,6 +78,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
     sig = {
         "dla_create": (i, [C.POINTER(vp), i]), "dla_destroy": (i, [vp]), "dla_default_ctx": (vp, []),
+        "dla_trim": (i, [vp, C.POINTER(sz)]),
         "dla_set_option": (i, [vp, i, i]), "dla_get_option": (i, [vp, i]),
         "dla_last_error": (C.c_char_p, [vp]), "dla_backend_name": (C.c_char_p, [vp]),
         "dla_get_stats": (i, [vp, C.POINTER(Stats)]), "dla_reset_stats": (i, [vp]), "dla_stream": (vp, [vp]),
@@ -200,6 +201,12 @@ class Context:
 
     def sync(self) -> None:
         self._chk(self.lib.dla_sync(self.h))
+
+    def trim(self) -> int:
+        """release the allocator's cached (freed) panels; returns the bytes handed back"""
+        rel = C.c_size_t(0)
+        self._chk(self.lib.dla_trim(self.h, C.byref(rel)))
+        return rel.value
 
     def stats(self) -> dict:
         s = Stats()

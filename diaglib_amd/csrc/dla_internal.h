@@ -20,6 +20,7 @@ struct Engine {
   virtual int alloc(size_t bytes, void** dev) = 0;
   virtual int free_(void* dev) = 0;
   virtual int zero(void* dev, size_t bytes) = 0;
+  virtual int trim(size_t* released) { if (released) *released = 0; return 0; }   // release cached free blocks
   virtual int h2d(void* dev, const void* host, size_t bytes) = 0;
   virtual int d2h(void* host, const void* dev, size_t bytes) = 0;
   virtual int d2d(void* dst, const void* src, size_t bytes) = 0;

@@ -1204,6 +1204,17 @@ struct HipEngine : dla::Engine {
     t_free += now() - t0;
     return DLA_OK;
   }
+  // hand the cached (freed) blocks back to the runtime; live blocks are untouched
+  int trim(size_t* released) override
+  {
+    (void)hipStreamSynchronize(st);
+    size_t rel = 0;
+    for (auto& b : cache) { HIPCHK(hipFree(b.ptr)); rel += b.bytes; }
+    cache.clear();
+    cached_bytes = 0;
+    if (released) *released = rel;
+    return DLA_OK;
+  }
   int zero(void* dev, size_t bytes) override
   {
     Scope s(this, DLA_OP_ELEM, (double)bytes, 0.0);

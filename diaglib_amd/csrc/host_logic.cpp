@@ -211,6 +211,7 @@ int dla_zero(dla_ctx* c, void* dev, size_t bytes) { DLA_T("dla_zero"); return en
 int dla_upload(dla_ctx* c, void* dev, const void* host, size_t bytes) { DLA_T("dla_upload"); return engfail(c, c->eng->h2d(dev, host, bytes)); }
 int dla_download(dla_ctx* c, void* host, const void* dev, size_t bytes) { DLA_T("dla_download"); return engfail(c, c->eng->d2h(host, dev, bytes)); }
 int dla_copy(dla_ctx* c, void* dst, const void* src, size_t bytes) { DLA_T("dla_copy"); return engfail(c, c->eng->d2d(dst, src, bytes)); }
+int dla_trim(dla_ctx* c, size_t* released) { if (!c) return DLA_ERR_ARG; return engfail(c, c->eng->trim(released)); }
 int dla_sync(dla_ctx* c) { DLA_T("dla_sync"); return engfail(c, c->eng->sync()); }
 
 // ------------------------------------------------------------------ block algebra

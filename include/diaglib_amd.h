@@ -122,6 +122,10 @@ int  dla_set_shard(dla_ctx* ctx, long long n_global, long long row0);        /* 
  * replaces allocate/zero/dcopy of the panels: diaglib.f90:1607-1638,1648,1798-1805, 258-287 */
 int  dla_alloc(dla_ctx* ctx, size_t bytes, void** dev);
 int  dla_free(dla_ctx* ctx, void* dev);
+/* Freed panels are kept for reuse (a driver call allocates the same GiB-sized panels every solve and hipMalloc of such
+ * blocks costs tens of milliseconds); dla_trim hands the cached blocks back to the runtime (bytes released in *released,
+ * may be NULL).  dla_destroy releases everything. */
+int  dla_trim(dla_ctx* ctx, size_t* released);
 int  dla_zero(dla_ctx* ctx, void* dev, size_t bytes);
 int  dla_upload(dla_ctx* ctx, void* dev, const void* host, size_t bytes);
 int  dla_download(dla_ctx* ctx, void* host, const void* dev, size_t bytes);

@@ -170,3 +170,16 @@ def test_ortho_vs_x_wide_blocks_contiguous(ctx, oracle, rng, n, m, k):
     assert np.abs(x.T @ got).max() < 50 * EPS
     assert np.abs(got - want).max() < 1e-11
     assert np.array_equal(panel.col(0, m).download(), np.asfortranarray(x))      # X untouched
+
+
+def test_allocator_cache_and_trim(ctx):
+    """Freed panels are cached for reuse; dla_trim hands them back (include/diaglib_amd.h)."""
+    ctx.trim()
+    p = ctx.panel(4096, 64)          # 2 MiB granule
+    addr = p.ptr
+    p.free()
+    q = ctx.panel(4096, 64)
+    assert q.ptr == addr             # the cached block came back
+    q.free()
+    assert ctx.trim() >= 4096 * 64 * 8
+    assert ctx.trim() == 0
