@@ -76,6 +76,12 @@ module diaglib
       type(c_ptr), value :: ctx, dev
       integer(c_int) :: st
     end function
+    function dla_trim(ctx,released) bind(C,name='dla_trim') result(st)
+      import :: c_ptr, c_int, c_size_t
+      type(c_ptr), value :: ctx
+      integer(c_size_t) :: released
+      integer(c_int) :: st
+    end function
     function dla_zero(ctx,dev,bytes) bind(C,name='dla_zero') result(st)
       import :: c_ptr, c_int, c_size_t
       type(c_ptr), value :: ctx, dev
@@ -235,13 +241,19 @@ contains
 ! configuration (extension; defaults reproduce the reference contract: host callbacks,
 ! host eig/evec)
 ! ---------------------------------------------------------------------------------------
-  subroutine diaglib_amd_config(callbacks_on_device, evec_on_device)
+  subroutine diaglib_amd_config(callbacks_on_device, evec_on_device, release_cache)
     logical, intent(in), optional :: callbacks_on_device, evec_on_device
+!   release_cache = .true.: hand the panels the allocator keeps between solves back to the runtime (dla_trim)
+    logical, intent(in), optional :: release_cache
+    integer(c_size_t) :: released
     type(c_ptr)    :: ctx
     integer(c_int) :: st
     ctx = dla_default_ctx()
     if (present(callbacks_on_device)) st = dla_set_option(ctx, opt_cb_dev, merge(1_c_int,0_c_int,callbacks_on_device))
     if (present(evec_on_device))      st = dla_set_option(ctx, opt_evec_dev, merge(1_c_int,0_c_int,evec_on_device))
+    if (present(release_cache)) then
+      if (release_cache) st = dla_trim(ctx, released)
+    end if
   end subroutine diaglib_amd_config
 !
 ! address of column j (1-based) of a device panel with leading dimension n
