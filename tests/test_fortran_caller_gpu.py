@@ -49,3 +49,34 @@ def test_fortran_caller_drop_in(tmp_path, ctx):
     lr = [float(v) for v in re.search(r"CASLR_EFF eig:(.*)", out).group(1).split()]
     assert all(b > a > 0 for a, b in zip(lr, lr[1:])), lr
     assert float(re.search(r"CASLR_EFF max residual:\s+([0-9.Ee+-]+)", out).group(1)) < 1e-6
+
+
+def test_fortran_caller_device_mode(tmp_path, ctx, oracle):
+    """examples/fortran_device_caller: the opt-in device mode from Fortran (diaglib_amd_config, device-address
+    callbacks under the reference's signatures), against the oracle on the same operator."""
+    if not os.path.exists(FLANG):
+        pytest.skip("no Fortran compiler on this box")
+    lib = os.path.join(ROOT, "diaglib_amd", "lib")
+    srcs = [os.path.join(ROOT, "diaglib_amd", "fortran", "real_precision.f90"),
+            os.path.join(ROOT, "diaglib_amd", "fortran", "diaglib.f90"),
+            os.path.join(ROOT, "examples", "fortran_device_caller", "device_caller.f90")]
+    objs = []
+    for s in srcs:
+        o = str(tmp_path / (os.path.basename(s) + ".o"))
+        subprocess.run([FLANG, "-O2", "-c", s, "-o", o, "-module-dir", str(tmp_path), "-I", str(tmp_path)], check=True)
+        objs.append(o)
+    exe = str(tmp_path / "device_caller.exe")
+    subprocess.run([FLANG, "-o", exe] + objs + ["-L" + lib, "-ldiaglib_amd", "-Wl,-rpath," + lib], check=True)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = p.stdout
+    n, t, m = 200000, 8, 13
+    oracle.synth_setup(n, 0, n)
+    g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
+    eo, _, oko, _ = oracle.davidson(n, t, m, 100, 1e-10, 20, 0.0, oracle.fn("orc_synth_matvec"), oracle.fn("orc_synth_precnd"), g)
+    assert oko
+    for tag in ("DAVIDSON", "LOBPCG"):
+        assert re.search("DEVICE " + tag + r" ok:\s+T", out), out
+        vals = [float(v) for v in re.search("DEVICE " + tag + r" eig:(.*)", out).group(1).split()]
+        assert np.allclose(vals, eo[:t], atol=2e-8), (tag, vals, eo[:t])
+    assert abs(float(re.search(r"DEVICE \|x1\|:\s+([0-9.]+)", out).group(1)) - 1.0) < 1e-9
