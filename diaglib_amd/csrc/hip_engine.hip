@@ -1779,7 +1779,24 @@ struct HipEngine : dla::Engine {
     const int kt = (m + 15) / 16;
     const int l4 = ((l + 3) / 4) * 4;
     const size_t lds_c = sizeof(double) * (size_t)kt * l4 * 16;
-    if (lds_c > 150 * 1024) { err = "ritz_residual: subspace too large for the LDS copy of Y"; return DLA_ERR_ARG; }
+    if (lds_c > 150 * 1024) {
+      // Y does not fit the LDS copy in one piece (wide block times deep subspace, e.g. 37 columns x 20 blocks): form the
+      // two products with the chunked panel GEMM, then run the fused sweep on the n x m results with Y = identity
+      // for the residual correction and the norms (same arithmetic for r; evec and AV Y are plain products)
+      void* tmp = nullptr;
+      int stf = alloc(sizeof(double) * (size_t)n * m, &tmp);
+      if (stf) return stf;
+      stf = gemm(n, l, av, m, y_host, ldy, (double*)tmp, 0);
+      if (!stf) stf = gemm(n, l, v, m, y_host, ldy, evec, 0);
+      if (!stf && avy) stf = d2d(avy, tmp, sizeof(double) * (size_t)n * m);
+      if (!stf) {
+        std::vector<double> ident((size_t)m * m, 0.0);
+        for (int j = 0; j < m; ++j) ident[(size_t)j * m + j] = 1.0;
+        stf = ritz_residual(n, m, m, evec, (const double*)tmp, ident.data(), m, eig, n_res, skip, evec, r, nullptr, out);
+      }
+      int stq = free_(tmp);
+      return stf ? stf : stq;
+    }
     int stc = upload_packed(y_host, ldy, 0, l, m, kt, l4);
     if (stc) return stc;
     RitzArgs a{};

@@ -183,3 +183,31 @@ def test_allocator_cache_and_trim(ctx):
     q.free()
     assert ctx.trim() >= 4096 * 64 * 8
     assert ctx.trim() == 0
+
+
+@pytest.mark.parametrize("n,l,m", [(2000, 500, 37), (1501, 420, 48), (1000, 700, 21)])
+def test_ritz_residual_deep_subspace(ctx, oracle, rng, n, l, m):
+    """Wide block times deep subspace (Davidson with n_max = 37 and 20 blocks reaches L = 740): Y no longer fits the
+    kernel's LDS copy and the engine goes through the chunked products."""
+    v = np.asfortranarray(rng.standard_normal((n, l)))
+    av = np.asfortranarray(rng.standard_normal((n, l)))
+    y = np.asfortranarray(rng.standard_normal((l, m)) / np.sqrt(l))
+    eig = rng.standard_normal(m)
+    n_res = m - 3
+    skip = np.zeros(m, np.int32); skip[1] = 1
+    pe, pr, pa = ctx.panel(n, m), ctx.panel(n, m), ctx.panel(n, m)
+    rn = ctx.ritz_residual(ctx.panel(v), ctx.panel(av), y, eig, n_res, skip, pe, pr, pa)
+    ev = v @ y
+    r = av @ y
+    raw = r.copy()
+    for i in range(n_res):
+        if not skip[i]:
+            r[:, i] -= eig[i] * ev[:, i]
+    tol = 64 * EPS * (np.abs(v) @ np.abs(y) * (1 + np.abs(eig)[None, :]) + np.abs(av) @ np.abs(y)) + 1e-300
+    assert np.all(np.abs(pe.download() - ev) <= tol)
+    assert np.all(np.abs(pr.download() - r) <= tol)
+    assert np.all(np.abs(pa.download() - raw) <= tol)
+    for i in range(n_res):
+        if not skip[i]:
+            assert np.isclose(rn[0, i], np.linalg.norm(r[:, i]) / np.sqrt(n), rtol=1e-10)
+            assert np.isclose(rn[1, i], np.abs(r[:, i]).max(), rtol=1e-10)
