@@ -1775,7 +1775,19 @@ struct HipEngine : dla::Engine {
                     const double* eig, int n_res, const int* skip, double* evec, double* r, double* avy,
                     double* out) override
   {
-    if (m > 48) { err = "ritz_residual: m > 48"; return DLA_ERR_ARG; }
+    if (m > 48) {
+      // more than three 16-column tiles: blocks of 48 columns, each a sweep of its own over V and AV
+      for (int j0 = 0; j0 < m; j0 += 48) {
+        const int mc = std::min(48, m - j0);
+        const int nr = std::max(0, std::min(n_res - j0, mc));
+        std::vector<double> o2((size_t)2 * std::max(nr, 1), 0.0);
+        int stq = ritz_residual(n, l, mc, v, av, y_host + (size_t)j0 * ldy, ldy, eig + j0, nr, skip ? skip + j0 : nullptr,
+                                evec + (size_t)j0 * n, r + (size_t)j0 * n, avy ? avy + (size_t)j0 * n : nullptr, o2.data());
+        if (stq) return stq;
+        for (int j = 0; j < nr; ++j) { out[2 * (j0 + j)] = o2[2 * j]; out[2 * (j0 + j) + 1] = o2[2 * j + 1]; }
+      }
+      return DLA_OK;
+    }
     const int kt = (m + 15) / 16;
     const int l4 = ((l + 3) / 4) * 4;
     const size_t lds_c = sizeof(double) * (size_t)kt * l4 * 16;

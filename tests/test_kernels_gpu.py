@@ -185,10 +185,11 @@ def test_allocator_cache_and_trim(ctx):
     assert ctx.trim() == 0
 
 
-@pytest.mark.parametrize("n,l,m", [(2000, 500, 37), (1501, 420, 48), (1000, 700, 21)])
+@pytest.mark.parametrize("n,l,m", [(2000, 500, 37), (1501, 420, 48), (1000, 700, 21), (1200, 130, 55), (900, 300, 100)])
 def test_ritz_residual_deep_subspace(ctx, oracle, rng, n, l, m):
     """Wide block times deep subspace (Davidson with n_max = 37 and 20 blocks reaches L = 740): Y no longer fits the
-    kernel's LDS copy and the engine goes through the chunked products."""
+    kernel's LDS copy and the engine goes through the chunked products; blocks wider than 48 columns go in 48-column
+    pieces."""
     v = np.asfortranarray(rng.standard_normal((n, l)))
     av = np.asfortranarray(rng.standard_normal((n, l)))
     y = np.asfortranarray(rng.standard_normal((l, m)) / np.sqrt(l))
