@@ -1365,17 +1365,32 @@ struct HipEngine : dla::Engine {
     return DLA_OK;
   }
 
+  // more than 64 KiB of dynamic LDS has to be enabled per kernel function and device (gfx950 has 160 KiB per CU);
+  // remembered per engine, i.e. per device
+  std::vector<std::pair<const void*, size_t>> lds_raised;
+  void raise_lds(const void* kfn, size_t lds)
+  {
+    if (lds <= (size_t)64 * 1024) return;
+    for (auto& e : lds_raised)
+      if (e.first == kfn) {
+        if (e.second >= lds) return;
+        e.second = lds;
+        if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) (void)hipGetLastError();
+        return;
+      }
+    // (kernels with static LDS of their own cannot take the full 160 KiB: ask for what the launch needs; a refusal is
+    // not fatal -- this runtime accepts the launch anyway -- and must not stay behind as the "last error")
+    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) (void)hipGetLastError();
+    lds_raised.push_back({kfn, lds});
+  }
+
   // ---- Gram
   template <int TLW, int KT, int R>
   int launch_gram_lds(const GramArgs& a, dim3 grid)
   {
     auto kfn = gram_lds_kernel<TLW, KT, 1, R>;
     const size_t lds = sizeof(double) * 4 * 16 * (TLW + KT) * (R + 2);
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
+    raise_lds((const void*)kfn, lds);
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
     return DLA_OK;
   }
@@ -1608,8 +1623,7 @@ struct HipEngine : dla::Engine {
     do {                                                                                                      \
       auto kfn = gemm_kernel<KT, V, M, ARGS, true>;                                                           \
       if (lds > (size_t)64 * 1024) {                                                                          \
-        static bool raised = false;                                                                           \
-        if (!raised) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; } \
+        raise_lds((const void*)kfn, lds);                                                                     \
       }                                                                                                       \
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);                                           \
     } while (0)
@@ -1617,8 +1631,7 @@ struct HipEngine : dla::Engine {
     do {                                                                                                      \
       auto kfn = gemm_kernel<KT, 2, M, ARGS, true, 1, P>;                                                     \
       if (lds > (size_t)64 * 1024) {                                                                          \
-        static bool raised = false;                                                                           \
-        if (!raised) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; } \
+        raise_lds((const void*)kfn, lds);                                                                     \
       }                                                                                                       \
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);                                           \
     } while (0)
@@ -1833,21 +1846,23 @@ struct HipEngine : dla::Engine {
       char kn[64];
       std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d>", kt, vec2 ? 2 : 1, kt >= 2 ? 2 : 0);
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
+#define RZ(K) do { auto kfn = K; raise_lds((const void*)kfn, lds); hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
       if (vec2 && kt >= 2 && tune[0] == 1) {
-        if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 2, 3, 0>), dim3(blocks), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((ritz_kernel<3, 2, 3, 0>), dim3(blocks), dim3(256), lds, st, a);
+        if (kt == 2) RZ((ritz_kernel<2, 2, 3, 0>));
+        else RZ((ritz_kernel<3, 2, 3, 0>));
       } else if (vec2 && kt >= 2 && tune[0] == 4) {
-        if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 2, 3, 4>), dim3(blocks), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((ritz_kernel<3, 2, 3, 4>), dim3(blocks), dim3(256), lds, st, a);
+        if (kt == 2) RZ((ritz_kernel<2, 2, 3, 4>));
+        else RZ((ritz_kernel<3, 2, 3, 4>));
       } else if (vec2) {
-        if (kt == 1) hipLaunchKernelGGL((ritz_kernel<1, 2>), dim3(blocks), dim3(256), lds, st, a);
-        else if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 2>), dim3(blocks), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((ritz_kernel<3, 2>), dim3(blocks), dim3(256), lds, st, a);
+        if (kt == 1) RZ((ritz_kernel<1, 2>));
+        else if (kt == 2) RZ((ritz_kernel<2, 2>));
+        else RZ((ritz_kernel<3, 2>));
       } else {
-        if (kt == 1) hipLaunchKernelGGL((ritz_kernel<1, 1>), dim3(blocks), dim3(256), lds, st, a);
-        else if (kt == 2) hipLaunchKernelGGL((ritz_kernel<2, 1>), dim3(blocks), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((ritz_kernel<3, 1>), dim3(blocks), dim3(256), lds, st, a);
+        if (kt == 1) RZ((ritz_kernel<1, 1>));
+        else if (kt == 2) RZ((ritz_kernel<2, 1>));
+        else RZ((ritz_kernel<3, 1>));
       }
+#undef RZ
     }
     {
       Scope s2(this, DLA_OP_RITZ, 0.0, 0.0, "ritz_reduce_kernel");
