@@ -1455,6 +1455,9 @@ struct HipEngine : dla::Engine {
     long long want = (nchunks + 4 * 4 - 1) / (4 * 4);   // >= 4 chunks per wave
     // one 4-wave block per CU and pass (256 on MI355X) measured best: 512 is -1.5 %, 384 / 128 are -15 / -30 %
     int blocks_per_pass = (int)std::max(1LL, std::min((long long)ncu, want));
+    // the narrowest sweeps (a block against itself, or fewer than 8 columns against a block) have too few loads in
+    // flight with one block per CU: two per CU measured +11 % / +19 % there and -1..-3 % everywhere else
+    if (tlw * kt == 1 && ((x == u && l == k) || l <= 8)) blocks_per_pass = (int)std::max(1LL, std::min(2LL * ncu, want));
     if (tune[4] > 0) blocks_per_pass = (int)std::max(1LL, std::min((long long)tune[4], want));
     const int slots = tlw * kt;
     int stc = ensure_partial(sizeof(double) * (size_t)passes * blocks_per_pass * slots * 256);
