@@ -270,44 +270,6 @@ void tridiagonalize(int n, std::vector<double>& s, Tridiag& t)
   for (int i = 0; i < n; ++i) t.d[i] = s[(size_t)i * n + i];
 }
 
-// implicit QL, eigenvalues only (d is overwritten, unsorted on exit); e is destroyed
-int ql_values(int n, std::vector<double>& d, std::vector<double>& e)
-{
-  const double eps = 2.220446049250313e-16;
-  for (int l = 0; l < n; ++l) {
-    int iter = 0;
-    while (true) {
-      int m = l;
-      for (; m + 1 < n; ++m) {
-        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
-        if (std::fabs(e[m]) <= eps * dd) break;
-      }
-      if (m == l) break;
-      if (++iter > 60) return l + 1;
-      double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-      double r = pythag(g, 1.0);
-      g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? r : -r));
-      double sn = 1.0, cs = 1.0, pp = 0.0;
-      int i = m - 1;
-      for (; i >= l; --i) {
-        const double f = sn * e[i], b = cs * e[i];
-        r = pythag(f, g);
-        e[i + 1] = r;
-        if (r == 0.0) { d[i + 1] -= pp; e[m] = 0.0; break; }
-        sn = f / r; cs = g / r;
-        g = d[i + 1] - pp;
-        r = (d[i] - g) * sn + 2.0 * cs * b;
-        pp = sn * r;
-        d[i + 1] = g + pp;
-        g = cs * r - b;
-      }
-      if (r == 0.0 && i >= l) continue;
-      d[l] -= pp; e[l] = g; e[m] = 0.0;
-    }
-  }
-  return 0;
-}
-
 // (T - lam I) = P L U by Gaussian elimination with partial pivoting on the tridiagonal matrix; tiny pivots
 // are replaced by +-tiny (inverse iteration only needs the direction).  One factorisation serves all the
 // iterations of one eigenvector.
