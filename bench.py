@@ -267,7 +267,7 @@ def main() -> None:
     if os.environ.get("DIAGLIB_AMD_HOSTTIME"):
         for p_ in (ax, ev, g_dev):
             p_.free()
-        ctx.lib.dla_destroy(ctx.h)       # prints the engine's host-wait totals
+        ctx.destroy()                    # prints the engine's host-wait totals
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ MATVEC_T = C.CFUNCTYPE(None, c_ip, c_ip, c_dp, c_dp)
 PRECND_T = C.CFUNCTYPE(None, c_ip, c_ip, c_dp, c_dp, c_dp)
 ALLREDUCE_T = C.CFUNCTYPE(None, C.c_void_p, c_dp, C.c_int, C.c_int)
 
-OPT_CALLBACKS_ON_DEVICE, OPT_EVEC_ON_DEVICE, OPT_PROFILE, OPT_VERBOSE_ORTHO = 1, 2, 3, 4
+OPT_CALLBACKS_ON_DEVICE, OPT_EVEC_ON_DEVICE, OPT_PROFILE, OPT_VERBOSE_ORTHO, OPT_CALLBACK_ORDER, OPT_ORTHO_MAXIT = 1, 2, 3, 4, 5, 6
 OP_NAMES = ["gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd"]
 
 # every symbol include/diaglib_amd.h declares (checked by tests/test_abi.py)
@@ -33,7 +33,7 @@ EXPORTS = [
     "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_set_allreduce_hook", "dla_set_shard",
     "dla_alloc", "dla_free", "dla_trim", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
     "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_ritz_residual", "dla_axpy",
-    "dla_nrm2", "dla_random_fill",
+    "dla_nrm2", "dla_random_fill", "dla_fill_guess",
     "dla_ortho_cd", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
     "dla_call_matvec", "dla_call_precnd",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
@@ -74,6 +74,14 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     if not os.path.exists(path):
         raise DlaError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)")
+    # The PyTorch wheel ships its own libamdhip64.so (soname libamdhip64.so.7, like /opt/rocm's).  Loaded first, it also
+    # serves this library's DT_NEEDED entry, so the process has ONE HIP runtime; loaded second, the process ends up
+    # with two runtimes that share neither devices, streams nor events ("No HIP GPUs are available").  A Python
+    # process that uses both must therefore import torch first -- do it here, once, when torch is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path, mode=C.RTLD_LOCAL)
     vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
     sig = {
@@ -96,7 +104,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_trmm_linvt": (i, [vp, i, i, vp, c_dp, i]),
         "dla_ritz_residual": (i, [vp, i, i, i, vp, vp, c_dp, i, c_dp, i, c_ip, vp, vp, vp, c_dp]),
         "dla_axpy": (i, [vp, sz, d, vp, vp]), "dla_nrm2": (i, [vp, sz, vp, c_dp]),
-        "dla_random_fill": (i, [vp, i, i, vp]),
+        "dla_random_fill": (i, [vp, i, i, vp]), "dla_fill_guess": (i, [vp, i, i, vp, C.c_ulonglong, C.c_longlong]),
         "dla_ortho_cd": (i, [vp, i, i, vp, c_dp, c_ip]), "dla_ortho_vs_x": (i, [vp, i, i, i, vp, vp]),
         "dla_b_ortho": (i, [vp, i, i, vp, vp]), "dla_b_ortho_vs_x": (i, [vp, i, i, i, vp, vp, vp]),
         "dla_check_guess": (i, [vp, i, i, vp]),
@@ -163,9 +171,10 @@ class DevPanel:
         return self
 
     def free(self) -> None:
-        if self.owner and self.ptr:
+        # (a panel that outlives its context must not call into the destroyed engine)
+        if self.owner and self.ptr and getattr(self.ctx, "h", None):
             self.ctx.lib.dla_free(self.ctx.h, self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -186,6 +195,15 @@ class Context:
         if not self.h:
             raise DlaError("no HIP device")
         self._keep = []
+        # device-mode Python callbacks: True = the trampolines drain the engine's stream before the call and torch's
+        # after it; False = rely on the engine's own ordering (OPT_CALLBACK_ORDER), as a compiled caller would
+        self.sync_python_callbacks = True
+
+    def destroy(self) -> None:
+        """dla_destroy; panels still alive afterwards no longer call into the engine"""
+        if self.h:
+            h, self.h = self.h, None
+            self.lib.dla_destroy(h)
 
     # ---- plumbing
     def _chk(self, st: int) -> None:
@@ -304,6 +322,11 @@ class Context:
     def random_fill(self, x: DevPanel) -> None:
         self._chk(self.lib.dla_random_fill(self.h, x.n, x.m, x.ptr))
 
+    def fill_guess(self, x: DevPanel, seed: int = 2, support_rows: int = 0) -> None:
+        """uniform [-0.5, 0.5) guess from the documented counter-based generator (SURVEY 8d guess (b)); with
+        support_rows > 0 only the leading support_rows global rows are random, the rest zero"""
+        self._chk(self.lib.dla_fill_guess(self.h, x.n, x.m, x.ptr, seed, support_rows))
+
     # ---- orthogonalisation
     def ortho_cd(self, u: DevPanel):
         g = C.c_double(0.0); ok = C.c_int(0)
@@ -360,9 +383,11 @@ class Context:
 
             def tramp(pn, pm, px, pax):
                 n, m = pn[0], pm[0]
-                self.sync()
+                if self.sync_python_callbacks:
+                    self.sync()
                 self._dev_tensor(pax, n, m).copy_(f(self._dev_tensor(px, n, m)))
-                torch.cuda.synchronize()
+                if self.sync_python_callbacks:
+                    torch.cuda.synchronize()
         else:
             def tramp(pn, pm, px, pax):
                 n, m = pn[0], pm[0]
@@ -382,9 +407,11 @@ class Context:
 
             def tramp(pn, pm, pf, px, ppx):
                 n, m = pn[0], pm[0]
-                self.sync()
+                if self.sync_python_callbacks:
+                    self.sync()
                 self._dev_tensor(ppx, n, m).copy_(f(pf[0], self._dev_tensor(px, n, m)))
-                torch.cuda.synchronize()
+                if self.sync_python_callbacks:
+                    torch.cuda.synchronize()
         else:
             def tramp(pn, pm, pf, px, ppx):
                 n, m = pn[0], pm[0]

@@ -9,6 +9,15 @@
 
 namespace dla {
 
+// Outcome of a device-driven orthogonalisation (Engine::ortho_chain)
+struct OrthoReport {
+  int handled = 0;      // 0: the engine does not take this shape / mode, run the host-driven loop
+  int status = 0;       // 1 done, 2 ortho_cd ran out of iterations, 3 factorisation failed after level shifting,
+                        // 4 ortho_vs_x ran out of iterations
+  int outer_its = 0, macro_its = 0, shifts = 0;
+  double growth = 1.0;
+};
+
 // What the host logic needs from a device.  All panel pointers are device addresses,
 // column-major, ld = n.  Reductions (gram / residual norms / nrm2) return host-visible,
 // cross-rank-reduced results and imply a stream synchronisation.
@@ -49,21 +58,37 @@ struct Engine {
   // Gram matrix of the new U.  Used to fold a pending triangular update into the projection step.
   virtual bool can_combo(int /*m*/, int /*k*/) { return false; }
   virtual int combo_gram(int, int, const double*, int, const double*, int, double*, double*, int) { return DLA_ERR_ARG; }
+  // ortho_vs_x (m > 0: U is the block that follows X in one panel; bx = X, or B X for the B-metric variant) or plain
+  // ortho_cd (m == 0) with the k x k factorisations and the loop decisions on the device: one host wait per call.
+  virtual int ortho_chain(int /*n*/, int /*m*/, int /*k*/, const double* /*x*/, const double* /*bx*/, double* /*u*/,
+                          OrthoReport* rep) { rep->handled = 0; return 0; }
   virtual int ritz_residual(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
                             const double* eig, int n_res, const int* skip, double* evec, double* r,
                             double* avy /* optional n x m: uncorrected AV*Y */,
                             double* sumsq_max /* 2*n_res: sum r^2, max|r| */) = 0;
   virtual int axpy(size_t len, double alpha, const double* x, double* y) = 0;
   virtual int sumsq(size_t len, const double* x, double* out) = 0;
-  virtual int random_fill(int n, int m, double* evec, long long row0) = 0;
+  // evec(i,j) = u01(seed, row0+i+1, j+1) + offset (counter-based generator, global row indices); rows whose global
+  // index exceeds support_rows (when > 0) are set to zero
+  virtual int random_fill(int n, int m, double* evec, long long row0, unsigned long long seed, double offset,
+                          long long support_rows) = 0;
 
   virtual int synth_setup(long long n_global, long long row0, int n_local, int rank_w, double sigma) = 0;
   virtual int synth_matvec(int n, int m, const double* x, double* ax) = 0;
   virtual int synth_precnd(int n, int m, double fac, const double* x, double* px) = 0;
 
+  // Ordering of a DEVICE-mode callback against the engine's stream (the user's kernels may run on another stream):
+  // mode 0 = stream-ordered through events (the legacy null stream waits for the engine's pending work before the
+  // callback, the engine's stream waits for the null stream's work after it; no host wait), 1 = host-synchronise the
+  // engine's stream before and the whole device after, 2 = nothing (the callback enqueues on dla_stream itself).
+  virtual int callback_begin(int /*mode*/) { return 0; }
+  virtual int callback_end(int /*mode*/) { return 0; }
+
   // pinned host staging for host-mode callbacks
   virtual int host_alloc(size_t bytes, void** p) = 0;
   virtual int host_free(void* p) = 0;
+
+  int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests
 
   // collectives
   virtual int comm_init(int nranks, int rank, const char id[128]) = 0;
@@ -108,6 +133,7 @@ struct dla_ctx {
   int callbacks_on_device = 0;
   int evec_on_device = 0;
   int verbose_ortho = 0;
+  int callback_order = 1;    // DLA_OPT_CALLBACK_ORDER (default: host-synchronised, safe for callbacks on any stream)
   long long n_global = -1;   // -1: single shard, n_global == n
   long long row0 = 0;
   std::string err;

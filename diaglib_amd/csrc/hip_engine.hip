@@ -93,13 +93,20 @@ struct GramArgs {
   int l, k;
   int passes_x;
   int lower;         // 1: only tile pairs on or below the block diagonal are needed (symmetric result, 'l' consumer)
+  const int* phase;  // device-driven chains (ortho_chain): run only if *phase == want; nullptr = always
+  int want;
 };
+
+// A launch of a device-driven chain is speculative: the step it belongs to may not be the one the device-side state
+// machine has reached (OrthoDev::phase).  Every block reads the same word, so the whole grid leaves together.
+#define DLA_PREDICATED(a) do { if ((a).phase != nullptr && *(a).phase != (a).want) return; } while (0)
 
 // (NT stays 0 here: the two 64-byte halves of a line are fetched by consecutive instructions and rely on
 // the cache to merge; non-temporal loads measured -10 %)
 template <int TLW, int KT, int VEC, int RSTEP, int NT = 0, int PF = -1>
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 {
+  DLA_PREDICATED(a);
   constexpr int CH = 4 * VEC * RSTEP;  // rows per chunk
   constexpr bool PREFETCH = (PF < 0) ? (TLW * KT <= 12) : (PF != 0);   // A/B: also the 12-slot shapes gain (k = 37: +24 %)
   typedef typename VecOf<VEC>::type vec_t;
@@ -240,6 +247,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 template <int TLW, int KT, int NT = 1, int R = 16>
 __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
 {
+  DLA_PREDICATED(a);
   // R rows per wave tile (16 or 32): R/2 lanes cover one column segment, 128/R columns per load instruction
   constexpr int RS = R + 2;                // doubles per staged column (+2 keeps 16-byte alignment)
   constexpr int LPC = R / 2;               // lanes per column
@@ -368,10 +376,13 @@ struct GramReduceArgs {
   double* c;           // l x k, ld = l (device)
   double* c_host;      // same, pinned host mirror (device-visible address)
   int nblk, l, k, tlw, kt, passes_x;
+  const int* phase;
+  int want;
 };
 
 __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
 {
+  DLA_PREDICATED(a);
   const int slots = a.tlw * a.kt;
   const int ps = blockIdx.x, grp = blockIdx.y, G = gridDim.y;
   const int pass = ps / slots, slot = ps % slots;
@@ -442,6 +453,8 @@ struct GemmArgs {
   double* gpart;       // GRAM variants: per-block partial of Z^T Z, [nblk][256]
   long long n;
   int l, l4, k;
+  const int* phase;    // see DLA_PREDICATED
+  int want;
 };
 
 // small C (l <= 16, k <= 16) travels inside the kernel arguments: no staging copy, no extra launch
@@ -451,6 +464,8 @@ struct GemmArgsInl {
   double* gpart;
   long long n;
   int l, l4, k;
+  const int* phase;
+  int want;
   double cin[256];     // packed C: [l4 <= 16][16]
 };
 __device__ __forceinline__ const double* packed_c(const GemmArgs& a) { return a.cpk; }
@@ -470,7 +485,7 @@ __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return
 template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1), int PIPE = (KT >= 2 ? 2 : 0), int ZPAD = 9>
 __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 {
-
+  DLA_PREDICATED(a);
   constexpr int RT = 2;                    // row groups per wave tile
   constexpr int RG = 16 * VEC;             // rows per group
   constexpr int WT = RT * RG;              // rows per wave tile (64 for VEC=2)
@@ -904,14 +919,16 @@ __device__ __host__ inline double u01(unsigned long long seed, unsigned long lon
   return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
 
-__global__ void random_fill_kernel(long long n, int m, double* evec, long long row0)
+__global__ void random_fill_kernel(long long n, int m, double* evec, long long row0, unsigned long long seed, double offset,
+                                   long long support_rows)
 {
   const long long total = n * (long long)m;
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (; idx < total; idx += stride) {
     const long long i = idx % n, j = idx / n;
-    evec[idx] = u01(7ULL, (unsigned long long)(row0 + i + 1), (unsigned long long)(j + 1));
+    const bool in = support_rows <= 0 || row0 + i < support_rows;
+    evec[idx] = in ? u01(seed, (unsigned long long)(row0 + i + 1), (unsigned long long)(j + 1)) + offset : 0.0;
   }
 }
 
@@ -982,6 +999,232 @@ __global__ void synth_precnd_kernel(int n, int m, double fac, const double* __re
       for (int e = 0; e < VEC; ++e) o[e] = use[e] ? vget<VEC>(xv, e) / inv[e] : vget<VEC>(xv, e);
       pstore<VEC, 2>(px + (size_t)c * n + i, vmake<VEC>(o[0], o[VEC - 1]));
     }
+  }
+}
+
+// ======================================================================================
+// Device-resident control of the orthogonalisation loops
+// ======================================================================================
+// ortho_cd (reference diaglib.f90:3185-3341) and ortho_vs_x (:3481-3574) alternate n-length sweeps with k x k work
+// whose outcome decides what the next sweep is (another triangular update, a projection pass, the exit).  Taking that
+// decision on the host costs a stream drain per sweep (~8 per ortho_vs_x call).  Here the k x k work -- Cholesky
+// factorisation with the level-shift ladder (:3261-3295), triangular inverse (:3310), norm estimates (:3314-3323,
+// 3447-3479), growth / convergence tests (:3331-3332, :3562-3564) and the assembly of the coefficient block of the
+// next sweep -- runs in a one-block kernel between the sweeps, and the decision is left in device memory
+// (OrthoDev::phase).  The host enqueues the sequence of sweeps it expects (the one the previous call took); every
+// sweep and every tail kernel checks the phase and leaves at once when it is not its turn (DLA_PREDICATED), so a
+// wrong guess costs empty launches, never a wrong result.  One host wait at the end reads the state back.
+enum { OP_NONE = 0, OP_GRAM_UU = 1, OP_TRMMG = 2, OP_XU = 3, OP_COMBO = 4, OP_FINAL = 5 };
+enum { OST_RUNNING = 0, OST_DONE = 1, OST_CD_MAXIT = 2, OST_FACTOR_FAIL = 3, OST_VSX_MAXIT = 4 };
+
+struct OrthoDev {
+  int phase;          // the sweep the state machine waits for (OP_*)
+  int status;         // OST_*
+  int it_macro;       // macro-iterations of the current ortho_cd pass
+  int it_outer;       // outer iterations of ortho_vs_x
+  int force_defer;    // the ortho_cd that precedes the loop always leaves its last W pending (it is folded into the projection)
+  int can_defer;      // 1: ortho_vs_x on the block that follows X (combined sweep available); 0: plain ortho_cd
+  int nops;           // sweeps executed so far
+  int macro_total;    // macro-iterations over all ortho_cd passes (report)
+  int shifts;         // level shifts taken (report)
+  int maxit;          // maxit, diaglib.f90:3224,3521
+  double growth;      // prod ||L^-1||_est of the current ortho_cd pass
+  int log[48];        // the sweeps executed, in order
+};
+
+struct OrthoTailArgs {
+  OrthoDev* st;
+  OrthoDev* st_host;   // pinned mirror (device-visible address)
+  const double* gsrc;  // the reduced small product: k x k (ld k, lower triangle used) or m x k (ld m)
+  double* wpk;         // packed W = L^-T for the sweeps: [kt][k4][16]
+  double* wfull;       // W, k x k column-major (kept for the C' assembly)
+  double* cpk;         // packed C' = [-xu W ; W]: [kt][l4][16], l = m + k
+  int after;           // the sweep this tail follows
+  int m, k;
+};
+
+#define TLD 49   // row stride of the k x k LDS images (k <= 48)
+
+// lower Cholesky factor in place (row-major LDS image), same operation order as the host routine (smalldense.cpp
+// dla_potrf_lower: left-looking, dot products in ascending index order); all 256 threads call it
+__device__ int tail_potrf(int k, double* A)
+{
+  const int tid = threadIdx.x;
+  for (int j = 0; j < k; ++j) {
+    __syncthreads();
+    double dj = A[j * TLD + j];
+    for (int p = 0; p < j; ++p) dj -= A[j * TLD + p] * A[j * TLD + p];
+    if (!(dj > 0.0) || !isfinite(dj)) return j + 1;     // uniform: every thread computed the same dj
+    dj = sqrt(dj);
+    const double inv = 1.0 / dj;
+    const int i = j + 1 + tid;
+    double sij = 0.0;
+    if (i < k) {
+      sij = A[i * TLD + j];
+      for (int p = 0; p < j; ++p) sij -= A[i * TLD + p] * A[j * TLD + p];
+    }
+    __syncthreads();                                    // row j has been read by everyone
+    if (i < k) A[i * TLD + j] = sij * inv;
+    if (tid == 0) A[j * TLD + j] = dj;
+  }
+  __syncthreads();
+  return 0;
+}
+
+// inverse of a lower triangular matrix in place, column by column from the right (dla_trtri_lower)
+__device__ void tail_trtri(int k, double* A)
+{
+  const int tid = threadIdx.x;
+  for (int j = k - 1; j >= 0; --j) {
+    __syncthreads();
+    const double xj = 1.0 / A[j * TLD + j];
+    const int i = j + 1 + tid;
+    double xi = 0.0;
+    if (i < k) {
+      double sacc = 0.0;
+      for (int p = j + 1; p <= i; ++p) sacc += A[i * TLD + p] * A[p * TLD + j];
+      xi = -sacc * xj;
+    }
+    __syncthreads();
+    if (i < k) A[i * TLD + j] = xi;
+    if (tid == 0) A[j * TLD + j] = xj;
+  }
+  __syncthreads();
+}
+
+// norm_est (diaglib.f90:3447-3479): max |a_ii| + Frobenius norm of the strictly lower part; rows in parallel, the
+// row sums added in row order by every thread (uniform result)
+__device__ double tail_norm_est(int k, const double* A, double* rowsum)
+{
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if (tid < k) {
+    double on = 0.0;
+    for (int j = 0; j < tid; ++j) on += A[tid * TLD + j] * A[tid * TLD + j];
+    rowsum[tid] = on;
+  }
+  __syncthreads();
+  double dn = 0.0, on = 0.0;
+  for (int i = 0; i < k; ++i) { dn = fmax(dn, fabs(A[i * TLD + i])); on += rowsum[i]; }
+  return dn + sqrt(on);
+}
+
+__global__ __launch_bounds__(256) void ortho_tail_kernel(OrthoTailArgs a)
+{
+  OrthoDev* st = a.st;
+  if (st->phase != a.after) return;
+  __shared__ double A[48 * TLD], S[48 * TLD], rowsum[48];
+  const int tid = threadIdx.x, k = a.k, m = a.m;
+  const int kt = (k + 15) / 16;
+  const double eps = 2.220446049250313e-16, tol = 2.0 * eps;   // epsilon(one), tol_ortho (diaglib.f90:151)
+  // the state as this step found it (thread 0 rewrites it at the end, after the last barrier)
+  const int maxit = st->maxit, can_defer = st->can_defer, force_defer = st->force_defer;
+  int it_macro = st->it_macro, it_outer = st->it_outer, nops = st->nops, macro_total = st->macro_total, shifts = st->shifts;
+  double growth = st->growth;
+  int phase = OP_NONE, status = OST_RUNNING;
+
+  if (a.after == OP_FINAL) {
+    status = OST_DONE;
+  } else if (a.after == OP_XU) {
+    // C' = [-(xu W) ; W]  (host_logic.cpp ortho_vs_x_impl, X^T (U W) = (X^T U) W), packed for the combined sweep
+    const int l = m + k, l4 = ((l + 3) / 4) * 4;
+    for (int idx = tid; idx < kt * l4 * 16; idx += 256) {
+      const int q = idx / (l4 * 16), p = (idx / 16) % l4, j = 16 * q + (idx % 16);
+      double v = 0.0;
+      if (j < k) {
+        if (p < m) {
+          double sacc = 0.0;
+          for (int pp = 0; pp <= j; ++pp) sacc += a.gsrc[(size_t)p + (size_t)pp * m] * a.wfull[pp + j * k];
+          v = -sacc;
+        } else if (p < l) {
+          v = a.wfull[(p - m) + j * k];
+        }
+      }
+      a.cpk[idx] = v;
+    }
+    it_macro = 0;           // the ortho_cd that follows the combined sweep starts afresh (*growth = 1, it = 0)
+    growth = 1.0;
+    phase = OP_COMBO;
+  } else {
+    // one macro-iteration of ortho_cd on the Gram matrix the sweep left in gsrc
+    ++it_macro;
+    if (it_macro > maxit) {
+      status = OST_CD_MAXIT;                                  // :3252-3254, the host prints and reports ok = .false.
+    } else {
+      ++macro_total;
+      for (int idx = tid; idx < k * k; idx += 256) {
+        const int i = idx % k, j = idx / k;
+        if (i >= j) { const double v = a.gsrc[(size_t)i + (size_t)j * k]; A[i * TLD + j] = v; S[i * TLD + j] = v; }
+      }
+      int info = tail_potrf(k, A);
+      if (info != 0) {
+        // level-shift ladder (:3265-3295): shift = max(eps alpha ||U||_F, 2 eps), alpha = 100, 1000, ...
+        double tr = 0.0;
+        for (int i = 0; i < k; ++i) tr += S[i * TLD + i];
+        const double unorm = sqrt(tr > 0.0 ? tr : 0.0);
+        double alpha = 100.0;
+        int it_micro = 0;
+        while (info != 0) {
+          if (++it_micro > maxit) break;
+          const double shift = fmax(eps * alpha * unorm, tol);
+          __syncthreads();
+          for (int idx = tid; idx < k * k; idx += 256) {
+            const int i = idx % k, j = idx / k;
+            if (i >= j) A[i * TLD + j] = S[i * TLD + j] + (i == j ? shift : 0.0);
+          }
+          info = tail_potrf(k, A);
+          alpha *= 10.0;
+          ++shifts;
+        }
+      }
+      if (info != 0) {
+        status = OST_FACTOR_FAIL;                             // reference: stop (:3283)
+      } else {
+        __syncthreads();
+        for (int idx = tid; idx < k * k; idx += 256) {
+          const int i = idx % k, j = idx / k;
+          if (i >= j) S[i * TLD + j] = A[i * TLD + j];          // S = L, A becomes L^-1
+        }
+        tail_trtri(k, A);
+        const double l_norm = tail_norm_est(k, S, rowsum);
+        const double linv_norm = tail_norm_est(k, A, rowsum);
+        const double rcond = l_norm * linv_norm;
+        growth *= linv_norm;
+        const bool macro_done = eps * rcond * rcond < tol;      // :3331-3332
+        // W = L^-T (upper triangular): W(p, j) = Linv(j, p), p <= j
+        const int k4 = ((k + 3) / 4) * 4;
+        for (int idx = tid; idx < k * k; idx += 256) {
+          const int p = idx % k, j = idx / k;
+          a.wfull[idx] = (p <= j) ? A[j * TLD + p] : 0.0;
+        }
+        for (int idx = tid; idx < kt * k4 * 16; idx += 256) {
+          const int q = idx / (k4 * 16), p = (idx / 16) % k4, j = 16 * q + (idx % 16);
+          a.wpk[idx] = (j < k && p <= j) ? A[j * TLD + p] : 0.0;
+        }
+        if (!macro_done) {
+          phase = OP_TRMMG;
+        } else if (can_defer && (force_defer || growth * eps >= tol)) {
+          // the pass ends with W pending; ortho_vs_x goes on with a projection pass (xu_norm = growth eps >= tol)
+          if (!force_defer && it_outer > maxit) status = OST_VSX_MAXIT;     // :3568
+          else { ++it_outer; phase = OP_XU; }
+        } else {
+          if (can_defer && it_outer > maxit) status = OST_VSX_MAXIT;
+          else phase = OP_FINAL;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (nops < 48) st->log[nops] = a.after;
+    st->nops = nops + 1;
+    st->it_macro = it_macro; st->it_outer = it_outer; st->macro_total = macro_total; st->shifts = shifts;
+    st->growth = growth;
+    if (a.after != OP_FINAL && a.after != OP_XU && force_defer && phase == OP_XU) st->force_defer = 0;
+    st->status = status;
+    st->phase = (status == OST_RUNNING) ? phase : OP_NONE;
+    __threadfence();
+    *a.st_host = *st;
   }
 }
 
@@ -1061,6 +1304,14 @@ struct HipEngine : dla::Engine {
     if (d_lvl2) (void)hipFree(d_lvl2);
     if (d_ticket) (void)hipFree(d_ticket);
     if (ev_wait) (void)hipEventDestroy(ev_wait);
+    if (ev_cb) (void)hipEventDestroy(ev_cb);
+    if (ev_cb2) (void)hipEventDestroy(ev_cb2);
+    if (d_ost) (void)hipFree(d_ost);
+    if (h_ost) (void)hipHostFree(h_ost);
+    if (h_ost_init) (void)hipHostFree(h_ost_init);
+    if (d_wpk) (void)hipFree(d_wpk);
+    if (d_wfull) (void)hipFree(d_wfull);
+    if (d_cpk2) (void)hipFree(d_cpk2);
     for (int i = 0; i < RING; ++i) if (h_ring[i]) { (void)hipHostFree(h_ring[i]); (void)hipEventDestroy(ring_ev[i]); }
     if (d_cpk) (void)hipFree(d_cpk);
     if (d_w) (void)hipFree(d_w);
@@ -1074,9 +1325,19 @@ struct HipEngine : dla::Engine {
     int cnt = 0;
     HIPCHK(hipGetDeviceCount(&cnt));
     if (cnt <= 0) { err = "no HIP device"; return DLA_ERR_NO_DEVICE; }
-    if (dev >= cnt) dev = dev % cnt;
+    if (dev >= cnt) {
+      // a wrong LOCAL_RANK must not silently put two ranks on one GPU (RCCL would fail later with an obscure error);
+      // sharing a device is an explicit rehearsal mode
+      if (!std::getenv("DIAGLIB_AMD_SHARE_DEVICES")) {
+        err = "device index " + std::to_string(dev) + " out of range (" + std::to_string(cnt) +
+              " visible); set DIAGLIB_AMD_SHARE_DEVICES=1 to let ranks share devices (rehearsal only)";
+        return DLA_ERR_NO_DEVICE;
+      }
+      dev = dev % cnt;
+    }
     device = dev;
     trace = std::getenv("DIAGLIB_AMD_TRACE") != nullptr;
+    force_lds_refusal = std::getenv("DIAGLIB_AMD_FORCE_LDS_REFUSAL") ? 1 : 0;
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t p;
     HIPCHK(hipGetDeviceProperties(&p, device));
@@ -1097,6 +1358,12 @@ struct HipEngine : dla::Engine {
     HipEngine* e; int cls; hipEvent_t a = nullptr, b = nullptr; std::string kname;
     Scope(HipEngine* e_, int cls_, double bytes, double flops, const std::string& kname_ = std::string()) : e(e_), cls(cls_), kname(kname_)
     {
+      if (e->spec_rec) {
+        // speculative launch of a device-driven chain: counted after the read-back, if the device executed it
+        e->spec_rec->push_back({e->spec_tag, cls_, kname_, bytes, flops});
+        if (e->profile) { a = e->get_event(); b = e->get_event(); (void)hipEventRecord(a, e->st); }
+        return;
+      }
       if (!kname.empty()) { auto& ks = e->kstats[kname]; ks.launches += 1; ks.alg_bytes += bytes; }
       if (e->trace) {
         timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -1241,6 +1508,28 @@ struct HipEngine : dla::Engine {
     return DLA_OK;
   }
   int sync() override { HIPCHK(hipStreamSynchronize(st)); return DLA_OK; }
+  // device-mode callbacks (dla_internal.h): order the user's stream(s) against ours
+  hipEvent_t ev_cb = nullptr, ev_cb2 = nullptr;
+  int callback_begin(int mode) override
+  {
+    if (mode == 2) return DLA_OK;
+    if (mode == 1) { int stw = wait_stream(); if (stw) return stw; stats.host_syncs++; return DLA_OK; }
+    if (!ev_cb) {
+      HIPCHK(hipEventCreateWithFlags(&ev_cb, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_cb2, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(ev_cb, st));
+    HIPCHK(hipStreamWaitEvent(nullptr, ev_cb, 0));     // legacy null stream: every blocking stream follows it
+    return DLA_OK;
+  }
+  int callback_end(int mode) override
+  {
+    if (mode == 2) return DLA_OK;
+    if (mode == 1) { HIPCHK(hipDeviceSynchronize()); return DLA_OK; }
+    HIPCHK(hipEventRecord(ev_cb2, nullptr));
+    HIPCHK(hipStreamWaitEvent(st, ev_cb2, 0));
+    return DLA_OK;
+  }
   int host_alloc(size_t bytes, void** p) override { HIPCHK(hipHostMalloc(p, bytes, hipHostMallocDefault)); return DLA_OK; }
   int host_free(void* p) override { if (p) HIPCHK(hipHostFree(p)); return DLA_OK; }
 
@@ -1368,20 +1657,189 @@ struct HipEngine : dla::Engine {
   // more than 64 KiB of dynamic LDS has to be enabled per kernel function and device (gfx950 has 160 KiB per CU);
   // remembered per engine, i.e. per device
   std::vector<std::pair<const void*, size_t>> lds_raised;
-  void raise_lds(const void* kfn, size_t lds)
+  // More than 64 KiB of dynamic LDS has to be enabled per kernel function.  A refusal is NOT swallowed: the launch
+  // is not made, lds_limit drops to 64 KiB (every shape decision below honours it: narrower Gram passes, chunked
+  // contraction, unfused epilogues) and the operation is redone once under that limit.
+  size_t lds_limit = (size_t)160 * 1024;
+  bool lds_retry = false;
+  int force_lds_refusal = 0;   // $DIAGLIB_AMD_FORCE_LDS_REFUSAL=1 (tests): treat the first > 64 KiB request as refused
+  bool raise_lds(const void* kfn, size_t lds)
   {
-    if (lds <= (size_t)64 * 1024) return;
-    for (auto& e : lds_raised)
-      if (e.first == kfn) {
-        if (e.second >= lds) return;
-        e.second = lds;
-        if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) (void)hipGetLastError();
-        return;
+    if (lds <= (size_t)64 * 1024) return true;
+    bool refused = false;
+    if (force_lds_refusal > 0) { force_lds_refusal = 0; refused = true; }
+    if (!refused)
+      for (auto& e : lds_raised)
+        if (e.first == kfn) {
+          if (e.second >= lds) return true;
+          if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) { e.second = lds; return true; }
+          refused = true;
+          break;
+        }
+    // (kernels with static LDS of their own cannot take the full 160 KiB: ask for what the launch needs)
+    if (!refused) {
+      if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+        lds_raised.push_back({kfn, lds});
+        return true;
       }
-    // (kernels with static LDS of their own cannot take the full 160 KiB: ask for what the launch needs; a refusal is
-    // not fatal -- this runtime accepts the launch anyway -- and must not stay behind as the "last error")
-    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) (void)hipGetLastError();
-    lds_raised.push_back({kfn, lds});
+    }
+    (void)hipGetLastError();
+    lds_limit = (size_t)64 * 1024;
+    lds_retry = true;
+    err = "hipFuncSetAttribute refused " + std::to_string(lds) + " bytes of dynamic LDS";
+    return false;
+  }
+  // run op(); when it stopped at a refused LDS request, run it once more under the 64 KiB limit
+  template <typename F> int with_lds_retry(F&& op)
+  {
+    lds_retry = false;
+    int st = op();
+    if (st != DLA_OK && lds_retry) { lds_retry = false; st = op(); }
+    return st;
+  }
+
+  // ---- device-driven orthogonalisation chain (see ortho_tail_kernel)
+  const int* pred_phase = nullptr;   // predicate of the launches being enqueued (nullptr = unconditional)
+  int pred_want = 0;
+  struct SpecRec { int tag, cls; std::string kname; double bytes, flops; };
+  std::vector<SpecRec>* spec_rec = nullptr;
+  int spec_tag = 0;
+  OrthoDev* d_ost = nullptr;        // state machine (device)
+  OrthoDev* h_ost = nullptr;        // pinned mirror the tail kernels write
+  OrthoDev* h_ost_dev = nullptr;
+  OrthoDev* h_ost_init = nullptr;   // pinned source of the initial state
+  double* d_wpk = nullptr; double* d_wfull = nullptr; double* d_cpk2 = nullptr;
+  std::map<long long, std::vector<int>> ortho_history;   // (m > 0, k) -> the sweeps the last call executed
+
+  int ensure_chain_buffers()
+  {
+    if (d_ost) return DLA_OK;
+    HIPCHK(hipMalloc((void**)&d_ost, sizeof(OrthoDev)));
+    HIPCHK(hipHostMalloc((void**)&h_ost, sizeof(OrthoDev), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&h_ost_dev, h_ost, 0));
+    HIPCHK(hipHostMalloc((void**)&h_ost_init, sizeof(OrthoDev), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&d_wpk, sizeof(double) * 3 * 48 * 16));
+    HIPCHK(hipMalloc((void**)&d_wfull, sizeof(double) * 48 * 48));
+    HIPCHK(hipMalloc((void**)&d_cpk2, (size_t)80 * 1024));
+    return DLA_OK;
+  }
+
+  int launch_tail(int after, int m, int k)
+  {
+    OrthoTailArgs ta{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, after, m, k};
+    Scope s(this, after == OP_XU ? DLA_OP_GEMM : DLA_OP_GRAM, 0.0, 0.0, "ortho_tail_kernel");
+    hipLaunchKernelGGL(ortho_tail_kernel, dim3(1), dim3(256), 0, st, ta);
+    HIPCHK(hipGetLastError());
+    return DLA_OK;
+  }
+
+  // one speculative step: the sweep, its reduction (+ cross-rank sum) and the tail that takes the next decision
+  int launch_op(int op, int n, int m, int k, const double* x, const double* bx, double* u)
+  {
+    pred_phase = &d_ost->phase; pred_want = op;
+    int stc = DLA_OK;
+    switch (op) {
+      case OP_GRAM_UU: stc = gram_dev_once(n, k, u, k, u, DLA_OP_GRAM, false); break;
+      case OP_XU:      stc = gram_dev_once(n, m, bx, k, u, DLA_OP_GRAM, false); break;
+      case OP_TRMMG:
+        stc = gemm_chunk(n, 0, k, u, k, nullptr, 0, u, 2, DLA_OP_TRMM, true, d_wpk);
+        if (!stc) stc = fused_reduce(k);
+        break;
+      case OP_COMBO:
+        stc = gemm_chunk(n, 0, m + k, x, k, nullptr, 0, u, 0, DLA_OP_GEMM, true, d_cpk2);
+        if (!stc) stc = fused_reduce(k);
+        break;
+      case OP_FINAL:   stc = gemm_chunk(n, 0, k, u, k, nullptr, 0, u, 2, DLA_OP_TRMM, false, d_wpk); break;
+      default: err = "ortho_chain: bad op"; stc = DLA_ERR_ARG;
+    }
+    pred_phase = nullptr; pred_want = 0;
+    if (stc) return stc;
+    return launch_tail(op, m, k);
+  }
+
+  int ortho_chain(int n, int m, int k, const double* x, const double* bx, double* u, dla::OrthoReport* rep) override
+  {
+    rep->handled = 0;
+    if (tune[6] == 3) return DLA_OK;                               // A/B: host-driven loop
+    if (hook || local_only || k <= 0 || k > 48) return DLA_OK;     // hook reductions need the host between sweeps
+    const bool vsx = m > 0;
+    if (vsx && !(u == x + (size_t)n * m && can_combo(m, k))) return DLA_OK;
+    if (!vsx && fused_lds(k, k) > lds_limit) return DLA_OK;
+    int stc = ensure_chain_buffers();
+    if (stc) return stc;
+    // the widest reductions of the chain: make sure nothing reallocates (and drains the stream) half way
+    stc = ensure_small(sizeof(double) * (size_t)std::max(m, k) * k);
+    if (stc) return stc;
+
+    OrthoDev init{};
+    init.phase = OP_GRAM_UU; init.status = OST_RUNNING; init.force_defer = vsx ? 1 : 0; init.can_defer = vsx ? 1 : 0;
+    init.maxit = ortho_maxit; init.growth = 1.0;
+    *h_ost_init = init;
+    HIPCHK(hipMemcpyAsync(d_ost, h_ost_init, sizeof(OrthoDev), hipMemcpyHostToDevice, st));
+
+    const long long key = (long long)(vsx ? 1 : 0) * 1000 + k;
+    std::vector<int>& hist = ortho_history[key];
+    std::vector<int> plan = hist;
+    if (plan.empty()) {
+      // the schedule measured on the reference: cd x2, [projection, cd x2], [projection, cd x1]
+      if (vsx) plan = {OP_GRAM_UU, OP_TRMMG, OP_XU, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
+      else plan = {OP_GRAM_UU, OP_TRMMG, OP_FINAL};
+    }
+    std::vector<SpecRec> recs;
+    std::vector<int> launched;
+    OrthoDev sres{};
+    for (int round = 0; round < 256; ++round) {
+      spec_rec = &recs;
+      for (int op : plan) {
+        spec_tag = (int)launched.size();
+        launched.push_back(op);
+        stc = launch_op(op, n, m, k, x, bx, u);
+        if (stc) break;
+      }
+      spec_rec = nullptr;
+      if (stc) { (void)hipStreamSynchronize(st); return stc; }
+      stc = wait_stream();
+      if (stc) return stc;
+      stats.host_syncs++;
+      sres = *h_ost;
+      if (sres.status != OST_RUNNING) break;
+      // the device went another way than expected: continue from where it stands with the most likely tail
+      switch (sres.phase) {
+        case OP_TRMMG: plan = vsx ? std::vector<int>{OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL} : std::vector<int>{OP_TRMMG, OP_FINAL}; break;
+        case OP_XU:    plan = {OP_XU, OP_COMBO, OP_FINAL}; break;
+        case OP_COMBO: plan = {OP_COMBO, OP_FINAL}; break;
+        case OP_FINAL: plan = {OP_FINAL}; break;
+        default: err = "ortho_chain: device state machine in an unexpected phase"; return DLA_ERR_RUNTIME;
+      }
+    }
+    if (sres.status == OST_RUNNING) { err = "ortho_chain: no progress"; return DLA_ERR_RUNTIME; }
+    // account for the launches the device executed: they are the greedy match of its log inside the launch sequence
+    {
+      const int nlog = std::min(sres.nops, 48);
+      std::vector<char> ran(launched.size(), 0);
+      int j = 0;
+      for (size_t i = 0; i < launched.size() && j < nlog; ++i)
+        if (launched[i] == sres.log[j]) { ran[i] = 1; ++j; }
+      for (auto& r : recs) {
+        if (!ran[r.tag]) continue;
+        stats.launches[r.cls] += 1; stats.alg_bytes[r.cls] += r.bytes; stats.flops[r.cls] += r.flops;
+        if (!r.kname.empty()) { auto& ks = kstats[r.kname]; ks.launches += 1; ks.alg_bytes += r.bytes; }
+      }
+      // reference-schedule flops of what the fused sweeps fold in (same bookkeeping as trmm_gram / combo_gram)
+      for (size_t i = 0; i < launched.size(); ++i) {
+        if (!ran[i]) continue;
+        if (launched[i] == OP_TRMMG) stats.flops[DLA_OP_GRAM] += 2.0 * (double)n * k * k;
+        if (launched[i] == OP_COMBO) { stats.flops[DLA_OP_GRAM] += 2.0 * (double)n * k * k; stats.flops[DLA_OP_GEMM] -= 1.0 * (double)n * k * k; }
+      }
+      if (sres.status == OST_DONE && sres.nops <= 48) hist.assign(sres.log, sres.log + nlog);
+    }
+    rep->handled = 1;
+    rep->status = sres.status;
+    rep->growth = sres.growth;
+    rep->outer_its = sres.it_outer;
+    rep->macro_its = sres.macro_total;
+    rep->shifts = sres.shifts;
+    return DLA_OK;
   }
 
   // ---- Gram
@@ -1390,13 +1848,17 @@ struct HipEngine : dla::Engine {
   {
     auto kfn = gram_lds_kernel<TLW, KT, 1, R>;
     const size_t lds = sizeof(double) * 4 * 16 * (TLW + KT) * (R + 2);
-    raise_lds((const void*)kfn, lds);
+    if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
     return DLA_OK;
   }
   // tile rows of the LDS-staged kernel: 32 for narrow passes (few loads per tile otherwise) and for 3-tile U blocks,
   // 16 elsewhere (A/B at n = 2e6, tools/tune_gram.py)
-  static int lds_rows(int tlw, int kt) { return (tlw <= 2 || kt == 3) ? 32 : 16; }
+  int lds_rows(int tlw, int kt) const
+  {
+    const int r = (tlw <= 2 || kt == 3) ? 32 : 16;
+    return (r == 32 && sizeof(double) * 4 * 16 * (size_t)(tlw + kt) * 34 > lds_limit) ? 16 : r;
+  }
   // (a pass narrower than one tile, e.g. the 4-column W^T x of the benchmark operator, would stage mostly
   // duplicates of its last column: it keeps the direct-load kernel)
   bool use_lds_gram(bool vec2, int l, int kt) const { return vec2 && kt <= 3 && l > 8 && tune[5] != 2; }
@@ -1425,6 +1887,10 @@ struct HipEngine : dla::Engine {
   // result stays on the device in d_small (l x k, ld = l), reduced over ranks
   int gram_dev(int n, int l, const double* x, int k, const double* u, int cls = DLA_OP_GRAM, bool lower = false)
   {
+    return with_lds_retry([&]() { return gram_dev_once(n, l, x, k, u, cls, lower); });
+  }
+  int gram_dev_once(int n, int l, const double* x, int k, const double* u, int cls, bool lower)
+  {
     const int tx = (l + 15) / 16, tu = (k + 15) / 16;
     // tile shape of one pass: KT U-tiles x TLW X-tiles, at most 12 accumulators
     int kt = std::min(tu, 4);
@@ -1435,7 +1901,9 @@ struct HipEngine : dla::Engine {
     // widest pass: the direct-load kernel loses its register prefetch stage beyond 8 tiles (measured); the LDS-staged
     // one keeps all of X's columns of up to 12 tiles in one pass, so U is read once for L <= 192
     static const int maxtl[5] = {0, 8, 6, 4, 3};
-    const int mt = (ldsk && kt == 1) ? 12 : maxtl[kt];
+    int mt = (ldsk && kt == 1) ? 12 : maxtl[kt];
+    // the LDS-staged kernel stages 16 (tlw + kt) columns of 18 doubles per wave: keep the pass inside lds_limit
+    if (ldsk) mt = std::max(1, std::min(mt, (int)(lds_limit / (sizeof(double) * 4 * 16 * 18)) - kt));
     const int passes_x = (tx + mt - 1) / mt;
     int tlw = (tx + passes_x - 1) / passes_x;
     // round up to an instantiated width
@@ -1464,7 +1932,7 @@ struct HipEngine : dla::Engine {
     if (stc) return stc;
     stc = ensure_small(sizeof(double) * (size_t)l * k);
     if (stc) return stc;
-    GramArgs a{x, u, d_partial, (long long)n, l, k, px, lower ? 1 : 0};
+    GramArgs a{x, u, d_partial, (long long)n, l, k, px, lower ? 1 : 0, pred_phase, pred_want};
     dim3 grid(blocks_per_pass, passes);
     {
       const bool same = (x == u) && (l == k);
@@ -1495,7 +1963,7 @@ struct HipEngine : dla::Engine {
         HIPCHK(hipMalloc((void**)&d_lvl2, lvl2_bytes));
       }
       if (passes * slots > 4096) { err = "gram: too many output tiles"; return DLA_ERR_ARG; }
-      GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, h_small_dev, blocks_per_pass, l, k, tlw, kt, px};
+      GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, h_small_dev, blocks_per_pass, l, k, tlw, kt, px, pred_phase, pred_want};
       hipLaunchKernelGGL(gram_reduce_kernel, dim3(passes * slots, groups), dim3(256), 0, st, ra);
     }
     HIPCHK(hipGetLastError());
@@ -1524,8 +1992,9 @@ struct HipEngine : dla::Engine {
 
   int fused_blocks = 0;
 
-  // second stage + host copy of a Gram whose per-block partials a fused kernel left in d_partial
-  int finish_fused_gram(int k, double* g_host, int ldg)
+  // second stage of a Gram whose per-block partials a fused kernel left in d_partial: result in d_small (k x k,
+  // lower block triangle), summed over ranks
+  int fused_reduce(int k)
   {
     int stc = ensure_small(sizeof(double) * (size_t)k * k);
     if (stc) return stc;
@@ -1538,13 +2007,19 @@ struct HipEngine : dla::Engine {
       lvl2_bytes = std::max(need2, (size_t)1 << 20);
       HIPCHK(hipMalloc((void**)&d_lvl2, lvl2_bytes));
     }
-    GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, h_small_dev, fused_blocks, k, k, kt, kt, 1};
+    GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, h_small_dev, fused_blocks, k, k, kt, kt, 1, pred_phase, pred_want};
     {
       Scope s2(this, DLA_OP_GRAM, 0.0, 0.0, "gram_reduce_kernel");
       hipLaunchKernelGGL(gram_reduce_kernel, dim3(kt * kt, groups), dim3(256), 0, st, ra);
     }
     HIPCHK(hipGetLastError());
-    stc = allreduce_dev(d_small, k * k, 0, h_small);
+    return allreduce_dev(d_small, k * k, 0, h_small);
+  }
+
+  // ... and its copy to the host
+  int finish_fused_gram(int k, double* g_host, int ldg)
+  {
+    int stc = fused_reduce(k);
     if (stc) return stc;
     stc = small_to_host((size_t)k * k);
     if (stc) return stc;
@@ -1557,10 +2032,21 @@ struct HipEngine : dla::Engine {
     return DLA_OK;
   }
 
+  // dynamic LDS of a fused sweep: packed C (l rows) + 4 wave-private transpose tiles
+  static size_t fused_lds(int l, int k)
+  {
+    const int kt = (k + 15) / 16, l4 = ((l + 3) / 4) * 4;
+    return std::max(sizeof(double) * ((size_t)kt * l4 * 16 + (size_t)4 * 16 * (16 * kt + 9)), (size_t)8192);
+  }
+
   // U <- U W and G = U^T U of the result, one sweep (k <= 48); otherwise two sweeps
   int trmm_gram(int n, int k, double* u, const double* w_host, int ld, double* g_host, int ldg) override
   {
-    if (k > 48) return Engine::trmm_gram(n, k, u, w_host, ld, g_host, ldg);
+    return with_lds_retry([&]() { return trmm_gram_once(n, k, u, w_host, ld, g_host, ldg); });
+  }
+  int trmm_gram_once(int n, int k, double* u, const double* w_host, int ld, double* g_host, int ldg)
+  {
+    if (k > 48 || fused_lds(k, k) > lds_limit) return Engine::trmm_gram(n, k, u, w_host, ld, g_host, ldg);
     {
       // accounted as TRMM traffic (16nk) -- the Gram rides along
       int stc = gemm_chunk(n, 0, k, u, k, w_host, ld, u, 2, DLA_OP_TRMM, true);
@@ -1575,9 +2061,26 @@ struct HipEngine : dla::Engine {
   bool can_combo(int m, int k) override
   {
     const int kt = (k + 15) / 16;
-    return k <= 48 && m > 0 && (size_t)(m + k + 3) * 16 * kt * sizeof(double) <= (size_t)64 * 1024;   // C' in one LDS chunk
+    return k <= 48 && m > 0 && (size_t)(m + k + 3) * 16 * kt * sizeof(double) <= (size_t)64 * 1024 &&   // C' in one LDS chunk
+           fused_lds(m + k, k) <= lds_limit;
   }
   int combo_gram(int n, int m, const double* x, int k, const double* c_host, int ldc, double* u, double* g_host, int ldg) override
+  {
+    int st = with_lds_retry([&]() { return combo_gram_once(n, m, x, k, c_host, ldc, u, g_host, ldg); });
+    if (st != DLA_OK && lds_limit <= (size_t)64 * 1024 && !can_combo(m, k) && u == x + (size_t)n * m && k <= 48) {
+      // the fused sweep was refused its LDS and nothing was launched: same result in separate sweeps
+      // (U <- [X | U] C' through a scratch panel, then the Gram)
+      void* tmp = nullptr;
+      st = alloc(sizeof(double) * (size_t)n * k, &tmp);
+      if (!st) st = gemm(n, m + k, x, k, c_host, ldc, (double*)tmp, 0);
+      if (!st) st = d2d(u, tmp, sizeof(double) * (size_t)n * k);
+      if (!st) st = gram(n, k, u, k, u, g_host, ldg);
+      int stf = free_(tmp);
+      return st ? st : stf;
+    }
+    return st;
+  }
+  int combo_gram_once(int n, int m, const double* x, int k, const double* c_host, int ldc, double* u, double* g_host, int ldg)
   {
     if (!can_combo(m, k) || u != x + (size_t)n * m) { err = "combo_gram: unsupported shape"; return DLA_ERR_ARG; }
     int stc = gemm_chunk(n, 0, m + k, x, k, c_host, ldc, u, 0, DLA_OP_GEMM, true);
@@ -1592,7 +2095,12 @@ struct HipEngine : dla::Engine {
   // U -= X C and G = U^T U of the result, one sweep (k <= 48, C fits one LDS chunk)
   int update_gram(int n, int l, const double* x, int k, const double* c_host, int ldc, double* u, double* g_host, int ldg) override
   {
-    if (k > 48 || l == 0 || (size_t)(l + 3) * 16 * ((k + 15) / 16) * sizeof(double) > (size_t)64 * 1024)
+    return with_lds_retry([&]() { return update_gram_once(n, l, x, k, c_host, ldc, u, g_host, ldg); });
+  }
+  int update_gram_once(int n, int l, const double* x, int k, const double* c_host, int ldc, double* u, double* g_host, int ldg)
+  {
+    if (k > 48 || l == 0 || (size_t)(l + 3) * 16 * ((k + 15) / 16) * sizeof(double) > (size_t)64 * 1024 ||
+        fused_lds(l, k) > lds_limit)
       return Engine::update_gram(n, l, x, k, c_host, ldc, u, g_host, ldg);
     int stc = gemm_chunk(n, 0, l, x, k, c_host, ldc, u, 1, DLA_OP_GEMM, true);
     if (stc) return stc;
@@ -1619,42 +2127,18 @@ struct HipEngine : dla::Engine {
   }
 
   template <int KT, typename ARGS>
-  void launch_gemm_gram(const ARGS& a, int blocks, size_t lds, bool vec2, int mode)
+  int launch_gemm_gram(const ARGS& a, int blocks, size_t lds, bool vec2, int mode)
   {
-    // more than 64 KiB of dynamic LDS has to be enabled per kernel (gfx950 has 160 KiB per CU)
 #define GG(V, M)                                                                                              \
     do {                                                                                                      \
       auto kfn = gemm_kernel<KT, V, M, ARGS, true>;                                                           \
-      if (lds > (size_t)64 * 1024) {                                                                          \
-        raise_lds((const void*)kfn, lds);                                                                     \
-      }                                                                                                       \
+      if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;                                          \
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);                                           \
     } while (0)
-#define GGP(M, P)                                                                                             \
-    do {                                                                                                      \
-      auto kfn = gemm_kernel<KT, 2, M, ARGS, true, 1, P>;                                                     \
-      if (lds > (size_t)64 * 1024) {                                                                          \
-        raise_lds((const void*)kfn, lds);                                                                     \
-      }                                                                                                       \
-      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);                                           \
-    } while (0)
-    if constexpr (KT == 1) {
-      if (vec2 && (mode == 0 || mode == 1) && (tune[7] == 4 || tune[7] == 8)) {
-        if (tune[7] == 4) { if (mode == 0) GGP(0, 4); else GGP(1, 4); }
-        else              { if (mode == 0) GGP(0, 8); else GGP(1, 8); }
-        return;
-      }
-    }
-    if constexpr (KT == 1) {
-      if (vec2 && mode == 2 && tune[6] == 1) {   // A/B: the old transpose-tile stride
-        hipLaunchKernelGGL((gemm_kernel<1, 2, 2, ARGS, true, 0, 0, 8>), dim3(blocks), dim3(256), lds, st, a);
-        return;
-      }
-    }
     if (vec2) { if (mode == 1) GG(2, 1); else if (mode == 2) GG(2, 2); else GG(2, 0); }
     else      { if (mode == 1) GG(1, 1); else if (mode == 2) GG(1, 2); else GG(1, 0); }
 #undef GG
-#undef GGP
+    return DLA_OK;
   }
 
   template <int KT, typename ARGS>
@@ -1673,13 +2157,14 @@ struct HipEngine : dla::Engine {
 #undef GMP
   }
 
+  // cpk_dev != nullptr: the coefficient block is already packed in device memory (ortho_tail_kernel wrote it)
   int gemm_chunk(int n, int l0, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode, int cls,
-                 bool fuse = false)
+                 bool fuse = false, const double* cpk_dev = nullptr)
   {
     const int kt = (k + 15) / 16;
     const int l4 = ((l + 3) / 4) * 4;
-    const bool inl = (kt == 1 && l4 <= 16);
-    if (!inl) {
+    const bool inl = (cpk_dev == nullptr && kt == 1 && l4 <= 16);
+    if (!inl && cpk_dev == nullptr) {
       int stc = upload_packed(c_host, ldc, l0, l, k, kt, l4);
       if (stc) return stc;
     }
@@ -1698,27 +2183,32 @@ struct HipEngine : dla::Engine {
       fused_blocks = blocks;
     }
     GemmArgs a{};
-    a.x = x + (size_t)l0 * n; a.cpk = d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k; a.gpart = d_partial;
+    a.x = x + (size_t)l0 * n; a.cpk = cpk_dev ? cpk_dev : d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k; a.gpart = d_partial;
+    a.phase = pred_phase; a.want = pred_want;
     const double rd = (mode == 0) ? 8.0 * n * (double)l : (mode == 2 ? 8.0 * n * (double)k : 8.0 * n * (double)(l + k));
     char kn[96];
     std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, %d, %d, 9>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
                   fuse ? "true" : "false", mode == 2 ? 0 : 1,
-                  kt >= 2 ? 2 : ((fuse && kt == 1 && vec2 && !inl && mode <= 1 && (tune[7] == 4 || tune[7] == 8)) ? tune[7] : 0));
+                  kt >= 2 ? 2 : 0);
     Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k, kn);
     if (inl) {
       GemmArgsInl ai{};
       ai.x = a.x; ai.z = z; ai.n = n; ai.l = l; ai.l4 = l4; ai.k = k; ai.gpart = d_partial;
       for (int j = 0; j < k; ++j)
         for (int p = 0; p < l; ++p) ai.cin[p * 16 + j] = c_host[(size_t)(l0 + p) + (size_t)j * ldc];
-      if (fuse) launch_gemm_gram<1>(ai, blocks, lds, vec2, mode);
+      int stl = DLA_OK;
+      if (fuse) stl = launch_gemm_gram<1>(ai, blocks, lds, vec2, mode);
       else launch_gemm<1>(ai, blocks, lds, vec2, mode);
+      if (stl) return stl;
       HIPCHK(hipGetLastError());
       return DLA_OK;
     }
     if (fuse) {
-      if (kt == 1) launch_gemm_gram<1>(a, blocks, lds, vec2, mode);
-      else if (kt == 2) launch_gemm_gram<2>(a, blocks, lds, vec2, mode);
-      else launch_gemm_gram<3>(a, blocks, lds, vec2, mode);
+      int stl;
+      if (kt == 1) stl = launch_gemm_gram<1>(a, blocks, lds, vec2, mode);
+      else if (kt == 2) stl = launch_gemm_gram<2>(a, blocks, lds, vec2, mode);
+      else stl = launch_gemm_gram<3>(a, blocks, lds, vec2, mode);
+      if (stl) return stl;
       HIPCHK(hipGetLastError());
       return DLA_OK;
     }
@@ -1760,7 +2250,12 @@ struct HipEngine : dla::Engine {
 
   int gemm(int n, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode) override
   {
-    // wide outputs are processed 48 columns at a time
+    // wide outputs are processed 48 columns at a time: a later block would read columns of X that an earlier
+    // block has already overwritten, so the output must not alias the input panel then
+    if (k > 48 && z >= x && z < x + (size_t)n * l) {
+      err = "panel_gemm: output aliases the input panel and has more than 48 columns";
+      return DLA_ERR_ARG;
+    }
     for (int k0 = 0; k0 < k; k0 += 48) {
       const int kc = std::min(48, k - k0);
       int stc = gemm_cols(n, l, x, kc, c_host + (size_t)k0 * ldc, ldc, z + (size_t)k0 * n, mode, DLA_OP_GEMM);
@@ -1791,6 +2286,12 @@ struct HipEngine : dla::Engine {
                     const double* eig, int n_res, const int* skip, double* evec, double* r, double* avy,
                     double* out) override
   {
+    return with_lds_retry([&]() { return ritz_residual_once(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, out); });
+  }
+  int ritz_residual_once(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
+                         const double* eig, int n_res, const int* skip, double* evec, double* r, double* avy,
+                         double* out)
+  {
     if (m > 48) {
       // more than three 16-column tiles: blocks of 48 columns, each a sweep of its own over V and AV
       for (int j0 = 0; j0 < m; j0 += 48) {
@@ -1807,7 +2308,7 @@ struct HipEngine : dla::Engine {
     const int kt = (m + 15) / 16;
     const int l4 = ((l + 3) / 4) * 4;
     const size_t lds_c = sizeof(double) * (size_t)kt * l4 * 16;
-    if (lds_c > 150 * 1024) {
+    if (lds_c > std::min((size_t)150 * 1024, lds_limit)) {
       // Y does not fit the LDS copy in one piece (wide block times deep subspace, e.g. 37 columns x 20 blocks): form the
       // two products with the chunked panel GEMM, then run the fused sweep on the n x m results with Y = identity
       // for the residual correction and the norms (same arithmetic for r; evec and AV Y are plain products)
@@ -1849,7 +2350,7 @@ struct HipEngine : dla::Engine {
       char kn[64];
       std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d>", kt, vec2 ? 2 : 1, kt >= 2 ? 2 : 0);
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
-#define RZ(K) do { auto kfn = K; raise_lds((const void*)kfn, lds); hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
+#define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME; hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
       if (vec2 && kt >= 2 && tune[0] == 1) {
         if (kt == 2) RZ((ritz_kernel<2, 2, 3, 0>));
         else RZ((ritz_kernel<3, 2, 3, 0>));
@@ -1911,12 +2412,12 @@ struct HipEngine : dla::Engine {
     return DLA_OK;
   }
 
-  int random_fill(int n, int m, double* evec, long long row0) override
+  int random_fill(int n, int m, double* evec, long long row0, unsigned long long seed, double offset, long long support_rows) override
   {
     Scope s(this, DLA_OP_ELEM, 8.0 * (double)n * m, 0.0);
     const size_t total = (size_t)n * m;
     const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 8, (total + 255) / 256));
-    hipLaunchKernelGGL(random_fill_kernel, dim3(blocks), dim3(256), 0, st, (long long)n, m, evec, row0);
+    hipLaunchKernelGGL(random_fill_kernel, dim3(blocks), dim3(256), 0, st, (long long)n, m, evec, row0, seed, offset, support_rows);
     HIPCHK(hipGetLastError());
     return DLA_OK;
   }

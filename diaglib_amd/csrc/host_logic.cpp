@@ -37,7 +37,6 @@ namespace {
 
 const double kEps = DBL_EPSILON;           // epsilon(one)
 const double kTolOrtho = 2.0 * DBL_EPSILON;  // tol_ortho, diaglib.f90:151
-const int kMaxIt = 10;                     // maxit, diaglib.f90:3224,3521
 
 dla_ctx* g_default = nullptr;
 // built-in operator callbacks have the reference's context-free shape; they act on this ctx
@@ -117,6 +116,14 @@ int dla_set_option(dla_ctx* c, int option, int value)
     case DLA_OPT_EVEC_ON_DEVICE: c->evec_on_device = value; break;
     case DLA_OPT_PROFILE: c->eng->profile = value != 0; break;
     case DLA_OPT_VERBOSE_ORTHO: c->verbose_ortho = value; break;
+    case DLA_OPT_ORTHO_MAXIT:
+      if (value < 1 || value > 10) return fail(c, DLA_ERR_ARG, "ortho maxit must be 1..10");
+      c->eng->ortho_maxit = value;
+      break;
+    case DLA_OPT_CALLBACK_ORDER:
+      if (value < 0 || value > 2) return fail(c, DLA_ERR_ARG, "callback order must be 0, 1 or 2");
+      c->callback_order = value;
+      break;
     default:
       if (option >= DLA_OPT_TUNE0 && option < DLA_OPT_TUNE0 + 8) { c->eng->set_tune(option - DLA_OPT_TUNE0, value); break; }
       return fail(c, DLA_ERR_ARG, "unknown option");
@@ -132,6 +139,8 @@ int dla_get_option(dla_ctx* c, int option)
     case DLA_OPT_EVEC_ON_DEVICE: return c->evec_on_device;
     case DLA_OPT_PROFILE: return c->eng->profile ? 1 : 0;
     case DLA_OPT_VERBOSE_ORTHO: return c->verbose_ortho;
+    case DLA_OPT_CALLBACK_ORDER: return c->callback_order;
+    case DLA_OPT_ORTHO_MAXIT: return c->eng->ortho_maxit;
     default: return -1;
   }
 }
@@ -286,7 +295,13 @@ int dla_nrm2(dla_ctx* c, size_t len, const double* x, double* out)
   return DLA_OK;
 }
 
-int dla_random_fill(dla_ctx* c, int n, int m, double* evec) { return engfail(c, c->eng->random_fill(n, m, evec, c->row0)); }
+int dla_random_fill(dla_ctx* c, int n, int m, double* evec) { return engfail(c, c->eng->random_fill(n, m, evec, c->row0, 7ULL, 0.0, 0)); }
+
+// benchmark guess (b) of SURVEY 8d: uniform [-0.5, 0.5) from the documented counter-based generator, GLOBAL row indices
+int dla_fill_guess(dla_ctx* c, int n, int m, double* evec, unsigned long long seed, long long support_rows)
+{
+  return engfail(c, c->eng->random_fill(n, m, evec, c->row0, seed, -0.5, support_rows));
+}
 
 // ------------------------------------------------------------------ orthogonalisation
 // ortho_cd, diaglib.f90:3185-3341.  The reference's macro-iteration is: Gram sweep, host Cholesky /
@@ -310,6 +325,7 @@ static int ortho_cd_impl(dla_ctx* c, int n, int k, double* u, double* growth, in
   if (have_g) gnext.assign(g_in, g_in + (size_t)k * k);
   int it = 0;
   bool macro_done = false;
+  const int kMaxIt = c->eng->ortho_maxit;    // maxit, diaglib.f90:3224
   while (!macro_done) {
     if (++it > kMaxIt) {
       // reference prints and returns with ok=.false. (:3252-3254)
@@ -380,6 +396,22 @@ static int ortho_cd_impl(dla_ctx* c, int n, int k, double* u, double* growth, in
 int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
 {
   DLA_T("dla_ortho_cd");
+  if (k > 0) {
+    dla::OrthoReport rep;
+    int stc = c->eng->ortho_chain(n, 0, k, nullptr, nullptr, u, &rep);
+    if (stc) return engfail(c, stc);
+    if (rep.handled) {
+      *growth = rep.growth;
+      *ok = rep.status == 1;
+      if (c->verbose_ortho) std::printf("  [dla] ortho_cd (device chain): %d macro iterations, growth %.3e\n", rep.macro_its, rep.growth);
+      if (rep.status == 2) std::printf("  ortho_cd failed with the following error: maximum number of iterations reached.\n");
+      if (rep.status == 3) {
+        std::printf("  ortho_cd failed with the following error: maximum number of iterations for factorization reached.\n");
+        return fail(c, DLA_ERR_ORTHO, "ortho_cd: factorization failed after level shifting");
+      }
+      return DLA_OK;
+    }
+  }
   return ortho_cd_impl(c, n, k, u, growth, ok, nullptr);
 }
 
@@ -413,6 +445,25 @@ static int ortho_fallback(dla_ctx* c, int n, int k, double* u)
 static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, const double* bx, double* u)
 {
   if (k <= 0) return DLA_OK;
+  const int kMaxIt = c->eng->ortho_maxit;    // maxit, diaglib.f90:3521
+  // device-driven chain first (one host wait per call); shapes / modes it does not take run the host-driven loop below
+  {
+    dla::OrthoReport rep;
+    int stc = c->eng->ortho_chain(n, m, k, x, bx, u, &rep);
+    if (stc) return engfail(c, stc);
+    if (rep.handled) {
+      if (c->verbose_ortho)
+        std::printf("  [dla] ortho_vs_x (device chain): %d outer iterations, %d macro iterations, status %d\n", rep.outer_its,
+                    rep.macro_its, rep.status);
+      if (rep.status == 1) return DLA_OK;
+      if (rep.status == 3) {
+        std::printf("  ortho_cd failed with the following error: maximum number of iterations for factorization reached.\n");
+        return fail(c, DLA_ERR_ORTHO, "ortho_cd: factorization failed after level shifting");
+      }
+      // ortho_cd or the outer loop ran out of iterations on the device: U holds an intermediate (same span); the
+      // host-driven loop below takes over from it, including the QR fallback (reference :3534, :3549)
+    }
+  }
   int ok = 0, it = 0;
   bool done = false;
   double growth = 1.0, xu_norm;
@@ -599,7 +650,7 @@ struct CoeffAlgebra final : dla::Engine {
     *out = acc;
     return DLA_OK;
   }
-  int random_fill(int, int, double*, long long) override { return DLA_ERR_ARG; }
+  int random_fill(int, int, double*, long long, unsigned long long, double, long long) override { return DLA_ERR_ARG; }
   int synth_setup(long long, long long, int, int, double) override { return DLA_ERR_ARG; }
   int synth_matvec(int, int, const double*, double*) override { return DLA_ERR_ARG; }
   int synth_precnd(int, int, double, const double*, double*) override { return DLA_ERR_ARG; }
@@ -655,8 +706,12 @@ int dla_call_matvec(dla_ctx* c, dla_matvec_fn fn, int n, int m, const double* x,
   DLA_T("dla_call_matvec");
   if (m <= 0) return DLA_OK;
   if (c->callbacks_on_device) {
+    // the built-in operator runs on the engine's own stream: nothing to order
+    const int order = ((void*)fn == (void*)&dla_synth_matvec) ? 2 : c->callback_order;
+    int st = c->eng->callback_begin(order);
+    if (st) return engfail(c, st);
     fn(&n, &m, x, ax);
-    return DLA_OK;
+    return engfail(c, c->eng->callback_end(order));
   }
   size_t bytes = sizeof(double) * (size_t)n * m;
   int st = ensure_stage(c, bytes);
@@ -673,8 +728,11 @@ int dla_call_precnd(dla_ctx* c, dla_precnd_fn fn, int n, int m, double fac, cons
   DLA_T("dla_call_precnd");
   if (m <= 0) return DLA_OK;
   if (c->callbacks_on_device) {
+    const int order = ((void*)fn == (void*)&dla_synth_precnd) ? 2 : c->callback_order;
+    int st = c->eng->callback_begin(order);
+    if (st) return engfail(c, st);
     fn(&n, &m, &fac, x, px);
-    return DLA_OK;
+    return engfail(c, c->eng->callback_end(order));
   }
   size_t bytes = sizeof(double) * (size_t)n * m;
   int st = ensure_stage(c, bytes);
@@ -694,8 +752,10 @@ int dla_call_lrprec(dla_ctx* c, dla_lrprec_fn fn, int n, int m, double fac, cons
   DLA_T("dla_call_lrprec");
   if (m <= 0) return DLA_OK;
   if (c->callbacks_on_device) {
+    int st = c->eng->callback_begin(c->callback_order);
+    if (st) return engfail(c, st);
     fn(&n, &m, &fac, xp, xm, yp, ym);
-    return DLA_OK;
+    return engfail(c, c->eng->callback_end(c->callback_order));
   }
   const size_t bytes = sizeof(double) * (size_t)n * m;
   int st = ensure_stage(c, 2 * bytes);

@@ -288,8 +288,9 @@ contains
     call c_f_pointer(msg, cm, [ln])
     write(6,'(t3,a,a,a,i4)') 'diaglib_amd: ', what, ' failed with status ', st
     write(6,'(t3,200a1)') (cm(i), i = 1, min(ln,200))
-    if (st.eq.5) stop ' catastrophic failure of ortho_vs_x'
-    stop
+!   a non-zero exit status: a plain `stop` would let a solve that died on a GPU error look successful to a launcher
+    if (st.eq.5) write(6,'(a)') ' catastrophic failure of ortho_vs_x'
+    error stop 1
   end subroutine chk
 !
   subroutine get_time(t)

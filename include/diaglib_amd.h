@@ -59,6 +59,20 @@ enum {
                                       1: evec is a device address (guess in, Ritz vectors out), eig stays host  */
   DLA_OPT_PROFILE = 3,             /* 1: bracket every kernel launch with HIP events (dla_get_stats)          */
   DLA_OPT_VERBOSE_ORTHO = 4,       /* 1: print ortho_cd/ortho_vs_x pass counts                                 */
+  DLA_OPT_CALLBACK_ORDER = 5,      /* ordering contract of DEVICE-mode callbacks against the engine's stream (which is a
+                                      non-blocking stream, dla_stream()):
+                                      1 (default): host-synchronised -- the engine's stream is drained before the call
+                                         and the whole device after it: correct for callbacks on ANY stream (hipfort,
+                                         OpenMP target, torch, private streams) that do not synchronise themselves.
+                                      0: stream-ordered, no host wait -- before the call the legacy null stream is made
+                                         to wait for the engine's pending work, after the call the engine's stream
+                                         waits for everything the callback enqueued on the null stream.  For callbacks
+                                         that launch on the null stream only.
+                                      2: none -- the callback promises to enqueue on dla_stream() only (the built-in
+                                         operator does; it is always called this way).                              */
+  DLA_OPT_ORTHO_MAXIT = 6,         /* iteration cap of ortho_cd / ortho_vs_x (reference parameter maxit = 10,
+                                      diaglib.f90:3224,3521).  TEST knob: a small value makes ortho_cd give up so that
+                                      the Householder-QR fallback `ortho` (diaglib.f90:3052-3092, 3534, 3549) runs */
   DLA_OPT_TUNE0 = 100              /* 100..107: kernel-shape experiment knobs for the interleaved A/B tools
                                       (tools/tune_*.py, tools/kernel_bench.py); 0 = the shipped default          */
 };
@@ -164,6 +178,13 @@ int  dla_nrm2(dla_ctx* ctx, size_t len, const double* x_dev, double* out);
 /* fill evec(n x m) with the documented counter-based uniform [0,1) stream (replaces the
  * compiler-specific random_number at diaglib.f90:3754). */
 int  dla_random_fill(dla_ctx* ctx, int n, int m, double* evec_dev);
+/* evec(i,j) = u01(seed, global row i, j) - 0.5: the "hard" benchmark guess (SURVEY.md 8d guess (b), seed 2); the role of
+ * guess_evec mode 4 in the reference harness (main.f90:1362-1367), with a generator that does not depend on the compiler.
+ * support_rows > 0 restricts the random entries to the leading support_rows GLOBAL rows (zero below): on the benchmark
+ * operator (diagonal 2..n+1) a guess spread over all of n >= 1e6 rows starts at Rayleigh quotients ~n/2 and needs
+ * thousands of iterations (measured: 400 iterations at n = 1e7 leave the lowest Ritz value at 4.4e6), so the large
+ * restart/locking runs confine it to as many rows as the reference's own toy problem has (main.f90:14: n = 1000..2000). */
+int  dla_fill_guess(dla_ctx* ctx, int n, int m, double* evec_dev, unsigned long long seed, long long support_rows);
 
 /* ---------------------------------------------------------------- orthogonalisation */
 int  dla_ortho_cd(dla_ctx* ctx, int n, int k, double* u_dev, double* growth, int* ok);      /* diaglib.f90:3185-3341 */

@@ -113,11 +113,12 @@ struct HostSimEngine : dla::Engine {
     *out = s;
     return st;
   }
-  int random_fill(int n, int m, double* evec, long long row0) override
+  int random_fill(int n, int m, double* evec, long long row0, unsigned long long seed, double offset, long long support_rows) override
   {
     for (int j = 0; j < m; ++j)
       for (int i = 0; i < n; ++i)
-        evec[(size_t)j * n + i] = orc_u01(7ULL, (unsigned long long)(row0 + i + 1), (unsigned long long)(j + 1));
+        evec[(size_t)j * n + i] = (support_rows <= 0 || row0 + i < support_rows)
+                                      ? orc_u01(seed, (unsigned long long)(row0 + i + 1), (unsigned long long)(j + 1)) + offset : 0.0;
     return 0;
   }
   int synth_setup(long long n_global, long long row0, int n_local, int rank_w, double sigma) override

@@ -199,6 +199,20 @@ class Oracle:
     def u01(self, seed, i, j):
         return float(self.lib.orc_u01(seed, i, j))
 
+    @staticmethod
+    def guess_u01(seed, n, m, row0=0, offset=-0.5):
+        """n x m block of orc_u01(seed, row0+i+1, j+1) + offset, vectorised restatement of oracle.c:orc_u01
+        (64-bit wrap-around arithmetic); SURVEY 8d guess (b) is seed 2, offset -0.5."""
+        with np.errstate(over="ignore"):
+            i = (np.arange(n, dtype=np.uint64) + np.uint64(row0 + 1))[:, None]
+            j = (np.arange(m, dtype=np.uint64) + np.uint64(1))[None, :]
+            z = np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + i * np.uint64(0xBF58476D1CE4E5B9) \
+                + j * np.uint64(0x94D049BB133111EB)
+            z ^= z >> np.uint64(30); z *= np.uint64(0xBF58476D1CE4E5B9)
+            z ^= z >> np.uint64(27); z *= np.uint64(0x94D049BB133111EB)
+            z ^= z >> np.uint64(31)
+        return np.asfortranarray((z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0) + offset)
+
     # ---- drivers
     def _mk_trace(self, max_iter, n_targ):
         t = Trace(n_act=np.zeros(max_iter, np.int32), ldu=np.zeros(max_iter, np.int32),

@@ -118,7 +118,9 @@ def _rand_panel(ctx, n, m):
     return p
 
 
-@pytest.mark.parametrize("n,l,k", [(500_000, 260, 13), (2_000_000, 39, 13)])
+@pytest.mark.parametrize("n,l,k", [(500_000, 260, 13), (2_000_000, 39, 13),
+                                   (2_000_000, 420, 21),      # BASELINE cfg 4: lda = 20 blocks of n_max = 21
+                                   (10_000_000, 111, 37)])    # BASELINE cfg 5: [X | P | W] of n_max = 37
 def test_full_size_block_algebra_properties(ctx, n, l, k):
     x, u1, u2 = _rand_panel(ctx, n, l), _rand_panel(ctx, n, k), ctx.panel(n, k)
     # u2 = u1 + 0.5 * (X C): linearity of the Gram kernel in U
@@ -141,22 +143,45 @@ def test_full_size_block_algebra_properties(ctx, n, l, k):
     assert np.abs(ctx.gram(x, u2) - before).max() < 50 * EPS
 
 
-@pytest.mark.parametrize("solver,n", [("davidson", 500_000), ("lobpcg", 2_000_000)])
-def test_full_size_solve_residual(ctx, solver, n):
-    """BASELINE cfg 2 (Davidson n=5e5) and cfg 3 (LOBPCG n=2e6), 8 roots, n_max=13: the returned pairs
-    satisfy ||A x - lambda x||_2 / |lambda| <= 1e-10 (north star) and X^T X = I."""
-    t, m = 8, 13
+def _unit_guess_panel(ctx, n, m):
+    ev = ctx.panel(n, m).zero()
+    top = np.zeros((m, m), order="F"); np.fill_diagonal(top, 1.0)
+    # e_1..e_m without a host array of n x m: zero on the device, then the leading m x m block column by column
+    for j in range(m):
+        ctx._chk(ctx.lib.dla_upload(ctx.h, ev.ptr + 8 * n * j, top[:, j].ctypes.data, 8 * m))
+    return ev
+
+
+@pytest.mark.parametrize("solver,n,t,m,max_dav,guess", [
+    ("davidson", 500_000, 8, 13, 20, "unit"),        # BASELINE cfg 2
+    ("lobpcg", 2_000_000, 8, 13, 20, "unit"),        # cfg 3
+    ("davidson", 2_000_000, 16, 21, 20, "unit"),     # cfg 4 (one GPU holds what the 8-GPU config shards: 2 x 6.7 GB panels)
+    ("lobpcg", 10_000_000, 32, 37, 20, "unit"),      # cfg 5 (3 basis panels of 8.9 GB, kept twice)
+    ("davidson", 10_000_000, 32, 37, 10, "seed2"),   # cfg 5 "restart / thick-restart stress" (SURVEY 8d): max_dav = 10,
+])                                                   # seed-2 random guess on the leading 6000 rows (dla_fill_guess)
+def test_full_size_solve_residual(ctx, solver, n, t, m, max_dav, guess):
+    """BASELINE cfg 2-5 at full size on the device operator: the returned pairs satisfy
+    ||A x - lambda x||_2 / |lambda| <= 1e-10 (north star), X^T X = I, X^T A X = diag(eig); the restart-stress
+    leg must restart at least twice with locked roots (reference diaglib.f90:1795-1825)."""
     ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
     try:
         ctx.synth_setup(n, 0, n)
-        g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
-        ev = ctx.panel(g)
-        mv, pc = capi.fn_address("dla_synth_matvec"), capi.fn_address("dla_synth_precnd")
-        if solver == "davidson":
-            eig, _, ok, info = ctx.davidson_driver(n, t, m, 200, 1e-13, 20, 0.0, mv, pc, ev)
+        if guess == "unit":
+            ev = _unit_guess_panel(ctx, n, m)
         else:
-            eig, _, ok, info = ctx.lobpcg_driver(n, t, m, 200, 1e-13, 0.0, mv, pc, ev)
+            ev = ctx.panel(n, m); ctx.fill_guess(ev, 2, support_rows=6000)
+        mv, pc = capi.fn_address("dla_synth_matvec"), capi.fn_address("dla_synth_precnd")
+        # reference tolerance semantics (rms < tol, max < 10 tol, diaglib.f90:1741); at n = 1e7 the rounding floor of
+        # max|r| sits at ~1e-12, so the tightest tolerance that still converges is the benchmark's 2e-13
+        tol = 1e-13 if n < 10_000_000 else 2e-13
+        if solver == "davidson":
+            eig, _, ok, info = ctx.davidson_driver(n, t, m, 400, tol, max_dav, 0.0, mv, pc, ev)
+        else:
+            eig, _, ok, info = ctx.lobpcg_driver(n, t, m, 400, tol, 0.0, mv, pc, ev)
         assert ok, info
+        if guess != "unit":
+            assert info["restarts"] >= 2, info
+        assert np.all(np.diff(eig[:t]) > 0)
         ax = ctx.panel(n, m)
         ctx.synth_matvec(ev, ax)
         xt = ev.col(0, t)
@@ -168,8 +193,40 @@ def test_full_size_solve_residual(ctx, solver, n):
         rn = ctx.ritz_residual(xt, ax.col(0, t), np.eye(t), eig[:t], t, np.zeros(t, np.int32), e2, r)
         rel = rn[0, :] * np.sqrt(n) / np.abs(eig[:t])
         assert rel.max() <= 1e-10, rel
+        for p_ in (r, e2, ax, ev):
+            p_.free()
     finally:
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.trim()                       # hand the multi-GB panels back before the next case
+
+
+def test_restart_stress_cfg5_width_vs_oracle(ctx, oracle):
+    """SURVEY 8d restart stress at an oracle-sized n: Davidson, 32 roots, n_max = 37, max_dav = 10, the seed-2 random
+    guess, device callbacks -> several restarts with locked roots (reference diaglib.f90:1795-1825 incl. the
+    n_rst zero-column quirk, :1696-1702 diagonal patch).  Eigenpairs against the oracle; iteration / restart
+    counts within the documented 10 % (random guess: counts depend on last-bit differences of the Gram sums)."""
+    n, t, m, max_dav, tol = 6000, 32, 37, 10, 1e-10
+    g = oracle.guess_u01(2, n, m)
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+    try:
+        ctx.synth_setup(n, 0, n); oracle.synth_setup(n, 0, n)
+        ev = ctx.panel(n, m); ctx.fill_guess(ev, 2)
+        assert np.array_equal(ev.download(), g)                    # device generator == oracle generator, bit for bit
+        eig, _, ok, info = ctx.davidson_driver(n, t, m, 600, tol, max_dav, 0.0, capi.fn_address("dla_synth_matvec"),
+                                               capi.fn_address("dla_synth_precnd"), ev)
+        vec = ev.download()
+    finally:
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+    eo, vo, oko, tr = oracle.davidson(n, t, m, 600, tol, max_dav, 0.0, oracle.fn("orc_synth_matvec"),
+                                      oracle.fn("orc_synth_precnd"), g)
+    assert ok and oko, (info, tr.iters)
+    assert info["restarts"] >= 2 and tr.restarts >= 2, (info, tr.restarts)
+    assert abs(info["iters"] - tr.iters) <= max(1, tr.iters // 10), (info, tr.iters)
+    assert abs(info["restarts"] - tr.restarts) <= 1
+    assert np.allclose(eig[:t], eo[:t], rtol=1e-10, atol=0)
+    sgn = np.sign((vec[:, :t] * vo[:, :t]).sum(0))
+    assert np.abs(vec[:, :t] * sgn - vo[:, :t]).max() < 1e-5
+    assert np.abs(vec[:, :t].T @ vec[:, :t] - np.eye(t)).max() < 1e-11
 
 
 def test_gen_davidson_restart_keeps_metric_block(ctx, oracle, rng):

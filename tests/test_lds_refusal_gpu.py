@@ -1,0 +1,43 @@
+"""GPU: a refused request for more than 64 KiB of dynamic LDS is not swallowed: the launch is not
+made, the engine drops to its 64 KiB shapes and redoes the operation.  Runs in a process of its own because the
+refusal is forced through $DIAGLIB_AMD_FORCE_LDS_REFUSAL at engine creation and lowers the engine's limit for good."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CODE = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from diaglib_amd import capi
+from oracle.pyoracle import Oracle
+o = Oracle(); ctx = capi.Context()
+rng = np.random.default_rng(3)
+n, l, k = 4096, 180, 13
+x = np.asfortranarray(rng.standard_normal((n, l))); u = np.asfortranarray(rng.standard_normal((n, k)))
+px, pu = ctx.panel(x), ctx.panel(u)
+got = ctx.gram(px, pu)                       # 12-tile LDS-staged pass asks for ~117 KiB: refused once, redone narrower
+want = o.gemm_tn(x, u)
+assert np.abs(got - want).max() <= 64 * np.finfo(float).eps * (np.abs(x).T @ np.abs(u)).max(), np.abs(got - want).max()
+# fused update + Gram and the Ritz sweep under the 64 KiB limit
+q, _ = np.linalg.qr(x); pq = ctx.panel(np.asfortranarray(q))
+ctx.ortho_vs_x(pq, pu)
+un = pu.download()
+assert np.abs(q.T @ un).max() < 1e-13 and np.abs(un.T @ un - np.eye(k)).max() < 1e-13
+y = np.asfortranarray(rng.standard_normal((l, k)))
+ev, r = ctx.panel(n, k), ctx.panel(n, k)
+rn = ctx.ritz_residual(px, pq, y, np.arange(1.0, k + 1), k, np.zeros(k, np.int32), ev, r)
+assert np.abs(ev.download() - x @ y).max() < 1e-10
+assert np.abs(r.download() - (q @ y - (x @ y) * np.arange(1.0, k + 1))).max() < 1e-9
+print("refusal handled")
+"""
+
+
+def test_refused_lds_request_is_redone_under_the_limit():
+    env = dict(os.environ, DIAGLIB_AMD_FORCE_LDS_REFUSAL="1")
+    p = subprocess.run([sys.executable, "-c", CODE % ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and "refusal handled" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])

@@ -443,3 +443,62 @@ def test_torch_sparse_operator_as_device_callback(tmp_path):
     script.write_text(TORCH_CB_WORKER.format(root=root))
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("order,side_stream", [(0, False), (1, True)])
+def test_device_callbacks_on_another_stream(ctx, oracle, order, side_stream):
+    """the engine's stream is non-blocking, so a device-mode callback that launches on another stream must
+    be ordered against it (include/diaglib_amd.h DLA_OPT_CALLBACK_ORDER).  order 0: callback on the legacy null stream
+    (torch's default stream) with NO synchronisation of its own; order 1: callback on a private non-blocking stream,
+    again without synchronising.  Both must reproduce the host-callback solve."""
+    import torch
+    n, t, m = 60000, 4, 8
+    oracle.synth_setup(n, 0, n)
+    w = torch.from_numpy(oracle.synth_w()).cuda()
+    d = torch.from_numpy(oracle.synth_diag() - 0.5 * (oracle.synth_w() ** 2).sum(1)).cuda()     # i + 1
+    dg = torch.from_numpy(oracle.synth_diag()).cuda()
+    # the whole callback (operator AND the copy into the output block) runs on torch's current stream: the default
+    # (= legacy null) stream, or a private non-blocking stream made current for the duration of the solve
+    side = torch.cuda.Stream() if side_stream else torch.cuda.default_stream()
+
+    def mv(x):
+        return d[:, None] * x + 0.5 * (w @ (w.T @ x))
+
+    def pc(fac, x):
+        den = dg + fac
+        return torch.where(den.abs()[:, None] > 1e-5, x / den[:, None], x)
+
+    g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
+    eo, vo, oko, tr = oracle.davidson(n, t, m, 100, 1e-10, 20, 0.0, oracle.fn("orc_synth_matvec"),
+                                      oracle.fn("orc_synth_precnd"), g)
+    # torch's lazy initialisation (BLAS handle, workspaces) is not part of the ordering contract
+    xx = torch.zeros(n, m, dtype=torch.float64, device="cuda")
+    mv(xx); pc(1.0, xx); torch.cuda.synchronize()
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+    ctx.set_option(capi.OPT_CALLBACK_ORDER, order)
+    ctx.sync_python_callbacks = False            # rely on the engine's ordering only, like a compiled caller
+    try:
+        ev = ctx.panel(g)
+        with torch.cuda.stream(side):
+            eig, _, ok, info = ctx.davidson_driver(n, t, m, 100, 1e-10, 20, 0.0, mv, pc, ev)
+        vec = ev.download()
+    finally:
+        ctx.sync_python_callbacks = True
+        ctx.set_option(capi.OPT_CALLBACK_ORDER, 1)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+    assert ok and oko
+    assert np.allclose(eig[:t], eo[:t], rtol=1e-11, atol=0)
+    assert abs(info["iters"] - tr.iters) <= 1
+    _cmp_vecs(vec, vo, t, 1e-6)
+
+
+def test_wide_gemm_rejects_aliasing(ctx, rng):
+    """more than 48 output columns are produced 48 at a time, so the output may not alias the input."""
+    n, l = 512, 60
+    x = ctx.panel(np.asfortranarray(rng.standard_normal((n, l))))
+    c = np.asfortranarray(rng.standard_normal((l, 50)))
+    with pytest.raises(capi.DlaError):
+        ctx.panel_gemm(x, c, x.col(0, 50))
+    z = ctx.panel(n, 50)
+    ctx.panel_gemm(x, c, z)
+    assert np.abs(z.download() - x.download() @ c).max() < 1e-11
