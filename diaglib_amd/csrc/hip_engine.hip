@@ -363,81 +363,6 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
     }
 }
 
-// second stage: sum the block partials in a fixed order and scatter into column-major C (ld = l).
-// One launch, two levels: block (ps, grp) sums its share of the partials into lvl2[ps][grp]; the
-// block that draws the last ticket for ps adds the `groups` level-2 rows in index order (so the
-// result does not depend on arrival order) and writes C to the device buffer and to its pinned
-// host mirror.  Hand-off = agent-scope release / acquire around a relaxed ticket
-// (cdna_hip_programming.md guideline 16); the ticket is reset by its last arriver.
-struct GramReduceArgs {
-  const double* partial;
-  double* lvl2;        // [passes*slots][groups][256]
-  unsigned* ticket;    // [passes*slots], zero between launches
-  double* c;           // l x k, ld = l (device)
-  double* c_host;      // same, pinned host mirror (device-visible address)
-  int nblk, l, k, tlw, kt, passes_x;
-  const int* phase;
-  int want;
-};
-
-__global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
-{
-  DLA_PREDICATED(a);
-  const int slots = a.tlw * a.kt;
-  const int ps = blockIdx.x, grp = blockIdx.y, G = gridDim.y;
-  const int pass = ps / slots, slot = ps % slots;
-  const int e = threadIdx.x;
-  const double* p = a.partial + ((size_t)pass * a.nblk) * (size_t)slots * 256 + (size_t)slot * 256 + e;
-  const int per = (a.nblk + G - 1) / G;
-  const int b0 = grp * per, b1 = min(a.nblk, b0 + per);
-  // loads are issued in batches of 8 (independent), the adds stay in index order
-  double s = 0.0;
-  int b = b0;
-  for (; b + 8 <= b1; b += 8) {
-    double v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + q) * slots * 256];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s += v[q];
-  }
-  for (; b < b1; ++b) s += p[(size_t)b * slots * 256];
-  a.lvl2[((size_t)ps * G + grp) * 256 + e] = s;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  __shared__ int s_last;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(&a.ticket[ps], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == (unsigned)(G - 1));
-    if (last) {
-      __hip_atomic_store(&a.ticket[ps], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  double tot = 0.0;
-  {
-    double v[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = (q < G) ? a.lvl2[((size_t)ps * G + q) * 256 + e] : 0.0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) tot += v[q];   // G <= 16; padding zeros do not change the sum
-  }
-  const int xg = pass % a.passes_x, ug = pass / a.passes_x;
-  const int t = slot / a.kt, q = slot % a.kt;
-  const int reg = e >> 6, lane = e & 63;
-  const int xcol = (xg * a.tlw + t) * 16 + (lane >> 4) + 4 * reg;
-  const int ucol = (ug * a.kt + q) * 16 + (lane & 15);
-  if (xcol < a.l && ucol < a.k) {
-    a.c[(size_t)xcol + (size_t)ucol * a.l] = tot;
-    a.c_host[(size_t)xcol + (size_t)ucol * a.l] = tot;
-  }
-}
-
 // ======================================================================================
 // Panel products along rows:  Z = X C  |  Z -= X C  |  U <- U W (in place)
 // ======================================================================================
@@ -1021,13 +946,11 @@ struct OrthoDev {
   int phase;          // the sweep the state machine waits for (OP_*)
   int status;         // OST_*
   int it_macro;       // macro-iterations of the current ortho_cd pass
-  int it_outer;       // outer iterations of ortho_vs_x
-  int force_defer;    // the ortho_cd that precedes the loop always leaves its last W pending (it is folded into the projection)
-  int can_defer;      // 1: ortho_vs_x on the block that follows X (combined sweep available); 0: plain ortho_cd
+  int it_outer;       // outer iterations of ortho_vs_x (0: still in the ortho_cd that precedes the loop)
   int nops;           // sweeps executed so far
   int macro_total;    // macro-iterations over all ortho_cd passes (report)
   int shifts;         // level shifts taken (report)
-  int maxit;          // maxit, diaglib.f90:3224,3521
+  int pad_;
   double growth;      // prod ||L^-1||_est of the current ortho_cd pass
   int log[48];        // the sweeps executed, in order
 };
@@ -1041,191 +964,357 @@ struct OrthoTailArgs {
   double* cpk;         // packed C' = [-xu W ; W]: [kt][l4][16], l = m + k
   int after;           // the sweep this tail follows
   int m, k;
+  int can_defer;       // 1: ortho_vs_x on the block that follows X (combined sweep available); 0: plain ortho_cd
+  int maxit;           // maxit, diaglib.f90:3224,3521
+  int publish;         // 1: last launch of the host's plan -- leave the state in the host mirror whatever happened
 };
 
-#define TLD 49   // row stride of the k x k LDS images (k <= 48)
-
-// lower Cholesky factor in place (row-major LDS image), same operation order as the host routine (smalldense.cpp
-// dla_potrf_lower: left-looking, dot products in ascending index order); all 256 threads call it
-__device__ int tail_potrf(int k, double* A)
+// The k x k work is done by ONE wave on LDS images (row-major, row stride TLD): lane i owns row i (k <= 48 < 64).  LDS
+// operations of a wave complete in order, so no workgroup barrier is needed (the routine can run at the end of a kernel
+// whose other waves have already left); TSYNC keeps the compiler from moving LDS accesses across the points where
+// lanes exchange data.  The code is deliberately compact (loops, not unrolled matrices): it runs once per launch, from
+// a cold instruction cache, and a fully unrolled register version measured slower for that reason.  Operation order =
+// the host routines (smalldense.cpp dla_potrf_lower / dla_trtri_lower): dot products in ascending index order.
+#define TLD 49
+#define TSYNC() __builtin_amdgcn_wave_barrier()
+__device__ __forceinline__ double rlane(double v, int src)      // src: wave-uniform
 {
-  const int tid = threadIdx.x;
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// lower Cholesky factor in place; returns 0 or the (1-based) index of the first non-positive pivot
+__device__ __forceinline__ int lds_potrf(int k, double* A, int lane)
+{
+  const int i = lane < k ? lane : k - 1;                // idle lanes shadow the last row (no stores)
   for (int j = 0; j < k; ++j) {
-    __syncthreads();
-    double dj = A[j * TLD + j];
-    for (int p = 0; p < j; ++p) dj -= A[j * TLD + p] * A[j * TLD + p];
-    if (!(dj > 0.0) || !isfinite(dj)) return j + 1;     // uniform: every thread computed the same dj
+    TSYNC();
+    // s = a_ij - sum_{p<j} l_ip l_jp for every row i >= j at once; row j itself yields the pivot
+    double sij = lds_load1(A + i * TLD + j);
+#pragma unroll 4
+    for (int p = 0; p < j; ++p) sij -= lds_load1(A + i * TLD + p) * lds_load1(A + j * TLD + p);
+    double dj = rlane(sij, j);
+    if (!(dj > 0.0) || !isfinite(dj)) return j + 1;
     dj = sqrt(dj);
     const double inv = 1.0 / dj;
-    const int i = j + 1 + tid;
-    double sij = 0.0;
-    if (i < k) {
-      sij = A[i * TLD + j];
-      for (int p = 0; p < j; ++p) sij -= A[i * TLD + p] * A[j * TLD + p];
-    }
-    __syncthreads();                                    // row j has been read by everyone
-    if (i < k) A[i * TLD + j] = sij * inv;
-    if (tid == 0) A[j * TLD + j] = dj;
+    TSYNC();                                            // row j has been read by everyone
+    if (lane < k && lane > j) lds_store1(A + lane * TLD + j, sij * inv);
+    if (lane == j) lds_store1(A + j * TLD + j, dj);
   }
-  __syncthreads();
+  TSYNC();
   return 0;
 }
 
-// inverse of a lower triangular matrix in place, column by column from the right (dla_trtri_lower)
-__device__ void tail_trtri(int k, double* A)
+// inverse of a lower triangular matrix in place, column by column from the right
+__device__ __forceinline__ void lds_trtri(int k, double* A, int lane)
 {
-  const int tid = threadIdx.x;
+  const int i = lane < k ? lane : k - 1;
   for (int j = k - 1; j >= 0; --j) {
-    __syncthreads();
-    const double xj = 1.0 / A[j * TLD + j];
-    const int i = j + 1 + tid;
-    double xi = 0.0;
-    if (i < k) {
-      double sacc = 0.0;
-      for (int p = j + 1; p <= i; ++p) sacc += A[i * TLD + p] * A[p * TLD + j];
-      xi = -sacc * xj;
-    }
-    __syncthreads();
-    if (i < k) A[i * TLD + j] = xi;
-    if (tid == 0) A[j * TLD + j] = xj;
+    TSYNC();
+    const double xj = 1.0 / lds_load1(A + j * TLD + j);
+    double sacc = 0.0;
+#pragma unroll 4
+    for (int p = j + 1; p <= i; ++p) sacc += lds_load1(A + i * TLD + p) * lds_load1(A + p * TLD + j);
+    TSYNC();
+    if (lane < k && lane > j) lds_store1(A + lane * TLD + j, -sacc * xj);
+    if (lane == j) lds_store1(A + j * TLD + j, xj);
   }
-  __syncthreads();
+  TSYNC();
 }
 
-// norm_est (diaglib.f90:3447-3479): max |a_ii| + Frobenius norm of the strictly lower part; rows in parallel, the
-// row sums added in row order by every thread (uniform result)
-__device__ double tail_norm_est(int k, const double* A, double* rowsum)
+// norm_est (diaglib.f90:3447-3479): max |a_ii| + Frobenius norm of the strictly lower part; rows in parallel, then the
+// row sums in row order (every lane computes the same result)
+__device__ __forceinline__ double lds_norm_est(int k, const double* A, int lane)
 {
-  const int tid = threadIdx.x;
-  __syncthreads();
-  if (tid < k) {
-    double on = 0.0;
-    for (int j = 0; j < tid; ++j) on += A[tid * TLD + j] * A[tid * TLD + j];
-    rowsum[tid] = on;
+  TSYNC();
+  double on_i = 0.0, diag = 0.0;
+  if (lane < k) {
+#pragma unroll 4
+    for (int j = 0; j < lane; ++j) { const double v = lds_load1(A + lane * TLD + j); on_i += v * v; }
+    diag = fabs(lds_load1(A + lane * TLD + lane));
   }
-  __syncthreads();
   double dn = 0.0, on = 0.0;
-  for (int i = 0; i < k; ++i) { dn = fmax(dn, fabs(A[i * TLD + i])); on += rowsum[i]; }
+  for (int r = 0; r < k; ++r) { dn = fmax(dn, rlane(diag, r)); on += rlane(on_i, r); }
   return dn + sqrt(on);
 }
 
-__global__ __launch_bounds__(256) void ortho_tail_kernel(OrthoTailArgs a)
+struct TailState { int it_macro, it_outer, macro_total, shifts, nops, phase, status; double growth; };
+#define TAIL_LDS_DOUBLES (48 * TLD + 48 * 64)   // image A, then image S (also used as 48 x 64 scratch)
+
+// One step of the state machine, executed by the 64 lanes of one wave; lds: TAIL_LDS_DOUBLES doubles.
+// pre != nullptr: the caller has checked the phase and read the state already (fused into a reduction kernel);
+// g_in_lds: the caller has put the k x k Gram matrix into both LDS images (A and S) already.
+__device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const TailState* pre = nullptr, bool g_in_lds = false)
 {
   OrthoDev* st = a.st;
-  if (st->phase != a.after) return;
-  __shared__ double A[48 * TLD], S[48 * TLD], rowsum[48];
-  const int tid = threadIdx.x, k = a.k, m = a.m;
-  const int kt = (k + 15) / 16;
+  if (pre == nullptr) {
+    const int ph = __hip_atomic_load(&st->phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ph != a.after) {
+      // not this step's turn.  The last launch of a plan still tells the host where the machine stands -- unless the
+      // chain has already ended (a terminal step reported it and re-armed the machine: nops == 0)
+      if (a.publish && lane == 0 && st->nops > 0) *a.st_host = *st;
+      return;
+    }
+  }
+  const int k = a.k, m = a.m;
+  const int kt = (k + 15) / 16, k4 = ((k + 3) / 4) * 4;
   const double eps = 2.220446049250313e-16, tol = 2.0 * eps;   // epsilon(one), tol_ortho (diaglib.f90:151)
-  // the state as this step found it (thread 0 rewrites it at the end, after the last barrier)
-  const int maxit = st->maxit, can_defer = st->can_defer, force_defer = st->force_defer;
-  int it_macro = st->it_macro, it_outer = st->it_outer, nops = st->nops, macro_total = st->macro_total, shifts = st->shifts;
-  double growth = st->growth;
-  int phase = OP_NONE, status = OST_RUNNING;
+  const int maxit = a.maxit, can_defer = a.can_defer;
+  TailState t = pre ? *pre : TailState{st->it_macro, st->it_outer, st->macro_total, st->shifts, st->nops, OP_NONE, OST_RUNNING, st->growth};
+  const int force_defer = can_defer && t.it_outer == 0;   // the ortho_cd that precedes the loop always leaves W pending
+  double* A = lds;
+  double* S = lds + 48 * TLD;
 
   if (a.after == OP_FINAL) {
-    status = OST_DONE;
+    t.status = OST_DONE;
   } else if (a.after == OP_XU) {
     // C' = [-(xu W) ; W]  (host_logic.cpp ortho_vs_x_impl, X^T (U W) = (X^T U) W), packed for the combined sweep
     const int l = m + k, l4 = ((l + 3) / 4) * 4;
-    for (int idx = tid; idx < kt * l4 * 16; idx += 256) {
+    for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx % k) * TLD + idx / k, a.wfull[idx]);   // A[pp][j] = W(pp, j)
+    TSYNC();
+    // rows that are not products: the W block, the zero padding of rows and columns
+    for (int idx = lane; idx < kt * l4 * 16; idx += 64) {
       const int q = idx / (l4 * 16), p = (idx / 16) % l4, j = 16 * q + (idx % 16);
-      double v = 0.0;
-      if (j < k) {
-        if (p < m) {
-          double sacc = 0.0;
-          for (int pp = 0; pp <= j; ++pp) sacc += a.gsrc[(size_t)p + (size_t)pp * m] * a.wfull[pp + j * k];
-          v = -sacc;
-        } else if (p < l) {
-          v = a.wfull[(p - m) + j * k];
-        }
-      }
-      a.cpk[idx] = v;
+      if (p >= m || j >= k) a.cpk[idx] = (p < l && j < k) ? lds_load1(A + (p - m) * TLD + j) : 0.0;
     }
-    it_macro = 0;           // the ortho_cd that follows the combined sweep starts afresh (*growth = 1, it = 0)
-    growth = 1.0;
-    phase = OP_COMBO;
+    for (int p = lane; p < m; p += 64) {
+      // row p of xu into the lane's own LDS row (the S image is free here), then the k dot products
+      for (int pp = 0; pp < k; ++pp) lds_store1(S + pp * 64 + lane, a.gsrc[(size_t)p + (size_t)pp * m]);
+      for (int j = 0; j < k; ++j) {
+        double sacc = 0.0;
+#pragma unroll 4
+        for (int pp = 0; pp <= j; ++pp) sacc += lds_load1(S + pp * 64 + lane) * lds_load1(A + pp * TLD + j);
+        a.cpk[((size_t)(j / 16) * l4 + p) * 16 + (j % 16)] = -sacc;
+      }
+    }
+    t.it_macro = 0;           // the ortho_cd that follows the combined sweep starts afresh (*growth = 1, it = 0)
+    t.growth = 1.0;
+    t.phase = OP_COMBO;
   } else {
     // one macro-iteration of ortho_cd on the Gram matrix the sweep left in gsrc
-    ++it_macro;
-    if (it_macro > maxit) {
-      status = OST_CD_MAXIT;                                  // :3252-3254, the host prints and reports ok = .false.
+    ++t.it_macro;
+    if (t.it_macro > maxit) {
+      t.status = OST_CD_MAXIT;                                  // :3252-3254, the host prints and reports ok = .false.
     } else {
-      ++macro_total;
-      for (int idx = tid; idx < k * k; idx += 256) {
-        const int i = idx % k, j = idx / k;
-        if (i >= j) { const double v = a.gsrc[(size_t)i + (size_t)j * k]; A[i * TLD + j] = v; S[i * TLD + j] = v; }
+      ++t.macro_total;
+      if (!g_in_lds) {
+        for (int idx = lane; idx < k * k; idx += 64) {
+          const int i = idx % k, j = idx / k;
+          if (i >= j) { const double v = a.gsrc[(size_t)i + (size_t)j * k]; lds_store1(A + i * TLD + j, v); lds_store1(S + i * TLD + j, v); }
+        }
       }
-      int info = tail_potrf(k, A);
+      int info = lds_potrf(k, A, lane);
       if (info != 0) {
         // level-shift ladder (:3265-3295): shift = max(eps alpha ||U||_F, 2 eps), alpha = 100, 1000, ...
         double tr = 0.0;
-        for (int i = 0; i < k; ++i) tr += S[i * TLD + i];
+        for (int i = 0; i < k; ++i) tr += lds_load1(S + i * TLD + i);
         const double unorm = sqrt(tr > 0.0 ? tr : 0.0);
         double alpha = 100.0;
         int it_micro = 0;
         while (info != 0) {
           if (++it_micro > maxit) break;
           const double shift = fmax(eps * alpha * unorm, tol);
-          __syncthreads();
-          for (int idx = tid; idx < k * k; idx += 256) {
+          TSYNC();
+          for (int idx = lane; idx < k * k; idx += 64) {
             const int i = idx % k, j = idx / k;
-            if (i >= j) A[i * TLD + j] = S[i * TLD + j] + (i == j ? shift : 0.0);
+            if (i >= j) lds_store1(A + i * TLD + j, lds_load1(S + i * TLD + j) + (i == j ? shift : 0.0));
           }
-          info = tail_potrf(k, A);
+          info = lds_potrf(k, A, lane);
           alpha *= 10.0;
-          ++shifts;
+          ++t.shifts;
         }
       }
       if (info != 0) {
-        status = OST_FACTOR_FAIL;                             // reference: stop (:3283)
+        t.status = OST_FACTOR_FAIL;                             // reference: stop (:3283)
       } else {
-        __syncthreads();
-        for (int idx = tid; idx < k * k; idx += 256) {
-          const int i = idx % k, j = idx / k;
-          if (i >= j) S[i * TLD + j] = A[i * TLD + j];          // S = L, A becomes L^-1
-        }
-        tail_trtri(k, A);
-        const double l_norm = tail_norm_est(k, S, rowsum);
-        const double linv_norm = tail_norm_est(k, A, rowsum);
-        const double rcond = l_norm * linv_norm;
-        growth *= linv_norm;
-        const bool macro_done = eps * rcond * rcond < tol;      // :3331-3332
+        const double l_norm = lds_norm_est(k, A, lane);
+        lds_trtri(k, A, lane);
+        const double linv_norm = lds_norm_est(k, A, lane);
         // W = L^-T (upper triangular): W(p, j) = Linv(j, p), p <= j
-        const int k4 = ((k + 3) / 4) * 4;
-        for (int idx = tid; idx < k * k; idx += 256) {
-          const int p = idx % k, j = idx / k;
-          a.wfull[idx] = (p <= j) ? A[j * TLD + p] : 0.0;
+        for (int idx = lane; idx < k * k; idx += 64) {
+          const int pp = idx % k, j = idx / k;
+          a.wfull[idx] = (pp <= j) ? lds_load1(A + j * TLD + pp) : 0.0;
         }
-        for (int idx = tid; idx < kt * k4 * 16; idx += 256) {
-          const int q = idx / (k4 * 16), p = (idx / 16) % k4, j = 16 * q + (idx % 16);
-          a.wpk[idx] = (j < k && p <= j) ? A[j * TLD + p] : 0.0;
+        for (int idx = lane; idx < kt * k4 * 16; idx += 64) {
+          const int q = idx / (k4 * 16), pp = (idx / 16) % k4, j = 16 * q + (idx % 16);
+          a.wpk[idx] = (j < k && pp <= j) ? lds_load1(A + j * TLD + pp) : 0.0;
         }
+        const double rcond = l_norm * linv_norm;
+        t.growth *= linv_norm;
+        const bool macro_done = eps * rcond * rcond < tol;      // :3331-3332
         if (!macro_done) {
-          phase = OP_TRMMG;
-        } else if (can_defer && (force_defer || growth * eps >= tol)) {
+          t.phase = OP_TRMMG;
+        } else if (can_defer && (force_defer || t.growth * eps >= tol)) {
           // the pass ends with W pending; ortho_vs_x goes on with a projection pass (xu_norm = growth eps >= tol)
-          if (!force_defer && it_outer > maxit) status = OST_VSX_MAXIT;     // :3568
-          else { ++it_outer; phase = OP_XU; }
+          if (!force_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;     // :3568
+          else { ++t.it_outer; t.phase = OP_XU; }
         } else {
-          if (can_defer && it_outer > maxit) status = OST_VSX_MAXIT;
-          else phase = OP_FINAL;
+          if (can_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;
+          else t.phase = OP_FINAL;
         }
       }
     }
   }
-  __syncthreads();
-  if (tid == 0) {
+  if (lane == 0) {
+    const int ph_out = (t.status == OST_RUNNING) ? t.phase : OP_NONE;
+    const int nops = t.nops;
     if (nops < 48) st->log[nops] = a.after;
-    st->nops = nops + 1;
-    st->it_macro = it_macro; st->it_outer = it_outer; st->macro_total = macro_total; st->shifts = shifts;
-    st->growth = growth;
-    if (a.after != OP_FINAL && a.after != OP_XU && force_defer && phase == OP_XU) st->force_defer = 0;
-    st->status = status;
-    st->phase = (status == OST_RUNNING) ? phase : OP_NONE;
-    __threadfence();
-    *a.st_host = *st;
+    if (t.status != OST_RUNNING || a.publish) {
+      // report to the host: scalars from registers, the log from device memory
+      a.st_host->phase = ph_out; a.st_host->status = t.status; a.st_host->it_macro = t.it_macro;
+      a.st_host->it_outer = t.it_outer; a.st_host->nops = nops + 1; a.st_host->macro_total = t.macro_total;
+      a.st_host->shifts = t.shifts; a.st_host->growth = t.growth;
+      const int nl = nops + 1 < 48 ? nops + 1 : 48;
+      for (int q = 0; q < nl; ++q) a.st_host->log[q] = (q == nops) ? a.after : st->log[q];
+    }
+    if (t.status != OST_RUNNING) {
+      // finished (or failed): re-arm the machine for the next chain, so that no initial state has to be copied in
+      st->it_macro = 0; st->it_outer = 0; st->nops = 0; st->macro_total = 0; st->shifts = 0; st->growth = 1.0;
+      st->status = OST_RUNNING;
+      __hip_atomic_store(&st->phase, (int)OP_GRAM_UU, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      st->it_macro = t.it_macro; st->it_outer = t.it_outer; st->nops = nops + 1; st->macro_total = t.macro_total;
+      st->shifts = t.shifts; st->growth = t.growth; st->status = t.status;
+      __hip_atomic_store(&st->phase, ph_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+}
+
+__global__ __launch_bounds__(64) void ortho_tail_kernel(OrthoTailArgs a)
+{
+  __shared__ __attribute__((aligned(16))) double lds[TAIL_LDS_DOUBLES];
+  ortho_tail(a, lds, threadIdx.x);
+}
+
+// second stage: sum the block partials in a fixed order and scatter into column-major C (ld = l).
+// One launch, two levels: block (ps, grp) sums its share of the partials into lvl2[ps][grp]; the
+// block that draws the last ticket for ps adds the `groups` level-2 rows in index order (so the
+// result does not depend on arrival order) and writes C to the device buffer and to its pinned
+// host mirror.  Hand-off = agent-scope release / acquire around a relaxed ticket
+// (cdna_hip_programming.md guideline 16); the ticket is reset by its last arriver.
+struct GramReduceArgs {
+  const double* partial;
+  double* lvl2;        // [passes*slots][groups][256]
+  unsigned* ticket;    // [passes*slots], zero between launches
+  double* c;           // l x k, ld = l (device)
+  double* c_host;      // same, pinned host mirror (device-visible address)
+  int nblk, l, k, tlw, kt, passes_x;
+  const int* phase;
+  int want;
+  // device-driven chains on one rank: the block that completes the LAST output tile also runs the state machine's
+  // step (ortho_tail) on the reduced matrix, so that no further launch stands between two sweeps
+  int do_tail;
+  int n_ps;            // passes * slots = number of output tiles
+  unsigned* gticket;   // zero between launches
+  OrthoTailArgs tail;
+};
+
+// TAIL: the block that completes the last output tile also runs the state machine's step
+template <bool TAIL>
+__global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
+{
+  DLA_PREDICATED(a);
+  const int slots = a.tlw * a.kt;
+  const int ps = blockIdx.x, grp = blockIdx.y, G = gridDim.y;
+  const int pass = ps / slots, slot = ps % slots;
+  const int e = threadIdx.x;
+  const double* p = a.partial + ((size_t)pass * a.nblk) * (size_t)slots * 256 + (size_t)slot * 256 + e;
+  const int per = (a.nblk + G - 1) / G;
+  const int b0 = grp * per, b1 = min(a.nblk, b0 + per);
+  // what the fused tail will need from the state machine: read now, hidden behind the reduction (this launch is the
+  // only writer of the state until its own tail runs)
+  TailState pre{};
+  if constexpr (TAIL) {
+    if (threadIdx.x < 64)
+      pre = TailState{a.tail.st->it_macro, a.tail.st->it_outer, a.tail.st->macro_total, a.tail.st->shifts, a.tail.st->nops,
+                      OP_NONE, OST_RUNNING, a.tail.st->growth};
+  }
+  // loads are issued in batches of 32 / 8 (independent), the adds stay in index order
+  double s = 0.0;
+  int b = b0;
+  for (; b + 32 <= b1; b += 32) {
+    double v[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) v[q] = p[(size_t)(b + q) * slots * 256];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) s += v[q];
+  }
+  for (; b + 8 <= b1; b += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + q) * slots * 256];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+  }
+  for (; b < b1; ++b) s += p[(size_t)b * slots * 256];
+  a.lvl2[((size_t)ps * G + grp) * 256 + e] = s;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(&a.ticket[ps], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == (unsigned)(G - 1));
+    if (last) {
+      __hip_atomic_store(&a.ticket[ps], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double tot = 0.0;
+  {
+    double v[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) v[q] = (q < G) ? a.lvl2[((size_t)ps * G + q) * 256 + e] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) tot += v[q];   // G <= 32; padding zeros do not change the sum
+  }
+  const int xg = pass % a.passes_x, ug = pass / a.passes_x;
+  const int t = slot / a.kt, q = slot % a.kt;
+  const int reg = e >> 6, lane = e & 63;
+  const int xcol = (xg * a.tlw + t) * 16 + (lane >> 4) + 4 * reg;
+  const int ucol = (ug * a.kt + q) * 16 + (lane & 15);
+  if (xcol < a.l && ucol < a.k) {
+    a.c[(size_t)xcol + (size_t)ucol * a.l] = tot;
+    if (a.c_host) a.c_host[(size_t)xcol + (size_t)ucol * a.l] = tot;
+  }
+  if constexpr (!TAIL) return;
+  __shared__ __attribute__((aligned(16))) double tail_lds[TAIL ? TAIL_LDS_DOUBLES : 1];
+  if (a.n_ps == 1 && a.tail.after != OP_XU) {
+    // a single 16 x 16 tile, complete in this block's registers: it reaches the tail through LDS, no fences
+    const int gi = (lane >> 4) + 4 * reg, gj = lane & 15;
+    tail_lds[gi * TLD + gj] = tot;
+    tail_lds[48 * TLD + gi * TLD + gj] = tot;
+    __syncthreads();
+    if (threadIdx.x < 64) ortho_tail(a.tail, tail_lds, threadIdx.x, &pre, true);
+    return;
+  }
+  // hand the finished tile(s) over to the one wave that runs the tail: same release / ticket / acquire pattern
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last = 1;
+    if (a.n_ps > 1) {
+      const unsigned t2 = __hip_atomic_fetch_add(a.gticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (t2 == (unsigned)(a.n_ps - 1));
+      if (last) __hip_atomic_store(a.gticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 64) return;
+  ortho_tail(a.tail, tail_lds, threadIdx.x, &pre);
 }
 
 // ======================================================================================
@@ -1348,8 +1437,8 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipMalloc((void**)&d_small, small_bytes));
     HIPCHK(hipHostMalloc((void**)&h_small, small_bytes, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&h_small_dev, h_small, 0));
-    HIPCHK(hipMalloc((void**)&d_ticket, sizeof(unsigned) * 4096));
-    HIPCHK(hipMemset(d_ticket, 0, sizeof(unsigned) * 4096));
+    HIPCHK(hipMalloc((void**)&d_ticket, sizeof(unsigned) * 4100));     // [4096] per output tile + 1 global
+    HIPCHK(hipMemset(d_ticket, 0, sizeof(unsigned) * 4100));
     return DLA_OK;
   }
 
@@ -1395,7 +1484,12 @@ struct HipEngine : dla::Engine {
   hipEvent_t get_event()
   {
     if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
-    hipEvent_t e; (void)hipEventCreate(&e); return e;
+    // timing events without the system-scope fence: a default event makes the kernel before it write its output back
+    // and the kernel after it start from cold caches, which slows the bracketed kernels by 5-15 % (measured against
+    // rocprofv3's dispatch times of an event-free run)
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) { (void)hipGetLastError(); (void)hipEventCreate(&e); }
+    return e;
   }
   void collect_times() override
   {
@@ -1711,6 +1805,11 @@ struct HipEngine : dla::Engine {
   double* d_wpk = nullptr; double* d_wfull = nullptr; double* d_cpk2 = nullptr;
   std::map<long long, std::vector<int>> ortho_history;   // (m > 0, k) -> the sweeps the last call executed
 
+  bool chain_armed = false;          // the device state machine stands at its initial state
+  bool fuse_tail = false;            // the reduction being enqueued may run the tail in its last block
+  bool tail_fused = false;           // ... and did
+  OrthoTailArgs pending_tail{};
+
   int ensure_chain_buffers()
   {
     if (d_ost) return DLA_OK;
@@ -1724,18 +1823,28 @@ struct HipEngine : dla::Engine {
     return DLA_OK;
   }
 
-  int launch_tail(int after, int m, int k)
+  void launch_reduce(GramReduceArgs& ra, dim3 grid)
   {
-    OrthoTailArgs ta{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, after, m, k};
-    Scope s(this, after == OP_XU ? DLA_OP_GEMM : DLA_OP_GRAM, 0.0, 0.0, "ortho_tail_kernel");
-    hipLaunchKernelGGL(ortho_tail_kernel, dim3(1), dim3(256), 0, st, ta);
-    HIPCHK(hipGetLastError());
-    return DLA_OK;
+    if (fuse_tail) {
+      ra.do_tail = 1; ra.tail = pending_tail; tail_fused = true;
+      hipLaunchKernelGGL(gram_reduce_kernel<true>, grid, dim3(256), 0, st, ra);
+    } else {
+      hipLaunchKernelGGL(gram_reduce_kernel<false>, grid, dim3(256), 0, st, ra);
+    }
+  }
+  void launch_tail_kernel(const OrthoTailArgs& ta)
+  {
+    hipLaunchKernelGGL(ortho_tail_kernel, dim3(1), dim3(64), 0, st, ta);
   }
 
-  // one speculative step: the sweep, its reduction (+ cross-rank sum) and the tail that takes the next decision
-  int launch_op(int op, int n, int m, int k, const double* x, const double* bx, double* u)
+  // one speculative step: the sweep, its reduction (+ cross-rank sum) and the tail that takes the next decision.
+  // On one rank the tail rides in the last block of the reduction kernel; with a communicator the all-reduce has to
+  // come between the two, so the tail is a launch of its own.
+  int launch_op(int op, int n, int m, int k, const double* x, const double* bx, double* u, bool publish)
   {
+    pending_tail = OrthoTailArgs{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, op, m, k, m > 0 ? 1 : 0, ortho_maxit, publish ? 1 : 0};
+    fuse_tail = (nranks <= 1 && !comm);
+    tail_fused = false;
     pred_phase = &d_ost->phase; pred_want = op;
     int stc = DLA_OK;
     switch (op) {
@@ -1753,8 +1862,12 @@ struct HipEngine : dla::Engine {
       default: err = "ortho_chain: bad op"; stc = DLA_ERR_ARG;
     }
     pred_phase = nullptr; pred_want = 0;
-    if (stc) return stc;
-    return launch_tail(op, m, k);
+    fuse_tail = false;
+    if (stc || tail_fused) return stc;
+    Scope s(this, DLA_OP_GRAM, 0.0, 0.0, "ortho_tail_kernel");
+    launch_tail_kernel(pending_tail);
+    HIPCHK(hipGetLastError());
+    return DLA_OK;
   }
 
   int ortho_chain(int n, int m, int k, const double* x, const double* bx, double* u, dla::OrthoReport* rep) override
@@ -1771,11 +1884,17 @@ struct HipEngine : dla::Engine {
     stc = ensure_small(sizeof(double) * (size_t)std::max(m, k) * k);
     if (stc) return stc;
 
-    OrthoDev init{};
-    init.phase = OP_GRAM_UU; init.status = OST_RUNNING; init.force_defer = vsx ? 1 : 0; init.can_defer = vsx ? 1 : 0;
-    init.maxit = ortho_maxit; init.growth = 1.0;
-    *h_ost_init = init;
-    HIPCHK(hipMemcpyAsync(d_ost, h_ost_init, sizeof(OrthoDev), hipMemcpyHostToDevice, st));
+    if (!chain_armed) {
+      // first chain (or the previous one was abandoned on an error): copy the initial state in.  Afterwards the
+      // tail that ends a chain re-arms the machine itself.
+      OrthoDev init{};
+      init.phase = OP_GRAM_UU; init.status = OST_RUNNING; init.growth = 1.0;
+      *h_ost_init = init;
+      HIPCHK(hipMemcpyAsync(d_ost, h_ost_init, sizeof(OrthoDev), hipMemcpyHostToDevice, st));
+    }
+    chain_armed = false;
+    h_ost->status = -1;              // nothing reported yet (the tails write this mirror)
+    h_ost->nops = 0;
 
     const long long key = (long long)(vsx ? 1 : 0) * 1000 + k;
     std::vector<int>& hist = ortho_history[key];
@@ -1790,10 +1909,10 @@ struct HipEngine : dla::Engine {
     OrthoDev sres{};
     for (int round = 0; round < 256; ++round) {
       spec_rec = &recs;
-      for (int op : plan) {
+      for (size_t pi = 0; pi < plan.size(); ++pi) {
         spec_tag = (int)launched.size();
-        launched.push_back(op);
-        stc = launch_op(op, n, m, k, x, bx, u);
+        launched.push_back(plan[pi]);
+        stc = launch_op(plan[pi], n, m, k, x, bx, u, pi + 1 == plan.size());
         if (stc) break;
       }
       spec_rec = nullptr;
@@ -1802,6 +1921,7 @@ struct HipEngine : dla::Engine {
       if (stc) return stc;
       stats.host_syncs++;
       sres = *h_ost;
+      if (sres.status < 0) { err = "ortho_chain: the device reported nothing"; return DLA_ERR_RUNTIME; }
       if (sres.status != OST_RUNNING) break;
       // the device went another way than expected: continue from where it stands with the most likely tail
       switch (sres.phase) {
@@ -1811,8 +1931,10 @@ struct HipEngine : dla::Engine {
         case OP_FINAL: plan = {OP_FINAL}; break;
         default: err = "ortho_chain: device state machine in an unexpected phase"; return DLA_ERR_RUNTIME;
       }
+      h_ost->status = -1;
     }
     if (sres.status == OST_RUNNING) { err = "ortho_chain: no progress"; return DLA_ERR_RUNTIME; }
+    chain_armed = true;              // a terminal tail has put the machine back to its initial state
     // account for the launches the device executed: they are the greedy match of its log inside the launch sequence
     {
       const int nlog = std::min(sres.nops, 48);
@@ -1954,7 +2076,7 @@ struct HipEngine : dla::Engine {
     }
     {
       Scope s2(this, cls, 0.0, 0.0, "gram_reduce_kernel");
-      const int groups = std::max(1, std::min(16, (blocks_per_pass + 31) / 32));
+      const int groups = std::max(1, std::min(32, (blocks_per_pass + 31) / 32));
       const size_t need2 = sizeof(double) * (size_t)passes * slots * groups * 256;
       if (need2 > lvl2_bytes) {
         HIPCHK(hipStreamSynchronize(st));
@@ -1963,8 +2085,9 @@ struct HipEngine : dla::Engine {
         HIPCHK(hipMalloc((void**)&d_lvl2, lvl2_bytes));
       }
       if (passes * slots > 4096) { err = "gram: too many output tiles"; return DLA_ERR_ARG; }
-      GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, h_small_dev, blocks_per_pass, l, k, tlw, kt, px, pred_phase, pred_want};
-      hipLaunchKernelGGL(gram_reduce_kernel, dim3(passes * slots, groups), dim3(256), 0, st, ra);
+      GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, pred_phase ? nullptr : h_small_dev, blocks_per_pass, l, k, tlw, kt, px,
+                        pred_phase, pred_want, 0, passes * slots, d_ticket + 4096, OrthoTailArgs{}};
+      launch_reduce(ra, dim3(passes * slots, groups));
     }
     HIPCHK(hipGetLastError());
     return allreduce_dev(d_small, l * k, 0, h_small);
@@ -1999,7 +2122,7 @@ struct HipEngine : dla::Engine {
     int stc = ensure_small(sizeof(double) * (size_t)k * k);
     if (stc) return stc;
     const int kt = (k + 15) / 16;
-    const int groups = std::max(1, std::min(16, (fused_blocks + 31) / 32));
+    const int groups = std::max(1, std::min(32, (fused_blocks + 31) / 32));
     const size_t need2 = sizeof(double) * (size_t)kt * kt * groups * 256;
     if (need2 > lvl2_bytes) {
       HIPCHK(hipStreamSynchronize(st));
@@ -2007,10 +2130,11 @@ struct HipEngine : dla::Engine {
       lvl2_bytes = std::max(need2, (size_t)1 << 20);
       HIPCHK(hipMalloc((void**)&d_lvl2, lvl2_bytes));
     }
-    GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, h_small_dev, fused_blocks, k, k, kt, kt, 1, pred_phase, pred_want};
+    GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, pred_phase ? nullptr : h_small_dev, fused_blocks, k, k, kt, kt, 1,
+                      pred_phase, pred_want, 0, kt * kt, d_ticket + 4096, OrthoTailArgs{}};
     {
       Scope s2(this, DLA_OP_GRAM, 0.0, 0.0, "gram_reduce_kernel");
-      hipLaunchKernelGGL(gram_reduce_kernel, dim3(kt * kt, groups), dim3(256), 0, st, ra);
+      launch_reduce(ra, dim3(kt * kt, groups));
     }
     HIPCHK(hipGetLastError());
     return allreduce_dev(d_small, k * k, 0, h_small);
