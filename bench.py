@@ -30,7 +30,20 @@ import re
 import sys
 import time
 
-CPU_THREADS = int(os.environ.get("DIAGLIB_BENCH_CPU_THREADS", "16"))
+def _usable_cpus() -> int:
+    """Host cores this process may use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+HOST_CPUS = os.cpu_count() or 1
+CPU_THREADS = int(os.environ.get("DIAGLIB_BENCH_CPU_THREADS", str(_usable_cpus())))
 os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS))
 os.environ.setdefault("MKL_NUM_THREADS", str(CPU_THREADS))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -52,6 +65,39 @@ def shard_rows(n: int, nranks: int, rank: int):
     return r0, r1 - r0
 
 
+class _CaptureStdout:
+    """The reference prints its timing table on Fortran unit 6: catch file descriptor 1 for the duration of the call."""
+
+    def __enter__(self):
+        import tempfile
+        sys.stdout.flush()
+        self.tmp = tempfile.TemporaryFile(mode="w+b")
+        self.saved = os.dup(1)
+        os.dup2(self.tmp.fileno(), 1)
+        return self
+
+    def __exit__(self, *exc):
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        self.tmp.seek(0)
+        self.text = self.tmp.read().decode(errors="replace")
+        self.tmp.close()
+        return False
+
+
+def _reference_buckets(text: str):
+    """(cpu, wall) pairs of the reference's four timers (diaglib.f90:1835-1841), wall seconds returned."""
+    out = {}
+    for key, pat in (("matvec", r"matrix-vector multiplications:\s+([\d.]+)\s+([\d.]+)"),
+                     ("diag", r"diagonalization:\s+([\d.]+)\s+([\d.]+)"),
+                     ("ortho", r"orthogonalization:\s+([\d.]+)\s+([\d.]+)"),
+                     ("total", r"total:\s+([\d.]+)\s+([\d.]+)")):
+        m = re.search(pat, text)
+        if m:
+            out[key] = float(m.group(2))
+    return out or None
+
+
 def cpu_baseline(n_sample: int, n_targ: int, n_max: int, max_dav: int, tol: float, flops_per_row: float):
     """Reference (or port) on the host cores, bounded sample of the same workload."""
     from oracle.pyoracle import Oracle, Reference
@@ -60,21 +106,38 @@ def cpu_baseline(n_sample: int, n_targ: int, n_max: int, max_dav: int, tol: floa
     guess = np.zeros((n_sample, n_max), order="F")
     guess[np.arange(n_max), np.arange(n_max)] = 1.0
     mv, pc = o.fn("orc_synth_matvec"), o.fn("orc_synth_precnd")
-    kind = "port"
+    kind, buckets = "port", None
     t0 = time.perf_counter()
     try:
         ref = Reference()
         kind = "reference"
-        t0 = time.perf_counter()
-        _, _, ok = ref.davidson(n_sample, n_targ, n_max, 100, tol, max_dav, 0.0, mv, pc, guess)
+        with _CaptureStdout() as cap:
+            t0 = time.perf_counter()
+            _, _, ok = ref.davidson(n_sample, n_targ, n_max, 100, tol, max_dav, 0.0, mv, pc, guess, verbose=True)
+            dt = time.perf_counter() - t0
+            if hasattr(ref.lib, "ref_flush"):
+                ref.lib.ref_flush()                    # the table sits in the Fortran runtime's buffer of unit 6
+        buckets = _reference_buckets(cap.text)
     except (OSError, FileNotFoundError):
         t0 = time.perf_counter()
         _, _, ok, _ = o.davidson(n_sample, n_targ, n_max, 100, tol, max_dav, 0.0, mv, pc, guess)
-    dt = time.perf_counter() - t0
-    return {"value": flops_per_row * n_sample / dt / 1e9, "unit": "GFLOP/s", "cores": CPU_THREADS, "kind": kind,
-            "sample": f"same Davidson-Liu solve (synthetic operator, {n_targ} roots, n_max={n_max}, tol={tol:g}) at "
-                      f"n={n_sample} rows, whole call incl. allocation, {dt:.2f} s, converged={bool(ok)}; "
-                      "flops = GPU run's reference-schedule flops per row x n_sample"}
+        dt = time.perf_counter() - t0
+    flops = flops_per_row * n_sample
+    res = {"value": flops / dt / 1e9, "unit": "GFLOP/s", "cores": CPU_THREADS, "host_cpus": HOST_CPUS, "kind": kind,
+           "seconds_whole_call": round(dt, 3),
+           "sample": f"same Davidson-Liu solve (synthetic operator, {n_targ} roots, n_max={n_max}, tol={tol:g}) at "
+                     f"n={n_sample} rows, whole call incl. the reference's allocation + zero-fill of its panels, "
+                     f"{dt:.2f} s on {CPU_THREADS} threads (MKL + OpenMP callbacks), converged={bool(ok)}; "
+                     "flops = GPU run's reference-schedule flops per row x n_sample"}
+    if buckets and buckets.get("total"):
+        # the reference's own timers (diaglib.f90:1835-1841): in-loop wall time and its three buckets; the rest of the
+        # loop (projection, Ritz vectors, residuals) is un-bucketed in the reference
+        res["seconds_in_loop"] = buckets["total"]
+        res["value_in_loop"] = flops / buckets["total"] / 1e9
+        res["buckets_s"] = {"matvec": buckets.get("matvec"), "diagonalization": buckets.get("diag"),
+                            "orthogonalization": buckets.get("ortho"),
+                            "unbucketed": round(buckets["total"] - sum(buckets.get(k, 0.0) for k in ("matvec", "diag", "ortho")), 4)}
+    return res
 
 
 def main() -> None:
@@ -89,6 +152,11 @@ def main() -> None:
     ap.add_argument("--max-dav", type=int, default=20)
     ap.add_argument("--event-steps", type=int, default=1,
                     help="timed steps during which per-kernel HIP events are recorded (roofline figures)")
+    ap.add_argument("--guess", default="unit", choices=["unit", "seed2"],
+                    help="unit: e_1..e_M (SURVEY 8d guess (a), the headline); seed2: guess (b), uniform [-0.5,0.5) from the "
+                         "documented generator on the leading --guess-rows rows (restart + locking)")
+    ap.add_argument("--guess-rows", type=int, default=2000)
+    ap.add_argument("--no-random-leg", action="store_true", help="skip the untimed-region seed-2 leg reported under config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=2_000_000)
     args = ap.parse_args()
@@ -148,11 +216,16 @@ def main() -> None:
     g_dev = ctx.panel(guess)
     ev = ctx.panel(n_loc, n_max)
 
-    def solve():
-        ctx.lib.dla_copy(ctx.h, ev.ptr, g_dev.ptr, 8 * n_loc * n_max)
+    workload_key = f"{args.solver} n={n} roots={n_targ} n_max={n_max} max_dav={args.max_dav} guess={args.guess}"
+
+    def solve(max_iter=400):
+        if args.guess == "unit":
+            ctx.lib.dla_copy(ctx.h, ev.ptr, g_dev.ptr, 8 * n_loc * n_max)
+        else:
+            ctx.fill_guess(ev, 2, args.guess_rows)
         if args.solver == "davidson":
-            return ctx.davidson_driver(n_loc, n_targ, n_max, 200, args.tol, args.max_dav, 0.0, mv, pc, ev)
-        return ctx.lobpcg_driver(n_loc, n_targ, n_max, 200, args.tol, 0.0, mv, pc, ev)
+            return ctx.davidson_driver(n_loc, n_targ, n_max, max_iter, args.tol, args.max_dav, 0.0, mv, pc, ev)
+        return ctx.lobpcg_driver(n_loc, n_targ, n_max, max_iter, args.tol, 0.0, mv, pc, ev)
 
     def barrier():
         if world > 1:
@@ -223,11 +296,13 @@ def main() -> None:
                       "GBps": round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6, 1) if v["alg_bytes"] > 0 else None}
                   for k, v in sorted(kst.items(), key=lambda kv: -kv[1]["ms"])[:10]}
     ach = dk["alg_bytes"] / max(dk["ms"], 1e-9) / 1e6
+    # HBM bytes per launch from the PMC passes (tools/pmc_traffic.py): only a figure collected for THIS workload and THIS
+    # kernel symbol is quoted -- profiles/pmc_traffic.json is keyed by the workload string; anything else stays null
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile) and world == 1:      # the PMC passes were taken at N = 1 (whole problem on one GPU)
         try:
-            traffic = json.load(open(tfile)).get(dom, json.load(open(tfile)).get(cls_of))
+            traffic = json.load(open(tfile)).get(workload_key, {}).get(dom)
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -235,6 +310,28 @@ def main() -> None:
                 "launches": dk["launches"], "event_steps": ev_steps,
                 "avg_launch_ms": round(dk["ms"] / max(1, dk["launches"]), 4),
                 "alg_bytes_per_launch": round(dk["alg_bytes"] / max(1, dk["launches"]), 1)}
+    # the north star's "ortho/matvec step": every O(n) launch of ortho_vs_x (Gram, projection update, triangular update,
+    # their reductions and k x k tail kernels, which move no panel bytes but take time) plus the operator; and the
+    # whole solve: all algorithmic bytes over the wall time of the solve, host work included
+    step_cls = ["gram", "gemm", "trmm", "matvec"]
+    step_b = sum(ev_stats[c]["alg_bytes"] for c in step_cls)
+    step_ms = sum(ev_stats[c]["ms"] for c in step_cls)
+    all_cls = classes + ["matvec", "precnd"]
+    all_b = sum(stats[c]["alg_bytes"] for c in all_cls) / args.steps
+    roofline["step"] = {"what": "ortho/matvec step = classes " + "+".join(step_cls) + " (HIP-event time, reductions included)",
+                        "achieved": round(step_b / max(step_ms, 1e-9) / 1e6, 1),
+                        "frac": round(step_b / max(step_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
+    roofline["solve"] = {"what": "all algorithmic bytes of one solve / wall time of the solve",
+                         "alg_GB": round(all_b / 1e9, 2),
+                         "achieved": round(all_b / (dt / args.steps) / 1e9, 1),
+                         "frac": round(all_b / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    if rank == 0 and world == 1:
+        try:
+            triad = ctx.stream_triad(1 << 27, 5)    # 3 x 1 GiB, far beyond the 256 MiB Infinity Cache
+            roofline["triad_GBps"] = round(triad, 1)
+            roofline["frac_of_triad"] = round(ach / max(triad, 1e-9), 4)
+        except capi.DlaError:
+            roofline["triad_GBps"] = None
 
     out = {
         "metric": "eigensolver GFLOP/s + iters-to-converge, n=2e6 m=8 Davidson, 1/2/4/8 GPU",
@@ -242,15 +339,45 @@ def main() -> None:
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.solver} n={n} roots={n_targ} n_max={n_max} max_dav={args.max_dav} tol={args.tol:g} "
-                               "operator=diag(i+1)+0.5*W*W^T(rank 4) guess=unit callbacks=device",
+                               f"operator=diag(i+1)+0.5*W*W^T(rank 4) guess={args.guess} callbacks=device",
+                   "workload_key": workload_key,
                    "iters": info["iters"], "matvec_cols": info["matvec_cols"], "restarts": info["restarts"],
                    "converged": bool(ok), "max_rel_residual": rel_res, "rows_per_gpu": n_loc,
                    "eig": [round(float(e), 9) for e in eig[:n_targ]]},
         "roofline": roofline,
         "kernel_classes": kern,
         "kernels": per_kernel,
-        "host": {"allreduces": stats["allreduces"], "host_syncs": stats["host_syncs"]},
+        "host": {"allreduces": stats["allreduces"], "host_syncs": stats["host_syncs"], "nproc": HOST_CPUS,
+                 "usable_cpus": CPU_THREADS},
     }
+    if args.guess == "unit" and not args.no_random_leg:
+        # second leg (SURVEY 8d guess (b)): the seed-2 random guess confined to the leading rows -- the run that restarts
+        # and locks roots one by one.  Timed on its own (outside the K timed steps), reported beside the headline.
+        args.guess = "seed2"
+        solve()                                         # warm-up (allocator, speculation history)
+        barrier()
+        t1 = time.perf_counter()
+        eig2, _, ok2, info2 = solve()
+        barrier()
+        dt2 = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt2], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt2 = float(tt[0])
+        ctx.synth_matvec(ev, ax)
+        x_h, ax_h = ev.download(), ax.download()
+        r2 = ((ax_h - x_h * eig2[None, :]) ** 2).sum(0)
+        if world > 1:
+            rt = torch.from_numpy(r2.copy())
+            dist.all_reduce(rt)
+            r2 = rt.numpy()
+        out["config"]["random_guess_leg"] = {
+            "guess": f"seed 2, uniform [-0.5,0.5) on the leading {args.guess_rows} rows (dla_fill_guess)",
+            "ms": round(dt2 * 1e3, 3), "iters": info2["iters"], "matvec_cols": info2["matvec_cols"],
+            "restarts": info2["restarts"], "converged": bool(ok2),
+            "max_rel_residual": float((np.sqrt(r2[:n_targ]) / np.abs(eig2[:n_targ])).max()),
+            "max_eig_diff_vs_unit_guess": float(np.abs(eig2[:n_targ] - eig[:n_targ]).max())}
+        args.guess = "unit"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, n_targ, n_max, args.max_dav, args.tol,

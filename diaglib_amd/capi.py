@@ -33,7 +33,7 @@ EXPORTS = [
     "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_set_allreduce_hook", "dla_set_shard",
     "dla_alloc", "dla_free", "dla_trim", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
     "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_ritz_residual", "dla_axpy",
-    "dla_nrm2", "dla_random_fill", "dla_fill_guess",
+    "dla_nrm2", "dla_stream_triad", "dla_random_fill", "dla_fill_guess",
     "dla_ortho_cd", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
     "dla_call_matvec", "dla_call_precnd",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
@@ -104,6 +104,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_trmm_linvt": (i, [vp, i, i, vp, c_dp, i]),
         "dla_ritz_residual": (i, [vp, i, i, i, vp, vp, c_dp, i, c_dp, i, c_ip, vp, vp, vp, c_dp]),
         "dla_axpy": (i, [vp, sz, d, vp, vp]), "dla_nrm2": (i, [vp, sz, vp, c_dp]),
+        "dla_stream_triad": (i, [vp, sz, i, c_dp]),
         "dla_random_fill": (i, [vp, i, i, vp]), "dla_fill_guess": (i, [vp, i, i, vp, C.c_ulonglong, C.c_longlong]),
         "dla_ortho_cd": (i, [vp, i, i, vp, c_dp, c_ip]), "dla_ortho_vs_x": (i, [vp, i, i, i, vp, vp]),
         "dla_b_ortho": (i, [vp, i, i, vp, vp]), "dla_b_ortho_vs_x": (i, [vp, i, i, i, vp, vp, vp]),
@@ -317,6 +318,12 @@ class Context:
     def nrm2(self, x: DevPanel) -> float:
         out = C.c_double(0.0)
         self._chk(self.lib.dla_nrm2(self.h, x.n * x.m, x.ptr, C.byref(out)))
+        return out.value
+
+    def stream_triad(self, length: int, reps: int = 5) -> float:
+        """device STREAM triad GB/s on three scratch arrays of `length` doubles (best of reps)"""
+        out = C.c_double(0.0)
+        self._chk(self.lib.dla_stream_triad(self.h, length, reps, C.byref(out)))
         return out.value
 
     def random_fill(self, x: DevPanel) -> None:

@@ -68,6 +68,7 @@ struct Engine {
                             double* sumsq_max /* 2*n_res: sum r^2, max|r| */) = 0;
   virtual int axpy(size_t len, double alpha, const double* x, double* y) = 0;
   virtual int sumsq(size_t len, const double* x, double* out) = 0;
+  virtual int stream_triad(size_t /*len*/, int /*reps*/, double* gbps) { *gbps = 0.0; return DLA_ERR_ARG; }
   // evec(i,j) = u01(seed, row0+i+1, j+1) + offset (counter-based generator, global row indices); rows whose global
   // index exceeds support_rows (when > 0) are set to zero
   virtual int random_fill(int n, int m, double* evec, long long row0, unsigned long long seed, double offset,

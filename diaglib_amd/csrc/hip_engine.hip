@@ -810,6 +810,30 @@ __global__ void axpy_kernel(size_t len, double alpha, const double* __restrict__
   for (; i < len; i += stride) y[i] += alpha * x[i];
 }
 
+// STREAM triad a = b + s c with the access shape of the sweeps (16 B per lane, non-temporal): the practical HBM
+// ceiling the roofline fractions are read against (SURVEY 8d "record a measured device-triad GB/s")
+template <int NT, int UNR>
+__global__ __launch_bounds__(256) void triad_kernel(size_t len2, double sc, const double* __restrict__ b,
+                                                    const double* __restrict__ c, double* __restrict__ a)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + (UNR - 1) * stride < len2; i += UNR * stride) {
+    v2d bv[UNR], cv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if constexpr (NT) { bv[u] = __builtin_nontemporal_load((const v2d*)b + i + u * stride); cv[u] = __builtin_nontemporal_load((const v2d*)c + i + u * stride); }
+      else { bv[u] = ((const v2d*)b)[i + u * stride]; cv[u] = ((const v2d*)c)[i + u * stride]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if constexpr (NT) __builtin_nontemporal_store(bv[u] + sc * cv[u], (v2d*)a + i + u * stride);
+      else ((v2d*)a)[i + u * stride] = bv[u] + sc * cv[u];
+    }
+  }
+  for (; i < len2; i += stride) ((v2d*)a)[i] = ((const v2d*)b)[i] + sc * ((const v2d*)c)[i];
+}
+
 // block partial sums of squares; fixed grid => deterministic
 __global__ __launch_bounds__(256) void sumsq_kernel(size_t len, const double* __restrict__ x, double* partial)
 {
@@ -1803,7 +1827,7 @@ struct HipEngine : dla::Engine {
   OrthoDev* h_ost_dev = nullptr;
   OrthoDev* h_ost_init = nullptr;   // pinned source of the initial state
   double* d_wpk = nullptr; double* d_wfull = nullptr; double* d_cpk2 = nullptr;
-  std::map<long long, std::vector<int>> ortho_history;   // (m > 0, k) -> the sweeps the last call executed
+  std::map<long long, std::vector<int>> ortho_history;   // (k, m) -> the sweeps the last call of that shape executed
 
   bool chain_armed = false;          // the device state machine stands at its initial state
   bool fuse_tail = false;            // the reduction being enqueued may run the tail in its last block
@@ -1896,9 +1920,12 @@ struct HipEngine : dla::Engine {
     h_ost->status = -1;              // nothing reported yet (the tails write this mirror)
     h_ost->nops = 0;
 
-    const long long key = (long long)(vsx ? 1 : 0) * 1000 + k;
+    // the schedule depends on how much of the new block already lies in span(X): remembered per basis width
+    const long long key = (long long)k * 1000000 + m;
     std::vector<int>& hist = ortho_history[key];
     std::vector<int> plan = hist;
+    std::vector<int>& last_k = ortho_history[-(long long)(2 * k + (vsx ? 1 : 0)) - 1];   // most recent call of this kind and width
+    if (plan.empty()) plan = last_k;
     if (plan.empty()) {
       // the schedule measured on the reference: cd x2, [projection, cd x2], [projection, cd x1]
       if (vsx) plan = {OP_GRAM_UU, OP_TRMMG, OP_XU, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
@@ -1953,7 +1980,7 @@ struct HipEngine : dla::Engine {
         if (launched[i] == OP_TRMMG) stats.flops[DLA_OP_GRAM] += 2.0 * (double)n * k * k;
         if (launched[i] == OP_COMBO) { stats.flops[DLA_OP_GRAM] += 2.0 * (double)n * k * k; stats.flops[DLA_OP_GEMM] -= 1.0 * (double)n * k * k; }
       }
-      if (sres.status == OST_DONE && sres.nops <= 48) hist.assign(sres.log, sres.log + nlog);
+      if (sres.status == OST_DONE && sres.nops <= 48) { hist.assign(sres.log, sres.log + nlog); last_k = hist; }
     }
     rep->handled = 1;
     rep->status = sres.status;
@@ -2515,6 +2542,40 @@ struct HipEngine : dla::Engine {
     hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, st, len, alpha, x, y);
     HIPCHK(hipGetLastError());
     return DLA_OK;
+  }
+
+  // a = b + s c over len doubles (len even), reps times; returns the best GB/s of the repetitions (24 B per element)
+  int stream_triad(size_t len, int reps, double* gbps) override
+  {
+    *gbps = 0.0;
+    len &= ~(size_t)1;
+    void *pa = nullptr, *pb = nullptr, *pc = nullptr;
+    int stc = alloc(sizeof(double) * len, &pa);
+    if (!stc) stc = alloc(sizeof(double) * len, &pb);
+    if (!stc) stc = alloc(sizeof(double) * len, &pc);
+    if (!stc) {
+      HIPCHK(hipMemsetAsync(pb, 0, sizeof(double) * len, st));
+      HIPCHK(hipMemsetAsync(pc, 0, sizeof(double) * len, st));
+      hipEvent_t e0 = get_event(), e1 = get_event();
+      // a few launch shapes; the best one is the ceiling quoted
+      const int shapes[4][3] = {{1, 4, 8}, {0, 4, 8}, {1, 1, 16}, {1, 2, 4}};     // {non-temporal, unroll, blocks per CU}
+      for (int r = 0; r < 4 * (reps + 1); ++r) {    // the first repetition of every shape warms up
+        const int* sh = shapes[r / (reps + 1)];
+        const int blocks = (int)std::min((size_t)ncu * sh[2], (len / 2 + 255) / 256);
+        HIPCHK(hipEventRecord(e0, st));
+#define TRIAD(NT, U) hipLaunchKernelGGL((triad_kernel<NT, U>), dim3(blocks), dim3(256), 0, st, len / 2, 0.5, (const double*)pb, (const double*)pc, (double*)pa)
+        if (sh[0] == 1 && sh[1] == 4) TRIAD(1, 4); else if (sh[0] == 0) TRIAD(0, 4); else if (sh[1] == 1) TRIAD(1, 1); else TRIAD(1, 2);
+#undef TRIAD
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (r % (reps + 1) > 0 && ms > 0.f) *gbps = std::max(*gbps, 24.0 * (double)len / (ms * 1e6));
+      }
+      ev_pool.push_back(e0); ev_pool.push_back(e1);
+    }
+    int s1 = free_(pa), s2 = free_(pb), s3 = free_(pc);
+    return stc ? stc : (s1 ? s1 : (s2 ? s2 : s3));
   }
 
   int sumsq(size_t len, const double* x, double* out) override

@@ -295,6 +295,13 @@ int dla_nrm2(dla_ctx* c, size_t len, const double* x, double* out)
   return DLA_OK;
 }
 
+// measurement aid: device STREAM triad on len doubles, best of reps repetitions (bench.py's practical HBM ceiling)
+int dla_stream_triad(dla_ctx* c, size_t len, int reps, double* gbps)
+{
+  if (!c || !gbps) return DLA_ERR_ARG;
+  return engfail(c, c->eng->stream_triad(len, reps, gbps));
+}
+
 int dla_random_fill(dla_ctx* c, int n, int m, double* evec) { return engfail(c, c->eng->random_fill(n, m, evec, c->row0, 7ULL, 0.0, 0)); }
 
 // benchmark guess (b) of SURVEY 8d: uniform [-0.5, 0.5) from the documented counter-based generator, GLOBAL row indices

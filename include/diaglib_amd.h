@@ -175,6 +175,9 @@ int  dla_ritz_residual(dla_ctx* ctx, int n, int l, int m, const double* v_dev, c
 int  dla_axpy(dla_ctx* ctx, size_t len, double alpha, const double* x_dev, double* y_dev);
 /* sqrt(sum x^2) over len contiguous doubles (all ranks).  dnrm2 at diaglib.f90:3749, 3268. */
 int  dla_nrm2(dla_ctx* ctx, size_t len, const double* x_dev, double* out);
+/* measurement aid (SURVEY 8d "measured device-triad GB/s as the practical ceiling"): STREAM triad a = b + s c on three
+ * scratch arrays of len doubles with the sweeps' access shape, best of reps repetitions, in GB/s (24 bytes per element) */
+int  dla_stream_triad(dla_ctx* ctx, size_t len, int reps, double* gbps);
 /* fill evec(n x m) with the documented counter-based uniform [0,1) stream (replaces the
  * compiler-specific random_number at diaglib.f90:3754). */
 int  dla_random_fill(dla_ctx* ctx, int n, int m, double* evec_dev);

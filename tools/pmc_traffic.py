@@ -1,74 +1,62 @@
 #!/usr/bin/env python3
-"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as
-MI355X_MICROARCH.md section HBM prescribes) into per-launch HBM traffic per kernel class.
+"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md section HBM
+prescribes) into HBM bytes per launch per KERNEL SYMBOL for ONE workload, merged into a table keyed by the workload.
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [out.json]
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <table.json> "<workload key>"
 
-Units / gfx950 corrections (MI355X_MICROARCH.md "HBM"): both counters are in KiB; FETCH_SIZE reports
-exactly half of the bytes of a wide coalesced streaming read on gfx950, so it is doubled; WRITE_SIZE
-is exact for 16-byte-per-lane streaming stores.
+The workload key is the one bench.py builds (`<solver> n=... roots=... n_max=... max_dav=... guess=...`); bench.py
+quotes `roofline.traffic` only from the entry of its own workload and kernel, never from another configuration.
+
+Units / gfx950 corrections (MI355X_MICROARCH.md "HBM"): both counters are in KiB; FETCH_SIZE reports exactly half of the
+bytes of a wide coalesced streaming read on gfx950, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming
+stores.  Dispatches of a device-driven chain that found it was not their turn (predicated launches, a few hundred bytes)
+are left out of the averages: they are the ones below 5 % of the kernel's largest dispatch.
 """
 import csv
 import json
+import os
 import re
 import sys
 from collections import defaultdict
 
-CLASS = [("gram_kernel", "gram"), ("gram_lds_kernel", "gram"), ("gram_reduce", "gram"), ("ritz_kernel", "ritz"), ("ritz_reduce", "ritz")]
 
-
-def klass(name, grid):
-    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+),", name)
-    if m:
-        return "trmm" if m.group(3) == "2" else "gemm"       # MODE 2 = in-place triangular update
-    for key, c in CLASS:
-        if key in name:
-            return c
-    return None
+def kname(full):
+    m = re.search(r"((gram_lds|gram|gemm|ritz)_kernel<[^>]*>)", full.replace("(anonymous namespace)::", ""))
+    return m.group(1) if m else None
 
 
 def load(path, counter):
-    """Per class: [sum of counter, launches].  The benchmark operator's own small Gram (W^T x, followed in
-    dispatch order by synth_apply_kernel) belongs to the matvec class, as in the engine's statistics."""
-    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
-    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    cls = [klass(r["Kernel_Name"], None) for r in rows]
-    for i, r in enumerate(rows):
-        if "synth_apply_kernel" in r["Kernel_Name"]:
-            j, seen = i - 1, 0
-            while j >= 0 and seen < 2:
-                if "gram_kernel" in rows[j]["Kernel_Name"] or "gram_lds_kernel" in rows[j]["Kernel_Name"] or "gram_reduce" in rows[j]["Kernel_Name"]:
-                    cls[j] = "matvec"; seen += 1
-                j -= 1
-    per = defaultdict(lambda: [0.0, 0])
-    for r, c in zip(rows, cls):
-        if c is None:
+    per = defaultdict(dict)     # kernel -> dispatch id -> value
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
             continue
-        per[c][0] += float(r["Counter_Value"])
-        if "reduce" not in r["Kernel_Name"]:
-            per[c][1] += 1
-        if c != "matvec":
-            # per kernel symbol as well (name as bench.py reports it)
-            m = re.search(r"((gram_lds|gram|gemm|ritz)_kernel<[^>]*>)", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
-            if m:
-                per[m.group(1)][0] += float(r["Counter_Value"])
-                per[m.group(1)][1] += 1
+        k = kname(r["Kernel_Name"])
+        if k:
+            d = per[k]
+            d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
     return per
 
 
 def main():
-    fetch = load(sys.argv[1], "FETCH_SIZE")
-    write = load(sys.argv[2], "WRITE_SIZE")
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    table_path, key = sys.argv[3], sys.argv[4]
     out = {}
-    for c in sorted(set(fetch) | set(write)):
-        launches = max(fetch[c][1], write[c][1], 1)
-        rd = 2.0 * fetch[c][0] * 1024.0
-        wr = write[c][0] * 1024.0
-        out[c] = round((rd + wr) / launches, 1)
-        print(f"{c:6s} launches {launches:4d}  read {rd / launches / 1e6:9.1f} MB  write {wr / launches / 1e6:8.1f} MB  "
-              f"total/launch {out[c] / 1e6:9.1f} MB")
-    if len(sys.argv) > 3:
-        json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k in sorted(set(fetch) | set(write)):
+        def mean_real(d):
+            if not d:
+                return 0.0, 0
+            top = max(d.values())
+            real = [v for v in d.values() if v >= 0.05 * top] if top > 0 else list(d.values())
+            return sum(real) / len(real), len(real)
+        f, nf = mean_real(fetch.get(k, {}))
+        w, nw = mean_real(write.get(k, {}))
+        out[k] = round(2.0 * f * 1024.0 + w * 1024.0, 1)
+        print(f"{k:52s} launches {max(nf, nw):4d}  read {2 * f * 1024 / 1e6:9.1f} MB  write {w * 1024 / 1e6:8.1f} MB  "
+              f"total/launch {out[k] / 1e6:9.1f} MB")
+    table = json.load(open(table_path)) if os.path.exists(table_path) else {}
+    table = {k: v for k, v in table.items() if isinstance(v, dict)}      # drop the flat round-1 layout
+    table[key] = out
+    json.dump(table, open(table_path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
