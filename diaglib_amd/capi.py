@@ -34,7 +34,7 @@ EXPORTS = [
     "dla_alloc", "dla_free", "dla_trim", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
     "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_ritz_residual", "dla_axpy",
     "dla_nrm2", "dla_stream_triad", "dla_random_fill", "dla_fill_guess",
-    "dla_ortho_cd", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
+    "dla_ortho_cd", "dla_ortho_qr", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
     "dla_call_matvec", "dla_call_precnd",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
     "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd",
@@ -106,7 +106,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_axpy": (i, [vp, sz, d, vp, vp]), "dla_nrm2": (i, [vp, sz, vp, c_dp]),
         "dla_stream_triad": (i, [vp, sz, i, c_dp]),
         "dla_random_fill": (i, [vp, i, i, vp]), "dla_fill_guess": (i, [vp, i, i, vp, C.c_ulonglong, C.c_longlong]),
-        "dla_ortho_cd": (i, [vp, i, i, vp, c_dp, c_ip]), "dla_ortho_vs_x": (i, [vp, i, i, i, vp, vp]),
+        "dla_ortho_cd": (i, [vp, i, i, vp, c_dp, c_ip]), "dla_ortho_qr": (i, [vp, i, i, vp]), "dla_ortho_vs_x": (i, [vp, i, i, i, vp, vp]),
         "dla_b_ortho": (i, [vp, i, i, vp, vp]), "dla_b_ortho_vs_x": (i, [vp, i, i, i, vp, vp, vp]),
         "dla_check_guess": (i, [vp, i, i, vp]),
         "dla_get_coeffs": (i, [vp, i, i, i, i, c_dp, c_dp, c_dp]),
@@ -339,6 +339,10 @@ class Context:
         g = C.c_double(0.0); ok = C.c_int(0)
         self._chk(self.lib.dla_ortho_cd(self.h, u.n, u.m, u.ptr, C.byref(g), C.byref(ok)))
         return g.value, bool(ok.value)
+
+    def ortho_qr(self, u: DevPanel) -> None:
+        """the reference's Householder fallback `ortho` (diaglib.f90:3052-3092): U <- U R^-1, LAPACK signs"""
+        self._chk(self.lib.dla_ortho_qr(self.h, u.n, u.m, u.ptr))
 
     def ortho_vs_x(self, x: DevPanel, u: DevPanel, m: Optional[int] = None) -> None:
         self._chk(self.lib.dla_ortho_vs_x(self.h, x.n, x.m if m is None else m, u.m, x.ptr, u.ptr))

@@ -422,11 +422,17 @@ int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
   return ortho_cd_impl(c, n, k, u, growth, ok, nullptr);
 }
 
-// Column-wise modified Gram-Schmidt (twice) on the device: the stand-in for the reference's
-// Householder fallback `ortho` (diaglib.f90:3052-3092), reached only when ortho_cd gives up.
-// Same span and orthonormality as U R^-1 from a QR factorisation; column signs follow the
-// input columns (R with positive diagonal).
-static int ortho_fallback(dla_ctx* c, int n, int k, double* u)
+// The reference's fallback `ortho` (diaglib.f90:3052-3092): Householder QR of a copy (dgeqrf), then U <- U R^-1 (dtrsm).
+// U R^-1 is the orthonormal factor Q of U = Q R with LAPACK's sign convention r_jj = -sign(alpha_j) ||x_j||, i.e. the
+// Cholesky-QR factor Q+ (positive diagonal) with some columns negated.  Here:
+//   1. Q+ comes from a column-wise modified Gram-Schmidt (twice) on the device -- robust exactly where this routine is
+//      needed, after ortho_cd has given up on an ill-conditioned block;
+//   2. the signs come from running the SAME Householder recurrence on a 2k x k host matrix that is isometric to U:
+//      with T = the top k rows of U and U_low = U without them, U_low = Z R_low (R_low from the Cholesky factor of
+//      U^T U - T^T T), the matrix M = [T; R_low] has the columns of U in the orthonormal basis [e_1..e_k, Z], and every
+//      Householder vector of U lies in that span; the reflections of M are those of U, so diag(R) has the same signs.
+// T is obtained as E^T U with E = (e_1 .. e_k) through the Gram door, so a row-sharded U needs no extra collective.
+static int mgs2_device(dla_ctx* c, int n, int k, double* u)
 {
   for (int pass = 0; pass < 2; ++pass)
     for (int j = 0; j < k; ++j) {
@@ -441,12 +447,105 @@ static int ortho_fallback(dla_ctx* c, int n, int k, double* u)
       double g = 0.0;
       int st = c->eng->gram(n, 1, uj, 1, uj, &g, 1);
       if (st) return engfail(c, st);
-      if (!(g > 0.0)) return fail(c, DLA_ERR_ORTHO, "ortho fallback: zero column");
+      if (!(g > 0.0)) return fail(c, DLA_ERR_ORTHO, "ortho: zero column");
       double w = 1.0 / std::sqrt(g);
       st = c->eng->trmm(n, 1, uj, &w, 1);
       if (st) return engfail(c, st);
     }
   return DLA_OK;
+}
+
+// signs of diag(R) of the Householder QR (dgeqr2 / dlarfg rules) of the rows x cols column-major matrix m (overwritten)
+static void householder_diag_signs(int rows, int cols, std::vector<double>& m, std::vector<double>& sign)
+{
+  sign.assign(cols, 1.0);
+  std::vector<double> v(rows);
+  for (int j = 0; j < cols && j < rows; ++j) {
+    double* cj = m.data() + (size_t)j * rows;
+    const double alpha = cj[j];
+    double xnorm2 = 0.0;
+    for (int i = j + 1; i < rows; ++i) xnorm2 += cj[i] * cj[i];
+    if (xnorm2 == 0.0) {                       // dlarfg: H = I, beta = alpha
+      sign[j] = alpha < 0.0 ? -1.0 : 1.0;
+      continue;
+    }
+    const double nrm = std::sqrt(alpha * alpha + xnorm2);
+    const double beta = alpha >= 0.0 ? -nrm : nrm;
+    sign[j] = beta < 0.0 ? -1.0 : 1.0;
+    for (int i = 0; i < rows; ++i) v[i] = i < j ? 0.0 : cj[i];
+    v[j] = alpha - beta;
+    double vtv = 0.0;
+    for (int i = j; i < rows; ++i) vtv += v[i] * v[i];
+    for (int cc = j; cc < cols; ++cc) {
+      double* col = m.data() + (size_t)cc * rows;
+      double dot = 0.0;
+      for (int i = j; i < rows; ++i) dot += v[i] * col[i];
+      const double f = 2.0 * dot / vtv;
+      for (int i = j; i < rows; ++i) col[i] -= f * v[i];
+    }
+  }
+}
+
+static int ortho_qr_impl(dla_ctx* c, int n, int k, double* u)
+{
+  if (k <= 0) return DLA_OK;
+  const long long ng = global_rows(c, n);
+  if (ng < k) return fail(c, DLA_ERR_ARG, "ortho: more columns than rows");
+  // T = E^T U and G = U^T U before U changes
+  std::vector<double> t((size_t)k * k), g((size_t)k * k);
+  {
+    void* ev = nullptr;
+    int st = c->eng->alloc(sizeof(double) * (size_t)n * k, &ev);
+    if (st) return engfail(c, st);
+    st = c->eng->zero(ev, sizeof(double) * (size_t)n * k);
+    const double unit = 1.0;
+    for (int j = 0; j < k && !st; ++j) {
+      const long long lr = (long long)j - c->row0;             // global row j on this shard?
+      if (lr >= 0 && lr < n) st = c->eng->h2d((double*)ev + (size_t)j * n + lr, &unit, sizeof(double));
+    }
+    if (!st) st = c->eng->gram(n, k, (const double*)ev, k, u, t.data(), k);
+    int stf = c->eng->free_(ev);
+    if (st || stf) return engfail(c, st ? st : stf);
+    st = c->eng->gram(n, k, u, k, u, g.data(), k);
+    if (st) return engfail(c, st);
+  }
+  int st = mgs2_device(c, n, k, u);
+  if (st) return st;
+  // R_low^T R_low = G - T^T T
+  std::vector<double> gl((size_t)k * k);
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < k; ++i) {
+      double acc = g[(size_t)i + (size_t)j * k];
+      for (int p = 0; p < k; ++p) acc -= t[(size_t)p + (size_t)i * k] * t[(size_t)p + (size_t)j * k];
+      gl[(size_t)i + (size_t)j * k] = acc;
+    }
+  std::vector<double> l = gl;
+  if (dla_potrf_lower(k, l.data(), k) != 0) {
+    // rank-deficient below the top block: a small shift keeps the recurrence defined (only signs are read off)
+    double tr = 0.0;
+    for (int i = 0; i < k; ++i) tr += std::fabs(gl[(size_t)i + (size_t)i * k]);
+    l = gl;
+    for (int i = 0; i < k; ++i) l[(size_t)i + (size_t)i * k] += 1e-14 * tr + 1e-300;
+    if (dla_potrf_lower(k, l.data(), k) != 0) std::fill(l.begin(), l.end(), 0.0);
+  }
+  std::vector<double> mm((size_t)2 * k * k, 0.0), sign;
+  for (int j = 0; j < k; ++j) {
+    for (int i = 0; i < k; ++i) mm[(size_t)i + (size_t)j * 2 * k] = t[(size_t)i + (size_t)j * k];
+    for (int i = 0; i <= j; ++i) mm[(size_t)(k + i) + (size_t)j * 2 * k] = l[(size_t)j + (size_t)i * k];   // R_low = L^T
+  }
+  householder_diag_signs(2 * k, k, mm, sign);
+  bool any = false;
+  for (int j = 0; j < k; ++j) any = any || sign[j] < 0.0;
+  if (!any) return DLA_OK;
+  std::vector<double> w((size_t)k * k, 0.0);
+  for (int j = 0; j < k; ++j) w[(size_t)j + (size_t)j * k] = sign[j];
+  return engfail(c, c->eng->trmm(n, k, u, w.data(), k));
+}
+
+int dla_ortho_qr(dla_ctx* c, int n, int k, double* u)
+{
+  DLA_T("dla_ortho_qr");
+  return ortho_qr_impl(c, n, k, u);
 }
 
 static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, const double* bx, double* u)
@@ -484,7 +583,7 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
   bool pending = false;
   int st = ortho_cd_impl(c, n, k, u, &growth, &ok, nullptr, combo ? wdef.data() : nullptr, &pending, true);   // :3533
   if (st) return st;
-  if (!ok) { st = ortho_fallback(c, n, k, u); if (st) return st; }
+  if (!ok) { st = ortho_qr_impl(c, n, k, u); if (st) return st; }         // :3534
   while (!done) {
     ++it;
     if (m > 0) {
@@ -512,7 +611,7 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
                        combo ? wdef.data() : nullptr, &pending, false);          // :3548
     if (st) return st;
     if (!ok) {
-      st = ortho_fallback(c, n, k, u);
+      st = ortho_qr_impl(c, n, k, u);                      // :3549
       if (st) return st;
       double s = 0.0;
       if (m > 0) {

@@ -1,25 +1,24 @@
 !
 ! diaglib (MI355X-native) -- drop-in for the public interface of Molecolab-Pisa/diaglib.
 !
-! Same module name, same public procedures and argument lists as the reference
-! (reference diaglib.f90:166-167, 1483-1539, 171-228, 3185, 3481, 3094, 3576, 3052), so an
-! existing CI / augmented-Hessian caller only re-links.  What differs is where the work
-! happens: the drivers below keep the host control flow (iteration, locking, restart,
-! the small Rayleigh-Ritz problem) and every O(n) operation is a call through
-! ISO_C_BINDING into the HIP engine (include/diaglib_amd.h).  The expansion panels
-! space/aspace/r live in HBM for the whole solve; only lda x lda matrices visit the host.
+! Same module name, same public procedures and argument lists as the reference (reference diaglib.f90:166-167,
+! 1483-1539, 171-228, 1855, 558, 1024, 3185, 3481, 3094, 3576, 3052), so an existing CI / augmented-Hessian /
+! linear-response caller only re-links.  Everything behind the argument lists is this project's own design:
 !
-! Callbacks keep the reference shape  matvec(n,m,x,ax) / precnd(n,m,fac,x,px)
-! (reference README.md:34-35).  By default they receive HOST arrays (the engine stages
-! blocks through pinned memory); after  call diaglib_amd_config(callbacks_on_device=.true.)
-! they receive DEVICE addresses under the same signature (SURVEY.md 8b).
+!   * every O(n) operation is a call through ISO_C_BINDING into the HIP engine (include/diaglib_amd.h); the
+!     expansion panels live in HBM for the whole solve, only lda x lda matrices visit the host;
+!   * the host control flow is written once: a `subspace` object does the block bookkeeping (growth, locking,
+!     restart) for all Davidson-type drivers, `davidson_core` serves davidson_driver and gen_david_driver,
+!     `lr_core` serves caslr_driver and caslr_eff_driver, and the table / timing printers exist once;
+!   * there is no module-level state (the reference keeps LAPACK work arrays and timers in the module,
+!     diaglib.f90:155-161): a driver call owns its state on the stack, and the engine context it uses belongs
+!     to the calling thread (dla_default_ctx), so two host threads can solve at the same time.
 !
-! The generalised problem (metric B through a bvec callback) is served by gen_david_driver and by
-! lobpcg_driver with gen_eig=.true. (reference diaglib.f90:1855-2250, 299-302/357-364/523-526).
-! The linear-response problem is served by caslr_eff_driver (reference diaglib.f90:1024-1481) and caslr_driver
-! (:558-1022, its default algorithm i_alg = 0), built from the same device operations.  Not provided (SURVEY.md 2
-! row 5): nonsym_driver, and the Helmich-Paris variant of caslr_driver (i_alg = 1, a switch of the reference
-! harness' module utils).
+! Callbacks keep the reference shape  matvec(n,m,x,ax) / precnd(n,m,fac,x,px)  (reference README.md:34-35).  By
+! default they receive HOST arrays (the engine stages blocks through pinned memory); after
+! `call diaglib_amd_config(callbacks_on_device=.true.)` they receive DEVICE addresses under the same signature.
+!
+! Not provided (SURVEY.md 2 row 5): nonsym_driver.
 !
 module diaglib
   use real_precision
@@ -32,15 +31,52 @@ module diaglib
   public :: diaglib_amd_config
 !
   real(dp), parameter :: zero = 0.0_dp, one = 1.0_dp, ten = 10.0_dp
-  integer,  parameter :: min_dav = 10          ! reference diaglib.f90:1544
+  integer,  parameter :: min_dav = 10          ! smallest basis, in blocks (reference diaglib.f90:1544)
 !
 ! option ids of include/diaglib_amd.h
 !
   integer(c_int), parameter :: opt_cb_dev = 1, opt_evec_dev = 2
 !
-! timers: (cpu, wall) pairs like the reference's t_mv, t_diag, t_ortho, t_tot
+! Helmich-Paris variant of caslr_driver (reference: harness variable i_alg of module utils, diaglib.f90:560,675);
+! here a setting of the library, see diaglib_amd_config
 !
-  real(dp) :: t_mv(2), t_diag(2), t_ortho(2), t_tot(2), t1(2), t2(2)
+  integer, save :: lr_algorithm = 0
+!
+! ---------------------------------------------------------------------------------------
+! bookkeeping of a basis that grows block by block (all Davidson-type drivers)
+! ---------------------------------------------------------------------------------------
+  type :: subspace
+    integer  :: blk    = 0     ! block width                          (reference n_max)
+    integer  :: want   = 0     ! roots asked for                      (n_targ)
+    integer  :: cap    = 0     ! blocks the panels can hold           (dim_dav)
+    integer  :: ld     = 0     ! cap * blk, leading dimension of the projected matrices (lda)
+    integer  :: nblk   = 0     ! blocks in use                        (m_dim)
+    integer  :: cols   = 0     ! columns in use                       (ldu)
+    integer  :: head   = 1     ! first column of the newest block     (i_beg)
+    integer  :: act    = 0     ! width of the newest block            (n_act)
+    integer  :: frozen = 0     ! leading roots that were converged when the newest block was built (n_frozen)
+    real(dp) :: tol_rms = zero, tol_max = zero
+    logical,        allocatable :: locked(:)     ! (done)
+    integer(c_int), allocatable :: mask(:)       ! locked, as the engine wants it
+    real(dp),       allocatable :: rnorm(:,:)    ! (1,:) rms, (2,:) max of the residuals
+  end type subspace
+!
+! the reference's four timers, (cpu, wall) pairs (diaglib.f90:160-161)
+!
+  type :: stopwatch
+    real(dp) :: mv(2) = zero, diag(2) = zero, ortho(2) = zero, total(2) = zero, mark(2) = zero
+  end type stopwatch
+!
+! device side of one driver call
+!
+  type :: solve_env
+    type(c_ptr) :: ctx   = c_null_ptr
+    type(c_ptr) :: ritz  = c_null_ptr    ! the eigenvector block on the device: the caller's (evec_on_device) or a copy
+    logical     :: ritz_is_callers = .false.
+    integer     :: rows = 0, width = 0   ! shape of that block
+    integer     :: op_cols = 0           ! columns handed to the operator callbacks
+    integer     :: restarts = 0
+  end type solve_env
 !
   interface
     function dla_default_ctx() bind(C,name='dla_default_ctx') result(ctx)
@@ -151,6 +187,12 @@ module diaglib
       integer(c_int) :: ok
       integer(c_int) :: st
     end function
+    function dla_ortho_qr(ctx,n,k,u) bind(C,name='dla_ortho_qr') result(st)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, u
+      integer(c_int), value :: n, k
+      integer(c_int) :: st
+    end function
     function dla_ortho_vs_x(ctx,n,m,k,x,u) bind(C,name='dla_ortho_vs_x') result(st)
       import :: c_ptr, c_int
       type(c_ptr), value :: ctx, x, u
@@ -217,6 +259,13 @@ module diaglib
       real(c_double) :: a(*)
       integer(c_int) :: info
     end function
+    function dla_syev(uplo,n,a,lda,w) bind(C,name='dla_syev') result(info)
+      import :: c_char, c_int, c_double
+      character(kind=c_char), value :: uplo
+      integer(c_int), value :: n, lda
+      real(c_double) :: a(*), w(*)
+      integer(c_int) :: info
+    end function
     function dla_syev_lowest(uplo,n,a,lda,w,m) bind(C,name='dla_syev_lowest') result(info)
       import :: c_char, c_int, c_double
       character(kind=c_char), value :: uplo
@@ -238,13 +287,15 @@ module diaglib
 contains
 !
 ! ---------------------------------------------------------------------------------------
-! configuration (extension; defaults reproduce the reference contract: host callbacks,
-! host eig/evec)
+! configuration (extension; defaults reproduce the reference contract: host callbacks, host eig/evec)
 ! ---------------------------------------------------------------------------------------
-  subroutine diaglib_amd_config(callbacks_on_device, evec_on_device, release_cache)
+  subroutine diaglib_amd_config(callbacks_on_device, evec_on_device, release_cache, caslr_algorithm)
     logical, intent(in), optional :: callbacks_on_device, evec_on_device
 !   release_cache = .true.: hand the panels the allocator keeps between solves back to the runtime (dla_trim)
     logical, intent(in), optional :: release_cache
+!   caslr_algorithm: 0 = the reduced pencil of caslr_driver as one generalised eigenproblem (reference default),
+!   1 = the Helmich-Paris route through the singular values of the scaled coupling block (reference i_alg = 1)
+    integer, intent(in), optional :: caslr_algorithm
     integer(c_size_t) :: released
     type(c_ptr)    :: ctx
     integer(c_int) :: st
@@ -254,7 +305,12 @@ contains
     if (present(release_cache)) then
       if (release_cache) st = dla_trim(ctx, released)
     end if
+    if (present(caslr_algorithm)) lr_algorithm = caslr_algorithm
   end subroutine diaglib_amd_config
+!
+! ---------------------------------------------------------------------------------------
+! small plumbing
+! ---------------------------------------------------------------------------------------
 !
 ! address of column j (1-based) of a device panel with leading dimension n
 !
@@ -272,6 +328,12 @@ contains
     integer(c_size_t)   :: b
     b = 8_c_size_t * int(n,c_size_t) * int(m,c_size_t)
   end function nbytes
+!
+  function nelem(n,m) result(b)
+    integer, intent(in) :: n, m
+    integer(c_size_t)   :: b
+    b = int(n,c_size_t) * int(m,c_size_t)
+  end function nelem
 !
 ! any engine failure is fatal, like the reference's `stop` paths (diaglib.f90:414,3283,3568,3800)
 !
@@ -293,885 +355,705 @@ contains
     error stop 1
   end subroutine chk
 !
-  subroutine get_time(t)
-    real(dp), intent(inout) :: t(2)
+! a device panel of n x m doubles
+!
+  function dev_panel(ctx,n,m,what) result(p)
+    type(c_ptr),      intent(in) :: ctx
+    integer,          intent(in) :: n, m
+    character(len=*), intent(in) :: what
+    type(c_ptr) :: p
+    call chk(ctx, dla_alloc(ctx, nbytes(n,m), p), 'allocation of '//what)
+  end function dev_panel
+!
+  subroutine drop_panel(ctx,p)
+    type(c_ptr), intent(in)    :: ctx
+    type(c_ptr), intent(inout) :: p
+    if (c_associated(p)) call chk(ctx, dla_free(ctx, p), 'free')
+    p = c_null_ptr
+  end subroutine drop_panel
+!
+! failure of the small symmetric eigensolver: the reference's message and stop (diaglib.f90:412-415)
+!
+  subroutine need_eigensolver(info)
+    integer(c_int), intent(in) :: info
+    if (info.eq.0) return
+    write(6,'(t3,a,i6)') 'dsyev failed. info = ',info
+    error stop 1
+  end subroutine need_eigensolver
+!
+! ---------------------------------------------------------------------------------------
+! stopwatch: cpu / wall clock pairs, started and charged explicitly
+! ---------------------------------------------------------------------------------------
+  subroutine clock_now(t)
+    real(dp), intent(out) :: t(2)
     integer(8) :: cnt, rate
     call cpu_time(t(1))
     call system_clock(cnt, rate)
     t(2) = real(cnt,dp)/real(rate,dp)
-  end subroutine get_time
+  end subroutine clock_now
+!
+  subroutine lap_start(w)
+    type(stopwatch), intent(inout) :: w
+    call clock_now(w%mark)
+  end subroutine lap_start
+!
+  subroutine lap_charge(w, bucket)
+    type(stopwatch), intent(in)    :: w
+    real(dp),        intent(inout) :: bucket(2)
+    real(dp) :: now(2)
+    call clock_now(now)
+    bucket = bucket + now - w%mark
+  end subroutine lap_charge
 !
 ! ---------------------------------------------------------------------------------------
-! Davidson-Liu (reference diaglib.f90:1483-1853)
+! device side of a driver call: context, eigenvector block, statistics
 ! ---------------------------------------------------------------------------------------
-  subroutine davidson_driver(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift,matvec,precnd,eig,evec,ok)
-    logical,                              intent(in)    :: verbose
-    integer,                              intent(in)    :: n, n_targ, n_max
-    integer,                              intent(in)    :: max_iter, max_dav
-    real(dp),                             intent(in)    :: tol, shift
-    real(dp), dimension(n_max),           intent(inout) :: eig
-    real(dp), dimension(n,n_max), target, intent(inout) :: evec
-    logical,                              intent(inout) :: ok
-    external                                            :: matvec, precnd
-!
-    type(c_ptr)    :: ctx, space, aspace, r, evd
-    type(c_funptr) :: mv, pc
-    integer        :: dim_dav, lda, n_act, ind, i_beg, m_dim, ldu, n_frozen, it, i_eig, n_rst, c0
-    integer        :: n_mv, n_restarts
-    logical        :: restart, evec_dev
-    real(dp)       :: tol_rms, tol_max
-    logical,        allocatable :: done(:)
-    integer(c_int), allocatable :: skip(:)
-    real(dp),       allocatable :: a_red(:,:), a_copy(:,:), e_red(:), r_norm(:,:)
-    integer(c_int) :: info
-!
-    ctx = dla_default_ctx()
-    mv  = c_funloc(matvec)
-    pc  = c_funloc(precnd)
-    evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
-!
-!   expansion space size: never smaller than 10 blocks (reference :1595-1596)
-!
-    dim_dav = max(min_dav,max_dav)
-    lda     = dim_dav*n_max
-!
-!   device panels (reference :1607) and host-size matrices (:1612-1617)
-!
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), space),  'allocation of space')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), aspace), 'allocation of aspace')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), r),    'allocation of r')
-    if (evec_dev) then
-      evd = c_loc(evec)
+  subroutine env_open(e, rows, width, evec)
+    type(solve_env),  intent(out) :: e
+    integer,          intent(in)  :: rows, width
+    real(dp), target, intent(in)  :: evec(rows,width)
+    e%ctx   = dla_default_ctx()
+    e%rows  = rows
+    e%width = width
+    e%ritz_is_callers = dla_get_option(e%ctx, opt_evec_dev) .ne. 0
+    if (e%ritz_is_callers) then
+      e%ritz = c_loc(evec)
     else
-      call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), evd), 'allocation of evec')
-      call chk(ctx, dla_upload(ctx, evd, c_loc(evec), nbytes(n,n_max)), 'upload of the guess')
+      e%ritz = dev_panel(e%ctx, rows, width, 'evec')
+      call chk(e%ctx, dla_upload(e%ctx, e%ritz, c_loc(evec), nbytes(rows,width)), 'upload of the guess')
     end if
-    allocate (done(n_max), skip(n_max), r_norm(2,n_max), a_red(lda,lda), a_copy(lda,lda), e_red(lda))
+  end subroutine env_open
 !
-    tol_rms = tol
-    tol_max = ten * tol
-    t_diag  = zero
-    t_ortho = zero
-    t_mv    = zero
-    t_tot   = zero
+! hand the eigenvector block back (evec holds the current vectors on every exit, like the reference) and report
 !
-!   the reference zero-fills both n x lda panels here (:1632-1633).  On the device no column is
-!   ever read before it has been written (guess copy, matvec output, ortho_vs_x output), so the
-!   two 8*n*lda-byte memsets are skipped; the columns the restart quirk reads as zeros are
-!   zeroed at the restart (below).
+  subroutine env_close(e, evec, iterations)
+    type(solve_env),  intent(inout) :: e
+    real(dp), target, intent(inout) :: evec(e%rows,e%width)
+    integer,          intent(in)    :: iterations
+    if (.not.e%ritz_is_callers) then
+      call chk(e%ctx, dla_download(e%ctx, c_loc(evec), e%ritz, nbytes(e%rows,e%width)), 'download of evec')
+      call drop_panel(e%ctx, e%ritz)
+    end if
+    call dla_set_solve_info(int(iterations,c_int), int(e%op_cols,c_int), int(e%restarts,c_int))
+  end subroutine env_close
 !
-    a_red   = zero
-    r_norm  = zero
-    ok      = .false.
-    done    = .false.
+! ---------------------------------------------------------------------------------------
+! subspace bookkeeping
+! ---------------------------------------------------------------------------------------
+  subroutine sub_setup(s, n_targ, n_max, blocks, tol)
+    type(subspace), intent(out) :: s
+    integer,        intent(in)  :: n_targ, n_max, blocks
+    real(dp),       intent(in)  :: tol
+    s%blk  = n_max
+    s%want = n_targ
+    s%cap  = blocks
+    s%ld   = blocks*n_max
+    s%tol_rms = tol                  ! reference: rms < tol and max < 10 tol (diaglib.f90:1625-1626, 1741)
+    s%tol_max = ten*tol
+    allocate (s%locked(n_max), s%mask(n_max), s%rnorm(2,n_max))
+    s%locked = .false.
+    s%mask   = 0_c_int
+    s%rnorm  = zero
+    call sub_collapse(s)
+  end subroutine sub_setup
 !
-    call get_time(t_tot)
+! back to a single block of full width (start and restart)
 !
-!   guess: orthonormalise if needed, random if zero (reference :1644), then copy (:1648)
+  subroutine sub_collapse(s)
+    type(subspace), intent(inout) :: s
+    s%nblk = 1
+    s%cols = 0
+    s%head = 1
+    s%act  = s%blk
+  end subroutine sub_collapse
 !
-    call chk(ctx, dla_check_guess(ctx, n, n_max, evd), 'check_guess')
-    call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
+! the newest block joins the basis
 !
-    n_act = n_max
-    ind   = 1
-    i_beg = 1
-    m_dim = 1
-    ldu   = 0
-    restart = .false.
-    n_rst   = 0
-    n_frozen = 0
-    n_mv = 0
-    n_restarts = 0
+  subroutine sub_admit(s)
+    type(subspace), intent(inout) :: s
+    s%cols = s%cols + s%act
+  end subroutine sub_admit
 !
-    1030 format(t5,'Davidson-Liu iterations (tol=',d10.2,'):',/, &
-                t5,'------------------------------------------------------------------',/, &
-                t7,'  iter  root              eigenvalue','         rms         max ok',/, &
-                t5,'------------------------------------------------------------------')
-    1040 format(t9,i4,2x,i4,f24.12,2d12.4,l3)
-    if (verbose) write(6,1030) tol
+! number of leading wanted roots that are locked
+!
+  function sub_leading(s) result(k)
+    type(subspace), intent(in) :: s
+    integer :: k
+    k = 0
+    do while (k.lt.s%want)
+      if (.not.s%locked(k+1)) exit
+      k = k + 1
+    end do
+  end function sub_leading
+!
+! Locking rule of the reference (diaglib.f90:1737-1746, LOBPCG :446-455): roots lock in order; a root locks when
+! both residual measures are under their thresholds and at least one iteration has gone by; the first root that
+! does not lock unlocks everything after it.
+!
+  subroutine sub_lock(s, iteration, upto)
+    type(subspace), intent(inout) :: s
+    integer,        intent(in)    :: iteration, upto
+    integer :: r
+    do r = 1, upto
+      if (s%locked(r)) cycle
+      if (iteration.gt.1 .and. s%rnorm(1,r).lt.s%tol_rms .and. s%rnorm(2,r).lt.s%tol_max) then
+        s%locked(r) = .true.
+      else
+        s%locked(r:s%blk) = .false.
+        return
+      end if
+    end do
+  end subroutine sub_lock
+!
+  function sub_finished(s) result(yes)
+    type(subspace), intent(in) :: s
+    logical :: yes
+    yes = all(s%locked(1:s%want))
+  end function sub_finished
+!
+  function sub_has_room(s) result(yes)
+    type(subspace), intent(in) :: s
+    logical :: yes
+    yes = s%nblk .lt. s%cap
+  end function sub_has_room
+!
+! open the next block: it gets one column per root that is not locked at the front (diaglib.f90:1765-1785);
+! first_root is the first of those roots
+!
+  subroutine sub_open_block(s, first_root)
+    type(subspace), intent(inout) :: s
+    integer,        intent(out)   :: first_root
+    s%nblk   = s%nblk + 1
+    s%head   = s%head + s%act
+    s%frozen = sub_leading(s)
+    s%act    = s%blk - s%frozen
+    first_root = s%frozen + 1
+  end subroutine sub_open_block
+!
+  subroutine sub_refresh_mask(s)
+    type(subspace), intent(inout) :: s
+    s%mask = merge(1_c_int, 0_c_int, s%locked)
+  end subroutine sub_refresh_mask
+!
+! ---------------------------------------------------------------------------------------
+! printers: byte-compatible with the reference's verbose output (formats 1030, 1040, 1050, 1000 of every driver)
+! ---------------------------------------------------------------------------------------
+  subroutine print_table_head(opening, tol)
+    character(len=*), intent(in) :: opening      ! e.g. 'Davidson-Liu iterations (tol='
+    real(dp),         intent(in) :: tol
+    write(6,'(t5,a,d10.2,a,/,t5,a,/,t7,a,a,/,t5,a)') opening, tol, '):', &
+          '------------------------------------------------------------------', &
+          '  iter  root              eigenvalue', '         rms         max ok', &
+          '------------------------------------------------------------------'
+  end subroutine print_table_head
+!
+  subroutine print_table_rows(s, iteration, values)
+    type(subspace), intent(in) :: s
+    integer,        intent(in) :: iteration
+    real(dp),       intent(in) :: values(:)
+    integer :: r
+    do r = 1, s%want
+      write(6,'(t9,i4,2x,i4,f24.12,2d12.4,l3)') iteration, r, values(r), s%rnorm(:,r), s%locked(r)
+    end do
+    write(6,*)
+  end subroutine print_table_rows
+!
+  subroutine print_block_report(s)
+    type(subspace), intent(in) :: s
+    write(6,'(t5,a,/,t7,a,i4,/,t7,a,i4,/,t7,a,i4,/,t5,a)') '----------------------------------------', &
+          '# target vectors:    ', s%want, '# new vectors added: ', s%act, '# converged vectors: ', s%frozen, &
+          '----------------------------------------'
+  end subroutine print_block_report
+!
+  subroutine print_timings(heading, w)
+    character(len=*), intent(in) :: heading      ! e.g. 'timings for davidson (cpu/wall): '
+    type(stopwatch),  intent(in) :: w
+    write(6,'(t3,a,/,t3,a,2f12.4,/,t3,a,2f12.4,/,t3,a,2f12.4,/,t3,a,a,/,t3,a,2f12.4)') heading, &
+          '  matrix-vector multiplications: ', w%mv, '  diagonalization:               ', w%diag, &
+          '  orthogonalization:             ', w%ortho, '                                 ', repeat('=',24), &
+          '  total:                         ', w%total
+  end subroutine print_timings
+!
+! ---------------------------------------------------------------------------------------
+! Davidson-Liu, standard and generalised problem (reference diaglib.f90:1483-1853 and :1855-2250).
+!
+! One routine serves both public drivers.  With a metric B the basis is kept B-orthonormal, bbasis = B * basis is
+! carried along, and the residual of a Ritz pair is A x - theta B x (:2108-2123).
+! Deliberate deviation at the restart of the generalised solve (SURVEY 8a A13): the reference zeroes all of its
+! bspace right after B-orthonormalising the kept Ritz block (:2196-2200) and never refills it, so its residuals
+! after a restart miss theta*B*x of that block; here the kept block's B*x stays in bbasis(:,1:n_max).
+! ---------------------------------------------------------------------------------------
+  subroutine davidson_core(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift,op,prec,metric,with_metric,eig,evec,ok)
+    logical,          intent(in)    :: verbose, with_metric
+    integer,          intent(in)    :: n, n_targ, n_max, max_iter, max_dav
+    real(dp),         intent(in)    :: tol, shift
+    type(c_funptr),   intent(in)    :: op, prec, metric
+    real(dp),         intent(inout) :: eig(n_max)
+    real(dp), target, intent(inout) :: evec(n,n_max)
+    logical,          intent(inout) :: ok
+!
+    type(subspace)  :: s
+    type(stopwatch) :: w
+    type(solve_env) :: e
+    type(c_ptr)     :: basis, abasis, bbasis, resid, britz
+    real(dp), allocatable :: h(:,:), y(:,:), theta(:)
+    real(dp)        :: t_begin(2), t_end(2)
+    integer         :: it, sweeps, kept, col, first, j
+    logical         :: patch_kept
+!
+    call env_open(e, n, n_max, evec)
+!
+!   the basis holds at least min_dav blocks whatever the caller asks for (reference :1595-1596)
+!
+    call sub_setup(s, n_targ, n_max, max(min_dav,max_dav), tol)
+    basis  = dev_panel(e%ctx, n, s%ld, 'space')
+    abasis = dev_panel(e%ctx, n, s%ld, 'aspace')
+    resid  = dev_panel(e%ctx, n, n_max, 'r')
+    bbasis = c_null_ptr
+    britz  = c_null_ptr
+    if (with_metric) then
+      bbasis = dev_panel(e%ctx, n, s%ld, 'bspace')
+      britz  = dev_panel(e%ctx, n, n_max, 'b_evec')
+    end if
+    allocate (h(s%ld,s%ld), y(s%ld,s%ld), theta(s%ld))
+!
+!   The reference zero-fills both n x lda panels (:1632-1633).  On the device no column is read before it has been
+!   written (guess copy, operator output, orthogonalisation output), so those two 8*n*lda-byte memsets do not exist;
+!   the few columns a restart reads as zeros are zeroed there.
+!
+    h  = zero
+    ok = .false.
+    call clock_now(t_begin)
+!
+!   guess: random if zero, orthonormalised if needed (reference :1644), then the first block of the basis (:1648)
+!
+    call chk(e%ctx, dla_check_guess(e%ctx, n, n_max, e%ritz), 'check_guess')
+    call chk(e%ctx, dla_copy(e%ctx, basis, e%ritz, nbytes(n,n_max)), 'copy')
+    if (with_metric) then
+      call chk(e%ctx, dla_call_matvec(e%ctx, metric, n, n_max, basis, bbasis), 'bvec')          ! :2033
+      call chk(e%ctx, dla_b_ortho(e%ctx, n, n_max, basis, bbasis), 'b_ortho')                   ! :2034
+    end if
+!
+    kept       = 0            ! locked Ritz vectors carried over a restart
+    patch_kept = .false.
+    sweeps     = max_iter
+    if (verbose) then
+      if (with_metric) then
+        call print_table_head('Generalized Davidson-Liu iterations (tol=', tol)
+      else
+        call print_table_head('Davidson-Liu iterations (tol=', tol)
+      end if
+    end if
 !
     do it = 1, max_iter
-      ldu = ldu + n_act
-      c0  = i_beg + n_rst
+      call sub_admit(s)
 !
-!     A times the new block (reference :1685)
+!     operator on the new block.  Right after a restart the block starts behind the kept (locked) vectors and runs
+!     `kept` zero columns past the Ritz block, exactly like the reference's offsets (:1685, SURVEY App. B 4).
 !
-      call get_time(t1)
-      call chk(ctx, dla_call_matvec(ctx, mv, n, n_act, colp(space,n,c0), colp(aspace,n,c0)), 'matvec')
-      call get_time(t2)
-      t_mv = t_mv + t2 - t1
-      n_mv = n_mv + n_act
+      col = s%head + kept
+      call lap_start(w)
+      call chk(e%ctx, dla_call_matvec(e%ctx, op, n, s%act, colp(basis,n,col), colp(abasis,n,col)), 'matvec')
+      call lap_charge(w, w%mv)
+      e%op_cols = e%op_cols + s%act
 !
-!     new columns of the projected matrix (reference :1691)
+!     new columns of the projected matrix (:1691); the kept roots enter through their Ritz values (:1696-1702)
 !
-      call chk(ctx, dla_gram(ctx, n, ldu, space, n_act, colp(aspace,n,c0), a_red(1,c0), lda), 'projection')
-!
-!     after a restart the locked roots enter through their eigenvalues (reference :1696-1702)
-!
-      if (restart) then
-        do i_eig = 1, n_rst
-          a_red(i_eig,i_eig) = e_red(i_eig)
+      call chk(e%ctx, dla_gram(e%ctx, n, s%cols, basis, s%act, colp(abasis,n,col), h(1,col), s%ld), 'projection')
+      if (patch_kept) then
+        do j = 1, kept
+          h(j,j) = theta(j)
         end do
-        restart = .false.
-        n_rst   = 0
-      end if
-      a_copy = a_red
-!
-      call get_time(t1)
-      info = dla_syev_lowest('u', ldu, a_copy, lda, e_red, n_max)   ! only a_copy(:,1:n_max) is used below
-      call get_time(t2)
-      t_diag = t_diag + t2 - t1
-      if (info.ne.0) then
-        write(6,'(t3,a,i6)') 'dsyev failed. info = ',info
-        stop
-      end if
-      eig = e_red(1:n_max)
-!
-!     Ritz vectors, residuals and their norms in one sweep (reference :1717-1732)
-!
-      do i_eig = 1, n_max
-        skip(i_eig) = merge(1_c_int, 0_c_int, done(i_eig))
-      end do
-      call chk(ctx, dla_ritz_residual(ctx, n, ldu, n_max, space, aspace, a_copy, lda, eig, n_targ, skip, &
-                                      evd, r, c_null_ptr, r_norm), 'ritz/residual')
-!
-!     lock the leading converged roots (reference :1737-1746)
-!
-      do i_eig = 1, n_targ
-        if (done(i_eig)) cycle
-        done(i_eig) = r_norm(1,i_eig).lt.tol_rms .and. r_norm(2,i_eig).lt.tol_max .and. it.gt.1
-        if (.not.done(i_eig)) then
-          done(i_eig+1:n_max) = .false.
-          exit
-        end if
-      end do
-!
-      if (verbose) then
-        do i_eig = 1, n_targ
-          write(6,1040) it, i_eig, eig(i_eig) - shift, r_norm(:,i_eig), done(i_eig)
-        end do
-        write(6,*)
+        patch_kept = .false.
+        kept = 0
       end if
 !
-      if (all(done(1:n_targ))) then
+!     Rayleigh-Ritz: the lowest n_max pairs of the upper triangle (:1703-1708)
+!
+      y = h
+      call lap_start(w)
+      call need_eigensolver(dla_syev_lowest('u', s%cols, y, s%ld, theta, n_max))
+      call lap_charge(w, w%diag)
+      eig = theta(1:n_max)
+!
+!     Ritz vectors, residuals of the wanted roots that are still open, and their norms: one sweep (:1717-1732)
+!
+      call sub_refresh_mask(s)
+      if (with_metric) then
+        call chk(e%ctx, dla_ritz_residual(e%ctx, n, s%cols, n_max, bbasis, abasis, y, s%ld, eig, n_targ, s%mask, &
+                                          britz, resid, c_null_ptr, s%rnorm), 'ritz/residual')
+        call chk(e%ctx, dla_panel_gemm(e%ctx, n, s%cols, basis, n_max, y, s%ld, e%ritz), 'ritz vectors')
+      else
+        call chk(e%ctx, dla_ritz_residual(e%ctx, n, s%cols, n_max, basis, abasis, y, s%ld, eig, n_targ, s%mask, &
+                                          e%ritz, resid, c_null_ptr, s%rnorm), 'ritz/residual')
+      end if
+!
+      call sub_lock(s, it, n_targ)
+      if (verbose) call print_table_rows(s, it, eig - shift)     ! the shift is cosmetic here (SURVEY App. B 1)
+      if (sub_finished(s)) then
         ok = .true.
+        sweeps = it
         exit
       end if
 !
-      if (m_dim .lt. dim_dav) then
+      if (sub_has_room(s)) then
 !
-!       expand: precondition the active residuals, orthogonalise against the space
-!       (reference :1773-1794)
+!       expand with the preconditioned open residuals, orthogonalised against the basis (:1773-1794)
 !
-        m_dim = m_dim + 1
-        i_beg = i_beg + n_act
-        n_act = n_max
-        n_frozen = 0
-        do i_eig = 1, n_targ
-          if (done(i_eig)) then
-            n_act = n_act - 1
-            n_frozen = n_frozen + 1
-          else
-            exit
-          end if
-        end do
-        ind = n_max - n_act + 1
-        call chk(ctx, dla_call_precnd(ctx, pc, n, n_act, -eig(ind), colp(r,n,ind), colp(space,n,i_beg)), 'precnd')
-        call get_time(t1)
-        call chk(ctx, dla_ortho_vs_x(ctx, n, ldu, n_act, space, colp(space,n,i_beg)), 'ortho_vs_x')
-        call get_time(t2)
-        t_ortho = t_ortho + t2 - t1
+        call sub_open_block(s, first)
+        call chk(e%ctx, dla_call_precnd(e%ctx, prec, n, s%act, -eig(first), colp(resid,n,first), &
+                                        colp(basis,n,s%head)), 'precnd')
+        call lap_start(w)
+        if (with_metric) then
+          call chk(e%ctx, dla_b_ortho_vs_x(e%ctx, n, s%cols, s%act, basis, bbasis, colp(basis,n,s%head)), 'b_ortho_vs_x')
+          call chk(e%ctx, dla_call_matvec(e%ctx, metric, n, s%act, colp(basis,n,s%head), colp(bbasis,n,s%head)), 'bvec')
+          call chk(e%ctx, dla_b_ortho(e%ctx, n, s%act, colp(basis,n,s%head), colp(bbasis,n,s%head)), 'b_ortho')
+        else
+          call chk(e%ctx, dla_ortho_vs_x(e%ctx, n, s%cols, s%act, basis, colp(basis,n,s%head)), 'ortho_vs_x')
+        end if
+        call lap_charge(w, w%ortho)
       else
 !
-!       restart from the current Ritz vectors (reference :1796-1824)
+!       basis full: restart from the current Ritz vectors (:1796-1824)
 !
         if (verbose) write(6,'(t7,a)') 'Restarting davidson.'
-        n_restarts = n_restarts + 1
-        n_act = n_max
-        call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
-        a_red = zero
-        ldu   = 0
-        i_beg = 1
-        m_dim = 1
-        n_rst = 0
-        do i_eig = 1, n_targ
-          if (done(i_eig)) then
-            n_rst = n_rst + 1
-          else
-            exit
-          end if
-        end do
-!
-!       the reference zeroes space and aspace entirely (:1798,1804).  What the next iteration
-!       actually reads from those zeros: matvec takes n_max columns starting at column 1+n_rst,
-!       i.e. it runs n_rst columns past the Ritz block (they must be zero), and the locked
-!       columns 1..n_rst of aspace stay zero (their eigenvalues are patched into a_red, :1696-1702).
-!
-        if (n_rst.gt.0) then
-          call chk(ctx, dla_zero(ctx, colp(space,n,n_max+1), nbytes(n,n_rst)), 'zero')
-          call chk(ctx, dla_zero(ctx, aspace, nbytes(n,n_rst)), 'zero')
+        e%restarts = e%restarts + 1
+        call chk(e%ctx, dla_copy(e%ctx, basis, e%ritz, nbytes(n,n_max)), 'copy')
+        if (with_metric) then
+          call chk(e%ctx, dla_copy(e%ctx, bbasis, britz, nbytes(n,n_max)), 'copy')
+          call chk(e%ctx, dla_b_ortho(e%ctx, n, n_max, basis, bbasis), 'b_ortho')               ! :2195-2197
         end if
-        restart = .true.
+        h = zero
+        call sub_collapse(s)
+        kept = sub_leading(s)
+!
+!       what the next sweep reads from the reference's zero-filled panels (:1798,1804): the operator block runs `kept`
+!       columns past the Ritz block, and the kept columns of A*basis are zero (their Ritz values go on the diagonal)
+!
+        if (kept.gt.0) then
+          call chk(e%ctx, dla_zero(e%ctx, colp(basis,n,n_max+1), nbytes(n,kept)), 'zero')
+          call chk(e%ctx, dla_zero(e%ctx, abasis, nbytes(n,kept)), 'zero')
+        end if
+        patch_kept = .true.
       end if
-      if (verbose) write(6,1050) n_targ, n_act, n_frozen
+      if (verbose) call print_block_report(s)
     end do
 !
-    call get_time(t2)
-    t_tot = t2 - t_tot
-    call dla_set_solve_info(int(min(it,max_iter),c_int), int(n_mv,c_int), int(n_restarts,c_int))
+    call clock_now(t_end)
+    w%total = t_end - t_begin
+    if (verbose) call print_timings('timings for davidson (cpu/wall): ', w)
 !
-    1000 format(t3,'timings for davidson (cpu/wall): ',/, &
-                t3,'  matrix-vector multiplications: ',2f12.4,/, &
-                t3,'  diagonalization:               ',2f12.4,/, &
-                t3,'  orthogonalization:             ',2f12.4,/, &
-                t3,'                                 ',24('='),/,  &
-                t3,'  total:                         ',2f12.4)
-    if (verbose) write(6,1000) t_mv, t_diag, t_ortho, t_tot
+    call env_close(e, evec, sweeps)
+    call drop_panel(e%ctx, basis)
+    call drop_panel(e%ctx, abasis)
+    call drop_panel(e%ctx, resid)
+    call drop_panel(e%ctx, bbasis)
+    call drop_panel(e%ctx, britz)
+    deallocate (h, y, theta)
+  end subroutine davidson_core
 !
-!   hand the Ritz vectors back (evec holds them on every exit, like the reference) and free
-!
-    if (.not.evec_dev) then
-      call chk(ctx, dla_download(ctx, c_loc(evec), evd, nbytes(n,n_max)), 'download of evec')
-      call chk(ctx, dla_free(ctx, evd), 'free')
-    end if
-    call chk(ctx, dla_free(ctx, space), 'free')
-    call chk(ctx, dla_free(ctx, aspace), 'free')
-    call chk(ctx, dla_free(ctx, r), 'free')
-    deallocate (done, skip, r_norm, a_red, a_copy, e_red)
-!
-    1050 format(t5,'----------------------------------------',/,&
-                t7,'# target vectors:    ',i4,/,&
-                t7,'# new vectors added: ',i4,/,&
-                t7,'# converged vectors: ',i4,/,&
-                t5,'----------------------------------------')
-    return
+  subroutine davidson_driver(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift,matvec,precnd,eig,evec,ok)
+    logical,  intent(in)            :: verbose
+    integer,  intent(in)            :: n, n_targ, n_max, max_iter, max_dav
+    real(dp), intent(in)            :: tol, shift
+    real(dp), intent(inout)         :: eig(n_max)
+    real(dp), intent(inout), target :: evec(n,n_max)
+    logical,  intent(inout)         :: ok
+    external                        :: matvec, precnd
+    call davidson_core(verbose, n, n_targ, n_max, max_iter, tol, max_dav, shift, c_funloc(matvec), c_funloc(precnd), &
+                       c_null_funptr, .false., eig, evec, ok)
   end subroutine davidson_driver
 !
-! ---------------------------------------------------------------------------------------
-! Davidson-Liu with a metric B (reference diaglib.f90:1855-2250): same loop plus bspace = B*space.
-! Deliberate deviation at the restart (SURVEY 8a A13): the reference zeroes all of bspace right after
-! B-orthonormalising the kept Ritz block (:2196-2200) and never refills it, so its residuals after a
-! restart miss theta*B*x of that block; here the kept block's B*x stays in bspace(:,1:n_max).
-! ---------------------------------------------------------------------------------------
   subroutine gen_david_driver(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift,matvec,precnd,bvec,eig,evec,ok)
-    logical,                              intent(in)    :: verbose
-    integer,                              intent(in)    :: n, n_targ, n_max
-    integer,                              intent(in)    :: max_iter, max_dav
-    real(dp),                             intent(in)    :: tol, shift
-    real(dp), dimension(n_max),           intent(inout) :: eig
-    real(dp), dimension(n,n_max), target, intent(inout) :: evec
-    logical,                              intent(inout) :: ok
-    external                                            :: matvec, precnd, bvec
-!
-    type(c_ptr)    :: ctx, space, aspace, bspace, b_evec, r, evd
-    type(c_funptr) :: mv, pc, bv
-    integer        :: dim_dav, lda, n_act, ind, i_beg, m_dim, ldu, n_frozen, it, i_eig, n_rst, c0
-    integer        :: n_mv, n_restarts
-    logical        :: restart, evec_dev
-    real(dp)       :: tol_rms, tol_max
-    logical,        allocatable :: done(:)
-    integer(c_int), allocatable :: skip(:)
-    real(dp),       allocatable :: a_red(:,:), a_copy(:,:), e_red(:), r_norm(:,:)
-    integer(c_int) :: info
-!
-    ctx = dla_default_ctx()
-    mv  = c_funloc(matvec)
-    pc  = c_funloc(precnd)
-    bv  = c_funloc(bvec)
-    evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
-!
-!   expansion space size: never smaller than 10 blocks (reference :1595-1596)
-!
-    dim_dav = max(min_dav,max_dav)
-    lda     = dim_dav*n_max
-!
-!   device panels (reference :1607) and host-size matrices (:1612-1617)
-!
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), space),  'allocation of space')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), aspace), 'allocation of aspace')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), r),    'allocation of r')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), bspace), 'allocation of bspace')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), b_evec), 'allocation of b_evec')
-    if (evec_dev) then
-      evd = c_loc(evec)
-    else
-      call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), evd), 'allocation of evec')
-      call chk(ctx, dla_upload(ctx, evd, c_loc(evec), nbytes(n,n_max)), 'upload of the guess')
-    end if
-    allocate (done(n_max), skip(n_max), r_norm(2,n_max), a_red(lda,lda), a_copy(lda,lda), e_red(lda))
-!
-    tol_rms = tol
-    tol_max = ten * tol
-    t_diag  = zero
-    t_ortho = zero
-    t_mv    = zero
-    t_tot   = zero
-!
-!   the reference zero-fills both n x lda panels here (:1632-1633).  On the device no column is
-!   ever read before it has been written (guess copy, matvec output, ortho_vs_x output), so the
-!   two 8*n*lda-byte memsets are skipped; the columns the restart quirk reads as zeros are
-!   zeroed at the restart (below).
-!
-    a_red   = zero
-    r_norm  = zero
-    ok      = .false.
-    done    = .false.
-!
-    call get_time(t_tot)
-!
-!   guess: orthonormalise if needed, random if zero (reference :1644), then copy (:1648)
-!
-    call chk(ctx, dla_check_guess(ctx, n, n_max, evd), 'check_guess')
-    call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
-!
-!   B times the guess, then B-orthonormalise it (reference :2033-2034)
-!
-    call chk(ctx, dla_call_matvec(ctx, bv, n, n_max, space, bspace), 'bvec')
-    call chk(ctx, dla_b_ortho(ctx, n, n_max, space, bspace), 'b_ortho')
-!
-    n_act = n_max
-    ind   = 1
-    i_beg = 1
-    m_dim = 1
-    ldu   = 0
-    restart = .false.
-    n_rst   = 0
-    n_frozen = 0
-    n_mv = 0
-    n_restarts = 0
-!
-    1030 format(t5,'Generalized Davidson-Liu iterations (tol=',d10.2,'):',/, &
-                t5,'------------------------------------------------------------------',/, &
-                t7,'  iter  root              eigenvalue','         rms         max ok',/, &
-                t5,'------------------------------------------------------------------')
-    1040 format(t9,i4,2x,i4,f24.12,2d12.4,l3)
-    if (verbose) write(6,1030) tol
-!
-    do it = 1, max_iter
-      ldu = ldu + n_act
-      c0  = i_beg + n_rst
-!
-!     A times the new block (reference :1685)
-!
-      call get_time(t1)
-      call chk(ctx, dla_call_matvec(ctx, mv, n, n_act, colp(space,n,c0), colp(aspace,n,c0)), 'matvec')
-      call get_time(t2)
-      t_mv = t_mv + t2 - t1
-      n_mv = n_mv + n_act
-!
-!     new columns of the projected matrix (reference :1691)
-!
-      call chk(ctx, dla_gram(ctx, n, ldu, space, n_act, colp(aspace,n,c0), a_red(1,c0), lda), 'projection')
-!
-!     after a restart the locked roots enter through their eigenvalues (reference :1696-1702)
-!
-      if (restart) then
-        do i_eig = 1, n_rst
-          a_red(i_eig,i_eig) = e_red(i_eig)
-        end do
-        restart = .false.
-        n_rst   = 0
-      end if
-      a_copy = a_red
-!
-      call get_time(t1)
-      info = dla_syev_lowest('u', ldu, a_copy, lda, e_red, n_max)   ! only a_copy(:,1:n_max) is used below
-      call get_time(t2)
-      t_diag = t_diag + t2 - t1
-      if (info.ne.0) then
-        write(6,'(t3,a,i6)') 'dsyev failed. info = ',info
-        stop
-      end if
-      eig = e_red(1:n_max)
-!
-!     Ritz vectors, residuals and their norms in one sweep (reference :1717-1732)
-!
-      do i_eig = 1, n_max
-        skip(i_eig) = merge(1_c_int, 0_c_int, done(i_eig))
-      end do
-!     b_evec = BS y and r = AS y - eig * b_evec in one sweep, then evec = S y (reference :2108-2123)
-      call chk(ctx, dla_ritz_residual(ctx, n, ldu, n_max, bspace, aspace, a_copy, lda, eig, n_targ, skip, &
-                                      b_evec, r, c_null_ptr, r_norm), 'ritz/residual')
-      call chk(ctx, dla_panel_gemm(ctx, n, ldu, space, n_max, a_copy, lda, evd), 'ritz vectors')
-!
-!     lock the leading converged roots (reference :1737-1746)
-!
-      do i_eig = 1, n_targ
-        if (done(i_eig)) cycle
-        done(i_eig) = r_norm(1,i_eig).lt.tol_rms .and. r_norm(2,i_eig).lt.tol_max .and. it.gt.1
-        if (.not.done(i_eig)) then
-          done(i_eig+1:n_max) = .false.
-          exit
-        end if
-      end do
-!
-      if (verbose) then
-        do i_eig = 1, n_targ
-          write(6,1040) it, i_eig, eig(i_eig) - shift, r_norm(:,i_eig), done(i_eig)
-        end do
-        write(6,*)
-      end if
-!
-      if (all(done(1:n_targ))) then
-        ok = .true.
-        exit
-      end if
-!
-      if (m_dim .lt. dim_dav) then
-!
-!       expand: precondition the active residuals, orthogonalise against the space
-!       (reference :1773-1794)
-!
-        m_dim = m_dim + 1
-        i_beg = i_beg + n_act
-        n_act = n_max
-        n_frozen = 0
-        do i_eig = 1, n_targ
-          if (done(i_eig)) then
-            n_act = n_act - 1
-            n_frozen = n_frozen + 1
-          else
-            exit
-          end if
-        end do
-        ind = n_max - n_act + 1
-        call chk(ctx, dla_call_precnd(ctx, pc, n, n_act, -eig(ind), colp(r,n,ind), colp(space,n,i_beg)), 'precnd')
-        call get_time(t1)
-        call chk(ctx, dla_b_ortho_vs_x(ctx, n, ldu, n_act, space, bspace, colp(space,n,i_beg)), 'b_ortho_vs_x')
-        call chk(ctx, dla_call_matvec(ctx, bv, n, n_act, colp(space,n,i_beg), colp(bspace,n,i_beg)), 'bvec')
-        call chk(ctx, dla_b_ortho(ctx, n, n_act, colp(space,n,i_beg), colp(bspace,n,i_beg)), 'b_ortho')
-        call get_time(t2)
-        t_ortho = t_ortho + t2 - t1
-      else
-!
-!       restart from the current Ritz vectors (reference :1796-1824)
-!
-        if (verbose) write(6,'(t7,a)') 'Restarting davidson.'
-        n_restarts = n_restarts + 1
-        n_act = n_max
-        call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
-        call chk(ctx, dla_copy(ctx, bspace, b_evec, nbytes(n,n_max)), 'copy')
-        call chk(ctx, dla_b_ortho(ctx, n, n_max, space, bspace), 'b_ortho')     ! reference :2195-2197
-        a_red = zero
-        ldu   = 0
-        i_beg = 1
-        m_dim = 1
-        n_rst = 0
-        do i_eig = 1, n_targ
-          if (done(i_eig)) then
-            n_rst = n_rst + 1
-          else
-            exit
-          end if
-        end do
-!
-!       the reference zeroes space and aspace entirely (:1798,1804).  What the next iteration
-!       actually reads from those zeros: matvec takes n_max columns starting at column 1+n_rst,
-!       i.e. it runs n_rst columns past the Ritz block (they must be zero), and the locked
-!       columns 1..n_rst of aspace stay zero (their eigenvalues are patched into a_red, :1696-1702).
-!
-        if (n_rst.gt.0) then
-          call chk(ctx, dla_zero(ctx, colp(space,n,n_max+1), nbytes(n,n_rst)), 'zero')
-          call chk(ctx, dla_zero(ctx, aspace, nbytes(n,n_rst)), 'zero')
-        end if
-        restart = .true.
-      end if
-      if (verbose) write(6,1050) n_targ, n_act, n_frozen
-    end do
-!
-    call get_time(t2)
-    t_tot = t2 - t_tot
-    call dla_set_solve_info(int(min(it,max_iter),c_int), int(n_mv,c_int), int(n_restarts,c_int))
-!
-    1000 format(t3,'timings for davidson (cpu/wall): ',/, &
-                t3,'  matrix-vector multiplications: ',2f12.4,/, &
-                t3,'  diagonalization:               ',2f12.4,/, &
-                t3,'  orthogonalization:             ',2f12.4,/, &
-                t3,'                                 ',24('='),/,  &
-                t3,'  total:                         ',2f12.4)
-    if (verbose) write(6,1000) t_mv, t_diag, t_ortho, t_tot
-!
-!   hand the Ritz vectors back (evec holds them on every exit, like the reference) and free
-!
-    if (.not.evec_dev) then
-      call chk(ctx, dla_download(ctx, c_loc(evec), evd, nbytes(n,n_max)), 'download of evec')
-      call chk(ctx, dla_free(ctx, evd), 'free')
-    end if
-    call chk(ctx, dla_free(ctx, space), 'free')
-    call chk(ctx, dla_free(ctx, aspace), 'free')
-    call chk(ctx, dla_free(ctx, r), 'free')
-    call chk(ctx, dla_free(ctx, bspace), 'free')
-    call chk(ctx, dla_free(ctx, b_evec), 'free')
-    deallocate (done, skip, r_norm, a_red, a_copy, e_red)
-!
-    1050 format(t5,'----------------------------------------',/,&
-                t7,'# target vectors:    ',i4,/,&
-                t7,'# new vectors added: ',i4,/,&
-                t7,'# converged vectors: ',i4,/,&
-                t5,'----------------------------------------')
-    return
+    logical,  intent(in)            :: verbose
+    integer,  intent(in)            :: n, n_targ, n_max, max_iter, max_dav
+    real(dp), intent(in)            :: tol, shift
+    real(dp), intent(inout)         :: eig(n_max)
+    real(dp), intent(inout), target :: evec(n,n_max)
+    logical,  intent(inout)         :: ok
+    external                        :: matvec, precnd, bvec
+    call davidson_core(verbose, n, n_targ, n_max, max_iter, tol, max_dav, shift, c_funloc(matvec), c_funloc(precnd), &
+                       c_funloc(bvec), .true., eig, evec, ok)
   end subroutine gen_david_driver
 !
 ! ---------------------------------------------------------------------------------------
-! LOBPCG (reference diaglib.f90:171-556).  gen_eig=.true. is not on this path yet.
+! LOBPCG (reference diaglib.f90:171-556), standard and generalised (gen_eig) problem.
+!
+! The reference keeps one basis [X | P | W] per panel and copies the new X (x_new, ax_new, bx_new) and the new P
+! (through its evec scratch) into it every iteration (:495-514).  Here every basis panel exists twice: an iteration
+! reads the basis from one copy and writes the new X and P blocks straight into the other, then the two swap roles,
+! so the four (six) block copies per iteration do not exist.  Only the lower block triangle of S^T A S is formed
+! (the eigensolver reads nothing else), and the P coefficients (get_coeffs, :3686-3732) are host-size work.
 ! ---------------------------------------------------------------------------------------
   subroutine lobpcg_driver(verbose,gen_eig,n,n_targ,n_max,max_iter,tol,shift,matvec,precnd,bvec,eig,evec,ok)
-    logical,                              intent(in)    :: verbose, gen_eig
-    integer,                              intent(in)    :: n, n_targ, n_max, max_iter
-    real(dp),                             intent(in)    :: tol, shift
-    real(dp), dimension(n_max),           intent(inout) :: eig
-    real(dp), dimension(n,n_max), target, intent(inout) :: evec
-    logical,                              intent(inout) :: ok
-    external                                            :: matvec, precnd, bvec
+    logical,  intent(in)            :: verbose, gen_eig
+    integer,  intent(in)            :: n, n_targ, n_max, max_iter
+    real(dp), intent(in)            :: tol, shift
+    real(dp), intent(inout)         :: eig(n_max)
+    real(dp), intent(inout), target :: evec(n,n_max)
+    logical,  intent(inout)         :: ok
+    external                        :: matvec, precnd, bvec
 !
-    type(c_ptr)    :: ctx, space, aspace, bspace, r, x_new, ax_new, bx_new, evd, xfin
-    type(c_ptr)    :: sp(2), asp(2), bsp(2)
-    integer        :: cur, nxt
-    type(c_funptr) :: mv, pc, bv
-    integer        :: it, i_eig, n_act, ind_x, ind_w, ind_p, len_a, len_u, n_mv
-    logical        :: evec_dev
-    real(dp)       :: tol_rms, tol_max
-    logical,        allocatable :: done(:)
-    integer(c_int), allocatable :: skip(:)
-    real(dp),       allocatable :: a_red(:,:), e_red(:), r_norm(:,:), u_x(:,:), u_p(:,:)
-    integer(c_int) :: info
+    type(subspace)  :: s
+    type(stopwatch) :: w
+    type(solve_env) :: e
+    type(c_funptr)  :: op, prec, metric
+    type(c_ptr)     :: sp(2), asp(2), bsp(2), resid, latest
+    integer         :: rd, wr              ! the copy the basis is read from / the copy that receives the new X and P
+    real(dp), allocatable :: h(:,:), theta(:), cx(:,:), cp(:,:)
+    real(dp)        :: t_begin(2), t_end(2)
+    integer         :: it, sweeps, width, live, c_x, c_p, c_w, wide
 !
-    ctx = dla_default_ctx()
-    mv  = c_funloc(matvec)
-    pc  = c_funloc(precnd)
-    bv  = c_funloc(bvec)
-    evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
-    bsp    = c_null_ptr
-    bspace = c_null_ptr
-    bx_new = c_null_ptr
-!
-!   The reference keeps one basis [X P W] per panel and copies the new X (x_new, ax_new, bx_new) and the new
-!   P (via its evec scratch) into it every iteration (:495-514).  Here every panel exists twice: an iteration
-!   reads the basis from one copy and writes the new X and P blocks straight into the other, then the two
-!   swap roles -- the four (six) block copies per iteration become none.
-!
-    len_a = 3*n_max
-    do cur = 1, 2
-      call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), sp(cur)),  'allocation of space')
-      call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), asp(cur)), 'allocation of aspace')
-!     (the reference allocates bspace/bx_new also for the standard problem, :259,270; here only when used)
-      if (gen_eig) call chk(ctx, dla_alloc(ctx, nbytes(n,len_a), bsp(cur)), 'allocation of bspace')
+    op     = c_funloc(matvec)
+    prec   = c_funloc(precnd)
+    metric = c_funloc(bvec)
+    call env_open(e, n, n_max, evec)
+    call sub_setup(s, n_targ, n_max, 3, tol)
+    wide = s%ld
+    bsp  = c_null_ptr
+    do rd = 1, 2
+      sp(rd)  = dev_panel(e%ctx, n, wide, 'space')
+      asp(rd) = dev_panel(e%ctx, n, wide, 'aspace')
+!     (the reference allocates bspace / bx_new for the standard problem too, :259,270; here only when used)
+      if (gen_eig) bsp(rd) = dev_panel(e%ctx, n, wide, 'bspace')
     end do
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), r), 'allocation of r')
-    cur = 1
-    nxt = 2
-    call select_panels()
-    if (evec_dev) then
-      evd = c_loc(evec)
-    else
-      call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), evd), 'allocation of evec')
-      call chk(ctx, dla_upload(ctx, evd, c_loc(evec), nbytes(n,n_max)), 'upload of the guess')
-    end if
-    allocate (a_red(len_a,len_a), e_red(len_a), done(n_max), skip(n_max), r_norm(2,n_max))
+    resid = dev_panel(e%ctx, n, n_max, 'r')
+    rd = 1
+    wr = 2
+    allocate (h(wide,wide), theta(wide))
+    h  = zero
+    ok = .false.
+    call clock_now(t_begin)
 !
-    t_diag  = zero
-    t_ortho = zero
-    t_mv    = zero
-    t_tot   = zero
-!   (the reference zero-fills space/aspace/bspace, :284-286; every column is written before
-!   it is read on this path, so the device panels are left uninitialised)
-    a_red  = zero
-    r_norm = zero
-    n_mv   = 0
+!   guess (:295), for the generalised problem made B-orthonormal (:299-302)
 !
-    call get_time(t_tot)
-    call chk(ctx, dla_check_guess(ctx, n, n_max, evd), 'check_guess')
-!
-!   generalised problem: B times the guess, then B-orthonormalise it (reference :299-302)
-!
+    call chk(e%ctx, dla_check_guess(e%ctx, n, n_max, e%ritz), 'check_guess')
     if (gen_eig) then
-      call chk(ctx, dla_call_matvec(ctx, bv, n, n_max, evd, bspace), 'bvec')
-      call chk(ctx, dla_b_ortho(ctx, n, n_max, evd, bspace), 'b_ortho')
+      call chk(e%ctx, dla_call_matvec(e%ctx, metric, n, n_max, e%ritz, bsp(rd)), 'bvec')
+      call chk(e%ctx, dla_b_ortho(e%ctx, n, n_max, e%ritz, bsp(rd)), 'b_ortho')
     end if
 !
-!   first Rayleigh-Ritz step on the guess (reference :306-325)
+!   Rayleigh-Ritz on the guess alone (:306-325): X, A X [, B X] of the first basis go to the other copy
 !
-    call chk(ctx, dla_copy(ctx, space, evd, nbytes(n,n_max)), 'copy')
-    call get_time(t1)
-    call chk(ctx, dla_call_matvec(ctx, mv, n, n_max, space, aspace), 'matvec')
-    call get_time(t2)
-    t_mv = t_mv + t2 - t1
-    n_mv = n_mv + n_max
-    if (shift.ne.zero) call chk(ctx, dla_axpy(ctx, int(n,c_size_t)*int(n_max,c_size_t), shift, space, aspace), 'axpy')
-    call chk(ctx, dla_gram(ctx, n, n_max, space, n_max, aspace, a_red, len_a), 'projection')
-    call get_time(t1)
-    info = dla_syev_lowest('l', n_max, a_red, len_a, e_red, n_max)
-    call get_time(t2)
-    t_diag = t_diag + t2 - t1
-    eig = e_red(1:n_max)
+    call chk(e%ctx, dla_copy(e%ctx, sp(rd), e%ritz, nbytes(n,n_max)), 'copy')
+    call apply_operator(1, n_max)
+    call chk(e%ctx, dla_gram(e%ctx, n, n_max, sp(rd), n_max, asp(rd), h, wide), 'projection')
+    call lap_start(w)
+    call need_eigensolver(dla_syev_lowest('l', n_max, h, wide, theta, n_max))
+    call lap_charge(w, w%diag)
+    eig = theta(1:n_max)
+    s%mask = 0_c_int
+    call ritz_step(n_max)
+    call turn_over()
 !
-!   Ritz vectors x, a x and the first residuals r = a x - eig x in one sweep (:322-345)
+!   first W block: preconditioned residuals orthogonalised against X (:350-367)
 !
-    skip = 0
-    if (gen_eig) then
-!     b x = BS y and r = AS y - eig * (BS y) in one sweep over bspace/aspace, then x = S y (:322-346)
-      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, bspace, aspace, a_red, len_a, eig, n_max, skip, &
-                                      bx_new, r, ax_new, r_norm), 'ritz/residual')
-      call chk(ctx, dla_panel_gemm(ctx, n, n_max, space, n_max, a_red, len_a, x_new), 'ritz vectors')
-    else
-      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, space, aspace, a_red, len_a, eig, n_max, skip, &
-                                      x_new, r, ax_new, r_norm), 'ritz/residual')
-    end if
-    xfin = x_new
-    call swap_panels()
+    c_x = 1
+    c_w = 1 + n_max
+    call chk(e%ctx, dla_call_precnd(e%ctx, prec, n, n_max, shift-eig(c_x), colp(resid,n,c_x), colp(sp(rd),n,c_w)), 'precnd')
+    call orthogonalise_w(n_max, n_max)
 !
-!   first block of preconditioned residuals (:350-367)
-!
-    ind_x = 1
-    ind_w = ind_x + n_max
-    call chk(ctx, dla_call_precnd(ctx, pc, n, n_max, shift-eig(ind_x), colp(r,n,ind_x), colp(space,n,ind_w)), 'precnd')
-    call get_time(t1)
-    if (gen_eig) then
-      call chk(ctx, dla_b_ortho_vs_x(ctx, n, n_max, n_max, space, bspace, colp(space,n,ind_w)), 'b_ortho_vs_x')
-      call chk(ctx, dla_call_matvec(ctx, bv, n, n_max, colp(space,n,ind_w), colp(bspace,n,ind_w)), 'bvec')
-      call chk(ctx, dla_b_ortho(ctx, n, n_max, colp(space,n,ind_w), colp(bspace,n,ind_w)), 'b_ortho')
-    else
-      call chk(ctx, dla_ortho_vs_x(ctx, n, n_max, n_max, space, colp(space,n,ind_w)), 'ortho_vs_x')
-    end if
-    call get_time(t2)
-    t_ortho = t_ortho + t2 - t1
-!
-    tol_rms = tol
-    tol_max = ten*tol
-    ok      = .false.
-    done    = .false.
-    n_act   = n_max
-!
-    1030 format(t5,'LOBPCG iterations (tol=',d10.2,'):',/, &
-                t5,'------------------------------------------------------------------',/, &
-                t7,'  iter  root              eigenvalue','         rms         max ok',/, &
-                t5,'------------------------------------------------------------------')
-    1040 format(t9,i4,2x,i4,f24.12,2d12.4,l3)
-    if (verbose) write(6,1030) tol
+    live   = n_max
+    sweeps = max_iter
+    if (verbose) call print_table_head('LOBPCG iterations (tol=', tol)
 !
     do it = 1, max_iter
 !
-!     A times the W block (:394-397)
+!     A on the W block (:394-397), then all of S^T A S for S = [X | P | W] (:401-403); no P block in the first sweep
 !
-      call get_time(t1)
-      call chk(ctx, dla_call_matvec(ctx, mv, n, n_act, colp(space,n,ind_w), colp(aspace,n,ind_w)), 'matvec')
-      call get_time(t2)
-      t_mv = t_mv + t2 - t1
-      n_mv = n_mv + n_act
-      if (shift.ne.zero) call chk(ctx, dla_axpy(ctx, int(n,c_size_t)*int(n_act,c_size_t), shift, &
-                                                colp(space,n,ind_w), colp(aspace,n,ind_w)), 'axpy')
+      call apply_operator(c_w, live)
+      width = n_max + 2*live
+      if (it.eq.1) width = 2*n_max
+      call chk(e%ctx, dla_gram_lower(e%ctx, n, width, sp(rd), asp(rd), h, wide), 'projection')
+      call lap_start(w)
+      call need_eigensolver(dla_syev_lowest('l', width, h, wide, theta, n_max))
+      call lap_charge(w, w%diag)
+      eig = theta(1:n_max)
 !
-!     reduced matrix S^T A S, all of it, every iteration (:401-403)
+!     new X, A X [, B X], residuals and norms in one sweep (:420-442)
 !
-      len_u = n_max + 2*n_act
-      if (it.eq.1) len_u = 2*n_max
-!     (dsyev below reads the lower triangle only, so only that part of the product is formed)
-      call chk(ctx, dla_gram_lower(ctx, n, len_u, space, aspace, a_red, len_a), 'projection')
-      call get_time(t1)
-      info = dla_syev_lowest('l', len_u, a_red, len_a, e_red, n_max)   ! get_coeffs uses a_red(:,1:n_max) only
-      call get_time(t2)
-      t_diag = t_diag + t2 - t1
-      if (info.ne.0) then
-        write(6,'(t3,a,i6)') 'dsyev failed. info = ',info
-        stop
-      end if
-      eig = e_red(1:n_max)
+      call sub_refresh_mask(s)
+      call ritz_step(width)
 !
-!     x_new, ax_new, residuals and norms in one sweep (:420-442)
-!
-      do i_eig = 1, n_max
-        skip(i_eig) = merge(1_c_int, 0_c_int, done(i_eig))
-      end do
-      if (gen_eig) then
-        call chk(ctx, dla_ritz_residual(ctx, n, len_u, n_max, bspace, aspace, a_red, len_a, eig, n_max, skip, &
-                                        bx_new, r, ax_new, r_norm), 'ritz/residual')
-        call chk(ctx, dla_panel_gemm(ctx, n, len_u, space, n_max, a_red, len_a, x_new), 'ritz vectors')
-      else
-        call chk(ctx, dla_ritz_residual(ctx, n, len_u, n_max, space, aspace, a_red, len_a, eig, n_max, skip, &
-                                        x_new, r, ax_new, r_norm), 'ritz/residual')
-      end if
-      xfin = x_new
-!
-!     lock the leading converged roots (:446-455)
-!
-      do i_eig = 1, n_max
-        if (done(i_eig)) cycle
-        done(i_eig) = r_norm(1,i_eig).lt.tol_rms .and. r_norm(2,i_eig).lt.tol_max .and. it.gt.1
-        if (.not.done(i_eig)) then
-          done(i_eig+1:n_max) = .false.
-          exit
-        end if
-      end do
-!
-      if (verbose) then
-        do i_eig = 1, n_targ
-          write(6,1040) it, i_eig, eig(i_eig) - shift, r_norm(:,i_eig), done(i_eig)
-        end do
-        write(6,*)
-      end if
-      if (all(done(1:n_targ))) then
+      call sub_lock(s, it, n_max)                                 ! LOBPCG scans all n_max roots (:446-455)
+      if (verbose) call print_table_rows(s, it, eig - shift)      ! the returned eig keeps the shift (:416,461)
+      if (sub_finished(s)) then
         ok = .true.
+        sweeps = it
         exit
       end if
 !
-      n_act = n_max - count(done)
-      ind_x = n_max - n_act + 1
-      ind_p = ind_x + n_act
-      ind_w = ind_p + n_act
+      live = n_max - count(s%locked)
+      c_x  = n_max - live + 1
+      c_p  = c_x + live
+      c_w  = c_p + live
 !
-!     coefficients of the new P block (:485-488), then P = S u_p, AP = AS u_p (:495-498)
+!     coefficients of the new P block (:485-488); P = S cp, A P = AS cp [, B P = BS cp] (:495-503) go straight into
+!     the P block of the other copy, whose X block already holds the new Ritz vectors (:510-514)
 !
-      allocate (u_x(len_u,n_max), u_p(len_u,max(n_act,1)))
-      call chk(ctx, dla_get_coeffs(ctx, len_a, len_u, n_max, n_act, a_red, u_x, u_p), 'get_coeffs')
-!     P = S u_p, AP = AS u_p [, BP = BS u_p] (:495-503) go straight into the P block of the other copy
-      call chk(ctx, dla_panel_gemm(ctx, n, len_u, space,  n_act, u_p, len_u, colp(sp(nxt),n,ind_p)), 'p block')
-      call chk(ctx, dla_panel_gemm(ctx, n, len_u, aspace, n_act, u_p, len_u, colp(asp(nxt),n,ind_p)), 'ap block')
-      if (gen_eig) call chk(ctx, dla_panel_gemm(ctx, n, len_u, bspace, n_act, u_p, len_u, colp(bsp(nxt),n,ind_p)), 'bp block')
-      deallocate (u_x, u_p)
+      allocate (cx(width,n_max), cp(width,max(live,1)))
+      call chk(e%ctx, dla_get_coeffs(e%ctx, wide, width, n_max, live, h, cx, cp), 'get_coeffs')
+      call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, sp(rd),  live, cp, width, colp(sp(wr),n,c_p)), 'p block')
+      call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, asp(rd), live, cp, width, colp(asp(wr),n,c_p)), 'ap block')
+      if (gen_eig) call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, bsp(rd), live, cp, width, colp(bsp(wr),n,c_p)), 'bp block')
+      deallocate (cx, cp)
+      call turn_over()
 !
-!     x_new, ax_new [, bx_new] already are the X block of the other copy (:510-511): it becomes the basis
+!     new W block: preconditioned open residuals, orthogonalised against [X | P] (:518-528)
 !
-      call swap_panels()
-!
-!     new W block: preconditioned active residuals, orthogonalised against [X P] (:518-528)
-!
-      call chk(ctx, dla_call_precnd(ctx, pc, n, n_act, shift-eig(1), colp(r,n,ind_x), colp(space,n,ind_w)), 'precnd')
-      call get_time(t1)
-      if (gen_eig) then
-        call chk(ctx, dla_b_ortho_vs_x(ctx, n, n_max+n_act, n_act, space, bspace, colp(space,n,ind_w)), 'b_ortho_vs_x')
-        call chk(ctx, dla_call_matvec(ctx, bv, n, n_act, colp(space,n,ind_w), colp(bspace,n,ind_w)), 'bvec')
-        call chk(ctx, dla_b_ortho(ctx, n, n_act, colp(space,n,ind_w), colp(bspace,n,ind_w)), 'b_ortho')
-      else
-        call chk(ctx, dla_ortho_vs_x(ctx, n, n_max+n_act, n_act, space, colp(space,n,ind_w)), 'ortho_vs_x')
-      end if
-      call get_time(t2)
-      t_ortho = t_ortho + t2 - t1
+      call chk(e%ctx, dla_call_precnd(e%ctx, prec, n, live, shift-eig(1), colp(resid,n,c_x), colp(sp(rd),n,c_w)), 'precnd')
+      call orthogonalise_w(n_max+live, live)
     end do
 !
-    call get_time(t2)
-    t_tot = t2 - t_tot
-    call dla_set_solve_info(int(min(it,max_iter),c_int), int(n_mv,c_int), 0_c_int)
+    call clock_now(t_end)
+    w%total = t_end - t_begin
 !
-!   the current Ritz vectors go back in evec (the reference does this on convergence, :466;
-!   on a non-converged exit it leaves its P-block scratch there -- we return x_new in both cases)
+!   the current Ritz vectors go back in evec (the reference does this on convergence, :466; on a non-converged
+!   exit it leaves its P-block scratch there -- here evec holds the Ritz vectors in both cases)
 !
-    call chk(ctx, dla_copy(ctx, evd, xfin, nbytes(n,n_max)), 'copy')
-!
-    1000 format(t3,'timings for lobpcg (cpu/wall):   ',/, &
-                t3,'  matrix-vector multiplications: ',2f12.4,/, &
-                t3,'  diagonalization:               ',2f12.4,/, &
-                t3,'  orthogonalization:             ',2f12.4,/, &
-                t3,'                                 ',24('='),/,  &
-                t3,'  total:                         ',2f12.4)
-    if (verbose) write(6,1000) t_mv, t_diag, t_ortho, t_tot
-!
-    if (.not.evec_dev) then
-      call chk(ctx, dla_download(ctx, c_loc(evec), evd, nbytes(n,n_max)), 'download of evec')
-      call chk(ctx, dla_free(ctx, evd), 'free')
-    end if
-    do cur = 1, 2
-      call chk(ctx, dla_free(ctx, sp(cur)), 'free')
-      call chk(ctx, dla_free(ctx, asp(cur)), 'free')
-      if (gen_eig) call chk(ctx, dla_free(ctx, bsp(cur)), 'free')
+    call chk(e%ctx, dla_copy(e%ctx, e%ritz, latest, nbytes(n,n_max)), 'copy')
+    if (verbose) call print_timings('timings for lobpcg (cpu/wall):   ', w)
+    call env_close(e, evec, sweeps)
+    do rd = 1, 2
+      call drop_panel(e%ctx, sp(rd))
+      call drop_panel(e%ctx, asp(rd))
+      call drop_panel(e%ctx, bsp(rd))
     end do
-    call chk(ctx, dla_free(ctx, r), 'free')
-    deallocate (a_red, e_red, done, skip, r_norm)
-    return
+    call drop_panel(e%ctx, resid)
+    deallocate (h, theta)
 !
   contains
 !
-    subroutine select_panels()
-!     the basis is read from copy cur; the new X block (x_new, ax_new, bx_new) is written into copy nxt
-      space  = sp(cur)
-      aspace = asp(cur)
-      bspace = bsp(cur)
-      x_new  = sp(nxt)
-      ax_new = asp(nxt)
-      bx_new = bsp(nxt)
-    end subroutine select_panels
+!   A (+ shift) on `cols` columns of the basis starting at column c0 (:306-312, 394-397)
 !
-    subroutine swap_panels()
-      integer :: tmp
-      tmp = cur
-      cur = nxt
-      nxt = tmp
-      call select_panels()
-    end subroutine swap_panels
+    subroutine apply_operator(c0, cols)
+      integer, intent(in) :: c0, cols
+      call lap_start(w)
+      call chk(e%ctx, dla_call_matvec(e%ctx, op, n, cols, colp(sp(rd),n,c0), colp(asp(rd),n,c0)), 'matvec')
+      call lap_charge(w, w%mv)
+      e%op_cols = e%op_cols + cols
+      if (shift.ne.zero) call chk(e%ctx, dla_axpy(e%ctx, nelem(n,cols), shift, colp(sp(rd),n,c0), colp(asp(rd),n,c0)), 'axpy')
+    end subroutine apply_operator
+!
+!   X = S y, A X = AS y, r = A X - eig X (B X instead of X with a metric) and the residual norms; the new blocks are
+!   the X block of the copy the next basis will be read from
+!
+    subroutine ritz_step(cols)
+      integer, intent(in) :: cols
+      if (gen_eig) then
+        call chk(e%ctx, dla_ritz_residual(e%ctx, n, cols, n_max, bsp(rd), asp(rd), h, wide, eig, n_max, s%mask, &
+                                          bsp(wr), resid, asp(wr), s%rnorm), 'ritz/residual')
+        call chk(e%ctx, dla_panel_gemm(e%ctx, n, cols, sp(rd), n_max, h, wide, sp(wr)), 'ritz vectors')
+      else
+        call chk(e%ctx, dla_ritz_residual(e%ctx, n, cols, n_max, sp(rd), asp(rd), h, wide, eig, n_max, s%mask, &
+                                          sp(wr), resid, asp(wr), s%rnorm), 'ritz/residual')
+      end if
+      latest = sp(wr)
+    end subroutine ritz_step
+!
+    subroutine turn_over()
+      integer :: keep
+      keep = rd
+      rd = wr
+      wr = keep
+    end subroutine turn_over
+!
+!   the W block (k columns behind m basis columns) against the basis, in the metric if there is one (:358-366, 523-529)
+!
+    subroutine orthogonalise_w(m, k)
+      integer, intent(in) :: m, k
+      call lap_start(w)
+      if (gen_eig) then
+        call chk(e%ctx, dla_b_ortho_vs_x(e%ctx, n, m, k, sp(rd), bsp(rd), colp(sp(rd),n,m+1)), 'b_ortho_vs_x')
+        call chk(e%ctx, dla_call_matvec(e%ctx, metric, n, k, colp(sp(rd),n,m+1), colp(bsp(rd),n,m+1)), 'bvec')
+        call chk(e%ctx, dla_b_ortho(e%ctx, n, k, colp(sp(rd),n,m+1), colp(bsp(rd),n,m+1)), 'b_ortho')
+      else
+        call chk(e%ctx, dla_ortho_vs_x(e%ctx, n, m, k, sp(rd), colp(sp(rd),n,m+1)), 'ortho_vs_x')
+      end if
+      call lap_charge(w, w%ortho)
+    end subroutine orthogonalise_w
   end subroutine lobpcg_driver
 !
 ! ---------------------------------------------------------------------------------------
-! public orthogonalisation routines on HOST arrays (reference signatures); each uploads,
-! runs the device path and downloads.  The drivers never use these wrappers.
+! public orthogonalisation routines on HOST arrays (reference signatures); each uploads, runs the device path and
+! downloads.  The drivers never use these wrappers.
 ! ---------------------------------------------------------------------------------------
   subroutine ortho_cd(n,m,u,growth,ok)
-    integer,                          intent(in)    :: n, m
-    real(dp), dimension(n,m), target, intent(inout) :: u
-    real(dp),                         intent(inout) :: growth
-    logical,                          intent(inout) :: ok
+    integer,  intent(in)            :: n, m
+    real(dp), intent(inout), target :: u(n,m)
+    real(dp), intent(inout)         :: growth
+    logical,  intent(inout)         :: ok
     type(c_ptr)    :: ctx, ud
-    integer(c_int) :: iok
+    integer(c_int) :: flag
     ctx = dla_default_ctx()
-    call chk(ctx, dla_alloc(ctx, nbytes(n,m), ud), 'allocation')
+    ud  = dev_panel(ctx, n, m, 'u')
     call chk(ctx, dla_upload(ctx, ud, c_loc(u), nbytes(n,m)), 'upload')
-    call chk(ctx, dla_ortho_cd(ctx, n, m, ud, growth, iok), 'ortho_cd')
-    ok = iok .ne. 0
+    call chk(ctx, dla_ortho_cd(ctx, n, m, ud, growth, flag), 'ortho_cd')
+    ok = flag .ne. 0
     call chk(ctx, dla_download(ctx, c_loc(u), ud, nbytes(n,m)), 'download')
-    call chk(ctx, dla_free(ctx, ud), 'free')
+    call drop_panel(ctx, ud)
   end subroutine ortho_cd
 !
   subroutine ortho_vs_x(n,m,k,x,u,ax,au)
-    integer,                          intent(in)    :: n, m, k
-    real(dp), dimension(n,m), target, intent(in)    :: x
-    real(dp), dimension(n,k), target, intent(inout) :: u
-    real(dp), dimension(*)                          :: ax, au     ! dead in the reference too (SURVEY App. B 5)
+    integer,  intent(in)            :: n, m, k
+    real(dp), intent(in),    target :: x(n,m)
+    real(dp), intent(inout), target :: u(n,k)
+    real(dp)                        :: ax(*), au(*)      ! dead in the reference too (SURVEY App. B 5)
     type(c_ptr) :: ctx, xd, ud
     ctx = dla_default_ctx()
-    call chk(ctx, dla_alloc(ctx, nbytes(n,max(m,1)), xd), 'allocation')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,k), ud), 'allocation')
+    xd  = dev_panel(ctx, n, max(m,1), 'x')
+    ud  = dev_panel(ctx, n, k, 'u')
     if (m.gt.0) call chk(ctx, dla_upload(ctx, xd, c_loc(x), nbytes(n,m)), 'upload')
     call chk(ctx, dla_upload(ctx, ud, c_loc(u), nbytes(n,k)), 'upload')
     call chk(ctx, dla_ortho_vs_x(ctx, n, m, k, xd, ud), 'ortho_vs_x')
     call chk(ctx, dla_download(ctx, c_loc(u), ud, nbytes(n,k)), 'download')
-    call chk(ctx, dla_free(ctx, xd), 'free')
-    call chk(ctx, dla_free(ctx, ud), 'free')
+    call drop_panel(ctx, xd)
+    call drop_panel(ctx, ud)
   end subroutine ortho_vs_x
 !
+! Householder-QR orthonormalisation U <- U R^-1 (reference diaglib.f90:3052-3092: dgeqrf on a copy, dtrsm with its R).
+! R carries the signs LAPACK's reflectors give its diagonal, so columns of the result may be the negatives of what a
+! Cholesky-QR returns; dla_ortho_qr reproduces that convention.  The second argument is never touched (nor in the
+! reference).
+!
   subroutine ortho(n,m,u,w)
-    integer,                          intent(in)    :: n, m
-    real(dp), dimension(n,m), target, intent(inout) :: u
-    real(dp), dimension(*)                          :: w          ! never touched by the reference either
-    real(dp) :: growth
-    logical  :: ok
-!   the reference orthonormalises by Householder QR here; the device path offers the
-!   Cholesky-QR family only, which spans the same space with the same orthonormality
-    call ortho_cd(n,m,u,growth,ok)
+    integer,  intent(in)            :: n, m
+    real(dp), intent(inout), target :: u(n,m)
+    real(dp)                        :: w(*)
+    type(c_ptr) :: ctx, ud
+    ctx = dla_default_ctx()
+    ud  = dev_panel(ctx, n, m, 'u')
+    call chk(ctx, dla_upload(ctx, ud, c_loc(u), nbytes(n,m)), 'upload')
+    call chk(ctx, dla_ortho_qr(ctx, n, m, ud), 'ortho')
+    call chk(ctx, dla_download(ctx, c_loc(u), ud, nbytes(n,m)), 'download')
+    call drop_panel(ctx, ud)
   end subroutine ortho
 !
   subroutine b_ortho(n,m,u,bu)
-    integer,                          intent(in)    :: n, m
-    real(dp), dimension(n,m), target, intent(inout) :: u, bu
+    integer,  intent(in)            :: n, m
+    real(dp), intent(inout), target :: u(n,m), bu(n,m)
     type(c_ptr) :: ctx, ud, bd
     ctx = dla_default_ctx()
-    call chk(ctx, dla_alloc(ctx, nbytes(n,m), ud), 'allocation')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,m), bd), 'allocation')
+    ud  = dev_panel(ctx, n, m, 'u')
+    bd  = dev_panel(ctx, n, m, 'bu')
     call chk(ctx, dla_upload(ctx, ud, c_loc(u), nbytes(n,m)), 'upload')
     call chk(ctx, dla_upload(ctx, bd, c_loc(bu), nbytes(n,m)), 'upload')
     call chk(ctx, dla_b_ortho(ctx, n, m, ud, bd), 'b_ortho')
     call chk(ctx, dla_download(ctx, c_loc(u), ud, nbytes(n,m)), 'download')
     call chk(ctx, dla_download(ctx, c_loc(bu), bd, nbytes(n,m)), 'download')
-    call chk(ctx, dla_free(ctx, ud), 'free')
-    call chk(ctx, dla_free(ctx, bd), 'free')
+    call drop_panel(ctx, ud)
+    call drop_panel(ctx, bd)
   end subroutine b_ortho
 !
   subroutine b_ortho_vs_x(n,m,k,x,bx,u)
-    integer,                          intent(in)    :: n, m, k
-    real(dp), dimension(n,m), target, intent(in)    :: x, bx
-    real(dp), dimension(n,k), target, intent(inout) :: u
+    integer,  intent(in)            :: n, m, k
+    real(dp), intent(in),    target :: x(n,m), bx(n,m)
+    real(dp), intent(inout), target :: u(n,k)
     type(c_ptr) :: ctx, xd, bd, ud
     ctx = dla_default_ctx()
-    call chk(ctx, dla_alloc(ctx, nbytes(n,max(m,1)), xd), 'allocation')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,max(m,1)), bd), 'allocation')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,k), ud), 'allocation')
+    xd  = dev_panel(ctx, n, max(m,1), 'x')
+    bd  = dev_panel(ctx, n, max(m,1), 'bx')
+    ud  = dev_panel(ctx, n, k, 'u')
     if (m.gt.0) then
       call chk(ctx, dla_upload(ctx, xd, c_loc(x), nbytes(n,m)), 'upload')
       call chk(ctx, dla_upload(ctx, bd, c_loc(bx), nbytes(n,m)), 'upload')
@@ -1179,620 +1061,350 @@ contains
     call chk(ctx, dla_upload(ctx, ud, c_loc(u), nbytes(n,k)), 'upload')
     call chk(ctx, dla_b_ortho_vs_x(ctx, n, m, k, xd, bd, ud), 'b_ortho_vs_x')
     call chk(ctx, dla_download(ctx, c_loc(u), ud, nbytes(n,k)), 'download')
-    call chk(ctx, dla_free(ctx, xd), 'free')
-    call chk(ctx, dla_free(ctx, bd), 'free')
-    call chk(ctx, dla_free(ctx, ud), 'free')
+    call drop_panel(ctx, xd)
+    call drop_panel(ctx, bd)
+    call drop_panel(ctx, ud)
   end subroutine b_ortho_vs_x
 !
 ! ---------------------------------------------------------------------------------------
-! caslr_eff_driver: linear-response generalised eigenproblem
+! Linear-response generalised eigenproblem
 !
 !   / A  B \ / Y \     /  S  D \ / Y \
-!   |      | |   | = w |       | |   |     (reference diaglib.f90:1024-1481)
+!   |      | |   | = w |       | |   |        (reference diaglib.f90:558-1022 caslr_driver, :1024-1481 caslr_eff_driver)
 !   \ B  A / \ Z /     \ -D -S / \ Z /
 !
-! solved in the symmetric/antisymmetric combinations b+ = Y+Z, b- = Y-Z with the Casida matrix as
-! the metric: the expansion spaces vp, vm are (A+B)- and (A-B)-orthonormal, the reduced problem is
-! s^T s u+ = (1/w)^2 u+ with s = vm^T (S+D) vp, and u- = w s u+ (reference :1052-1060).
-! Device-resident: vp, vm, their images under (A+B), (A-B), (S-D), (S+D), and the residuals.
-! Deviations from the reference's operation order, none of which changes a result beyond rounding:
-!   - s is extended by its new block row and block column instead of being recomputed (:1289);
-!   - the Ritz vectors (:1324-1333) are formed when they are needed (convergence, restart, exit),
-!     not in every iteration.
+! solved in the combinations b+ = Y + Z, b- = Y - Z with two expansion spaces vp, vm.  One routine serves both public
+! drivers; they differ in what is kept orthonormal and in the reduced problem:
+!
+!   efficient (caslr_eff_driver): vp is (A+B)-orthonormal, vm is (A-B)-orthonormal; with s = vm^T (S+D) vp the
+!     reduced problem is  s^T s u+ = (1/w)^2 u+,  u- = w s u+  (:1052-1060);
+!   traditional (caslr_driver): vp, vm are Euclidean-orthonormal; with E+ = vp^T (A+B) vp, E- = vm^T (A-B) vm the
+!     reduced problem is the 2 ldu-dimensional pencil  (0 s^T; s 0) u = (1/w) diag(E+,E-) u  (dsygv, :783).
+!
+! Everything lives on the device: vp, vm, their images under the four operators, the residual blocks.
+! Own operation order, none of which changes a result beyond rounding: the reduced matrices grow by their new block
+! rows / columns instead of being recomputed from the full panels every iteration (:754-756, 1289), and the Ritz
+! vectors (:862-868, 1324-1333) are formed when they are needed (convergence, restart, exit).
+! `ok` reports convergence (the reference's caslr_driver hands its `ok` to ortho_cd, :715-716, and so returns .true.
+! even when max_iter is exhausted).
 ! ---------------------------------------------------------------------------------------
-  subroutine caslr_eff_driver(verbose,n,n2,n_targ,n_max,max_iter,tol,max_dav, &
-                              apbmul,ambmul,spdmul,smdmul,lrprec,eig,evec,ok)
-    logical,                               intent(in)    :: verbose
-    integer,                               intent(in)    :: n, n2, n_targ, n_max
-    integer,                               intent(in)    :: max_iter, max_dav
-    real(dp),                              intent(in)    :: tol
-    real(dp), dimension(n_max),            intent(inout) :: eig
-    real(dp), dimension(n2,n_max), target, intent(inout) :: evec
-    logical,                               intent(inout) :: ok
-    external                                             :: apbmul, ambmul, spdmul, smdmul, lrprec
+  subroutine lr_core(traditional,verbose,n,n2,n_targ,n_max,max_iter,tol,max_dav,apb,amb,spd,smd,prec,eig,evec,ok)
+    logical,          intent(in)    :: traditional, verbose
+    integer,          intent(in)    :: n, n2, n_targ, n_max, max_iter, max_dav
+    real(dp),         intent(in)    :: tol
+    type(c_funptr),   intent(in)    :: apb, amb, spd, smd, prec
+    real(dp),         intent(inout) :: eig(n_max)
+    real(dp), target, intent(inout) :: evec(n2,n_max)
+    logical,          intent(inout) :: ok
 !
-    type(c_ptr)    :: ctx, vp, vm, lvp, lvm, bvp, bvm, rp, rm, bp, bm, tp, tm, evd
-    type(c_funptr) :: f_apb, f_amb, f_spd, f_smd, f_prec
-    integer        :: dim_dav, lda, n_act, ind, i_beg, m_dim, ldu, n_frozen, it, i_eig, j, n_mv, n_restarts
-    logical        :: evec_dev, have_evec
-    real(dp)       :: tol_rms, tol_max, sqrt2
-    logical,        allocatable :: done(:)
-    integer(c_int), allocatable :: skip(:)
-    real(dp),       allocatable :: smat(:,:), s_copy(:,:), e_red(:), up(:,:), um(:,:), ident(:,:)
-    real(dp),       allocatable :: r_norm(:,:), rn_p(:,:), rn_m(:,:)
-    integer(c_int) :: info
+    type(subspace)  :: s
+    type(stopwatch) :: w
+    type(solve_env) :: e
+    type(c_ptr)     :: vp, vm, lvp, lvm, bvp, bvm, rp, rm, bp, bm, tp, tm
+    real(dp), allocatable :: smat(:,:), epmat(:,:), emmat(:,:), sts(:,:), lam(:), up(:,:), um(:,:), eye(:,:)
+    real(dp), allocatable :: np(:,:), nm(:,:)
+    real(dp)        :: t_begin(2), t_end(2), sqrt2, growth
+    integer         :: it, sweeps, first, r, c, lo
+    integer(c_int)  :: flag
+    logical         :: vectors_current
 !
-    ctx    = dla_default_ctx()
-    f_apb  = c_funloc(apbmul)
-    f_amb  = c_funloc(ambmul)
-    f_spd  = c_funloc(spdmul)
-    f_smd  = c_funloc(smdmul)
-    f_prec = c_funloc(lrprec)
-    evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
+    call env_open(e, n2, n_max, evec)
+    call sub_setup(s, n_targ, n_max, max(min_dav,max_dav), tol)
+    sqrt2 = sqrt(2.0_dp)
 !
-    dim_dav = max(min_dav,max_dav)
-    lda     = dim_dav*n_max
-    sqrt2   = sqrt(2.0_dp)
-!
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), vp),  'allocation of vp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), vm),  'allocation of vm')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), lvp), 'allocation of lvp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), lvm), 'allocation of lvm')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), bvp), 'allocation of bvp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), bvm), 'allocation of bvm')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), rp), 'allocation of rp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), rm), 'allocation of rm')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), bp), 'allocation of bp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), bm), 'allocation of bm')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), tp), 'allocation of tp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), tm), 'allocation of tm')
-    if (evec_dev) then
-      evd = c_loc(evec)
+    vp  = dev_panel(e%ctx, n, s%ld, 'vp')
+    vm  = dev_panel(e%ctx, n, s%ld, 'vm')
+    lvp = dev_panel(e%ctx, n, s%ld, 'lvp')         ! (A+B) vp
+    lvm = dev_panel(e%ctx, n, s%ld, 'lvm')         ! (A-B) vm
+    bvp = dev_panel(e%ctx, n, s%ld, 'bvp')         ! (S-D) vm
+    bvm = dev_panel(e%ctx, n, s%ld, 'bvm')         ! (S+D) vp
+    rp  = dev_panel(e%ctx, n, n_max, 'rp')
+    rm  = dev_panel(e%ctx, n, n_max, 'rm')
+    bp  = dev_panel(e%ctx, n, n_max, 'bp')
+    bm  = dev_panel(e%ctx, n, n_max, 'bm')
+    tp  = dev_panel(e%ctx, n, n_max, 'tp')
+    tm  = dev_panel(e%ctx, n, n_max, 'tm')
+    allocate (smat(s%ld,s%ld), up(s%ld,n_max), um(s%ld,n_max), eye(n_max,n_max), np(2,n_max), nm(2,n_max))
+    if (traditional) then
+      allocate (epmat(s%ld,s%ld), emmat(s%ld,s%ld))
+      epmat = zero
+      emmat = zero
     else
-      call chk(ctx, dla_alloc(ctx, nbytes(n2,n_max), evd), 'allocation of evec')
-      call chk(ctx, dla_upload(ctx, evd, c_loc(evec), nbytes(n2,n_max)), 'upload of the guess')
+      allocate (sts(s%ld,s%ld), lam(s%ld))
     end if
-    allocate (done(n_max), skip(n_max), r_norm(2,n_max), rn_p(2,n_max), rn_m(2,n_max))
-    allocate (smat(lda,lda), s_copy(lda,lda), e_red(lda), up(lda,n_max), um(lda,n_max), ident(n_max,n_max))
-!
-    tol_rms = tol
-    tol_max = ten * tol
-    t_diag  = zero
-    t_ortho = zero
-    t_mv    = zero
-    t_tot   = zero
-    smat    = zero
-    r_norm  = zero
-    rn_p    = zero
-    rn_m    = zero
-    ident   = zero
-    do j = 1, n_max
-      ident(j,j) = one
+    smat = zero
+    np   = zero
+    nm   = zero
+    eye  = zero
+    do r = 1, n_max
+      eye(r,r) = one
     end do
-    ok      = .false.
-    done    = .false.
-    n_mv    = 0
-    n_restarts = 0
+    ok = .false.
+    call clock_now(t_begin)
 !
-    call get_time(t_tot)
+!   the guess in the plus / minus combinations, orthonormal in the sense of the variant (:709-716, 1249-1259)
 !
-!   the guess in the plus/minus combinations, orthonormal in the metric (reference :1249-1259)
-!
-    call split_evec()
-    call new_metric_blocks(1, n_max)
-!
-    n_act = n_max
-    ind   = 1
-    i_beg = 1
-    m_dim = 1
-    ldu   = 0
-    n_frozen = 0
-    have_evec = .false.
-!
-    1030 format(t5,'Davidson-Liu iterations (tol=',d10.2,'):',/, &
-                t5,'------------------------------------------------------------------',/, &
-                t7,'  iter  root              eigenvalue','         rms         max ok',/, &
-                t5,'------------------------------------------------------------------')
-    1040 format(t9,i4,2x,i4,f24.12,2d12.4,l3)
-    if (verbose) write(6,1030) tol
+    call lr_split(e%ctx, n, n2, n_max, e%ritz, vp, vm)
+    call condition_first_block()
+    vectors_current = .false.
+    sweeps = max_iter
+    if (verbose) call print_table_head('Davidson-Liu iterations (tol=', tol)
 !
     do it = 1, max_iter
-      ldu = ldu + n_act
-      have_evec = .false.
+      call sub_admit(s)
+      vectors_current = .false.
+      c = s%head
 !
-!     (S+D) times the new vp block, (S-D) times the new vm block (reference :1281-1282)
+!     operator products on the new blocks (:743-746, 1281-1282); the efficient variant already has (A+B) vp and
+!     (A-B) vm from making the blocks orthonormal
 !
-      call get_time(t1)
-      call chk(ctx, dla_call_matvec(ctx, f_spd, n, n_act, colp(vp,n,i_beg), colp(bvm,n,i_beg)), 'spdmul')
-      call chk(ctx, dla_call_matvec(ctx, f_smd, n, n_act, colp(vm,n,i_beg), colp(bvp,n,i_beg)), 'smdmul')
-      call get_time(t2)
-      t_mv = t_mv + t2 - t1
-      n_mv = n_mv + 2*n_act
-!
-!     s = vm^T bvm (reference :1289): the new block column and the new block row
-!
-      call chk(ctx, dla_gram(ctx, n, ldu, vm, n_act, colp(bvm,n,i_beg), smat(1,i_beg), lda), 'reduced matrix')
-      if (i_beg.gt.1) call chk(ctx, dla_gram(ctx, n, n_act, colp(vm,n,i_beg), i_beg-1, bvm, smat(i_beg,1), lda), &
-                               'reduced matrix')
-!
-!     s^T s and its largest eigenpairs (reference :1293-1311): the lowest ones of -s^T s
-!
-      s_copy(1:ldu,1:ldu) = -matmul(transpose(smat(1:ldu,1:ldu)), smat(1:ldu,1:ldu))
-      call get_time(t1)
-      info = dla_syev_lowest('u', ldu, s_copy, lda, e_red, n_max)
-      call get_time(t2)
-      t_diag = t_diag + t2 - t1
-      if (info.ne.0) then
-        write(6,'(t3,a,i6)') 'dsyev failed. info = ',info
-        stop
+      call lap_start(w)
+      if (traditional) then
+        call chk(e%ctx, dla_call_matvec(e%ctx, apb, n, s%act, colp(vp,n,c), colp(lvp,n,c)), 'apbmul')
+        call chk(e%ctx, dla_call_matvec(e%ctx, amb, n, s%act, colp(vm,n,c), colp(lvm,n,c)), 'ambmul')
+        e%op_cols = e%op_cols + 2*s%act
       end if
-      do i_eig = 1, n_max
-        eig(i_eig)      = sqrt(-e_red(i_eig))
-        up(1:ldu,i_eig) = s_copy(1:ldu,i_eig)
-      end do
+      call chk(e%ctx, dla_call_matvec(e%ctx, spd, n, s%act, colp(vp,n,c), colp(bvm,n,c)), 'spdmul')
+      call chk(e%ctx, dla_call_matvec(e%ctx, smd, n, s%act, colp(vm,n,c), colp(bvp,n,c)), 'smdmul')
+      e%op_cols = e%op_cols + 2*s%act
+      call lap_charge(w, w%mv)
 !
-!     u- = s u+ / eig (reference :1315-1318)
+!     reduced matrices: new block columns, and for the non-symmetric s = vm^T (S+D) vp also the new block row
 !
-      um(1:ldu,:) = matmul(smat(1:ldu,1:ldu), up(1:ldu,:))
-      do i_eig = 1, n_max
-        um(1:ldu,i_eig) = um(1:ldu,i_eig)/eig(i_eig)
-      end do
+      lo = c - 1
+      call chk(e%ctx, dla_gram(e%ctx, n, s%cols, vm, s%act, colp(bvm,n,c), smat(1,c), s%ld), 'reduced matrix')
+      if (lo.gt.0) call chk(e%ctx, dla_gram(e%ctx, n, s%act, colp(vm,n,c), lo, bvm, smat(c,1), s%ld), 'reduced matrix')
+      if (traditional) then
+        call chk(e%ctx, dla_gram(e%ctx, n, s%cols, vp, s%act, colp(lvp,n,c), epmat(1,c), s%ld), 'reduced matrix')
+        call chk(e%ctx, dla_gram(e%ctx, n, s%cols, vm, s%act, colp(lvm,n,c), emmat(1,c), s%ld), 'reduced matrix')
+        if (lo.gt.0) then
+          epmat(c:s%cols,1:lo) = transpose(epmat(1:lo,c:s%cols))
+          emmat(c:s%cols,1:lo) = transpose(emmat(1:lo,c:s%cols))
+        end if
+      end if
 !
-!     residuals rp = bvp u- - eig lvp u+, rm = bvm u+ - eig lvm u- and their norms (reference :1337-1353)
+!     reduced eigenproblem: eig = w (traditional) or 1/w (efficient), coefficient blocks up, um
 !
-      do i_eig = 1, n_max
-        skip(i_eig) = merge(1_c_int, 0_c_int, done(i_eig))
-      end do
-      call chk(ctx, dla_panel_gemm(ctx, n, ldu, lvp, n_max, up, lda, bp), 'bp')
-      call chk(ctx, dla_panel_gemm(ctx, n, ldu, bvp, n_max, um, lda, tp), 'rp')
-      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, bp, tp, ident, n_max, eig, n_targ, skip, &
-                                      tm, rp, c_null_ptr, rn_p), 'residual')
-      call chk(ctx, dla_panel_gemm(ctx, n, ldu, lvm, n_max, um, lda, bm), 'bm')
-      call chk(ctx, dla_panel_gemm(ctx, n, ldu, bvm, n_max, up, lda, tp), 'rm')
-      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, bm, tp, ident, n_max, eig, n_targ, skip, &
-                                      tm, rm, c_null_ptr, rn_m), 'residual')
-      do i_eig = 1, n_targ
-        if (done(i_eig)) cycle
-        r_norm(1,i_eig) = (rn_p(1,i_eig) + rn_m(1,i_eig))/(eig(i_eig)*sqrt2)
-        r_norm(2,i_eig) = (rn_p(2,i_eig) + rn_m(2,i_eig))/(sqrt2*eig(i_eig))
-      end do
+      call lap_start(w)
+      if (traditional) then
+        if (lr_algorithm.eq.1) then
+          call lr_pairs_helmich_paris(s%cols, s%ld, n_max, epmat, emmat, smat, eig, up, um)
+        else
+          call lr_reduced_pairs(s%cols, s%ld, n_max, epmat, emmat, smat, eig, up, um)
+        end if
+      else
+!       largest pairs of s^T s (:1293-1311) = lowest of -s^T s; u- = s u+ / eig (:1315-1318)
+        sts(1:s%cols,1:s%cols) = -matmul(transpose(smat(1:s%cols,1:s%cols)), smat(1:s%cols,1:s%cols))
+        call need_eigensolver(dla_syev_lowest('u', s%cols, sts, s%ld, lam, n_max))
+        do r = 1, n_max
+          eig(r)          = sqrt(-lam(r))
+          up(1:s%cols,r)  = sts(1:s%cols,r)
+        end do
+        um(1:s%cols,:) = matmul(smat(1:s%cols,1:s%cols), up(1:s%cols,:))
+        do r = 1, n_max
+          um(1:s%cols,r) = um(1:s%cols,r)/eig(r)
+        end do
+      end if
+      call lap_charge(w, w%diag)
 !
-!     lock the leading converged roots (reference :1358-1367)
+!     residuals of the open wanted roots and their norms.  The fused sweep forms  t - eig * b  from two n x n_max blocks:
+!       traditional (:872-889):  rp = lvp u+ - eig bvp u-      rm = lvm u- - eig bvm u+
+!       efficient   (:1337-1353): rp = bvp u- - eig lvp u+      rm = bvm u+ - eig lvm u-
 !
-      do i_eig = 1, n_targ
-        if (done(i_eig)) cycle
-        done(i_eig) = r_norm(1,i_eig).lt.tol_rms .and. r_norm(2,i_eig).lt.tol_max .and. it.gt.1
-        if (.not.done(i_eig)) then
-          done(i_eig+1:n_max) = .false.
-          exit
+      call sub_refresh_mask(s)
+      if (traditional) then
+        call residual_pair(bvp, um, lvp, up, rp, np)
+        call residual_pair(bvm, up, lvm, um, rm, nm)
+      else
+        call residual_pair(lvp, up, bvp, um, rp, np)
+        call residual_pair(lvm, um, bvm, up, rm, nm)
+      end if
+      do r = 1, n_targ
+        if (s%locked(r)) cycle
+        if (traditional) then
+          s%rnorm(:,r) = np(:,r) + nm(:,r)
+        else
+          s%rnorm(1,r) = (np(1,r) + nm(1,r))/(eig(r)*sqrt2)
+          s%rnorm(2,r) = (np(2,r) + nm(2,r))/(sqrt2*eig(r))
         end if
       end do
 !
+      call sub_lock(s, it, n_targ)
       if (verbose) then
-        do i_eig = 1, n_targ
-          write(6,1040) it, i_eig, one/eig(i_eig), r_norm(:,i_eig), done(i_eig)
-        end do
-        write(6,*)
+        if (traditional) then
+          call print_table_rows(s, it, eig)
+        else
+          call print_table_rows(s, it, one/eig)
+        end if
       end if
-!
-      if (all(done(1:n_targ))) then
+      if (sub_finished(s)) then
         ok = .true.
-        call merge_evec()
-        do i_eig = 1, n_targ
-          eig(i_eig) = one/eig(i_eig)
-        end do
+        sweeps = it
         exit
       end if
 !
-      if (m_dim .lt. dim_dav) then
+      if (sub_has_room(s)) then
 !
-!       expand both spaces with the preconditioned residuals (reference :1397-1424)
+!       expand both spaces with the preconditioned residuals (:928-955, 1397-1424)
 !
-        m_dim = m_dim + 1
-        i_beg = i_beg + n_act
-        n_act = n_max
-        n_frozen = 0
-        do i_eig = 1, n_targ
-          if (done(i_eig)) then
-            n_act = n_act - 1
-            n_frozen = n_frozen + 1
-          else
-            exit
-          end if
-        end do
-        ind = n_max - n_act + 1
-        call chk(ctx, dla_call_lrprec(ctx, f_prec, n, n_act, eig(ind), colp(rp,n,ind), colp(rm,n,ind), &
-                                      colp(vp,n,i_beg), colp(vm,n,i_beg)), 'lrprec')
-        call get_time(t1)
-        call chk(ctx, dla_b_ortho_vs_x(ctx, n, ldu, n_act, vp, lvp, colp(vp,n,i_beg)), 'b_ortho_vs_x')
-        call chk(ctx, dla_b_ortho_vs_x(ctx, n, ldu, n_act, vm, lvm, colp(vm,n,i_beg)), 'b_ortho_vs_x')
-        call new_metric_blocks(i_beg, n_act)
-        call get_time(t2)
-        t_ortho = t_ortho + t2 - t1
+        call sub_open_block(s, first)
+        call chk(e%ctx, dla_call_lrprec(e%ctx, prec, n, s%act, eig(first), colp(rp,n,first), colp(rm,n,first), &
+                                        colp(vp,n,s%head), colp(vm,n,s%head)), 'lrprec')
+        call lap_start(w)
+        if (traditional) then
+          call chk(e%ctx, dla_ortho_vs_x(e%ctx, n, s%cols, s%act, vp, colp(vp,n,s%head)), 'ortho_vs_x')
+          call chk(e%ctx, dla_ortho_vs_x(e%ctx, n, s%cols, s%act, vm, colp(vm,n,s%head)), 'ortho_vs_x')
+        else
+          call chk(e%ctx, dla_b_ortho_vs_x(e%ctx, n, s%cols, s%act, vp, lvp, colp(vp,n,s%head)), 'b_ortho_vs_x')
+          call chk(e%ctx, dla_b_ortho_vs_x(e%ctx, n, s%cols, s%act, vm, lvm, colp(vm,n,s%head)), 'b_ortho_vs_x')
+          call metric_blocks(s%head, s%act)
+        end if
+        call lap_charge(w, w%ortho)
       else
 !
-!       restart from the current Ritz vectors (reference :1426-1463)
+!       restart from the current Ritz vectors (:957-991, 1426-1463)
 !
         if (verbose) write(6,'(t7,a)') 'Restarting davidson.'
-        n_restarts = n_restarts + 1
-        call merge_evec()
-        ldu   = 0
-        i_beg = 1
-        m_dim = 1
-        n_act = n_max
-        call split_evec()
-        call new_metric_blocks(1, n_max)
+        e%restarts = e%restarts + 1
+        call gather_vectors()
+        call sub_collapse(s)
+        call lr_split(e%ctx, n, n2, n_max, e%ritz, vp, vm)
+        call condition_first_block()
         smat = zero
+        if (traditional) then
+          epmat = zero
+          emmat = zero
+        end if
       end if
-      if (verbose) write(6,1050) n_targ, n_act, n_frozen
+      if (verbose) call print_block_report(s)
     end do
 !
-!   evec holds the current approximation on every exit, like the reference (:1330-1333)
+!   evec holds the current approximation on every exit, like the reference (:865-868, 1330-1333); the efficient
+!   variant iterates on 1/w and hands w back for the converged solve (:1377-1380)
 !
-    if (.not.have_evec) call merge_evec()
-    call get_time(t2)
-    t_tot = t2 - t_tot
-    call dla_set_solve_info(int(min(it,max_iter),c_int), int(n_mv,c_int), int(n_restarts,c_int))
-!
-    1000 format(t3,'timings for caslr_eff (cpu/wall):   ',/, &
-                t3,'  matrix-vector multiplications: ',2f12.4,/, &
-                t3,'  diagonalization:               ',2f12.4,/, &
-                t3,'  orthogonalization:             ',2f12.4,/, &
-                t3,'                                 ',24('='),/,  &
-                t3,'  total:                         ',2f12.4)
-    if (verbose) write(6,1000) t_mv, t_diag, t_ortho, t_tot
-!
-    if (.not.evec_dev) then
-      call chk(ctx, dla_download(ctx, c_loc(evec), evd, nbytes(n2,n_max)), 'download of evec')
-      call chk(ctx, dla_free(ctx, evd), 'free')
+    if (.not.vectors_current) call gather_vectors()
+    if (ok .and. .not.traditional) eig(1:n_targ) = one/eig(1:n_targ)
+    call clock_now(t_end)
+    w%total = t_end - t_begin
+    if (verbose) then
+      if (traditional) then
+        call print_timings('timings for caslr (cpu/wall):   ', w)
+      else
+        call print_timings('timings for caslr_eff (cpu/wall):   ', w)
+      end if
     end if
-    call chk(ctx, dla_free(ctx, vp), 'free')
-    call chk(ctx, dla_free(ctx, vm), 'free')
-    call chk(ctx, dla_free(ctx, lvp), 'free')
-    call chk(ctx, dla_free(ctx, lvm), 'free')
-    call chk(ctx, dla_free(ctx, bvp), 'free')
-    call chk(ctx, dla_free(ctx, bvm), 'free')
-    call chk(ctx, dla_free(ctx, rp), 'free')
-    call chk(ctx, dla_free(ctx, rm), 'free')
-    call chk(ctx, dla_free(ctx, bp), 'free')
-    call chk(ctx, dla_free(ctx, bm), 'free')
-    call chk(ctx, dla_free(ctx, tp), 'free')
-    call chk(ctx, dla_free(ctx, tm), 'free')
-    deallocate (done, skip, r_norm, rn_p, rn_m, smat, s_copy, e_red, up, um, ident)
 !
-    1050 format(t5,'----------------------------------------',/,&
-                t7,'# target vectors:    ',i4,/,&
-                t7,'# new vectors added: ',i4,/,&
-                t7,'# converged vectors: ',i4,/,&
-                t5,'----------------------------------------')
-    return
+    call env_close(e, evec, sweeps)
+    call drop_panel(e%ctx, vp);  call drop_panel(e%ctx, vm)
+    call drop_panel(e%ctx, lvp); call drop_panel(e%ctx, lvm)
+    call drop_panel(e%ctx, bvp); call drop_panel(e%ctx, bvm)
+    call drop_panel(e%ctx, rp);  call drop_panel(e%ctx, rm)
+    call drop_panel(e%ctx, bp);  call drop_panel(e%ctx, bm)
+    call drop_panel(e%ctx, tp);  call drop_panel(e%ctx, tm)
 !
   contains
 !
-!   device address of the upper (half = 0) or lower (half = 1) n rows of column j of the n2 x n_max block
+!   make the first block of vp, vm orthonormal the way the variant wants it
 !
-    function halfp(j, half) result(p)
-      integer, intent(in) :: j, half
-      type(c_ptr)         :: p
-      integer(c_intptr_t) :: a
-      a = transfer(evd, a) + 8_c_intptr_t * (int(n2,c_intptr_t) * int(j-1,c_intptr_t) + int(half*n,c_intptr_t))
-      p = transfer(a, p)
-    end function halfp
+    subroutine condition_first_block()
+      if (traditional) then
+        call chk(e%ctx, dla_ortho_cd(e%ctx, n, n_max, vp, growth, flag), 'ortho_cd')
+        call chk(e%ctx, dla_ortho_cd(e%ctx, n, n_max, vm, growth, flag), 'ortho_cd')
+      else
+        call metric_blocks(1, n_max)
+      end if
+    end subroutine condition_first_block
 !
-!   vp = Y + Z, vm = Y - Z for the n_max columns of evec (reference :1249-1252, 1443-1446)
+!   efficient variant: (A+B) vp and (A-B) vm for a new block, which is then made orthonormal in its metric
+!   (:1256-1259, 1420-1424)
 !
-    subroutine split_evec()
-      integer :: jj
-      do jj = 1, n_max
-        call chk(ctx, dla_copy(ctx, colp(vp,n,jj), halfp(jj,0), nbytes(n,1)), 'copy')
-        call chk(ctx, dla_axpy(ctx, int(n,c_size_t), one, halfp(jj,1), colp(vp,n,jj)), 'axpy')
-        call chk(ctx, dla_copy(ctx, colp(vm,n,jj), halfp(jj,0), nbytes(n,1)), 'copy')
-        call chk(ctx, dla_axpy(ctx, int(n,c_size_t), -one, halfp(jj,1), colp(vm,n,jj)), 'axpy')
-      end do
-    end subroutine split_evec
-!
-!   Ritz vectors in the plus/minus combinations, eigp = vp u+, eigm = vm u- (reference :1324-1325; bp, bm
-!   are free here and hold them), then Y = eigp + eigm, Z = eigp - eigm (:1330-1333)
-!
-    subroutine merge_evec()
-      integer :: jj
-      call chk(ctx, dla_panel_gemm(ctx, n, ldu, vp, n_max, up, lda, bp), 'ritz vectors')
-      call chk(ctx, dla_panel_gemm(ctx, n, ldu, vm, n_max, um, lda, bm), 'ritz vectors')
-      do jj = 1, n_max
-        call chk(ctx, dla_copy(ctx, halfp(jj,0), colp(bp,n,jj), nbytes(n,1)), 'copy')
-        call chk(ctx, dla_axpy(ctx, int(n,c_size_t), one, colp(bm,n,jj), halfp(jj,0)), 'axpy')
-        call chk(ctx, dla_copy(ctx, halfp(jj,1), colp(bp,n,jj), nbytes(n,1)), 'copy')
-        call chk(ctx, dla_axpy(ctx, int(n,c_size_t), -one, colp(bm,n,jj), halfp(jj,1)), 'axpy')
-      end do
-      have_evec = .true.
-    end subroutine merge_evec
-!
-!   (A+B) vp and (A-B) vm for a new block, which is then made orthonormal in its metric
-!   (reference :1256-1259, 1420-1424)
-!
-    subroutine new_metric_blocks(c0, k)
+    subroutine metric_blocks(c0, k)
       integer, intent(in) :: c0, k
-      call chk(ctx, dla_call_matvec(ctx, f_apb, n, k, colp(vp,n,c0), colp(lvp,n,c0)), 'apbmul')
-      call chk(ctx, dla_b_ortho(ctx, n, k, colp(vp,n,c0), colp(lvp,n,c0)), 'b_ortho')
-      call chk(ctx, dla_call_matvec(ctx, f_amb, n, k, colp(vm,n,c0), colp(lvm,n,c0)), 'ambmul')
-      call chk(ctx, dla_b_ortho(ctx, n, k, colp(vm,n,c0), colp(lvm,n,c0)), 'b_ortho')
-      n_mv = n_mv + 2*k
-    end subroutine new_metric_blocks
+      call chk(e%ctx, dla_call_matvec(e%ctx, apb, n, k, colp(vp,n,c0), colp(lvp,n,c0)), 'apbmul')
+      call chk(e%ctx, dla_b_ortho(e%ctx, n, k, colp(vp,n,c0), colp(lvp,n,c0)), 'b_ortho')
+      call chk(e%ctx, dla_call_matvec(e%ctx, amb, n, k, colp(vm,n,c0), colp(lvm,n,c0)), 'ambmul')
+      call chk(e%ctx, dla_b_ortho(e%ctx, n, k, colp(vm,n,c0), colp(lvm,n,c0)), 'b_ortho')
+      e%op_cols = e%op_cols + 2*k
+    end subroutine metric_blocks
+!
+!   res = tpanel ct - eig * (bpanel cb) for the open wanted roots, with the residual norms; bb receives bpanel cb
+!
+    subroutine residual_pair(bpanel, cb, tpanel, ct, res, norms)
+      type(c_ptr), intent(in)    :: bpanel, tpanel, res
+      real(dp),    intent(in)    :: cb(s%ld,n_max), ct(s%ld,n_max)
+      real(dp),    intent(inout) :: norms(2,n_max)
+      call chk(e%ctx, dla_panel_gemm(e%ctx, n, s%cols, bpanel, n_max, cb, s%ld, bp), 'residual')
+      call chk(e%ctx, dla_panel_gemm(e%ctx, n, s%cols, tpanel, n_max, ct, s%ld, tp), 'residual')
+      call chk(e%ctx, dla_ritz_residual(e%ctx, n, n_max, n_max, bp, tp, eye, n_max, eig, n_targ, s%mask, &
+                                        tm, res, c_null_ptr, norms), 'residual')
+    end subroutine residual_pair
+!
+!   Ritz vectors vp u+ and vm u- (in the scratch blocks bp, bm), then Y = sum, Z = difference (:862-868, 1324-1333)
+!
+    subroutine gather_vectors()
+      integer :: jj
+      if (s%cols.le.0) return
+      call chk(e%ctx, dla_panel_gemm(e%ctx, n, s%cols, vp, n_max, up, s%ld, bp), 'ritz vectors')
+      call chk(e%ctx, dla_panel_gemm(e%ctx, n, s%cols, vm, n_max, um, s%ld, bm), 'ritz vectors')
+      do jj = 1, n_max
+        call chk(e%ctx, dla_copy(e%ctx, lr_half(e%ritz,n,n2,jj,0), colp(bp,n,jj), nbytes(n,1)), 'copy')
+        call chk(e%ctx, dla_axpy(e%ctx, nelem(n,1), one, colp(bm,n,jj), lr_half(e%ritz,n,n2,jj,0)), 'axpy')
+        call chk(e%ctx, dla_copy(e%ctx, lr_half(e%ritz,n,n2,jj,1), colp(bp,n,jj), nbytes(n,1)), 'copy')
+        call chk(e%ctx, dla_axpy(e%ctx, nelem(n,1), -one, colp(bm,n,jj), lr_half(e%ritz,n,n2,jj,1)), 'axpy')
+      end do
+      vectors_current = .true.
+    end subroutine gather_vectors
+  end subroutine lr_core
+!
+  subroutine caslr_driver(verbose,n,n2,n_targ,n_max,max_iter,tol,max_dav,apbmul,ambmul,spdmul,smdmul,lrprec,eig,evec,ok)
+    logical,  intent(in)            :: verbose
+    integer,  intent(in)            :: n, n2, n_targ, n_max, max_iter, max_dav
+    real(dp), intent(in)            :: tol
+    real(dp), intent(inout)         :: eig(n_max)
+    real(dp), intent(inout), target :: evec(n2,n_max)
+    logical,  intent(inout)         :: ok
+    external                        :: apbmul, ambmul, spdmul, smdmul, lrprec
+    call lr_core(.true., verbose, n, n2, n_targ, n_max, max_iter, tol, max_dav, c_funloc(apbmul), c_funloc(ambmul), &
+                 c_funloc(spdmul), c_funloc(smdmul), c_funloc(lrprec), eig, evec, ok)
+  end subroutine caslr_driver
+!
+  subroutine caslr_eff_driver(verbose,n,n2,n_targ,n_max,max_iter,tol,max_dav,apbmul,ambmul,spdmul,smdmul,lrprec, &
+                              eig,evec,ok)
+    logical,  intent(in)            :: verbose
+    integer,  intent(in)            :: n, n2, n_targ, n_max, max_iter, max_dav
+    real(dp), intent(in)            :: tol
+    real(dp), intent(inout)         :: eig(n_max)
+    real(dp), intent(inout), target :: evec(n2,n_max)
+    logical,  intent(inout)         :: ok
+    external                        :: apbmul, ambmul, spdmul, smdmul, lrprec
+    call lr_core(.false., verbose, n, n2, n_targ, n_max, max_iter, tol, max_dav, c_funloc(apbmul), c_funloc(ambmul), &
+                 c_funloc(spdmul), c_funloc(smdmul), c_funloc(lrprec), eig, evec, ok)
   end subroutine caslr_eff_driver
 !
-! ---------------------------------------------------------------------------------------
-! caslr_driver: the traditional solver of the same linear-response problem (reference
-! diaglib.f90:558-1022, its default algorithm i_alg = 0).  vp, vm are Euclidean-orthonormal
-! (ortho_cd / ortho_vs_x); the reduced problem is the 2 ldu-dimensional generalised one
+! vp = Y + Z, vm = Y - Z for the n_max columns of the 2n x n_max block ev (reference :709-712, 1249-1252)
 !
-!     /  0   s^T \ / u+ \   1  / E+  0  \ / u+ \          E+ = vp^T (A+B) vp,  E- = vm^T (A-B) vm,
-!     |          | |    | = -  |        | |    |          s  = vm^T (S+D) vp
-!     \  s    0  / \ u- /   w  \ 0   E- / \ u- /
-!
-! (dsygv itype 1 at :783).  Here the block-diagonal metric is factored blockwise, E+ = L+ L+^T, E- = L- L-^T,
-! which turns the pencil into the symmetric matrix (0 M^T; M 0), M = L-^-1 s L+^-T, whose largest eigenpairs come
-! from the partial solver; u = L^-T y has the dsygv normalisation u^T diag(E+,E-) u = 1.  As in caslr_eff_driver
-! the reduced matrices grow by their new block rows/columns (:754-756 recompute them), and the Ritz vectors
-! (:862-868) are formed at convergence, restart and exit.
-! ---------------------------------------------------------------------------------------
-  subroutine caslr_driver(verbose,n,n2,n_targ,n_max,max_iter,tol,max_dav, &
-                          apbmul,ambmul,spdmul,smdmul,lrprec,eig,evec,ok)
-    logical,                               intent(in)    :: verbose
-    integer,                               intent(in)    :: n, n2, n_targ, n_max
-    integer,                               intent(in)    :: max_iter, max_dav
-    real(dp),                              intent(in)    :: tol
-    real(dp), dimension(n_max),            intent(inout) :: eig
-    real(dp), dimension(n2,n_max), target, intent(inout) :: evec
-    logical,                               intent(inout) :: ok
-    external                                             :: apbmul, ambmul, spdmul, smdmul, lrprec
-!
-    type(c_ptr)    :: ctx, vp, vm, lvp, lvm, bvp, bvm, rp, rm, bp, bm, tp, tm, evd
-    type(c_funptr) :: f_apb, f_amb, f_spd, f_smd, f_prec
-    integer        :: dim_dav, lda, n_act, ind, i_beg, m_dim, ldu, n_frozen, it, i_eig, j, n_mv, n_restarts
-    logical        :: evec_dev, have_evec
-    real(dp)       :: tol_rms, tol_max, growth
-    logical,        allocatable :: done(:)
-    integer(c_int), allocatable :: skip(:)
-    real(dp),       allocatable :: epmat(:,:), emmat(:,:), smat(:,:), up(:,:), um(:,:), ident(:,:)
-    real(dp),       allocatable :: r_norm(:,:), rn_p(:,:), rn_m(:,:)
-    integer(c_int) :: okc
-!
-    ctx    = dla_default_ctx()
-    f_apb  = c_funloc(apbmul)
-    f_amb  = c_funloc(ambmul)
-    f_spd  = c_funloc(spdmul)
-    f_smd  = c_funloc(smdmul)
-    f_prec = c_funloc(lrprec)
-    evec_dev = dla_get_option(ctx, opt_evec_dev) .ne. 0
-!
-    dim_dav = max(min_dav,max_dav)
-    lda     = dim_dav*n_max
-!
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), vp),  'allocation of vp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), vm),  'allocation of vm')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), lvp), 'allocation of lvp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), lvm), 'allocation of lvm')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), bvp), 'allocation of bvp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,lda), bvm), 'allocation of bvm')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), rp), 'allocation of rp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), rm), 'allocation of rm')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), bp), 'allocation of bp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), bm), 'allocation of bm')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), tp), 'allocation of tp')
-    call chk(ctx, dla_alloc(ctx, nbytes(n,n_max), tm), 'allocation of tm')
-    if (evec_dev) then
-      evd = c_loc(evec)
-    else
-      call chk(ctx, dla_alloc(ctx, nbytes(n2,n_max), evd), 'allocation of evec')
-      call chk(ctx, dla_upload(ctx, evd, c_loc(evec), nbytes(n2,n_max)), 'upload of the guess')
-    end if
-    allocate (done(n_max), skip(n_max), r_norm(2,n_max), rn_p(2,n_max), rn_m(2,n_max))
-    allocate (epmat(lda,lda), emmat(lda,lda), smat(lda,lda), up(lda,n_max), um(lda,n_max), ident(n_max,n_max))
-!
-    tol_rms = tol
-    tol_max = ten * tol
-    t_diag  = zero
-    t_ortho = zero
-    t_mv    = zero
-    t_tot   = zero
-    epmat   = zero
-    emmat   = zero
-    smat    = zero
-    r_norm  = zero
-    rn_p    = zero
-    rn_m    = zero
-    ident   = zero
-    do j = 1, n_max
-      ident(j,j) = one
+  subroutine lr_split(ctx, n, n2, n_max, ev, vp, vm)
+    type(c_ptr), intent(in) :: ctx, ev, vp, vm
+    integer,     intent(in) :: n, n2, n_max
+    integer :: jj
+    do jj = 1, n_max
+      call chk(ctx, dla_copy(ctx, colp(vp,n,jj), lr_half(ev,n,n2,jj,0), nbytes(n,1)), 'copy')
+      call chk(ctx, dla_axpy(ctx, nelem(n,1), one, lr_half(ev,n,n2,jj,1), colp(vp,n,jj)), 'axpy')
+      call chk(ctx, dla_copy(ctx, colp(vm,n,jj), lr_half(ev,n,n2,jj,0), nbytes(n,1)), 'copy')
+      call chk(ctx, dla_axpy(ctx, nelem(n,1), -one, lr_half(ev,n,n2,jj,1), colp(vm,n,jj)), 'axpy')
     end do
-    ok      = .false.
-    done    = .false.
-    n_mv    = 0
-    n_restarts = 0
+  end subroutine lr_split
 !
-    call get_time(t_tot)
+! device address of the upper (half = 0) or lower (half = 1) n rows of column j of a 2n x m block
 !
-!   the guess in the plus/minus combinations, orthonormalised (reference :709-716)
-!
-    call lr_split_evec(ctx, n, n2, n_max, evd, vp, vm)
-    call chk(ctx, dla_ortho_cd(ctx, n, n_max, vp, growth, okc), 'ortho_cd')
-    call chk(ctx, dla_ortho_cd(ctx, n, n_max, vm, growth, okc), 'ortho_cd')
-!
-    n_act = n_max
-    ind   = 1
-    i_beg = 1
-    m_dim = 1
-    ldu   = 0
-    n_frozen = 0
-    have_evec = .false.
-!
-    1030 format(t5,'Davidson-Liu iterations (tol=',d10.2,'):',/, &
-                t5,'------------------------------------------------------------------',/, &
-                t7,'  iter  root              eigenvalue','         rms         max ok',/, &
-                t5,'------------------------------------------------------------------')
-    1040 format(t9,i4,2x,i4,f24.12,2d12.4,l3)
-    if (verbose) write(6,1030) tol
-!
-    do it = 1, max_iter
-      ldu = ldu + n_act
-      have_evec = .false.
-!
-!     the four products on the new blocks (reference :743-746)
-!
-      call get_time(t1)
-      call chk(ctx, dla_call_matvec(ctx, f_apb, n, n_act, colp(vp,n,i_beg), colp(lvp,n,i_beg)), 'apbmul')
-      call chk(ctx, dla_call_matvec(ctx, f_amb, n, n_act, colp(vm,n,i_beg), colp(lvm,n,i_beg)), 'ambmul')
-      call chk(ctx, dla_call_matvec(ctx, f_spd, n, n_act, colp(vp,n,i_beg), colp(bvm,n,i_beg)), 'spdmul')
-      call chk(ctx, dla_call_matvec(ctx, f_smd, n, n_act, colp(vm,n,i_beg), colp(bvp,n,i_beg)), 'smdmul')
-      call get_time(t2)
-      t_mv = t_mv + t2 - t1
-      n_mv = n_mv + 4*n_act
-!
-!     reduced matrices (reference :754-756): new block columns, and for the non-symmetric s also the new block row
-!
-      call chk(ctx, dla_gram(ctx, n, ldu, vp, n_act, colp(lvp,n,i_beg), epmat(1,i_beg), lda), 'reduced matrix')
-      call chk(ctx, dla_gram(ctx, n, ldu, vm, n_act, colp(lvm,n,i_beg), emmat(1,i_beg), lda), 'reduced matrix')
-      call chk(ctx, dla_gram(ctx, n, ldu, vm, n_act, colp(bvm,n,i_beg), smat(1,i_beg), lda), 'reduced matrix')
-      if (i_beg.gt.1) then
-        epmat(i_beg:ldu,1:i_beg-1) = transpose(epmat(1:i_beg-1,i_beg:ldu))
-        emmat(i_beg:ldu,1:i_beg-1) = transpose(emmat(1:i_beg-1,i_beg:ldu))
-        call chk(ctx, dla_gram(ctx, n, n_act, colp(vm,n,i_beg), i_beg-1, bvm, smat(i_beg,1), lda), 'reduced matrix')
-      end if
-!
-!     largest eigenpairs of the reduced pencil (reference :775-800)
-!
-      call get_time(t1)
-      call lr_reduced_pairs(ldu, lda, n_max, epmat, emmat, smat, eig, up, um)
-      call get_time(t2)
-      t_diag = t_diag + t2 - t1
-!
-!     residuals rp = lvp u+ - eig bvp u-, rm = lvm u- - eig bvm u+ and their norms (reference :872-889)
-!
-      do i_eig = 1, n_max
-        skip(i_eig) = merge(1_c_int, 0_c_int, done(i_eig))
-      end do
-      call chk(ctx, dla_panel_gemm(ctx, n, ldu, bvp, n_max, um, lda, bp), 'bp')
-      call chk(ctx, dla_panel_gemm(ctx, n, ldu, lvp, n_max, up, lda, tp), 'rp')
-      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, bp, tp, ident, n_max, eig, n_targ, skip, &
-                                      tm, rp, c_null_ptr, rn_p), 'residual')
-      call chk(ctx, dla_panel_gemm(ctx, n, ldu, bvm, n_max, up, lda, bm), 'bm')
-      call chk(ctx, dla_panel_gemm(ctx, n, ldu, lvm, n_max, um, lda, tp), 'rm')
-      call chk(ctx, dla_ritz_residual(ctx, n, n_max, n_max, bm, tp, ident, n_max, eig, n_targ, skip, &
-                                      tm, rm, c_null_ptr, rn_m), 'residual')
-      do i_eig = 1, n_targ
-        if (done(i_eig)) cycle
-        r_norm(1,i_eig) = rn_p(1,i_eig) + rn_m(1,i_eig)
-        r_norm(2,i_eig) = rn_p(2,i_eig) + rn_m(2,i_eig)
-      end do
-!
-!     lock the leading converged roots (reference :894-903)
-!
-      do i_eig = 1, n_targ
-        if (done(i_eig)) cycle
-        done(i_eig) = r_norm(1,i_eig).lt.tol_rms .and. r_norm(2,i_eig).lt.tol_max .and. it.gt.1
-        if (.not.done(i_eig)) then
-          done(i_eig+1:n_max) = .false.
-          exit
-        end if
-      end do
-!
-      if (verbose) then
-        do i_eig = 1, n_targ
-          write(6,1040) it, i_eig, eig(i_eig), r_norm(:,i_eig), done(i_eig)
-        end do
-        write(6,*)
-      end if
-!
-      if (all(done(1:n_targ))) then
-        ok = .true.
-        exit
-      end if
-!
-      if (m_dim .lt. dim_dav) then
-!
-!       expand both spaces with the preconditioned residuals (reference :928-955)
-!
-        m_dim = m_dim + 1
-        i_beg = i_beg + n_act
-        n_act = n_max
-        n_frozen = 0
-        do i_eig = 1, n_targ
-          if (done(i_eig)) then
-            n_act = n_act - 1
-            n_frozen = n_frozen + 1
-          else
-            exit
-          end if
-        end do
-        ind = n_max - n_act + 1
-        call chk(ctx, dla_call_lrprec(ctx, f_prec, n, n_act, eig(ind), colp(rp,n,ind), colp(rm,n,ind), &
-                                      colp(vp,n,i_beg), colp(vm,n,i_beg)), 'lrprec')
-        call get_time(t1)
-        call chk(ctx, dla_ortho_vs_x(ctx, n, ldu, n_act, vp, colp(vp,n,i_beg)), 'ortho_vs_x')
-        call chk(ctx, dla_ortho_vs_x(ctx, n, ldu, n_act, vm, colp(vm,n,i_beg)), 'ortho_vs_x')
-        call get_time(t2)
-        t_ortho = t_ortho + t2 - t1
-      else
-!
-!       restart from the current Ritz vectors (reference :957-991)
-!
-        if (verbose) write(6,'(t7,a)') 'Restarting davidson.'
-        n_restarts = n_restarts + 1
-        call lr_merge_evec(ctx, n, n2, n_max, ldu, lda, vp, vm, up, um, bp, bm, evd)
-        ldu   = 0
-        i_beg = 1
-        m_dim = 1
-        n_act = n_max
-        call lr_split_evec(ctx, n, n2, n_max, evd, vp, vm)
-        call chk(ctx, dla_ortho_cd(ctx, n, n_max, vp, growth, okc), 'ortho_cd')
-        call chk(ctx, dla_ortho_cd(ctx, n, n_max, vm, growth, okc), 'ortho_cd')
-        epmat = zero
-        emmat = zero
-        smat  = zero
-      end if
-      if (verbose) write(6,1050) n_targ, n_act, n_frozen
-    end do
-!
-!   evec holds the current approximation on every exit, like the reference (:865-868)
-!
-    if (ldu.gt.0) call lr_merge_evec(ctx, n, n2, n_max, ldu, lda, vp, vm, up, um, bp, bm, evd)
-    call get_time(t2)
-    t_tot = t2 - t_tot
-    call dla_set_solve_info(int(min(it,max_iter),c_int), int(n_mv,c_int), int(n_restarts,c_int))
-!
-    1000 format(t3,'timings for caslr (cpu/wall):   ',/, &
-                t3,'  matrix-vector multiplications: ',2f12.4,/, &
-                t3,'  diagonalization:               ',2f12.4,/, &
-                t3,'  orthogonalization:             ',2f12.4,/, &
-                t3,'                                 ',24('='),/,  &
-                t3,'  total:                         ',2f12.4)
-    if (verbose) write(6,1000) t_mv, t_diag, t_ortho, t_tot
-!
-    if (.not.evec_dev) then
-      call chk(ctx, dla_download(ctx, c_loc(evec), evd, nbytes(n2,n_max)), 'download of evec')
-      call chk(ctx, dla_free(ctx, evd), 'free')
-    end if
-    call chk(ctx, dla_free(ctx, vp), 'free')
-    call chk(ctx, dla_free(ctx, vm), 'free')
-    call chk(ctx, dla_free(ctx, lvp), 'free')
-    call chk(ctx, dla_free(ctx, lvm), 'free')
-    call chk(ctx, dla_free(ctx, bvp), 'free')
-    call chk(ctx, dla_free(ctx, bvm), 'free')
-    call chk(ctx, dla_free(ctx, rp), 'free')
-    call chk(ctx, dla_free(ctx, rm), 'free')
-    call chk(ctx, dla_free(ctx, bp), 'free')
-    call chk(ctx, dla_free(ctx, bm), 'free')
-    call chk(ctx, dla_free(ctx, tp), 'free')
-    call chk(ctx, dla_free(ctx, tm), 'free')
-    deallocate (done, skip, r_norm, rn_p, rn_m, epmat, emmat, smat, up, um, ident)
-!
-    1050 format(t5,'----------------------------------------',/,&
-                t7,'# target vectors:    ',i4,/,&
-                t7,'# new vectors added: ',i4,/,&
-                t7,'# converged vectors: ',i4,/,&
-                t5,'----------------------------------------')
-    return
-  end subroutine caslr_driver
+  function lr_half(ev, n, n2, j, half) result(p)
+    type(c_ptr), intent(in) :: ev
+    integer,     intent(in) :: n, n2, j, half
+    type(c_ptr)             :: p
+    integer(c_intptr_t)     :: a
+    a = transfer(ev, a) + 8_c_intptr_t * (int(n2,c_intptr_t) * int(j-1,c_intptr_t) + int(half*n,c_intptr_t))
+    p = transfer(a, p)
+  end function lr_half
 !
 ! the n_max largest eigenpairs of (0 s^T; s 0) u = (1/w) diag(E+,E-) u (dsygv itype 1, reference :783):
 ! eig = w, up/um = the two halves of u, normalised u^T diag(E+,E-) u = 1
@@ -1812,7 +1424,7 @@ contains
     if (info.eq.0) info = dla_potrf_lower(ldu, lm, ldu)
     if (info.ne.0) then
       write(6,'(t3,a)') 'DSYGV failed in caslr_driver'
-      stop
+      error stop 1
     end if
     do j = 2, ldu
       lp(1:j-1,j) = zero
@@ -1828,7 +1440,7 @@ contains
     info = dla_syev_lowest('l', l2, cc, l2, w, n_max)
     if (info.ne.0) then
       write(6,'(t3,a,i6)') 'dsyev failed. info = ',info
-      stop
+      error stop 1
     end if
     do i = 1, n_max
       eig(i)      = -one/w(i)
@@ -1838,47 +1450,72 @@ contains
     deallocate (lp, lm, mm, cc, w)
   end subroutine lr_reduced_pairs
 !
-! vp = Y + Z, vm = Y - Z for the n_max columns of the 2n x n_max block evd (reference :709-712, 1249-1252)
 !
-  subroutine lr_split_evec(ctx, n, n2, n_max, evd, vp, vm)
-    type(c_ptr), intent(in) :: ctx, evd, vp, vm
-    integer,     intent(in) :: n, n2, n_max
-    integer :: jj
-    do jj = 1, n_max
-      call chk(ctx, dla_copy(ctx, colp(vp,n,jj), lr_halfp(evd,n,n2,jj,0), nbytes(n,1)), 'copy')
-      call chk(ctx, dla_axpy(ctx, int(n,c_size_t), one, lr_halfp(evd,n,n2,jj,1), colp(vp,n,jj)), 'axpy')
-      call chk(ctx, dla_copy(ctx, colp(vm,n,jj), lr_halfp(evd,n,n2,jj,0), nbytes(n,1)), 'copy')
-      call chk(ctx, dla_axpy(ctx, int(n,c_size_t), -one, lr_halfp(evd,n,n2,jj,1), colp(vm,n,jj)), 'axpy')
+! Helmich-Paris route to the same pairs (reference diaglib.f90:805-860, its i_alg = 1): with s = U1 S1 V1^T,
+! Vs = V1 S1^-1/2, Us = U1 S1^-1/2, the scaled blocks E+~ = Vs^T E+ Vs = L+ L+^T and E-~ = Us^T E- Us = L- L-^T, and
+! C = L-^T L+ = U2 S2 V2^T, the eigenvalues w are the SMALLEST singular values of C and
+!   u+ = Vs L- u2 / (sqrt(2) w),   u- = Us L+ v2 / (sqrt(2) w).
+! The singular value decompositions come from the symmetric eigensolver applied to (0 M^T; M 0), whose positive
+! eigenpairs are (sigma, (v; u)/sqrt(2)): no LAPACK at run time, full accuracy for small singular values.
+!
+  subroutine lr_pairs_helmich_paris(ldu, lda, n_max, epmat, emmat, smat, eig, up, um)
+    integer,  intent(in)    :: ldu, lda, n_max
+    real(dp), intent(in)    :: epmat(lda,lda), emmat(lda,lda), smat(lda,lda)
+    real(dp), intent(inout) :: eig(n_max), up(lda,n_max), um(lda,n_max)
+    real(dp), allocatable   :: u1(:,:), v1(:,:), s1(:), u2(:,:), v2(:,:), s2(:), lp(:,:), lm(:,:), cm(:,:)
+    integer                 :: i, j, pick
+    integer(c_int)          :: info
+    allocate (u1(ldu,ldu), v1(ldu,ldu), s1(ldu), u2(ldu,ldu), v2(ldu,ldu), s2(ldu), lp(ldu,ldu), lm(ldu,ldu), cm(ldu,ldu))
+    call small_svd(ldu, smat(1:ldu,1:ldu), u1, s1, v1)
+    do i = 1, ldu
+      u1(:,i) = u1(:,i)/sqrt(s1(i))
+      v1(:,i) = v1(:,i)/sqrt(s1(i))
     end do
-  end subroutine lr_split_evec
-!
-! Ritz vectors eigp = vp u+, eigm = vm u- (in the scratch blocks bp, bm), then Y = eigp + eigm, Z = eigp - eigm
-! (reference :862-868, 1324-1333)
-!
-  subroutine lr_merge_evec(ctx, n, n2, n_max, ldu, lda, vp, vm, up, um, bp, bm, evd)
-    type(c_ptr), intent(in) :: ctx, vp, vm, bp, bm, evd
-    integer,     intent(in) :: n, n2, n_max, ldu, lda
-    real(dp),    intent(in) :: up(lda,n_max), um(lda,n_max)
-    integer :: jj
-    call chk(ctx, dla_panel_gemm(ctx, n, ldu, vp, n_max, up, lda, bp), 'ritz vectors')
-    call chk(ctx, dla_panel_gemm(ctx, n, ldu, vm, n_max, um, lda, bm), 'ritz vectors')
-    do jj = 1, n_max
-      call chk(ctx, dla_copy(ctx, lr_halfp(evd,n,n2,jj,0), colp(bp,n,jj), nbytes(n,1)), 'copy')
-      call chk(ctx, dla_axpy(ctx, int(n,c_size_t), one, colp(bm,n,jj), lr_halfp(evd,n,n2,jj,0)), 'axpy')
-      call chk(ctx, dla_copy(ctx, lr_halfp(evd,n,n2,jj,1), colp(bp,n,jj), nbytes(n,1)), 'copy')
-      call chk(ctx, dla_axpy(ctx, int(n,c_size_t), -one, colp(bm,n,jj), lr_halfp(evd,n,n2,jj,1)), 'axpy')
+    lp = matmul(transpose(v1), matmul(epmat(1:ldu,1:ldu), v1))
+    lm = matmul(transpose(u1), matmul(emmat(1:ldu,1:ldu), u1))
+    info = dla_potrf_lower(ldu, lp, ldu)
+    if (info.eq.0) info = dla_potrf_lower(ldu, lm, ldu)
+    if (info.ne.0) then
+      write(6,'(t3,a)') 'Cholesky factorisation failed in caslr_driver (Helmich-Paris route)'
+      error stop 1
+    end if
+    do j = 2, ldu
+      lp(1:j-1,j) = zero
+      lm(1:j-1,j) = zero
     end do
-  end subroutine lr_merge_evec
+    cm = matmul(transpose(lm), lp)
+    call small_svd(ldu, cm, u2, s2, v2)
+    do i = 1, n_max
+      pick = ldu - i + 1                                     ! singular values come in descending order
+      eig(i)      = s2(pick)
+      up(1:ldu,i) = matmul(v1, matmul(lm, u2(:,pick)))/(sqrt(2.0_dp)*s2(pick))
+      um(1:ldu,i) = matmul(u1, matmul(lp, v2(:,pick)))/(sqrt(2.0_dp)*s2(pick))
+    end do
+    deallocate (u1, v1, s1, u2, v2, s2, lp, lm, cm)
+  end subroutine lr_pairs_helmich_paris
 !
-! device address of the upper (half = 0) or lower (half = 1) n rows of column j of a 2n x m block
+! a = u diag(sv) v^T for a square matrix, singular values in descending order
 !
-  function lr_halfp(evd, n, n2, j, half) result(p)
-    type(c_ptr), intent(in) :: evd
-    integer,     intent(in) :: n, n2, j, half
-    type(c_ptr)             :: p
-    integer(c_intptr_t)     :: a
-    a = transfer(evd, a) + 8_c_intptr_t * (int(n2,c_intptr_t) * int(j-1,c_intptr_t) + int(half*n,c_intptr_t))
-    p = transfer(a, p)
-  end function lr_halfp
+  subroutine small_svd(m, a, u, sv, v)
+    integer,  intent(in)  :: m
+    real(dp), intent(in)  :: a(m,m)
+    real(dp), intent(out) :: u(m,m), sv(m), v(m,m)
+    real(dp), allocatable :: jw(:,:), ev(:)
+    integer               :: i, col
+    integer(c_int)        :: info
+    allocate (jw(2*m,2*m), ev(2*m))
+    jw = zero
+    jw(m+1:2*m,1:m) = a
+    jw(1:m,m+1:2*m) = transpose(a)
+    info = dla_syev('l', 2*m, jw, 2*m, ev)
+    call need_eigensolver(info)
+    do i = 1, m
+      col   = 2*m - i + 1
+      sv(i) = ev(col)
+      v(:,i) = jw(1:m,col)*sqrt(2.0_dp)
+      u(:,i) = jw(m+1:2*m,col)*sqrt(2.0_dp)
+    end do
+    deallocate (jw, ev)
+  end subroutine small_svd
 !
 end module diaglib

@@ -190,7 +190,11 @@ int  dla_random_fill(dla_ctx* ctx, int n, int m, double* evec_dev);
 int  dla_fill_guess(dla_ctx* ctx, int n, int m, double* evec_dev, unsigned long long seed, long long support_rows);
 
 /* ---------------------------------------------------------------- orthogonalisation */
-int  dla_ortho_cd(dla_ctx* ctx, int n, int k, double* u_dev, double* growth, int* ok);      /* diaglib.f90:3185-3341 */
+int  dla_ortho_cd(dla_ctx* ctx, int n, int k, double* u_dev, double* growth, int* ok);      /* ortho(n,m,u,w), diaglib.f90:3052-3092: Householder QR of a copy (dgeqrf) and U <- U R^-1 (dtrsm) -- the orthonormal factor
+ * with LAPACK's sign convention for diag(R).  The reference calls it when ortho_cd gives up (:3534, :3549).  Device path:
+ * column-wise Gram-Schmidt for the factor, the Householder recurrence on an isometric 2k x k host matrix for the signs. */
+int  dla_ortho_qr(dla_ctx* ctx, int n, int k, double* u_dev);
+/* diaglib.f90:3185-3341 */
 int  dla_ortho_vs_x(dla_ctx* ctx, int n, int m, int k, const double* x_dev, double* u_dev); /* diaglib.f90:3481-3574 */
 int  dla_b_ortho(dla_ctx* ctx, int n, int m, double* u_dev, double* bu_dev);                /* diaglib.f90:3094-3183 */
 int  dla_b_ortho_vs_x(dla_ctx* ctx, int n, int m, int k, const double* x_dev, const double* bx_dev,
