@@ -134,6 +134,7 @@ struct dla_ctx {
   int callbacks_on_device = 0;
   int evec_on_device = 0;
   int verbose_ortho = 0;
+  int caslr_algorithm = 0;   // DLA_OPT_CASLR_ALGORITHM
   int callback_order = 1;    // DLA_OPT_CALLBACK_ORDER (default: host-synchronised, safe for callbacks on any stream)
   long long n_global = -1;   // -1: single shard, n_global == n
   long long row0 = 0;

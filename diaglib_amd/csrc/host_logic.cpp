@@ -38,9 +38,14 @@ namespace {
 const double kEps = DBL_EPSILON;           // epsilon(one)
 const double kTolOrtho = 2.0 * DBL_EPSILON;  // tol_ortho, diaglib.f90:151
 
-dla_ctx* g_default = nullptr;
-// built-in operator callbacks have the reference's context-free shape; they act on this ctx
-dla_ctx* g_synth_ctx = nullptr;
+// Re-entrancy (the reference keeps LAPACK work arrays and timers in its module, diaglib.f90:155-161, and
+// cannot run two solves at once): nothing here is process-global.  The context the Fortran drivers use belongs to
+// the CALLING THREAD -- its own engine (stream, scratch, panel cache, statistics, options) -- so two host threads can
+// solve different problems with different operators at the same time.  It is created on the thread's first use and
+// lives until dla_destroy(dla_default_ctx()) or the end of the process.
+thread_local dla_ctx* g_default = nullptr;
+// built-in operator callbacks have the reference's context-free shape; they act on the calling thread's setup
+thread_local dla_ctx* g_synth_ctx = nullptr;
 
 int fail(dla_ctx* c, int code, const std::string& msg)
 {
@@ -116,6 +121,10 @@ int dla_set_option(dla_ctx* c, int option, int value)
     case DLA_OPT_EVEC_ON_DEVICE: c->evec_on_device = value; break;
     case DLA_OPT_PROFILE: c->eng->profile = value != 0; break;
     case DLA_OPT_VERBOSE_ORTHO: c->verbose_ortho = value; break;
+    case DLA_OPT_CASLR_ALGORITHM:
+      if (value < 0 || value > 1) return fail(c, DLA_ERR_ARG, "caslr algorithm must be 0 or 1");
+      c->caslr_algorithm = value;
+      break;
     case DLA_OPT_ORTHO_MAXIT:
       if (value < 1 || value > 10) return fail(c, DLA_ERR_ARG, "ortho maxit must be 1..10");
       c->eng->ortho_maxit = value;
@@ -141,6 +150,7 @@ int dla_get_option(dla_ctx* c, int option)
     case DLA_OPT_VERBOSE_ORTHO: return c->verbose_ortho;
     case DLA_OPT_CALLBACK_ORDER: return c->callback_order;
     case DLA_OPT_ORTHO_MAXIT: return c->eng->ortho_maxit;
+    case DLA_OPT_CASLR_ALGORITHM: return c->caslr_algorithm;
     default: return -1;
   }
 }
@@ -425,33 +435,36 @@ int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
 // The reference's fallback `ortho` (diaglib.f90:3052-3092): Householder QR of a copy (dgeqrf), then U <- U R^-1 (dtrsm).
 // U R^-1 is the orthonormal factor Q of U = Q R with LAPACK's sign convention r_jj = -sign(alpha_j) ||x_j||, i.e. the
 // Cholesky-QR factor Q+ (positive diagonal) with some columns negated.  Here:
-//   1. Q+ comes from a column-wise modified Gram-Schmidt (twice) on the device -- robust exactly where this routine is
+//   1. Q+ comes from a column-wise Gram-Schmidt with re-orthogonalisation on the device -- robust exactly where this routine is
 //      needed, after ortho_cd has given up on an ill-conditioned block;
-//   2. the signs come from running the SAME Householder recurrence on a 2k x k host matrix that is isometric to U:
-//      with T = the top k rows of U and U_low = U without them, U_low = Z R_low (R_low from the Cholesky factor of
-//      U^T U - T^T T), the matrix M = [T; R_low] has the columns of U in the orthonormal basis [e_1..e_k, Z], and every
-//      Householder vector of U lies in that span; the reflections of M are those of U, so diag(R) has the same signs.
-// T is obtained as E^T U with E = (e_1 .. e_k) through the Gram door, so a row-sharded U needs no extra collective.
-static int mgs2_device(dla_ctx* c, int n, int k, double* u)
+//   2. the signs come from running the SAME Householder recurrence on a 2k x k host matrix M that is isometric to U:
+//      M holds the columns of U in an orthonormal basis [e_1..e_k, Z] of span(U) + span(e_1..e_k); every Householder
+//      vector of U lies in that span, so the reflections of M are those of U and diag(R) has the same signs.
+// r (k x k, column-major): the triangular factor, U_in = Q r, accumulated from the projection coefficients
+static int mgs2_device(dla_ctx* c, int n, int k, double* u, double* r)
 {
-  for (int pass = 0; pass < 2; ++pass)
-    for (int j = 0; j < k; ++j) {
-      double* uj = u + (size_t)n * j;
-      if (j > 0) {
-        std::vector<double> h(j);
-        int st = c->eng->gram(n, j, u, 1, uj, h.data(), j);
-        if (st) return engfail(c, st);
-        st = c->eng->gemm(n, j, u, 1, h.data(), j, uj, 1);
-        if (st) return engfail(c, st);
-      }
-      double g = 0.0;
-      int st = c->eng->gram(n, 1, uj, 1, uj, &g, 1);
+  std::fill(r, r + (size_t)k * k, 0.0);
+  // column by column, each column projected against the finished ones TWICE before it is normalised ("twice is
+  // enough": the second projection removes what the first one left behind for an ill-conditioned block)
+  for (int j = 0; j < k; ++j) {
+    double* uj = u + (size_t)n * j;
+    for (int rep = 0; rep < 2 && j > 0; ++rep) {
+      std::vector<double> h(j);
+      int st = c->eng->gram(n, j, u, 1, uj, h.data(), j);
       if (st) return engfail(c, st);
-      if (!(g > 0.0)) return fail(c, DLA_ERR_ORTHO, "ortho: zero column");
-      double w = 1.0 / std::sqrt(g);
-      st = c->eng->trmm(n, 1, uj, &w, 1);
+      st = c->eng->gemm(n, j, u, 1, h.data(), j, uj, 1);
       if (st) return engfail(c, st);
+      for (int p = 0; p < j; ++p) r[(size_t)p + (size_t)j * k] += h[p];
     }
+    double g = 0.0;
+    int st = c->eng->gram(n, 1, uj, 1, uj, &g, 1);
+    if (st) return engfail(c, st);
+    if (!(g > 0.0)) return fail(c, DLA_ERR_ORTHO, "ortho: zero column");
+    r[(size_t)j + (size_t)j * k] = std::sqrt(g);
+    double w = 1.0 / std::sqrt(g);
+    st = c->eng->trmm(n, 1, uj, &w, 1);
+    if (st) return engfail(c, st);
+  }
   return DLA_OK;
 }
 
@@ -491,11 +504,15 @@ static int ortho_qr_impl(dla_ctx* c, int n, int k, double* u)
   if (k <= 0) return DLA_OK;
   const long long ng = global_rows(c, n);
   if (ng < k) return fail(c, DLA_ERR_ARG, "ortho: more columns than rows");
-  // T = E^T U and G = U^T U before U changes
-  std::vector<double> t((size_t)k * k), g((size_t)k * k);
+  // 1. U = Q+ R+ on the device (Q+ replaces U)
+  std::vector<double> rp((size_t)k * k);
+  int st = mgs2_device(c, n, k, u, rp.data());
+  if (st) return st;
+  // 2. top k (global) rows of Q+: Qt = E^T Q+ through the Gram door, so a row-sharded panel needs nothing new
+  std::vector<double> qt((size_t)k * k);
   {
     void* ev = nullptr;
-    int st = c->eng->alloc(sizeof(double) * (size_t)n * k, &ev);
+    st = c->eng->alloc(sizeof(double) * (size_t)n * k, &ev);
     if (st) return engfail(c, st);
     st = c->eng->zero(ev, sizeof(double) * (size_t)n * k);
     const double unit = 1.0;
@@ -503,36 +520,36 @@ static int ortho_qr_impl(dla_ctx* c, int n, int k, double* u)
       const long long lr = (long long)j - c->row0;             // global row j on this shard?
       if (lr >= 0 && lr < n) st = c->eng->h2d((double*)ev + (size_t)j * n + lr, &unit, sizeof(double));
     }
-    if (!st) st = c->eng->gram(n, k, (const double*)ev, k, u, t.data(), k);
+    if (!st) st = c->eng->gram(n, k, (const double*)ev, k, u, qt.data(), k);
     int stf = c->eng->free_(ev);
     if (st || stf) return engfail(c, st ? st : stf);
-    st = c->eng->gram(n, k, u, k, u, g.data(), k);
-    if (st) return engfail(c, st);
   }
-  int st = mgs2_device(c, n, k, u);
-  if (st) return st;
-  // R_low^T R_low = G - T^T T
-  std::vector<double> gl((size_t)k * k);
+  // 3. the isometric small matrix.  With Q_low = Q+ without its top k rows, Q_low^T Q_low = I - Qt^T Qt = C C^T and
+  //    Z = Q_low C^-T has orthonormal columns, so  U = [e_1..e_k, Z] [Qt; C^T] R+ :  M = [Qt; C^T] R+.  (Formed from the
+  //    well-conditioned pieces Qt, C and the triangular R+, column by column -- the small singular directions of an
+  //    ill-conditioned U keep their relative accuracy, which a Cholesky factor of U^T U - T^T T would not give them.)
+  std::vector<double> sm((size_t)k * k);
   for (int j = 0; j < k; ++j)
     for (int i = 0; i < k; ++i) {
-      double acc = g[(size_t)i + (size_t)j * k];
-      for (int p = 0; p < k; ++p) acc -= t[(size_t)p + (size_t)i * k] * t[(size_t)p + (size_t)j * k];
-      gl[(size_t)i + (size_t)j * k] = acc;
+      double acc = (i == j) ? 1.0 : 0.0;
+      for (int p = 0; p < k; ++p) acc -= qt[(size_t)p + (size_t)i * k] * qt[(size_t)p + (size_t)j * k];
+      sm[(size_t)i + (size_t)j * k] = acc;
     }
-  std::vector<double> l = gl;
-  if (dla_potrf_lower(k, l.data(), k) != 0) {
-    // rank-deficient below the top block: a small shift keeps the recurrence defined (only signs are read off)
-    double tr = 0.0;
-    for (int i = 0; i < k; ++i) tr += std::fabs(gl[(size_t)i + (size_t)i * k]);
-    l = gl;
-    for (int i = 0; i < k; ++i) l[(size_t)i + (size_t)i * k] += 1e-14 * tr + 1e-300;
-    if (dla_potrf_lower(k, l.data(), k) != 0) std::fill(l.begin(), l.end(), 0.0);
+  std::vector<double> cl = sm;
+  if (dla_potrf_lower(k, cl.data(), k) != 0) {
+    // (nearly) all of Q+ sits in its top k rows: a tiny shift keeps the factor defined; only signs are read off below
+    cl = sm;
+    for (int i = 0; i < k; ++i) cl[(size_t)i + (size_t)i * k] += 1e-14;
+    if (dla_potrf_lower(k, cl.data(), k) != 0) std::fill(cl.begin(), cl.end(), 0.0);
   }
   std::vector<double> mm((size_t)2 * k * k, 0.0), sign;
-  for (int j = 0; j < k; ++j) {
-    for (int i = 0; i < k; ++i) mm[(size_t)i + (size_t)j * 2 * k] = t[(size_t)i + (size_t)j * k];
-    for (int i = 0; i <= j; ++i) mm[(size_t)(k + i) + (size_t)j * 2 * k] = l[(size_t)j + (size_t)i * k];   // R_low = L^T
-  }
+  for (int j = 0; j < k; ++j)
+    for (int p = 0; p <= j; ++p) {
+      const double rpj = rp[(size_t)p + (size_t)j * k];
+      if (rpj == 0.0) continue;
+      for (int i = 0; i < k; ++i) mm[(size_t)i + (size_t)j * 2 * k] += qt[(size_t)i + (size_t)p * k] * rpj;        // Qt R+
+      for (int i = 0; i <= p; ++i) mm[(size_t)(k + i) + (size_t)j * 2 * k] += cl[(size_t)p + (size_t)i * k] * rpj; // C^T R+
+    }
   householder_diag_signs(2 * k, k, mm, sign);
   bool any = false;
   for (int j = 0; j < k; ++j) any = any || sign[j] < 0.0;
@@ -566,8 +583,16 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
         std::printf("  ortho_cd failed with the following error: maximum number of iterations for factorization reached.\n");
         return fail(c, DLA_ERR_ORTHO, "ortho_cd: factorization failed after level shifting");
       }
-      // ortho_cd or the outer loop ran out of iterations on the device: U holds an intermediate (same span); the
-      // host-driven loop below takes over from it, including the QR fallback (reference :3534, :3549)
+      // ortho_cd ran out of iterations on the device: U has had its maxit triangular updates, exactly what the
+      // reference's ortho_cd leaves behind when it returns ok = .false.; the reference then calls `ortho` (:3534, :3549).
+      // Do the same, then let the host-driven loop below finish the job on the now orthonormal block (Cholesky-QR
+      // steps have positive diagonals: they keep the column signs the Householder factor has set).
+      if (rep.status == 2) {
+        std::printf("  ortho_cd failed with the following error: maximum number of iterations reached.\n");
+        int stq = ortho_qr_impl(c, n, k, u);
+        if (stq) return stq;
+      }
+      // (status 4, the outer loop ran out of iterations: the host-driven loop repeats it and reports the failure)
     }
   }
   int ok = 0, it = 0;
@@ -878,7 +903,7 @@ int dla_call_lrprec(dla_ctx* c, dla_lrprec_fn fn, int n, int m, double fac, cons
 }
 
 // ------------------------------------------------------------------ solve report
-static int g_info[3] = {0, 0, 0};
+static thread_local int g_info[3] = {0, 0, 0};     // report of the calling thread's last driver call
 void dla_set_solve_info(int iters, int matvec_cols, int restarts) { g_info[0] = iters; g_info[1] = matvec_cols; g_info[2] = restarts; }
 void dla_last_solve_info(int* iters, int* matvec_cols, int* restarts)
 {

@@ -35,12 +35,7 @@ module diaglib
 !
 ! option ids of include/diaglib_amd.h
 !
-  integer(c_int), parameter :: opt_cb_dev = 1, opt_evec_dev = 2
-!
-! Helmich-Paris variant of caslr_driver (reference: harness variable i_alg of module utils, diaglib.f90:560,675);
-! here a setting of the library, see diaglib_amd_config
-!
-  integer, save :: lr_algorithm = 0
+  integer(c_int), parameter :: opt_cb_dev = 1, opt_evec_dev = 2, opt_lr_alg = 7
 !
 ! ---------------------------------------------------------------------------------------
 ! bookkeeping of a basis that grows block by block (all Davidson-type drivers)
@@ -294,7 +289,8 @@ contains
 !   release_cache = .true.: hand the panels the allocator keeps between solves back to the runtime (dla_trim)
     logical, intent(in), optional :: release_cache
 !   caslr_algorithm: 0 = the reduced pencil of caslr_driver as one generalised eigenproblem (reference default),
-!   1 = the Helmich-Paris route through the singular values of the scaled coupling block (reference i_alg = 1)
+!   1 = the Helmich-Paris route through the singular values of the scaled coupling block (the reference selects it
+!   with the harness variable i_alg of its module utils, diaglib.f90:560,675); a setting of the calling thread's context
     integer, intent(in), optional :: caslr_algorithm
     integer(c_size_t) :: released
     type(c_ptr)    :: ctx
@@ -305,7 +301,7 @@ contains
     if (present(release_cache)) then
       if (release_cache) st = dla_trim(ctx, released)
     end if
-    if (present(caslr_algorithm)) lr_algorithm = caslr_algorithm
+    if (present(caslr_algorithm)) st = dla_set_option(ctx, opt_lr_alg, int(caslr_algorithm,c_int))
   end subroutine diaglib_amd_config
 !
 ! ---------------------------------------------------------------------------------------
@@ -1187,7 +1183,7 @@ contains
 !
       call lap_start(w)
       if (traditional) then
-        if (lr_algorithm.eq.1) then
+        if (dla_get_option(e%ctx, opt_lr_alg).eq.1) then
           call lr_pairs_helmich_paris(s%cols, s%ld, n_max, epmat, emmat, smat, eig, up, um)
         else
           call lr_reduced_pairs(s%cols, s%ld, n_max, epmat, emmat, smat, eig, up, um)

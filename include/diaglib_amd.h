@@ -73,6 +73,8 @@ enum {
   DLA_OPT_ORTHO_MAXIT = 6,         /* iteration cap of ortho_cd / ortho_vs_x (reference parameter maxit = 10,
                                       diaglib.f90:3224,3521).  TEST knob: a small value makes ortho_cd give up so that
                                       the Householder-QR fallback `ortho` (diaglib.f90:3052-3092, 3534, 3549) runs */
+  DLA_OPT_CASLR_ALGORITHM = 7,     /* reduced problem of caslr_driver: 0 (default) the 2 ldu-dimensional pencil (reference
+                                      i_alg = 0, dsygv at diaglib.f90:783), 1 the Helmich-Paris route (i_alg = 1, :805-860) */
   DLA_OPT_TUNE0 = 100              /* 100..107: kernel-shape experiment knobs for the interleaved A/B tools
                                       (tools/tune_*.py, tools/kernel_bench.py); 0 = the shipped default          */
 };
@@ -110,8 +112,10 @@ typedef struct {
 /* ---------------------------------------------------------------- context */
 int  dla_create(dla_ctx** ctx, int device);          /* device < 0: $LOCAL_RANK or 0 */
 int  dla_destroy(dla_ctx* ctx);
-dla_ctx* dla_default_ctx(void);                      /* the context the Fortran drivers use (the reference is
-                                                        non-reentrant too: module state, diaglib.f90:155-161) */
+dla_ctx* dla_default_ctx(void);                      /* the context the Fortran drivers use: one per CALLING THREAD, created on
+                                                        first use (own stream, scratch, panel cache, statistics and
+                                                        options), so two host threads can solve at the same time.  The
+                                                        reference cannot: module-level state, diaglib.f90:155-161 */
 int  dla_set_option(dla_ctx* ctx, int option, int value);
 int  dla_get_option(dla_ctx* ctx, int option);
 const char* dla_last_error(dla_ctx* ctx);

@@ -322,6 +322,18 @@ class Reference:
         m = C.c_int(a.shape[0])
         return float(self._norm_est(C.byref(m), _p(a)))
 
+    def ortho(self, u):
+        """the reference's Householder fallback (diaglib.f90:3052-3092), through its module symbol"""
+        u = np.asfortranarray(u, dtype=np.float64).copy(order="F")
+        n, m = (C.c_int(v) for v in u.shape)
+        w = np.zeros(1)
+        getattr(self.lib, "_QMdiaglibPortho")(C.byref(n), C.byref(m), _p(u), _p(w))
+        return u
+
+    def set_i_alg(self, value):
+        """the harness switch of caslr_driver (module utils, reference utils.f90:7; read at diaglib.f90:675)"""
+        C.c_int.in_dll(self.lib, "_QMutilsEi_alg").value = int(value)
+
     def get_coeffs(self, a_red, len_u, n_max, n_act):
         a_red = np.asfortranarray(a_red)
         la, lu, nm, na = (C.c_int(v) for v in (a_red.shape[0], len_u, n_max, n_act))

@@ -14,7 +14,12 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIX = os.path.join(ROOT, "tests", "golden", "reference_lr_fixtures.npz")
-CASES = ["lr_n300_unit", "lr_n300_rand", "lr_n500_rand", "lrt_n300_unit", "lrt_n300_rand"]
+FIX_HP = os.path.join(ROOT, "tests", "golden", "reference_ortho_fixtures.npz")     # caslr_driver with i_alg = 1
+CASES = ["lr_n300_unit", "lr_n300_rand", "lr_n500_rand", "lrt_n300_unit", "lrt_n300_rand", "lrhp_n300_unit", "lrhp_n300_rand"]
+
+
+def _fixture(name):
+    return np.load(FIX_HP if name.startswith("lrhp") else FIX)
 
 WORKER = r"""
 import os, sys, json
@@ -36,6 +41,8 @@ g = np.load(spec["guess_file"])
 ctx = capi.Context()
 assert ctx.backend.startswith("hostsim" if {hostsim!r} else "hip:"), ctx.backend
 ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+# Helmich-Paris route of the traditional driver (reference harness switch i_alg = 1, diaglib.f90:675,805-860)
+ctx.set_option(capi.OPT_CASLR_ALGORITHM, 1 if spec["name"].startswith("lrhp") else 0)
 solve = ctx.caslr_driver if trad else ctx.caslr_eff_driver
 eig, vec, ok, info = solve(n, t, m, spec["max_iter"], spec["tol"], spec["max_dav"], *fn, g)
 np.savez(spec["out"], eig=eig, vec=vec, ok=ok, iters=info["iters"], restarts=info["restarts"])
@@ -87,7 +94,7 @@ def _check(fx, name, spec, res):
 
 @pytest.mark.parametrize("name", CASES)
 def test_lr_driver_on_host_engine_matches_reference_fixture(tmp_path, name):
-    fx = np.load(FIX)
+    fx = _fixture(name)
     spec, res = _solve(tmp_path, fx, name, True)
     _check(fx, name, spec, res)
 
@@ -95,6 +102,6 @@ def test_lr_driver_on_host_engine_matches_reference_fixture(tmp_path, name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
 def test_lr_driver_gpu_matches_reference_fixture(tmp_path, name):
-    fx = np.load(FIX)
+    fx = _fixture(name)
     spec, res = _solve(tmp_path, fx, name, False)
     _check(fx, name, spec, res)

@@ -171,3 +171,13 @@ def test_live_reference_if_present(oracle, rng):
     eo, vo, oko, tr = oracle.davidson(n, t, m, 100, 1e-9, 20, 0.0, mv, pc, g)
     er, vr, okr = ref.davidson(n, t, m, 100, 1e-9, 20, 0.0, mv, pc, g)
     assert oko and okr and np.allclose(eo[:t], er[:t], rtol=1e-11)
+
+
+def test_ortho_qr_against_reference_fixture(oracle):
+    """A11: the oracle's restatement of the Householder fallback `ortho` (reference diaglib.f90:3052-3092) against what
+    the unmodified reference returned (tests/golden/make_golden_ortho.py, module symbol _QMdiaglibPortho)."""
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_ortho_fixtures.npz"))
+    for i in range(int(fx["qr_count"])):
+        u, want, cond = fx[f"qr{i}_in"], fx[f"qr{i}_out"], float(fx[f"qr{i}_cond"])
+        got = oracle.ortho_qr(u)
+        assert np.abs(got - want).max() < 100 * cond * np.finfo(float).eps

@@ -502,3 +502,53 @@ def test_wide_gemm_rejects_aliasing(ctx, rng):
     z = ctx.panel(n, 50)
     ctx.panel_gemm(x, c, z)
     assert np.abs(z.download() - x.download() @ c).max() < 1e-11
+
+
+def test_two_host_threads_solve_at_the_same_time(oracle):
+    """A16 (the reference's module-level work arrays and timers, diaglib.f90:155-161, make it non-reentrant):
+    here the context of the drivers belongs to the calling thread, so two host threads run two different solves --
+    different sizes, different operators (sigma), different drivers -- concurrently, each against the oracle."""
+    import threading
+    specs = [dict(n=300_000, t=8, m=13, sigma=0.5, solver="davidson"), dict(n=200_000, t=4, m=8, sigma=0.25, solver="lobpcg")]
+    res, errs = [None, None], []
+
+    def work(i):
+        try:
+            sp = specs[i]
+            c = capi.Context()                       # the CALLING thread's context
+            c.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+            c.synth_setup(sp["n"], 0, sp["n"], 4, sp["sigma"])
+            g = np.zeros((sp["n"], sp["m"]), order="F"); g[np.arange(sp["m"]), np.arange(sp["m"])] = 1.0
+            mv, pc = capi.fn_address("dla_synth_matvec"), capi.fn_address("dla_synth_precnd")
+            outs = []
+            for _ in range(3):                       # a few solves each, so that the two threads really overlap
+                ev = c.panel(g)
+                if sp["solver"] == "davidson":
+                    eig, _, ok, info = c.davidson_driver(sp["n"], sp["t"], sp["m"], 100, 1e-10, 20, 0.0, mv, pc, ev)
+                else:
+                    eig, _, ok, info = c.lobpcg_driver(sp["n"], sp["t"], sp["m"], 100, 1e-10, 0.0, mv, pc, ev)
+                outs.append((eig.copy(), ok, dict(info)))
+            res[i] = (outs, c.h)
+        except Exception as exc:                     # noqa: BLE001
+            errs.append(repr(exc))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errs, errs
+    assert res[0][1] != res[1][1]                    # two distinct contexts
+    for sp, (outs, _) in zip(specs, res):
+        n, t, m = sp["n"], sp["t"], sp["m"]
+        oracle.lib.orc_synth_setup(n, 0, n, 4, sp["sigma"])
+        g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
+        if sp["solver"] == "davidson":
+            eo, _, oko, tr = oracle.davidson(n, t, m, 100, 1e-10, 20, 0.0, oracle.fn("orc_synth_matvec"), oracle.fn("orc_synth_precnd"), g)
+        else:
+            eo, _, oko, tr = oracle.lobpcg(n, t, m, 100, 1e-10, 0.0, oracle.fn("orc_synth_matvec"), oracle.fn("orc_synth_precnd"), g)
+        for eig, ok, info in outs:
+            assert ok and oko
+            assert np.allclose(eig[:t], eo[:t], rtol=1e-10, atol=0)
+            assert abs(info["iters"] - tr.iters) <= max(1, tr.iters // 10)
+            assert np.array_equal(eig, outs[0][0])   # the same thread gets the same bits every time
