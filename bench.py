@@ -157,6 +157,9 @@ def main() -> None:
                          "documented generator on the leading --guess-rows rows (restart + locking)")
     ap.add_argument("--guess-rows", type=int, default=2000)
     ap.add_argument("--no-random-leg", action="store_true", help="skip the untimed-region seed-2 leg reported under config")
+    ap.add_argument("--allreduce", default="p2p", choices=["p2p", "rccl"],
+                    help="transport of the small cross-rank sums with --gpus > 1: one-shot peer-to-peer mailboxes over "
+                         "hipIpc (falls back to RCCL when the mailboxes cannot be shared) or RCCL all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=2_000_000)
     args = ap.parse_args()
@@ -174,9 +177,11 @@ def main() -> None:
     # rehearsal of the N-rank glue on a box with fewer GPUs than ranks: ranks share devices and the small products
     # are reduced through gloo (dla_set_allreduce_hook) instead of RCCL, which refuses two ranks per device
     rehearsal = world > 1 and bool(os.environ.get("DIAGLIB_BENCH_HOOK"))
-    if rehearsal:
+    shared = world > 1 and bool(os.environ.get("DIAGLIB_BENCH_SHARE_GPU"))     # N ranks on fewer GPUs, peer-to-peer mailboxes
+    if rehearsal or shared:
         local_rank = local_rank % torch.cuda.device_count()
         os.environ["LOCAL_RANK"] = str(local_rank)
+        os.environ["DIAGLIB_AMD_SHARE_DEVICES"] = "1"
     torch.cuda.set_device(local_rank)
     if world > 1:
         # control plane (rendezvous, id broadcast, barriers, max-over-ranks of the time) on gloo;
@@ -187,6 +192,7 @@ def main() -> None:
     ctx = capi.Context()
     assert ctx.backend.startswith("hip:"), ctx.backend
 
+    transport = None
     n, n_targ = args.n, args.roots
     n_max = min(2 * n_targ, n_targ + 5)            # harness convention, reference main.f90:354
     row0, n_loc = shard_rows(n, world, rank)
@@ -197,9 +203,35 @@ def main() -> None:
         ctx.set_allreduce_hook(hook, world, rank)
         ctx.set_shard(n, row0)
     elif world > 1:
-        uid = [ctx.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(world, rank, uid[0])
+        transport = "rccl"
+        if not shared:
+            # RCCL communicator: the transport of --allreduce rccl, and of anything larger than a mailbox slot otherwise
+            uid = [ctx.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(world, rank, uid[0])
+        if args.allreduce == "p2p" or shared:
+            # one-shot peer-to-peer all-reduce: export the mailbox, gather the handles on the control plane, attach;
+            # all ranks take the same decision (a failure anywhere means RCCL everywhere)
+            try:
+                mine, okf = ctx.p2p_export(world), 1.0
+            except capi.DlaError:
+                mine, okf = b"\0" * 128, 0.0
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+            flag = torch.tensor([okf], dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag[0]) > 0:
+                try:
+                    ctx.p2p_attach(world, rank, everyone)
+                    okf = 1.0
+                except capi.DlaError:
+                    okf = 0.0
+                flag = torch.tensor([okf], dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag[0]) > 0:
+                    transport = "p2p"
+                elif shared:
+                    raise SystemExit("peer-to-peer mailboxes could not be attached")
         ctx.set_shard(n, row0)
     elif os.environ.get("DIAGLIB_BENCH_FORCE_COMM"):
         # latency rehearsal of one shard of an N-GPU run: every small product goes through a 1-rank RCCL all-reduce
@@ -348,6 +380,7 @@ def main() -> None:
         "kernel_classes": kern,
         "kernels": per_kernel,
         "host": {"allreduces": stats["allreduces"], "host_syncs": stats["host_syncs"], "nproc": HOST_CPUS,
+                 "allreduce_transport": (transport if world > 1 and not rehearsal else None),
                  "usable_cpus": CPU_THREADS},
     }
     if args.guess == "unit" and not args.no_random_leg:
@@ -388,6 +421,7 @@ def main() -> None:
     if rank == 0:
         print(json.dumps(out), flush=True)
     if (world > 1 and not rehearsal) or os.environ.get("DIAGLIB_BENCH_FORCE_COMM"):
+        barrier()
         ctx.comm_finalize()
     if world > 1:
         dist.destroy_process_group()

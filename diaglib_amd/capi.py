@@ -30,7 +30,7 @@ OP_NAMES = ["gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd"]
 EXPORTS = [
     "dla_create", "dla_destroy", "dla_default_ctx", "dla_set_option", "dla_get_option", "dla_last_error",
     "dla_backend_name", "dla_get_stats", "dla_reset_stats", "dla_get_kernel_stats", "dla_stream",
-    "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_set_allreduce_hook", "dla_set_shard",
+    "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_p2p_export", "dla_p2p_attach", "dla_set_allreduce_hook", "dla_set_shard",
     "dla_alloc", "dla_free", "dla_trim", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
     "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_ritz_residual", "dla_axpy",
     "dla_nrm2", "dla_stream_triad", "dla_random_fill", "dla_fill_guess",
@@ -93,6 +93,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_get_kernel_stats": (i, [vp, C.POINTER(KernelStat), i]),
         "dla_comm_unique_id": (i, [C.c_char_p]), "dla_comm_init": (i, [vp, i, i, C.c_char_p]),
         "dla_comm_info": (i, [vp, c_ip, c_ip]), "dla_comm_finalize": (i, [vp]),
+        "dla_p2p_export": (i, [vp, i, C.c_char_p]), "dla_p2p_attach": (i, [vp, i, i, C.c_char_p]),
         "dla_set_allreduce_hook": (i, [vp, vp, vp, i, i]), "dla_set_shard": (i, [vp, C.c_longlong, C.c_longlong]),
         "dla_alloc": (i, [vp, sz, C.POINTER(vp)]), "dla_free": (i, [vp, vp]), "dla_zero": (i, [vp, vp, sz]),
         "dla_upload": (i, [vp, vp, vp, sz]), "dla_download": (i, [vp, vp, vp, sz]), "dla_copy": (i, [vp, vp, vp, sz]),
@@ -258,6 +259,18 @@ class Context:
 
     def comm_init(self, nranks: int, rank: int, uid: bytes) -> None:
         self._chk(self.lib.dla_comm_init(self.h, nranks, rank, uid))
+
+    def p2p_export(self, nranks: int) -> bytes:
+        """this rank's mailbox handles (128 bytes) for the one-shot peer-to-peer all-reduce"""
+        buf = C.create_string_buffer(128)
+        self._chk(self.lib.dla_p2p_export(self.h, nranks, buf))
+        return buf.raw
+
+    def p2p_attach(self, nranks: int, rank: int, handles) -> None:
+        """handles: the 128-byte exports of all ranks, in rank order"""
+        blob = b"".join(handles)
+        assert len(blob) == 128 * nranks
+        self._chk(self.lib.dla_p2p_attach(self.h, nranks, rank, blob))
 
     def comm_finalize(self) -> None:
         self._chk(self.lib.dla_comm_finalize(self.h))

@@ -94,6 +94,10 @@ struct Engine {
   // collectives
   virtual int comm_init(int nranks, int rank, const char id[128]) = 0;
   virtual int comm_finalize() { nranks = 1; rank = 0; hook = nullptr; return 0; }
+  // one-shot peer-to-peer all-reduce over IPC mailboxes: export this rank's mailbox (2 handles of 64 bytes), then
+  // attach all ranks' handles (rank order)
+  virtual int p2p_export(int /*nranks*/, void* /*handles*/) { return DLA_ERR_COMM; }
+  virtual int p2p_attach(int /*nranks*/, int /*rank*/, const void* /*handles*/) { return DLA_ERR_COMM; }
   int nranks = 1, rank = 0;
   bool local_only = false;   // true while working on data that is replicated on every rank (no reductions)
   dla_allreduce_fn hook = nullptr;

@@ -783,8 +783,11 @@ __device__ __forceinline__ void block_sum_max(double& s, double& m, double* sh /
   m = fmax(fmax(sh[4], sh[5]), fmax(sh[6], sh[7]));
 }
 
-// out[j] = sum_b red[b][j][0], out[ncol + j] = max_b red[b][j][1]; one block per column j
-__global__ __launch_bounds__(256) void ritz_reduce_kernel(const double* red, int nblk, int ncol, double* out, double* out_host)
+// out[j] = sum_b red[b][j][0]; the maxima go to the rank's own slot, out[ncol + rank * ncol + j] = max_b red[b][j][1],
+// and the other ranks' slots are zeroed: ONE sum all-reduce then carries the sums and every rank's maxima
+// (max |r| >= 0, so the maximum over ranks is the maximum over the slots); one block per column j
+__global__ __launch_bounds__(256) void ritz_reduce_kernel(const double* red, int nblk, int ncol, double* out, double* out_host,
+                                                          int nranks, int rank)
 {
   const int j = blockIdx.x;
   double s = 0.0, m = 0.0;
@@ -795,8 +798,11 @@ __global__ __launch_bounds__(256) void ritz_reduce_kernel(const double* red, int
   __shared__ double sh[8];
   block_sum_max(s, m, sh);
   if (threadIdx.x == 0) {
-    out[j] = s; out[ncol + j] = m;
-    out_host[j] = s; out_host[ncol + j] = m;
+    out[j] = s; out_host[j] = s;
+    for (int r = 0; r < nranks; ++r) {
+      const double v = (r == rank) ? m : 0.0;
+      out[ncol + r * ncol + j] = v; out_host[ncol + r * ncol + j] = v;
+    }
   }
 }
 
@@ -1342,6 +1348,80 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
 }
 
 // ======================================================================================
+// One-shot all-reduce of a small buffer over peer mailboxes
+// ======================================================================================
+// Every reduction of this library is latency-bound (<= 64 KB: a k x k Gram matrix, an L x k projection block, a handful of
+// norms).  Instead of a ring collective every rank writes its contribution straight into a slot of every peer's
+// mailbox (one xGMI hop), raises a flag there, waits until all flags of its OWN mailbox are up and adds the slots in
+// RANK ORDER -- the same sum, bit for bit, on every rank, whatever the arrival order.
+//   * mailboxes are fine-grained device allocations shared through hipIpc handles (dla_p2p_export / dla_p2p_attach);
+//   * two mailbox sets alternate (parity of the sequence number): a peer can write for call s+2 only after it has seen
+//     this rank's flag for call s+1, which this rank raises only after it has finished reading call s;
+//   * the wait is bounded (P2P_TIMEOUT_TICKS of the 100 MHz wall clock): a missing peer sets a status word, the kernel
+//     ends and the host reports DLA_ERR_COMM at its next wait -- the grid always drains;
+//   * a launch belongs to the device-driven chains like any other: when it is not its turn (DLA_PREDICATED) it returns
+//     before touching a mailbox, on every rank alike (all ranks hold the same phase).
+#define P2P_MAX_RANKS 8
+#define P2P_MAX_DOUBLES 16384              // 128 KB per slot (the widest projection block of BASELINE cfg 4/5 fits)
+#define P2P_FLAG_STRIDE 16                 // one flag per 128-byte line
+#define P2P_TIMEOUT_TICKS 500000000ULL     // 5 s
+struct P2PArgs {
+  double* buf;                             // in: this rank's contribution, out: the reduced values
+  double* buf_host;                        // optional pinned mirror of the result
+  int count, op;                           // op 0 sum, 1 max
+  int nranks, rank;
+  unsigned long long seq;                  // 1, 2, 3, ... identical on all ranks
+  double* data[P2P_MAX_RANKS];             // mailbox of rank r: [2][nranks][P2P_MAX_DOUBLES]
+  unsigned long long* flags[P2P_MAX_RANKS];//                    [2][nranks][P2P_FLAG_STRIDE]
+  int* status;                             // device word: != 0 after a timeout
+  const int* phase; int want;
+};
+
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a)
+{
+  DLA_PREDICATED(a);
+  const int tid = threadIdx.x, par = (int)(a.seq & 1ULL);
+  const size_t slot = ((size_t)par * a.nranks + a.rank) * P2P_MAX_DOUBLES;
+  // 1. my contribution into every mailbox (my own included)
+  for (int r = 0; r < a.nranks; ++r) {
+    double* dst = a.data[r] + slot;
+    for (int i = tid; i < a.count; i += 256) __hip_atomic_store(dst + i, a.buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  // 2. raise my flag everywhere, 3. wait for everyone's flag in my mailbox
+  __shared__ int s_bad;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  if (tid < a.nranks) {
+    __hip_atomic_store(a.flags[tid] + ((size_t)par * a.nranks + a.rank) * P2P_FLAG_STRIDE, a.seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long* mine = a.flags[a.rank] + ((size_t)par * a.nranks + tid) * P2P_FLAG_STRIDE;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+      if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { s_bad = 1; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (tid == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  // 4. combine the slots of my mailbox in rank order
+  const double* mine = a.data[a.rank] + (size_t)par * a.nranks * P2P_MAX_DOUBLES;
+  for (int i = tid; i < a.count; i += 256) {
+    double v = __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int r = 1; r < a.nranks; ++r) {
+      const double x = __hip_atomic_load(mine + (size_t)r * P2P_MAX_DOUBLES + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v = a.op == 0 ? v + x : fmax(v, x);
+    }
+    a.buf[i] = v;
+    if (a.buf_host) a.buf_host[i] = v;
+  }
+}
+
+// ======================================================================================
 // host side of the engine
 // ======================================================================================
 struct TimedLaunch { hipEvent_t a, b; int cls; std::string kname; };
@@ -1408,6 +1488,7 @@ struct HipEngine : dla::Engine {
     if (st) (void)hipStreamSynchronize(st);
     for (auto& b : cache) (void)hipFree(b.ptr);
     for (auto& b : live) (void)hipFree(b.ptr);
+    p2p_release();
     if (comm) ncclCommDestroy(comm);
     for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -1697,14 +1778,14 @@ struct HipEngine : dla::Engine {
     }
     t_sync += now() - t0; n_sync++;
     if (q != hipSuccess) { err = std::string("hipEventQuery: ") + hipGetErrorString(q); return DLA_ERR_RUNTIME; }
-    return DLA_OK;
+    return p2p_check();
   }
 
   // reduced small result -> host: single rank reads the pinned mirror the kernel wrote,
   // multi-rank copies the all-reduced device buffer
   int small_to_host(size_t count)
   {
-    if (!local_only && (nranks > 1 || comm)) HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    if (!local_only && (nranks > 1 || comm || p2p.on)) HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * count, hipMemcpyDeviceToHost, st));
     int stw = wait_stream();
     if (stw) return stw;
     stats.host_syncs++;
@@ -1736,8 +1817,19 @@ struct HipEngine : dla::Engine {
   // ---- collectives on small device buffers
   int allreduce_dev(double* dev, int count, int op /*0 sum, 1 max*/, double* host_mirror)
   {
-    if (local_only || (nranks <= 1 && !comm)) return DLA_OK;
+    if (local_only || (nranks <= 1 && !comm && !p2p.on)) return DLA_OK;
     stats.allreduces++;
+    if (p2p.on && count <= P2P_MAX_DOUBLES) {
+      P2PArgs pa{};
+      pa.buf = dev; pa.buf_host = nullptr; pa.count = count; pa.op = op; pa.nranks = nranks; pa.rank = rank;
+      pa.seq = ++p2p.seq;
+      for (int r = 0; r < nranks; ++r) { pa.data[r] = p2p.data[r]; pa.flags[r] = p2p.flags[r]; }
+      pa.status = p2p.d_status; pa.phase = pred_phase; pa.want = pred_want;
+      Scope s(this, DLA_OP_ELEM, 0.0, 0.0, "p2p_allreduce_kernel");
+      hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(256), 0, st, pa);
+      HIPCHK(hipGetLastError());
+      return DLA_OK;
+    }
     if (comm) {
       ncclResult_t r = ncclAllReduce(dev, dev, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax, comm, st);
       if (r != ncclSuccess) { err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return DLA_ERR_COMM; }
@@ -1754,8 +1846,76 @@ struct HipEngine : dla::Engine {
     err = "nranks > 1 but neither an RCCL communicator nor a reduction hook is attached";
     return DLA_ERR_COMM;
   }
+  // ---- one-shot peer-to-peer all-reduce (p2p_allreduce_kernel)
+  struct P2P {
+    bool on = false;
+    double* my_data = nullptr; unsigned long long* my_flags = nullptr;
+    double* data[P2P_MAX_RANKS] = {nullptr}; unsigned long long* flags[P2P_MAX_RANKS] = {nullptr};
+    int* h_status = nullptr;             // pinned, device-mapped: a timed-out kernel sets it, the host reads it at its waits
+    int* d_status = nullptr;
+    unsigned long long seq = 0;
+    int slots = 0;                       // ranks the local mailbox was sized for
+  } p2p;
+  static size_t p2p_data_bytes(int nr) { return sizeof(double) * 2 * (size_t)nr * P2P_MAX_DOUBLES; }
+  static size_t p2p_flag_bytes(int nr) { return sizeof(unsigned long long) * 2 * (size_t)nr * P2P_FLAG_STRIDE; }
+
+  // allocate this rank's mailbox (fine-grained: peers write into it while kernels of this rank poll it) and export it
+  int p2p_export(int nr, void* handles /* 2 x hipIpcMemHandle_t */) override
+  {
+    if (nr < 1 || nr > P2P_MAX_RANKS) { err = "p2p: 1..8 ranks"; return DLA_ERR_ARG; }
+    HIPCHK(hipSetDevice(device));
+    p2p_release();
+    HIPCHK(hipExtMallocWithFlags((void**)&p2p.my_data, p2p_data_bytes(nr), hipDeviceMallocFinegrained));
+    HIPCHK(hipExtMallocWithFlags((void**)&p2p.my_flags, p2p_flag_bytes(nr), hipDeviceMallocFinegrained));
+    HIPCHK(hipMemset(p2p.my_data, 0, p2p_data_bytes(nr)));
+    HIPCHK(hipMemset(p2p.my_flags, 0, p2p_flag_bytes(nr)));
+    HIPCHK(hipHostMalloc((void**)&p2p.h_status, sizeof(int), hipHostMallocMapped));
+    *p2p.h_status = 0;
+    HIPCHK(hipHostGetDevicePointer((void**)&p2p.d_status, p2p.h_status, 0));
+    HIPCHK(hipDeviceSynchronize());
+    p2p.slots = nr;
+    hipIpcMemHandle_t* h = (hipIpcMemHandle_t*)handles;
+    HIPCHK(hipIpcGetMemHandle(&h[0], p2p.my_data));
+    HIPCHK(hipIpcGetMemHandle(&h[1], p2p.my_flags));
+    return DLA_OK;
+  }
+  // open every peer's mailbox; handles = nr entries of (data handle, flag handle) in rank order
+  int p2p_attach(int nr, int rk, const void* handles) override
+  {
+    if (nr != p2p.slots || rk < 0 || rk >= nr) { err = "p2p_attach: export first, with the same rank count"; return DLA_ERR_ARG; }
+    HIPCHK(hipSetDevice(device));
+    const hipIpcMemHandle_t* h = (const hipIpcMemHandle_t*)handles;
+    for (int r = 0; r < nr; ++r) {
+      if (r == rk) { p2p.data[r] = p2p.my_data; p2p.flags[r] = p2p.my_flags; continue; }
+      HIPCHK(hipIpcOpenMemHandle((void**)&p2p.data[r], h[2 * r], hipIpcMemLazyEnablePeerAccess));
+      HIPCHK(hipIpcOpenMemHandle((void**)&p2p.flags[r], h[2 * r + 1], hipIpcMemLazyEnablePeerAccess));
+    }
+    nranks = nr; rank = rk;
+    p2p.seq = 0;
+    p2p.on = true;
+    return DLA_OK;
+  }
+  void p2p_release()
+  {
+    if (p2p.on) {
+      (void)hipStreamSynchronize(st);
+      for (int r = 0; r < nranks && r < P2P_MAX_RANKS; ++r)
+        if (r != rank) { if (p2p.data[r]) (void)hipIpcCloseMemHandle(p2p.data[r]); if (p2p.flags[r]) (void)hipIpcCloseMemHandle(p2p.flags[r]); }
+    }
+    if (p2p.my_data) (void)hipFree(p2p.my_data);
+    if (p2p.my_flags) (void)hipFree(p2p.my_flags);
+    if (p2p.h_status) (void)hipHostFree(p2p.h_status);
+    p2p = P2P{};
+  }
+  int p2p_check()
+  {
+    if (p2p.on && *(volatile int*)p2p.h_status) { err = "p2p all-reduce: a peer did not arrive within 5 s"; return DLA_ERR_COMM; }
+    return DLA_OK;
+  }
+
   int comm_finalize() override
   {
+    p2p_release();
     if (comm) { (void)hipStreamSynchronize(st); ncclCommDestroy(comm); comm = nullptr; }
     nranks = 1; rank = 0;
     return DLA_OK;
@@ -1867,7 +2027,7 @@ struct HipEngine : dla::Engine {
   int launch_op(int op, int n, int m, int k, const double* x, const double* bx, double* u, bool publish)
   {
     pending_tail = OrthoTailArgs{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, op, m, k, m > 0 ? 1 : 0, ortho_maxit, publish ? 1 : 0};
-    fuse_tail = (nranks <= 1 && !comm);
+    fuse_tail = (nranks <= 1 && !comm && !p2p.on);
     tail_fused = false;
     pred_phase = &d_ost->phase; pred_want = op;
     int stc = DLA_OK;
@@ -2494,6 +2654,9 @@ struct HipEngine : dla::Engine {
     const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu * (tune[1] > 0 ? tune[1] : 1), (ntiles + 7) / 8));
     stc = ensure_partial(sizeof(double) * (size_t)blocks * 16 * kt * 2);
     if (stc) return stc;
+    const int nslots = (local_only || nranks < 1) ? 1 : nranks;
+    stc = ensure_small(sizeof(double) * (size_t)16 * kt * (1 + nslots));
+    if (stc) return stc;
     a.v = v; a.av = av; a.cpk = d_cpk; a.evec = evec; a.r = r; a.avy = avy; a.red = d_partial;
     a.n = n; a.l = l; a.l4 = l4; a.k = m;
     const int ncol = 16 * kt;
@@ -2522,16 +2685,19 @@ struct HipEngine : dla::Engine {
     {
       Scope s2(this, DLA_OP_RITZ, 0.0, 0.0, "ritz_reduce_kernel");
       hipLaunchKernelGGL(ritz_reduce_kernel, dim3(ncol), dim3(256), 0, st, (const double*)d_partial, blocks, ncol, d_small,
-                         h_small_dev);
+                         h_small_dev, nslots, local_only ? 0 : rank);
     }
     HIPCHK(hipGetLastError());
-    stc = allreduce_dev(d_small, ncol, 0, h_small);
+    // sums and all ranks' maxima in one collective (reference :1730-1731 are two reductions)
+    stc = allreduce_dev(d_small, ncol * (1 + nslots), 0, h_small);
     if (stc) return stc;
-    stc = allreduce_dev(d_small + ncol, ncol, 1, h_small + ncol);
+    stc = small_to_host((size_t)ncol * (1 + nslots));
     if (stc) return stc;
-    stc = small_to_host((size_t)2 * ncol);
-    if (stc) return stc;
-    for (int j = 0; j < n_res; ++j) { out[2 * j] = h_small[j]; out[2 * j + 1] = h_small[ncol + j]; }
+    for (int j = 0; j < n_res; ++j) {
+      double mx = 0.0;
+      for (int r = 0; r < nslots; ++r) mx = std::max(mx, h_small[ncol + r * ncol + j]);
+      out[2 * j] = h_small[j]; out[2 * j + 1] = mx;
+    }
     return DLA_OK;
   }
 

@@ -197,6 +197,19 @@ int dla_comm_finalize(dla_ctx* c)
   return engfail(c, c->eng->comm_finalize());
 }
 
+// one-shot peer-to-peer all-reduce: see include/diaglib_amd.h
+int dla_p2p_export(dla_ctx* c, int nranks, char handles[128])
+{
+  if (!c || !handles) return DLA_ERR_ARG;
+  return engfail(c, c->eng->p2p_export(nranks, handles));
+}
+
+int dla_p2p_attach(dla_ctx* c, int nranks, int rank, const char* all_handles)
+{
+  if (!c || !all_handles) return DLA_ERR_ARG;
+  return engfail(c, c->eng->p2p_attach(nranks, rank, all_handles));
+}
+
 int dla_comm_info(dla_ctx* c, int* nranks, int* rank)
 {
   if (!c) return DLA_ERR_ARG;

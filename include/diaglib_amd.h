@@ -130,6 +130,16 @@ int  dla_comm_unique_id(char id[128]);                                       /* 
 int  dla_comm_init(dla_ctx* ctx, int nranks, int rank, const char id[128]);  /* ncclCommInitRank         */
 int  dla_comm_finalize(dla_ctx* ctx);                                        /* ncclCommDestroy          */
 int  dla_comm_info(dla_ctx* ctx, int* nranks, int* rank);
+/* One-shot peer-to-peer all-reduce for the small products, an alternative transport to RCCL for buffers
+ * of at most 64 KB: every rank writes its contribution into a slot of every peer's mailbox (fine-grained device memory shared
+ * through hipIpc), raises a flag and adds the slots of its own mailbox in rank order -- one xGMI hop, a fixed summation order
+ * (bit-identical results on all ranks), no host involvement, and it takes part in the device-driven chains.
+ *   1. every rank: dla_p2p_export(ctx, nranks, h)   -> 128 bytes (two hipIpcMemHandle_t)
+ *   2. the caller's control plane (MPI, torch.distributed, ...) gathers the nranks x 128 bytes in rank order
+ *   3. every rank: dla_p2p_attach(ctx, nranks, rank, all)
+ * dla_comm_finalize detaches.  Larger buffers and contexts without mailboxes use the RCCL communicator / the hook. */
+int  dla_p2p_export(dla_ctx* ctx, int nranks, char handles[128]);
+int  dla_p2p_attach(dla_ctx* ctx, int nranks, int rank, const char* all_handles);
 /* host-buffer reduction hook (op 0 = sum, 1 = max); lets a caller supply the collective
  * (e.g. MPI or torch.distributed/gloo).  Used when no RCCL communicator is attached. */
 typedef void (*dla_allreduce_fn)(void* user, double* buf, int count, int op);

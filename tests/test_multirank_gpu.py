@@ -1,9 +1,11 @@
 """GPU: the row-sharded path of the HIP engine on real hardware with TWO ranks sharing one GPU.
-RCCL refuses two ranks on one device, so the small cross-rank sums travel through the
-dla_set_allreduce_hook door over gloo; every reduction point of the engine (Gram / fused Gram / Ritz norms /
-nrm2 / the operator's r x m product), the shard offsets of the generator and of the built-in operator, and
-the replicated small-matrix logic are the same code that runs under RCCL (whose transport is exercised by
-tests/test_solver_gpu.py::test_rccl_communicator_single_rank)."""
+RCCL refuses two ranks on one device, so the small cross-rank sums travel either
+  * through the dla_set_allreduce_hook door over gloo ("hook": host round trip per reduction, host-driven ortho loops), or
+  * through the one-shot peer-to-peer all-reduce over hipIpc mailboxes ("p2p", SURVEY 8f row 2: device-to-device, fixed
+    summation order, part of the device-driven orthogonalisation chains -- the transport meant for the 8-GPU runs).
+Every reduction point of the engine (Gram / fused Gram / Ritz norms / nrm2 / the operator's r x m product), the shard
+offsets of the generator and of the built-in operator, and the replicated small-matrix logic are the same code that runs
+under RCCL (whose transport is exercised by tests/test_solver_gpu.py::test_rccl_communicator_single_rank)."""
 import json
 import os
 import socket
@@ -34,7 +36,13 @@ assert ctx.backend.startswith("hip:")
 def hook(buf, op):
     tt = torch.from_numpy(buf)
     dist.all_reduce(tt, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
-if world > 1:
+if world > 1 and spec.get("transport", "hook") == "p2p":
+    mine = ctx.p2p_export(world)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    ctx.p2p_attach(world, rank, everyone)
+    ctx.set_shard(n, row0)
+elif world > 1:
     ctx.set_allreduce_hook(hook, world, rank)
     ctx.set_shard(n, row0)
 ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
@@ -53,9 +61,13 @@ elif spec["solver"] == "davidson":
     eig, _, ok, info = ctx.davidson_driver(n_loc, t, m, 200, spec["tol"], 20, 0.0, mv, pc, ev)
 else:
     eig, _, ok, info = ctx.lobpcg_driver(n_loc, t, m, 200, spec["tol"], 0.0, mv, pc, ev)
+st = ctx.stats()
 np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), eig=eig, ok=ok, iters=info["iters"], cols=info["matvec_cols"],
-         row0=row0, vec=ev.download(), allreduces=ctx.stats()["allreduces"])
-dist.barrier(); dist.destroy_process_group()
+         row0=row0, vec=ev.download(), allreduces=st["allreduces"], host_syncs=st["host_syncs"])
+dist.barrier()
+if world > 1 and spec.get("transport", "hook") == "p2p":
+    ctx.comm_finalize()
+dist.destroy_process_group()
 """
 
 
@@ -75,9 +87,10 @@ def _run_world(tmp_path, spec, world):
     return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
 
 
+@pytest.mark.parametrize("transport", ["hook", "p2p"])
 @pytest.mark.parametrize("solver,guess", [("davidson", "unit"), ("lobpcg", "unit"), ("check_guess", "zero")])
-def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, solver, guess):
-    spec = dict(n=200_000, n_targ=8, n_max=13, tol=1e-10, solver=solver, guess=guess)
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, solver, guess, transport):
+    spec = dict(n=200_000, n_targ=8, n_max=13, tol=1e-10, solver=solver, guess=guess, transport=transport)
     d1 = tmp_path / "w1"; d1.mkdir()
     d2 = tmp_path / "w2"; d2.mkdir()
     one = _run_world(d1, spec, 1)[0]
@@ -93,6 +106,9 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, solver, guess):
     assert int(two[0]["iters"]) == int(two[1]["iters"]) and int(two[0]["cols"]) == int(two[1]["cols"])
     assert np.array_equal(two[0]["eig"], two[1]["eig"])            # identical decisions on both ranks
     assert int(two[0]["allreduces"]) > 0 and int(one["allreduces"]) == 0
+    if transport == "p2p":
+        # device-to-device reductions keep the orthogonalisation chains on the device: about as many host waits as one rank
+        assert int(two[0]["host_syncs"]) <= int(one["host_syncs"]) + 8, (int(two[0]["host_syncs"]), int(one["host_syncs"]))
     assert np.allclose(two[0]["eig"][:t], one["eig"][:t], rtol=1e-11, atol=0)
     assert abs(int(two[0]["iters"]) - int(one["iters"])) <= max(1, int(one["iters"]) // 5)
     v2 = np.vstack([two[0]["vec"], two[1]["vec"]])
