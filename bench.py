@@ -250,7 +250,10 @@ def main() -> None:
 
     workload_key = f"{args.solver} n={n} roots={n_targ} n_max={n_max} max_dav={args.max_dav} guess={args.guess}"
 
+    marker = ctx.panel(1, 1)
+
     def solve(max_iter=400):
+        marker.zero()            # an 8-byte fill: separates the solves in a kernel trace (tools/kt_gaps.py)
         if args.guess == "unit":
             ctx.lib.dla_copy(ctx.h, ev.ptr, g_dev.ptr, 8 * n_loc * n_max)
         else:

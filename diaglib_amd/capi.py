@@ -37,7 +37,7 @@ EXPORTS = [
     "dla_ortho_cd", "dla_ortho_qr", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
     "dla_call_matvec", "dla_call_precnd",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
-    "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd",
+    "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd", "dla_spmm_setup_csr", "dla_spmm_matvec", "dla_spmm_precnd",
     "dla_davidson_driver", "dla_gen_david_driver", "dla_lobpcg_driver", "dla_caslr_eff_driver", "dla_caslr_driver", "dla_call_lrprec",
     "dla_last_solve_info", "dla_set_solve_info",
 ]
@@ -116,6 +116,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_potrf_lower": (i, [i, c_dp, i]),
         "dla_trtri_lower": (i, [i, c_dp, i]), "dla_norm_est": (d, [i, c_dp, i]),
         "dla_synth_setup": (i, [vp, C.c_longlong, C.c_longlong, i, i, d]),
+        "dla_spmm_setup_csr": (i, [vp, i, vp, vp, vp]),
         "dla_davidson_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, c_ip]),
         "dla_lobpcg_driver": (None, [i, i, i, i, i, i, d, d, vp, vp, vp, vp, vp, c_ip]),
         "dla_caslr_eff_driver": (None, [i, i, i, i, i, d, i, vp, vp, vp, vp, vp, vp, vp, c_ip]),
@@ -378,6 +379,14 @@ class Context:
     # ---- built-in operator
     def synth_setup(self, n_global: int, row0: int, n_local: int, rank_w: int = 4, sigma: float = 0.5) -> None:
         self._chk(self.lib.dla_synth_setup(self.h, n_global, row0, n_local, rank_w, sigma))
+
+    def spmm_setup(self, a) -> None:
+        """hand a scipy.sparse matrix (symmetric, square) to the sample ELLPACK operator of this thread's context"""
+        a = a.tocsr()
+        rp = np.ascontiguousarray(a.indptr, dtype=np.int64)
+        ci = np.ascontiguousarray(a.indices, dtype=np.int32)
+        va = np.ascontiguousarray(a.data, dtype=np.float64)
+        self._chk(self.lib.dla_spmm_setup_csr(self.h, a.shape[0], rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
 
     def synth_matvec(self, x: DevPanel, ax: DevPanel) -> None:
         self._chk(self.lib.dla_call_matvec(self.h, fn_address("dla_synth_matvec"), x.n, x.m, x.ptr, ax.ptr))

@@ -85,6 +85,11 @@ struct Engine {
   virtual int callback_begin(int /*mode*/) { return 0; }
   virtual int callback_end(int /*mode*/) { return 0; }
 
+  // sample sparse operator (ELLPACK SpMM + its diagonal preconditioner)
+  virtual int spmm_setup_csr(int /*n*/, const long long* /*rowptr*/, const int* /*colind*/, const double* /*values*/) { return DLA_ERR_ARG; }
+  virtual int spmm_matvec(int /*n*/, int /*m*/, const double* /*x*/, double* /*ax*/) { return DLA_ERR_ARG; }
+  virtual int spmm_precnd(int /*n*/, int /*m*/, double /*fac*/, const double* /*x*/, double* /*px*/) { return DLA_ERR_ARG; }
+
   // pinned host staging for host-mode callbacks
   virtual int host_alloc(size_t bytes, void** p) = 0;
   virtual int host_free(void* p) = 0;

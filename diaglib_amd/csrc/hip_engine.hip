@@ -958,6 +958,63 @@ __global__ void synth_precnd_kernel(int n, int m, double fac, const double* __re
 }
 
 // ======================================================================================
+// Sample sparse operator: ax = A x for a sparse symmetric A in ELLPACK form
+// ======================================================================================
+// A device-resident operator with the reference's callback shape matvec(n,m,x,ax) (reference README.md:34-35,
+// main.f90:72-90) for callers whose matrix is sparse: A is handed over once in CSR form (dla_spmm_setup_csr) and kept
+// as column-major ELLPACK (col[w][n], val[w][n], w = widest row, shorter rows padded with a zero that points at the
+// row itself) -- the row index runs along the lanes, so the two ELLPACK streams are read fully coalesced and every
+// thread keeps its w (column, value) pairs in registers while it walks the m right-hand sides.  The gathers
+// x[col][c] are the irregular part; for the banded / stencil matrices of the test suite neighbouring rows gather
+// neighbouring entries.  HBM-bound: 12 w n bytes of matrix + 16 n m bytes of vectors per call (+ gather overfetch).
+template <int W>
+__global__ __launch_bounds__(256) void ell_spmm_kernel(int n, int m, int w, const int* __restrict__ col,
+                                                       const double* __restrict__ val, const double* __restrict__ x,
+                                                       double* __restrict__ ax)
+{
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    if constexpr (W > 0) {
+      int cj[W]; double vj[W];
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        const bool in = q < w;
+        cj[q] = in ? col[(size_t)q * n + i] : i;
+        vj[q] = in ? val[(size_t)q * n + i] : 0.0;
+      }
+      for (int c = 0; c < m; ++c) {
+        const double* xc = x + (size_t)c * n;
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < W; ++q) s += vj[q] * xc[cj[q]];
+        __builtin_nontemporal_store(s, ax + (size_t)c * n + i);
+      }
+    } else {
+      for (int c = 0; c < m; ++c) {
+        const double* xc = x + (size_t)c * n;
+        double s = 0.0;
+        for (int q = 0; q < w; ++q) s += val[(size_t)q * n + i] * xc[col[(size_t)q * n + i]];
+        __builtin_nontemporal_store(s, ax + (size_t)c * n + i);
+      }
+    }
+  }
+}
+
+// px = x / (d + fac) where |d + fac| > 1e-5, else x: the harness' diagonal preconditioner (main.f90:161-169) on the
+// diagonal of the sparse operator
+__global__ void diag_precnd_kernel(int n, int m, double fac, const double* __restrict__ diag, const double* __restrict__ x,
+                                   double* __restrict__ px)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double den = diag[i] + fac;
+    const bool use = fabs(den) > 1.0e-5;
+    for (int c = 0; c < m; ++c) {
+      const double v = x[(size_t)c * n + i];
+      px[(size_t)c * n + i] = use ? v / den : v;
+    }
+  }
+}
+
+// ======================================================================================
 // Device-resident control of the orthogonalisation loops
 // ======================================================================================
 // ortho_cd (reference diaglib.f90:3185-3341) and ortho_vs_x (:3481-3574) alternate n-length sweeps with k x k work
@@ -1511,6 +1568,9 @@ struct HipEngine : dla::Engine {
     if (d_w) (void)hipFree(d_w);
     if (d_diag) (void)hipFree(d_diag);
     if (d_t) (void)hipFree(d_t);
+    if (d_ell_col) (void)hipFree(d_ell_col);
+    if (d_ell_val) (void)hipFree(d_ell_val);
+    if (d_ell_diag) (void)hipFree(d_ell_diag);
     if (st) (void)hipStreamDestroy(st);
   }
 
@@ -2769,6 +2829,63 @@ struct HipEngine : dla::Engine {
     const size_t total = (size_t)n * m;
     const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 8, (total + 255) / 256));
     hipLaunchKernelGGL(random_fill_kernel, dim3(blocks), dim3(256), 0, st, (long long)n, m, evec, row0, seed, offset, support_rows);
+    HIPCHK(hipGetLastError());
+    return DLA_OK;
+  }
+
+  // ---- sample sparse operator (ELLPACK)
+  int* d_ell_col = nullptr; double* d_ell_val = nullptr; double* d_ell_diag = nullptr;
+  int ell_n = 0, ell_w = 0;
+  int spmm_setup_csr(int n, const long long* rowptr, const int* colind, const double* values) override
+  {
+    if (n <= 0 || !rowptr || !colind || !values) { err = "spmm_setup_csr: bad arguments"; return DLA_ERR_ARG; }
+    int w = 0;
+    for (int i = 0; i < n; ++i) w = std::max(w, (int)(rowptr[i + 1] - rowptr[i]));
+    if (w <= 0) { err = "spmm_setup_csr: empty matrix"; return DLA_ERR_ARG; }
+    std::vector<int> col((size_t)w * n);
+    std::vector<double> val((size_t)w * n, 0.0), diag((size_t)n, 0.0);
+    for (int i = 0; i < n; ++i) {
+      const long long p0 = rowptr[i], p1 = rowptr[i + 1];
+      for (int q = 0; q < w; ++q) {
+        const bool in = p0 + q < p1;
+        const int cj = in ? colind[p0 + q] : i;
+        if (cj < 0 || cj >= n) { err = "spmm_setup_csr: column index out of range"; return DLA_ERR_ARG; }
+        col[(size_t)q * n + i] = cj;
+        val[(size_t)q * n + i] = in ? values[p0 + q] : 0.0;
+        if (in && cj == i) diag[i] += values[p0 + q];
+      }
+    }
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(st));
+    if (d_ell_col) HIPCHK(hipFree(d_ell_col));
+    if (d_ell_val) HIPCHK(hipFree(d_ell_val));
+    if (d_ell_diag) HIPCHK(hipFree(d_ell_diag));
+    HIPCHK(hipMalloc((void**)&d_ell_col, sizeof(int) * col.size()));
+    HIPCHK(hipMalloc((void**)&d_ell_val, sizeof(double) * val.size()));
+    HIPCHK(hipMalloc((void**)&d_ell_diag, sizeof(double) * diag.size()));
+    HIPCHK(hipMemcpy(d_ell_col, col.data(), sizeof(int) * col.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_ell_val, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_ell_diag, diag.data(), sizeof(double) * diag.size(), hipMemcpyHostToDevice));
+    ell_n = n; ell_w = w;
+    return DLA_OK;
+  }
+  int spmm_matvec(int n, int m, const double* x, double* ax) override
+  {
+    if (n != ell_n || !d_ell_col) { err = "spmm_matvec: n differs from setup"; return DLA_ERR_ARG; }
+    Scope s(this, DLA_OP_MATVEC, 12.0 * (double)ell_w * n + 16.0 * (double)n * m, 2.0 * (double)ell_w * n * m);
+    const int blocks = std::max(1, std::min(ncu * 8, (n + 255) / 256));
+#define ELL(W) hipLaunchKernelGGL((ell_spmm_kernel<W>), dim3(blocks), dim3(256), 0, st, n, m, ell_w, (const int*)d_ell_col, (const double*)d_ell_val, x, ax)
+    if (ell_w <= 4) ELL(4); else if (ell_w <= 8) ELL(8); else if (ell_w <= 16) ELL(16); else if (ell_w <= 32) ELL(32); else ELL(0);
+#undef ELL
+    HIPCHK(hipGetLastError());
+    return DLA_OK;
+  }
+  int spmm_precnd(int n, int m, double fac, const double* x, double* px) override
+  {
+    if (n != ell_n || !d_ell_diag) { err = "spmm_precnd: n differs from setup"; return DLA_ERR_ARG; }
+    Scope s(this, DLA_OP_PRECND, 8.0 * n * (2.0 * m + 1.0), (double)n * m);
+    const int blocks = std::max(1, std::min(ncu * 8, (n + 255) / 256));
+    hipLaunchKernelGGL(diag_precnd_kernel, dim3(blocks), dim3(256), 0, st, n, m, fac, (const double*)d_ell_diag, x, px);
     HIPCHK(hipGetLastError());
     return DLA_OK;
   }

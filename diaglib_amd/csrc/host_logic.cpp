@@ -46,6 +46,7 @@ const double kTolOrtho = 2.0 * DBL_EPSILON;  // tol_ortho, diaglib.f90:151
 thread_local dla_ctx* g_default = nullptr;
 // built-in operator callbacks have the reference's context-free shape; they act on the calling thread's setup
 thread_local dla_ctx* g_synth_ctx = nullptr;
+thread_local dla_ctx* g_spmm_ctx = nullptr;
 
 int fail(dla_ctx* c, int code, const std::string& msg)
 {
@@ -95,6 +96,7 @@ int dla_destroy(dla_ctx* c)
   delete c->eng;
   if (g_default == c) g_default = nullptr;
   if (g_synth_ctx == c) g_synth_ctx = nullptr;
+  if (g_spmm_ctx == c) g_spmm_ctx = nullptr;
   delete c;
   return DLA_OK;
 }
@@ -702,18 +704,19 @@ int dla_b_ortho(dla_ctx* c, int n, int m, double* u, double* bu)
 int dla_check_guess(dla_ctx* c, int n, int m, double* evec)
 {
   DLA_T("dla_check_guess");
-  double fac = 0.0, growth;
+  double growth;
   int ok;
-  int st = dla_nrm2(c, (size_t)n * m, evec, &fac);
-  if (st) return st;
-  if (fac == 0.0) {
+  // one reduction serves both tests of the reference: ||evec||_F (dnrm2 at :3749) is sqrt(trace) of the Gram matrix (:3762)
+  std::vector<double> ov((size_t)m * m);
+  int st = c->eng->gram(n, m, evec, m, evec, ov.data(), m);
+  if (st) return engfail(c, st);
+  double tr = 0.0;
+  for (int i = 0; i < m; ++i) tr += ov[(size_t)i + (size_t)i * m];
+  if (tr == 0.0) {
     st = dla_random_fill(c, n, m, evec);
     if (st) return st;
     return dla_ortho_cd(c, n, m, evec, &growth, &ok);
   }
-  std::vector<double> ov((size_t)m * m);
-  st = c->eng->gram(n, m, evec, m, evec, ov.data(), m);
-  if (st) return engfail(c, st);
   double dn = 0.0, on = 0.0;
   for (int i = 0; i < m; ++i) {
     dn += ov[(size_t)i + (size_t)i * m] * ov[(size_t)i + (size_t)i * m];
@@ -851,7 +854,7 @@ int dla_call_matvec(dla_ctx* c, dla_matvec_fn fn, int n, int m, const double* x,
   if (m <= 0) return DLA_OK;
   if (c->callbacks_on_device) {
     // the built-in operator runs on the engine's own stream: nothing to order
-    const int order = ((void*)fn == (void*)&dla_synth_matvec) ? 2 : c->callback_order;
+    const int order = ((void*)fn == (void*)&dla_synth_matvec || (void*)fn == (void*)&dla_spmm_matvec) ? 2 : c->callback_order;
     int st = c->eng->callback_begin(order);
     if (st) return engfail(c, st);
     fn(&n, &m, x, ax);
@@ -872,7 +875,7 @@ int dla_call_precnd(dla_ctx* c, dla_precnd_fn fn, int n, int m, double fac, cons
   DLA_T("dla_call_precnd");
   if (m <= 0) return DLA_OK;
   if (c->callbacks_on_device) {
-    const int order = ((void*)fn == (void*)&dla_synth_precnd) ? 2 : c->callback_order;
+    const int order = ((void*)fn == (void*)&dla_synth_precnd || (void*)fn == (void*)&dla_spmm_precnd) ? 2 : c->callback_order;
     int st = c->eng->callback_begin(order);
     if (st) return engfail(c, st);
     fn(&n, &m, &fac, x, px);
@@ -945,6 +948,28 @@ void dla_synth_precnd(const int* n, const int* m, const double* fac, const doubl
   dla_ctx* c = g_synth_ctx;
   if (!c) { std::fprintf(stderr, "diaglib_amd: dla_synth_precnd before dla_synth_setup\n"); std::abort(); }
   if (c->eng->synth_precnd(*n, *m, *fac, x, px)) { std::fprintf(stderr, "diaglib_amd: synth_precnd failed: %s\n", c->eng->err.c_str()); std::abort(); }
+}
+
+// ------------------------------------------------------------------ sample sparse operator
+int dla_spmm_setup_csr(dla_ctx* c, int n, const long long* rowptr, const int* colind, const double* values)
+{
+  if (!c) return DLA_ERR_ARG;
+  g_spmm_ctx = c;
+  return engfail(c, c->eng->spmm_setup_csr(n, rowptr, colind, values));
+}
+
+void dla_spmm_matvec(const int* n, const int* m, const double* x, double* ax)
+{
+  dla_ctx* c = g_spmm_ctx;
+  if (!c) { std::fprintf(stderr, "diaglib_amd: dla_spmm_matvec before dla_spmm_setup_csr\n"); std::abort(); }
+  if (c->eng->spmm_matvec(*n, *m, x, ax)) { std::fprintf(stderr, "diaglib_amd: spmm_matvec failed: %s\n", c->eng->err.c_str()); std::abort(); }
+}
+
+void dla_spmm_precnd(const int* n, const int* m, const double* fac, const double* x, double* px)
+{
+  dla_ctx* c = g_spmm_ctx;
+  if (!c) { std::fprintf(stderr, "diaglib_amd: dla_spmm_precnd before dla_spmm_setup_csr\n"); std::abort(); }
+  if (c->eng->spmm_precnd(*n, *m, *fac, x, px)) { std::fprintf(stderr, "diaglib_amd: spmm_precnd failed: %s\n", c->eng->err.c_str()); std::abort(); }
 }
 
 }  // extern "C"

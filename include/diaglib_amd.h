@@ -268,6 +268,17 @@ void dla_caslr_driver(int verbose, int n, int n_targ, int n_max, int max_iter, d
 void dla_last_solve_info(int* iters, int* matvec_cols, int* restarts);
 void dla_set_solve_info(int iters, int matvec_cols, int restarts);   /* used by the Fortran drivers */
 
+/* ---------------------------------------------------------------- sample sparse operator
+ * A device-resident operator for callers whose matrix is sparse and symmetric: hand A over once in CSR form (host arrays,
+ * 0-based, 64-bit row pointers); it is kept on the device as column-major ELLPACK.  dla_spmm_matvec / dla_spmm_precnd have the
+ * reference's callback shapes matvec(n,m,x,ax) / precnd(n,m,fac,x,px) (README.md:34-35, main.f90:72-90, 146-171) and expect
+ * DEVICE addresses (DLA_OPT_CALLBACKS_ON_DEVICE = 1); the preconditioner is the harness' x / (a_ii + fac).  They act on the
+ * operator the calling thread set up last and enqueue on that context's stream.  Not sharded: with several ranks every rank
+ * would have to hold the x rows its columns reference (outside the all-reduce-only contract). */
+int  dla_spmm_setup_csr(dla_ctx* ctx, int n, const long long* rowptr, const int* colind, const double* values);
+void dla_spmm_matvec(const int* n, const int* m, const double* x_dev, double* ax_dev);
+void dla_spmm_precnd(const int* n, const int* m, const double* fac, const double* x_dev, double* px_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,8 +14,11 @@ ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"
 # split into solves at gaps > 200 us that precede a matvec chain (host work between solves: copy of the guess, python)
 solves, cur = [], []
 for e in ev:
-    if e[2].startswith("sumsq_kernel") and cur:       # check_guess opens every solve
-        solves.append(cur); cur = []
+    if "fillBuffer" in e[2] and e[1] - e[0] < 4_000:     # bench.py's 8-byte marker in front of every solve
+        if cur:
+            solves.append(cur)
+        cur = []
+        continue
     cur.append(e)
 solves.append(cur)
 solves = [s for s in solves if len(s) > 100]
