@@ -90,6 +90,19 @@ struct Engine {
   virtual int spmm_matvec(int /*n*/, int /*m*/, const double* /*x*/, double* /*ax*/) { return DLA_ERR_ARG; }
   virtual int spmm_precnd(int /*n*/, int /*m*/, double /*fac*/, const double* /*x*/, double* /*px*/) { return DLA_ERR_ARG; }
 
+  // Staging pipeline of host-mode callbacks: column chunks of a block travel device -> host on one copy stream, the
+  // user's routine works on the chunk that has arrived, finished chunks travel host -> device on a second copy stream
+  // (PCIe is full duplex), and the engine's own stream only waits for the last upload -- no host wait at the end.
+  //   stage_begin():            the copy streams may start once everything queued on the engine's stream is done
+  //   stage_d2h(h, d, b, slot): enqueue a download; stage_wait(slot): host waits for that download
+  //   stage_h2d(d, h, b):       enqueue an upload;  stage_end(): the engine's stream waits for all uploads
+  // Defaults = plain synchronous copies (host-memory test engine).
+  virtual int stage_begin() { return 0; }
+  virtual int stage_d2h(void* host, const void* dev, size_t bytes, int /*slot*/) { return d2h(host, dev, bytes); }
+  virtual int stage_wait(int /*slot*/) { return 0; }
+  virtual int stage_h2d(void* dev, const void* host, size_t bytes) { return h2d(dev, host, bytes); }
+  virtual int stage_end() { return 0; }
+
   // pinned host staging for host-mode callbacks
   virtual int host_alloc(size_t bytes, void** p) = 0;
   virtual int host_free(void* p) = 0;
@@ -144,6 +157,7 @@ struct dla_ctx {
   int evec_on_device = 0;
   int verbose_ortho = 0;
   int caslr_algorithm = 0;   // DLA_OPT_CASLR_ALGORITHM
+  int stage_chunks = 0;      // DLA_OPT_STAGE_CHUNKS: 0 = automatic
   int callback_order = 1;    // DLA_OPT_CALLBACK_ORDER (default: host-synchronised, safe for callbacks on any stream)
   long long n_global = -1;   // -1: single shard, n_global == n
   long long row0 = 0;

@@ -1571,6 +1571,12 @@ struct HipEngine : dla::Engine {
     if (d_ell_col) (void)hipFree(d_ell_col);
     if (d_ell_val) (void)hipFree(d_ell_val);
     if (d_ell_diag) (void)hipFree(d_ell_diag);
+    if (st_down) {
+      (void)hipStreamSynchronize(st_down); (void)hipStreamSynchronize(st_up);
+      (void)hipStreamDestroy(st_down); (void)hipStreamDestroy(st_up);
+      (void)hipEventDestroy(ev_stage_ready); (void)hipEventDestroy(ev_stage_done);
+      for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ev_down[i]);
+    }
     if (st) (void)hipStreamDestroy(st);
   }
 
@@ -1787,6 +1793,57 @@ struct HipEngine : dla::Engine {
     if (mode == 1) { HIPCHK(hipDeviceSynchronize()); return DLA_OK; }
     HIPCHK(hipEventRecord(ev_cb2, nullptr));
     HIPCHK(hipStreamWaitEvent(st, ev_cb2, 0));
+    return DLA_OK;
+  }
+  // ---- staging pipeline of host-mode callbacks (dla_internal.h)
+  hipStream_t st_down = nullptr, st_up = nullptr;
+  bool stage_pending = false;
+  hipEvent_t ev_stage_ready = nullptr, ev_stage_done = nullptr, ev_down[16] = {nullptr};
+  int stage_init()
+  {
+    if (st_down) return DLA_OK;
+    HIPCHK(hipStreamCreateWithFlags(&st_down, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&st_up, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ev_stage_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_stage_done, hipEventDisableTiming));
+    for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreateWithFlags(&ev_down[i], hipEventDisableTiming));
+    return DLA_OK;
+  }
+  int stage_begin() override
+  {
+    int stc = stage_init();
+    if (stc) return stc;
+    // the previous callback's uploads read the pinned buffers this one is about to overwrite
+    if (stage_pending) { HIPCHK(hipEventSynchronize(ev_stage_done)); stage_pending = false; }
+    HIPCHK(hipEventRecord(ev_stage_ready, st));
+    HIPCHK(hipStreamWaitEvent(st_down, ev_stage_ready, 0));
+    HIPCHK(hipStreamWaitEvent(st_up, ev_stage_ready, 0));      // the output block may still be read by queued kernels
+    return DLA_OK;
+  }
+  int stage_d2h(void* host, const void* dev, size_t bytes, int slot) override
+  {
+    HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st_down));
+    HIPCHK(hipEventRecord(ev_down[slot & 15], st_down));
+    return DLA_OK;
+  }
+  int stage_wait(int slot) override
+  {
+    const double t0 = now();
+    HIPCHK(hipEventSynchronize(ev_down[slot & 15]));
+    t_sync += now() - t0; n_sync++;
+    stats.host_syncs++;
+    return DLA_OK;
+  }
+  int stage_h2d(void* dev, const void* host, size_t bytes) override
+  {
+    HIPCHK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st_up));
+    return DLA_OK;
+  }
+  int stage_end() override
+  {
+    HIPCHK(hipEventRecord(ev_stage_done, st_up));
+    HIPCHK(hipStreamWaitEvent(st, ev_stage_done, 0));
+    stage_pending = true;
     return DLA_OK;
   }
   int host_alloc(size_t bytes, void** p) override { HIPCHK(hipHostMalloc(p, bytes, hipHostMallocDefault)); return DLA_OK; }

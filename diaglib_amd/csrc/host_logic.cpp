@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 #include "dla_internal.h"
 
@@ -123,6 +124,10 @@ int dla_set_option(dla_ctx* c, int option, int value)
     case DLA_OPT_EVEC_ON_DEVICE: c->evec_on_device = value; break;
     case DLA_OPT_PROFILE: c->eng->profile = value != 0; break;
     case DLA_OPT_VERBOSE_ORTHO: c->verbose_ortho = value; break;
+    case DLA_OPT_STAGE_CHUNKS:
+      if (value < 0 || value > 16) return fail(c, DLA_ERR_ARG, "stage chunks must be 0..16");
+      c->stage_chunks = value;
+      break;
     case DLA_OPT_CASLR_ALGORITHM:
       if (value < 0 || value > 1) return fail(c, DLA_ERR_ARG, "caslr algorithm must be 0 or 1");
       c->caslr_algorithm = value;
@@ -153,6 +158,7 @@ int dla_get_option(dla_ctx* c, int option)
     case DLA_OPT_CALLBACK_ORDER: return c->callback_order;
     case DLA_OPT_ORTHO_MAXIT: return c->eng->ortho_maxit;
     case DLA_OPT_CASLR_ALGORITHM: return c->caslr_algorithm;
+    case DLA_OPT_STAGE_CHUNKS: return c->stage_chunks;
     default: return -1;
   }
 }
@@ -836,6 +842,7 @@ int dla_get_coeffs(dla_ctx* c, int len_a, int len_u, int n_max, int n_act, const
 static int ensure_stage(dla_ctx* c, size_t bytes)
 {
   if (bytes <= c->stage_bytes) return DLA_OK;
+  (void)c->eng->sync();                    // uploads of an earlier callback may still read the old buffers
   if (c->stage_x) c->eng->host_free(c->stage_x);
   if (c->stage_y) c->eng->host_free(c->stage_y);
   c->stage_x = c->stage_y = nullptr;
@@ -848,26 +855,58 @@ static int ensure_stage(dla_ctx* c, size_t bytes)
   return DLA_OK;
 }
 
+// Host-mode callback on an n x m block: the block is cut into column chunks (the reference contract lets m vary from call to
+// call, reference diaglib.f90:1685-1786) that flow through  download | user routine | upload  concurrently.
+// The staging buffers must outlive the uploads still in flight when this returns: they are only reused by the next
+// callback, whose stage_begin() follows those uploads on the engine's stream (ensure_stage reallocations drain first).
+static int staged_callback(dla_ctx* c, int n, int m, const double* x, double* y,
+                           const std::function<void(int, const double*, double*)>& call)
+{
+  const size_t col = sizeof(double) * (size_t)n;
+  int st = ensure_stage(c, col * m);
+  if (st) return st;
+  // Two chunks for blocks of 64 MB and more, one below: every chunk is a call of the user's routine, and a memory-bound
+  // host operator pays its fixed traffic (its own matrix) once per call -- measured on the benchmark with the harness'
+  // operator (tools/host_mode_probe.py): 2 chunks are the optimum, 4 and more are slower than no pipeline at all
+  int nchunk = (col * m >= ((size_t)64 << 20)) ? 2 : 1;
+  nchunk = std::min(nchunk, m);
+  if (c->stage_chunks > 0) nchunk = std::min(c->stage_chunks, m);
+  const int per = (m + nchunk - 1) / nchunk;
+  st = c->eng->stage_begin();
+  if (st) return engfail(c, st);
+  int slot = 0;
+  for (int c0 = 0; c0 < m; c0 += per, ++slot) {
+    const int mc = std::min(per, m - c0);
+    DLA_T("  stage d2h (enqueue)");
+    st = c->eng->stage_d2h(c->stage_x + (size_t)c0 * n, x + (size_t)c0 * n, col * mc, slot);
+    if (st) return engfail(c, st);
+  }
+  slot = 0;
+  for (int c0 = 0; c0 < m; c0 += per, ++slot) {
+    int mc = std::min(per, m - c0);
+    { DLA_T("  stage d2h (wait)"); st = c->eng->stage_wait(slot); }
+    if (st) return engfail(c, st);
+    { DLA_T("  user callback"); call(mc, c->stage_x + (size_t)c0 * n, c->stage_y + (size_t)c0 * n); }
+    DLA_T("  stage h2d (enqueue)");
+    st = c->eng->stage_h2d(y + (size_t)c0 * n, c->stage_y + (size_t)c0 * n, col * mc);
+    if (st) return engfail(c, st);
+  }
+  return engfail(c, c->eng->stage_end());
+}
+
 int dla_call_matvec(dla_ctx* c, dla_matvec_fn fn, int n, int m, const double* x, double* ax)
 {
   DLA_T("dla_call_matvec");
   if (m <= 0) return DLA_OK;
   if (c->callbacks_on_device) {
-    // the built-in operator runs on the engine's own stream: nothing to order
+    // the built-in operators run on the engine's own stream: nothing to order
     const int order = ((void*)fn == (void*)&dla_synth_matvec || (void*)fn == (void*)&dla_spmm_matvec) ? 2 : c->callback_order;
     int st = c->eng->callback_begin(order);
     if (st) return engfail(c, st);
     fn(&n, &m, x, ax);
     return engfail(c, c->eng->callback_end(order));
   }
-  size_t bytes = sizeof(double) * (size_t)n * m;
-  int st = ensure_stage(c, bytes);
-  if (st) return st;
-  { DLA_T("  stage d2h"); st = c->eng->d2h(c->stage_x, x, bytes); }
-  if (st) return engfail(c, st);
-  { DLA_T("  user matvec"); fn(&n, &m, c->stage_x, c->stage_y); }
-  DLA_T("  stage h2d");
-  return engfail(c, c->eng->h2d(ax, c->stage_y, bytes));
+  return staged_callback(c, n, m, x, ax, [&](int mc, const double* hx, double* hy) { fn(&n, &mc, hx, hy); });
 }
 
 int dla_call_precnd(dla_ctx* c, dla_precnd_fn fn, int n, int m, double fac, const double* x, double* px)
@@ -881,14 +920,7 @@ int dla_call_precnd(dla_ctx* c, dla_precnd_fn fn, int n, int m, double fac, cons
     fn(&n, &m, &fac, x, px);
     return engfail(c, c->eng->callback_end(order));
   }
-  size_t bytes = sizeof(double) * (size_t)n * m;
-  int st = ensure_stage(c, bytes);
-  if (st) return st;
-  { DLA_T("  stage d2h"); st = c->eng->d2h(c->stage_x, x, bytes); }
-  if (st) return engfail(c, st);
-  { DLA_T("  user precnd"); fn(&n, &m, &fac, c->stage_x, c->stage_y); }
-  DLA_T("  stage h2d");
-  return engfail(c, c->eng->h2d(px, c->stage_y, bytes));
+  return staged_callback(c, n, m, x, px, [&](int mc, const double* hx, double* hy) { fn(&n, &mc, &fac, hx, hy); });
 }
 
 // linear-response preconditioner lrprec(n,m,fac,xp,xm,yp,ym) (reference diaglib.f90:1317, caller main.f90:257-281):

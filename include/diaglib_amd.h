@@ -75,6 +75,8 @@ enum {
                                       the Householder-QR fallback `ortho` (diaglib.f90:3052-3092, 3534, 3549) runs */
   DLA_OPT_CASLR_ALGORITHM = 7,     /* reduced problem of caslr_driver: 0 (default) the 2 ldu-dimensional pencil (reference
                                       i_alg = 0, dsygv at diaglib.f90:783), 1 the Helmich-Paris route (i_alg = 1, :805-860) */
+  DLA_OPT_STAGE_CHUNKS = 8,        /* host-mode callbacks: column chunks a block is cut into for the download | user routine |
+                                      upload pipeline (0 = automatic: ~32 MB chunks, at most 8; 1 = whole block at once) */
   DLA_OPT_TUNE0 = 100              /* 100..107: kernel-shape experiment knobs for the interleaved A/B tools
                                       (tools/tune_*.py, tools/kernel_bench.py); 0 = the shipped default          */
 };

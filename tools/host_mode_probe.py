@@ -24,12 +24,16 @@ g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
 
 ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
 mv, pc = o.fn("orc_synth_matvec"), o.fn("orc_synth_precnd")
-for rep in range(2):
-    ctx.reset_stats()
-    t0 = time.perf_counter()
-    eig, v, ok, info = ctx.davidson_driver(n, t, m, 200, 2e-13, 20, 0.0, mv, pc, g)
-    dt_host = time.perf_counter() - t0
-print(f"host callbacks + host evec: {dt_host * 1e3:8.1f} ms per solve, {info['iters']} iterations, ok={ok}")
+for chunks in (0, 1, 2, 3, 4):
+    ctx.set_option(capi.OPT_STAGE_CHUNKS, chunks)
+    for rep in range(2):
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        eig, v, ok, info = ctx.davidson_driver(n, t, m, 200, 2e-13, 20, 0.0, mv, pc, g)
+        dt_host = time.perf_counter() - t0
+    print(f"host callbacks + host evec, stage chunks {chunks} (0 = automatic): {dt_host * 1e3:8.1f} ms per solve, "
+          f"{info['iters']} iterations, ok={ok}")
+ctx.set_option(capi.OPT_STAGE_CHUNKS, 0)
 
 ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
 ev = ctx.panel(g)
