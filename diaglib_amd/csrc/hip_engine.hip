@@ -244,7 +244,9 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 // [column][18] from which the MFMA fragments (lane (c, g): row 4s+g of column c) are read.  No block-level
 // synchronisation inside the sweep; the next tile's loads are in flight while the current one is multiplied.
 // Even n only (16-byte row pairs).
-template <int TLW, int KT, int NT = 1, int R = 16>
+// SELF: U is X itself (Gram matrix of one block, TLW == KT, a single pass): the tiles are loaded and staged once and serve as
+// both operands -- half the load instructions and LDS traffic of the general kernel on the same algorithmic bytes.
+template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0>
 __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
 {
   DLA_PREDICATED(a);
@@ -252,7 +254,8 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   constexpr int RS = R + 2;                // doubles per staged column (+2 keeps 16-byte alignment)
   constexpr int LPC = R / 2;               // lanes per column
   constexpr int CPI = 64 / LPC;            // columns per load instruction
-  constexpr int NC = 16 * (TLW + KT);      // staged columns: the pass's X tiles, then its U tiles
+  constexpr int NC = SELF ? 16 * TLW : 16 * (TLW + KT);      // staged columns: the pass's X tiles, then its U tiles
+  constexpr int UOFF = SELF ? 0 : 16 * TLW;                   // where the U tiles sit in the staged image
   constexpr int NI = NC / CPI;             // load instructions per tile
   extern __shared__ __attribute__((aligned(16))) double glds[];   // [4][NC][RS]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
     for (int s4 = 0; s4 < R / 4; ++s4) {
       double uf[KT];
 #pragma unroll
-      for (int q = 0; q < KT; ++q) uf[q] = lds_load1(my + (size_t)(16 * TLW + 16 * q + c) * RS + 4 * s4 + g);
+      for (int q = 0; q < KT; ++q) uf[q] = lds_load1(my + (size_t)(UOFF + 16 * q + c) * RS + 4 * s4 + g);
 #pragma unroll
       for (int t = 0; t < TLW; ++t) {
         const double xf = lds_load1(my + (size_t)(16 * t + c) * RS + 4 * s4 + g);
@@ -2272,6 +2275,15 @@ struct HipEngine : dla::Engine {
   template <int TLW, int KT, int R>
   int launch_gram_lds(const GramArgs& a, dim3 grid)
   {
+    if constexpr (TLW == KT) {
+      if (cur_self) {
+        auto kfs = gram_lds_kernel<TLW, KT, 1, R, 1>;
+        const size_t ldss = sizeof(double) * 4 * 16 * TLW * (R + 2);
+        if (!raise_lds((const void*)kfs, ldss)) return DLA_ERR_RUNTIME;
+        hipLaunchKernelGGL(kfs, grid, dim3(256), ldss, st, a);
+        return DLA_OK;
+      }
+    }
     auto kfn = gram_lds_kernel<TLW, KT, 1, R>;
     const size_t lds = sizeof(double) * 4 * 16 * (TLW + KT) * (R + 2);
     if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;
@@ -2289,6 +2301,7 @@ struct HipEngine : dla::Engine {
   // duplicates of its last column: it keeps the direct-load kernel)
   bool use_lds_gram(bool vec2, int l, int kt) const { return vec2 && kt <= 3 && l > 8 && tune[5] != 2; }
   bool cur_lds = false;   // decision of the Gram being launched
+  bool cur_self = false;  // ... a block against itself in one pass: staged once (gram_lds_kernel SELF)
   template <int TLW, int KT>
   int launch_gram(const GramArgs& a, dim3 grid, bool vec2)
   {
@@ -2319,10 +2332,12 @@ struct HipEngine : dla::Engine {
   {
     const int tx = (l + 15) / 16, tu = (k + 15) / 16;
     // tile shape of one pass: KT U-tiles x TLW X-tiles, at most 12 accumulators
-    int kt = std::min(tu, 4);
+    const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)u) % 16 == 0);
+    // (even n: at most 3 U tiles per pass, so that the LDS-staged kernel serves every pass -- the direct-load kernel a
+    // fourth tile would need measured 2.6 TB/s on the 111-column S^T A S of LOBPCG at n_max = 37)
+    int kt = std::min(tu, (vec2 && l > 8 && tune[5] != 2) ? 3 : 4);
     const int passes_u = (tu + kt - 1) / kt;
     kt = (tu + passes_u - 1) / passes_u;
-    const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)u) % 16 == 0);
     const bool ldsk = cur_lds = use_lds_gram(vec2, l, kt);
     // widest pass: the direct-load kernel loses its register prefetch stage beyond 8 tiles (measured); the LDS-staged
     // one keeps all of X's columns of up to 12 tiles in one pass, so U is read once for L <= 192
@@ -2344,6 +2359,10 @@ struct HipEngine : dla::Engine {
     else { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : 3; }
     const int px = (tx + tlw - 1) / tlw;
     const int passes = px * passes_u;
+    // a block against itself in a single pass: one staged image serves both operands, and only the tile pairs on or
+    // below the diagonal are formed (the host side mirrors, see gram())
+    cur_self = ldsk && x == u && l == k && passes == 1 && tlw == kt;
+    if (cur_self) lower = true;
     const int ch = vec2 ? 32 : 16;
     long long nchunks = ((long long)n + ch - 1) / ch;
     long long want = (nchunks + 4 * 4 - 1) / (4 * 4);   // >= 4 chunks per wave
@@ -2366,7 +2385,7 @@ struct HipEngine : dla::Engine {
       char kn[64];
       if (cur_lds) {
         const bool can32 = sizeof(double) * 4 * 16 * (tlw + kt) * 34 <= 150 * 1024;
-        std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d>", tlw, kt, (can32 && lds_rows(tlw, kt) == 32) ? 32 : 16);
+        std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d, %d>", tlw, kt, (can32 && lds_rows(tlw, kt) == 32) ? 32 : 16, cur_self ? 1 : 0);
       }
       else std::snprintf(kn, sizeof kn, "gram_kernel<%d, %d, %d, %d, 0, -1>", tlw, kt, vec2 ? 2 : 1, rs);
       Scope s(this, cls, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k, kn);
@@ -2413,6 +2432,15 @@ struct HipEngine : dla::Engine {
     if (stc) return stc;
     stc = small_to_host((size_t)l * k);
     if (stc) return stc;
+    if (cur_self) {
+      // only the lower block triangle was formed: mirror it (the Gram matrix of a block is symmetric)
+      for (int j = 0; j < k; ++j)
+        for (int i2 = 0; i2 < k; ++i2) {
+          const bool low = (i2 / 16) >= (j / 16);
+          c_host[(size_t)i2 + (size_t)j * ldc] = low ? h_small[(size_t)i2 + (size_t)j * l] : h_small[(size_t)j + (size_t)i2 * l];
+        }
+      return DLA_OK;
+    }
     for (int j = 0; j < k; ++j) std::memcpy(c_host + (size_t)j * ldc, h_small + (size_t)j * l, sizeof(double) * l);
     return DLA_OK;
   }
