@@ -32,7 +32,7 @@ EXPORTS = [
     "dla_backend_name", "dla_get_stats", "dla_reset_stats", "dla_get_kernel_stats", "dla_stream",
     "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_p2p_export", "dla_p2p_attach", "dla_set_allreduce_hook", "dla_set_shard",
     "dla_alloc", "dla_free", "dla_trim", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
-    "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_ritz_residual", "dla_axpy",
+    "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_trmm_gram", "dla_update_gram", "dla_combo_gram", "dla_ritz_residual", "dla_axpy",
     "dla_nrm2", "dla_stream_triad", "dla_random_fill", "dla_fill_guess",
     "dla_ortho_cd", "dla_ortho_qr", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
     "dla_call_matvec", "dla_call_precnd",
@@ -103,6 +103,9 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_panel_gemm": (i, [vp, i, i, vp, i, c_dp, i, vp]),
         "dla_panel_update": (i, [vp, i, i, vp, i, c_dp, i, vp]),
         "dla_trmm_linvt": (i, [vp, i, i, vp, c_dp, i]),
+        "dla_trmm_gram": (i, [vp, i, i, vp, c_dp, i, c_dp, i]),
+        "dla_update_gram": (i, [vp, i, i, vp, i, c_dp, i, vp, c_dp, i]),
+        "dla_combo_gram": (i, [vp, i, i, vp, i, c_dp, i, vp, c_dp, i]),
         "dla_ritz_residual": (i, [vp, i, i, i, vp, vp, c_dp, i, c_dp, i, c_ip, vp, vp, vp, c_dp]),
         "dla_axpy": (i, [vp, sz, d, vp, vp]), "dla_nrm2": (i, [vp, sz, vp, c_dp]),
         "dla_stream_triad": (i, [vp, sz, i, c_dp]),
@@ -314,6 +317,21 @@ class Context:
     def trmm_linvt(self, u: DevPanel, linv: np.ndarray) -> None:
         linv = np.asfortranarray(linv, dtype=np.float64)
         self._chk(self.lib.dla_trmm_linvt(self.h, u.n, u.m, u.ptr, _dp(linv), linv.shape[0]))
+
+    def trmm_gram(self, u: DevPanel, w: np.ndarray) -> np.ndarray:
+        w = np.asfortranarray(w, dtype=np.float64); g = np.zeros((u.m, u.m), order="F")
+        self._chk(self.lib.dla_trmm_gram(self.h, u.n, u.m, u.ptr, _dp(w), w.shape[0], _dp(g), u.m))
+        return g
+
+    def update_gram(self, x: DevPanel, c: np.ndarray, u: DevPanel) -> np.ndarray:
+        c = np.asfortranarray(c, dtype=np.float64); g = np.zeros((u.m, u.m), order="F")
+        self._chk(self.lib.dla_update_gram(self.h, x.n, x.m, x.ptr, u.m, _dp(c), c.shape[0], u.ptr, _dp(g), u.m))
+        return g
+
+    def combo_gram(self, x: DevPanel, c: np.ndarray, u: DevPanel) -> np.ndarray:
+        c = np.asfortranarray(c, dtype=np.float64); g = np.zeros((u.m, u.m), order="F")
+        self._chk(self.lib.dla_combo_gram(self.h, x.n, x.m, x.ptr, u.m, _dp(c), c.shape[0], u.ptr, _dp(g), u.m))
+        return g
 
     def ritz_residual(self, v: DevPanel, av: DevPanel, y: np.ndarray, eig: np.ndarray, n_res: int,
                       skip: np.ndarray, evec: DevPanel, r: DevPanel, avy: Optional[DevPanel] = None) -> np.ndarray:

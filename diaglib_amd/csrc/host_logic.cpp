@@ -293,6 +293,30 @@ int dla_trmm_linvt(dla_ctx* c, int n, int k, double* u, const double* linv, int 
   return engfail(c, c->eng->trmm(n, k, u, w.data(), k));
 }
 
+// The fused sweeps of the orthogonalisation loops, exposed for direct parity tests (tests/test_kernels_gpu.py): the
+// update and the Gram matrix of its result in one pass over the panel.
+int dla_trmm_gram(dla_ctx* c, int n, int k, double* u, const double* w, int ldw, double* g, int ldg)
+{
+  DLA_T("dla_trmm_gram");
+  if (k <= 0) return DLA_OK;
+  return engfail(c, c->eng->trmm_gram(n, k, u, w, ldw, g, ldg));
+}
+
+int dla_update_gram(dla_ctx* c, int n, int l, const double* x, int k, const double* ch, int ldc, double* u, double* g, int ldg)
+{
+  DLA_T("dla_update_gram");
+  if (k <= 0) return DLA_OK;
+  return engfail(c, c->eng->update_gram(n, l, x, k, ch, ldc, u, g, ldg));
+}
+
+int dla_combo_gram(dla_ctx* c, int n, int m, const double* x, int k, const double* ch, int ldc, double* u, double* g, int ldg)
+{
+  DLA_T("dla_combo_gram");
+  if (k <= 0) return DLA_OK;
+  if (!c->eng->can_combo(m, k) || u != x + (size_t)n * m) return fail(c, DLA_ERR_ARG, "combo_gram: U must follow X in one panel, k <= 48");
+  return engfail(c, c->eng->combo_gram(n, m, x, k, ch, ldc, u, g, ldg));
+}
+
 int dla_ritz_residual(dla_ctx* c, int n, int l, int m, const double* v, const double* av, const double* y, int ldy,
                       const double* eig, int n_res, const int* skip, double* evec, double* r, double* avy,
                       double* rnorm)

@@ -206,7 +206,19 @@ int  dla_random_fill(dla_ctx* ctx, int n, int m, double* evec_dev);
 int  dla_fill_guess(dla_ctx* ctx, int n, int m, double* evec_dev, unsigned long long seed, long long support_rows);
 
 /* ---------------------------------------------------------------- orthogonalisation */
-int  dla_ortho_cd(dla_ctx* ctx, int n, int k, double* u_dev, double* growth, int* ok);      /* ortho(n,m,u,w), diaglib.f90:3052-3092: Householder QR of a copy (dgeqrf) and U <- U R^-1 (dtrsm) -- the orthonormal factor
+int  dla_ortho_cd(dla_ctx* ctx, int n, int k, double* u_dev, double* growth, int* ok);      /* Fused sweeps of the orthogonalisation loops (one pass over the panel instead of two), as the engine runs them inside
+ * ortho_cd / ortho_vs_x; entry points of their own so that each can be checked against the BLAS pair it replaces:
+ *   dla_trmm_gram    U <- U W (k x k, general W; dtrmm at diaglib.f90:3327)          and G = U^T U of the result (:3256)
+ *   dla_update_gram  U <- U - X C (dgemm at :3544)                                   and G = U^T U of the result
+ *   dla_combo_gram   U <- [X | U] C' (C' is (m+k) x k; U follows X in one panel, k <= 48) and G = U^T U of the result:
+ *                    the pending triangular factor folded into the projection, X^T (U W) = (X^T U) W
+ * G (k x k, host, ld = ldg) comes back complete (symmetric). */
+int  dla_trmm_gram(dla_ctx* ctx, int n, int k, double* u_dev, const double* w_host, int ldw, double* g_host, int ldg);
+int  dla_update_gram(dla_ctx* ctx, int n, int l, const double* x_dev, int k, const double* c_host, int ldc, double* u_dev,
+                     double* g_host, int ldg);
+int  dla_combo_gram(dla_ctx* ctx, int n, int m, const double* x_dev, int k, const double* c_host, int ldc, double* u_dev,
+                    double* g_host, int ldg);
+/* ortho(n,m,u,w), diaglib.f90:3052-3092: Householder QR of a copy (dgeqrf) and U <- U R^-1 (dtrsm) -- the orthonormal factor
  * with LAPACK's sign convention for diag(R).  The reference calls it when ortho_cd gives up (:3534, :3549).  Device path:
  * column-wise Gram-Schmidt for the factor, the Householder recurrence on an isometric 2k x k host matrix for the signs. */
 int  dla_ortho_qr(dla_ctx* ctx, int n, int k, double* u_dev);

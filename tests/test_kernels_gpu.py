@@ -212,3 +212,39 @@ def test_ritz_residual_deep_subspace(ctx, oracle, rng, n, l, m):
         if not skip[i]:
             assert np.isclose(rn[0, i], np.linalg.norm(r[:, i]) / np.sqrt(n), rtol=1e-10)
             assert np.isclose(rn[1, i], np.abs(r[:, i]).max(), rtol=1e-10)
+
+
+@pytest.mark.parametrize("n,m,k", [(257, 13, 5), (1000, 26, 13), (4096, 104, 13), (3000, 63, 21), (2001, 74, 37), (2000, 111, 37),
+                                   (640, 16, 16), (5000, 247, 13)])
+def test_fused_sweeps_against_their_blas_pairs(ctx, oracle, rng, n, m, k):
+    """the fused epilogues checked directly, not only through ortho_vs_x.  Each fused sweep against the
+    oracle's dgemm('n','n') for the update and dgemm('t','n') for the Gram matrix of the updated block
+    (reference diaglib.f90:3327+3256, 3544+3256)."""
+    x = np.asfortranarray(rng.standard_normal((n, m)))
+    u = np.asfortranarray(rng.standard_normal((n, k)))
+
+    def check(got_u, got_g, want_u, scale):
+        bound = 64 * EPS * scale + 1e-300
+        assert np.all(np.abs(got_u - want_u) <= bound)
+        want_g = oracle.gemm_tn(want_u, want_u)
+        gb = 64 * EPS * (np.abs(want_u).T @ np.abs(want_u)) + 2 * (np.abs(want_u).T @ bound) + 1e-300
+        assert np.all(np.abs(got_g - want_g) <= gb)
+        assert np.array_equal(got_g, got_g.T)                       # complete and symmetric
+
+    # U <- U W with a general (upper triangular here) W
+    w = np.asfortranarray(np.triu(rng.standard_normal((k, k))) + 2 * np.eye(k))
+    pu = ctx.panel(u)
+    g = ctx.trmm_gram(pu, w)
+    check(pu.download(), g, oracle.gemm_nn(u, w), np.abs(u) @ np.abs(w))
+    # U <- U - X C
+    c = np.asfortranarray(rng.standard_normal((m, k)) * 0.1)
+    pu = ctx.panel(u)
+    g = ctx.update_gram(ctx.panel(x), c, pu)
+    check(pu.download(), g, oracle.gemm_nn(x, c, alpha=-1.0, beta=1.0, z=u), np.abs(x) @ np.abs(c) + np.abs(u))
+    # U <- [X | U] C' on one contiguous panel
+    cp = np.asfortranarray(np.vstack([-c, w]))
+    big = ctx.panel(np.asfortranarray(np.hstack([x, u])))
+    g = ctx.combo_gram(big.col(0, m), cp, big.col(m, k))
+    xu = np.asfortranarray(np.hstack([x, u]))
+    check(big.col(m, k).download(), g, oracle.gemm_nn(xu, cp), np.abs(xu) @ np.abs(cp))
+    assert np.array_equal(big.col(0, m).download(), x)              # X untouched
