@@ -18,27 +18,14 @@ struct OrthoReport {
   double growth = 1.0;
 };
 
-// What the host logic needs from a device.  All panel pointers are device addresses,
-// column-major, ld = n.  Reductions (gram / residual norms / nrm2) return host-visible,
-// cross-rank-reduced results and imply a stream synchronisation.
-struct Engine {
-  virtual ~Engine() {}
-  virtual const char* name() const = 0;
-  virtual void* stream() = 0;
-
-  virtual int alloc(size_t bytes, void** dev) = 0;
-  virtual int free_(void* dev) = 0;
-  virtual int zero(void* dev, size_t bytes) = 0;
-  virtual int trim(size_t* released) { if (released) *released = 0; return 0; }   // release cached free blocks
-  virtual int h2d(void* dev, const void* host, size_t bytes) = 0;
-  virtual int d2h(void* host, const void* dev, size_t bytes) = 0;
-  virtual int d2d(void* dst, const void* src, size_t bytes) = 0;
-  virtual int sync() = 0;
-
+// The block operations the orthogonalisation control flow (ortho_cd / ortho_vs_x / ortho in host_logic.cpp) is written
+// over.  The device engine implements them on n-length panels in HBM; get_coeffs runs the same control flow on
+// host-size coefficient blocks through a plain-loop implementation (CoeffOps in host_logic.cpp) -- it implements these
+// few operations and nothing else.  Panels are column-major, ld = n; small matrices are host arrays.
+struct BlockOps {
+  virtual ~BlockOps() {}
+  // C = X^T U (cross-rank reduced when the panels are row shards)
   virtual int gram(int n, int l, const double* x, int k, const double* u, double* c_host, int ldc) = 0;
-  // C = X^T U for two n x l panels when only the lower triangle of C will be read (dsyev 'l'): entries above
-  // the 16 x 16 block diagonal may be left zero.  Default = the full product.
-  virtual int gram_lower(int n, int l, const double* x, const double* u, double* c_host, int ldc) { return gram(n, l, x, l, u, c_host, ldc); }
   // mode 0: Z = X C ; mode 1: Z -= X C (Z read and written)
   virtual int gemm(int n, int l, const double* x, int k, const double* c_host, int ldc, double* z, int mode) = 0;
   // in place U <- U W, W (k x k, host, general) -- used for the triangular update
@@ -62,6 +49,47 @@ struct Engine {
   // ortho_cd (m == 0) with the k x k factorisations and the loop decisions on the device: one host wait per call.
   virtual int ortho_chain(int /*n*/, int /*m*/, int /*k*/, const double* /*x*/, const double* /*bx*/, double* /*u*/,
                           OrthoReport* rep) { rep->handled = 0; return 0; }
+  // the top k GLOBAL rows of the n x k block u (row0 = global index of local row 0), k x k to the host
+  virtual int top_rows(int n, int k, const double* u, long long row0, double* qt_host) = 0;
+  int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests
+  std::string err;
+};
+
+// What the host logic needs from a device.  All panel pointers are device addresses,
+// column-major, ld = n.  Reductions (gram / residual norms / nrm2) return host-visible,
+// cross-rank-reduced results and imply a stream synchronisation.
+struct Engine : BlockOps {
+  virtual const char* name() const = 0;
+  virtual void* stream() = 0;
+
+  virtual int alloc(size_t bytes, void** dev) = 0;
+  virtual int free_(void* dev) = 0;
+  virtual int zero(void* dev, size_t bytes) = 0;
+  virtual int trim(size_t* released) { if (released) *released = 0; return 0; }   // release cached free blocks
+  virtual int h2d(void* dev, const void* host, size_t bytes) = 0;
+  virtual int d2h(void* host, const void* dev, size_t bytes) = 0;
+  virtual int d2d(void* dst, const void* src, size_t bytes) = 0;
+  virtual int sync() = 0;
+
+  // C = X^T U for two n x l panels when only the lower triangle of C will be read (dsyev 'l'): entries above
+  // the 16 x 16 block diagonal may be left zero.  Default = the full product.
+  virtual int gram_lower(int n, int l, const double* x, const double* u, double* c_host, int ldc) { return gram(n, l, x, l, u, c_host, ldc); }
+  // top rows through the Gram door, E^T U with E = (e_1 .. e_k): works for row-sharded panels with what every engine has
+  int top_rows(int n, int k, const double* u, long long row0, double* qt_host) override
+  {
+    void* ev = nullptr;
+    int st = alloc(sizeof(double) * (size_t)n * k, &ev);
+    if (st) return st;
+    st = zero(ev, sizeof(double) * (size_t)n * k);
+    const double unit = 1.0;
+    for (int j = 0; j < k && !st; ++j) {
+      const long long lr = (long long)j - row0;             // global row j on this shard?
+      if (lr >= 0 && lr < n) st = h2d((double*)ev + (size_t)j * n + lr, &unit, sizeof(double));
+    }
+    if (!st) st = gram(n, k, (const double*)ev, k, u, qt_host, k);
+    int stf = free_(ev);
+    return st ? st : stf;
+  }
   virtual int ritz_residual(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
                             const double* eig, int n_res, const int* skip, double* evec, double* r,
                             double* avy /* optional n x m: uncorrected AV*Y */,
@@ -107,8 +135,6 @@ struct Engine {
   virtual int host_alloc(size_t bytes, void** p) = 0;
   virtual int host_free(void* p) = 0;
 
-  int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests
-
   // collectives
   virtual int comm_init(int nranks, int rank, const char id[128]) = 0;
   virtual int comm_finalize() { nranks = 1; rank = 0; hook = nullptr; return 0; }
@@ -128,7 +154,6 @@ struct Engine {
   virtual int kernel_stats(dla_kernel_stat*, int) { return 0; }
   virtual void reset_kernel_stats() {}
   virtual void set_tune(int, int) {}
-  std::string err;
 };
 
 // $DIAGLIB_AMD_HOSTTIME=1: wall time spent inside each C-ABI entry point (printed by dla_destroy)

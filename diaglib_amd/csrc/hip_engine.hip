@@ -3000,10 +3000,10 @@ struct HipEngine : dla::Engine {
     int stc = gram_dev(n, syn_rw, d_w, m, x, DLA_OP_MATVEC);   // t = W^T x (4 x m), reduced over ranks, on device
     if (stc) return stc;
     Scope s(this, DLA_OP_MATVEC, 8.0 * n * (2.0 * m + syn_rw), 2.0 * (double)n * m * (2 * syn_rw + 1));
-    HIPCHK(hipMemcpyAsync(d_t, d_small, sizeof(double) * syn_rw * m, hipMemcpyDeviceToDevice, st));
+    // (t = W^T x sits in d_small, reduced over ranks; nothing else touches that buffer before the kernel below has read it)
     const int blocks = std::max(1, std::min(ncu * 8, (n + 255) / 256));
     hipLaunchKernelGGL((synth_apply_kernel<4>), dim3(blocks), dim3(256), sizeof(double) * 4 * m, st,
-                       syn_row0, n, m, syn_sigma, d_w, d_t, x, ax);
+                       syn_row0, n, m, syn_sigma, d_w, (const double*)d_small, x, ax);
     HIPCHK(hipGetLastError());
     return DLA_OK;
   }

@@ -63,6 +63,13 @@ int engfail(dla_ctx* c, int code)
 
 long long global_rows(dla_ctx* c, int n) { return c->n_global > 0 ? c->n_global : (long long)n; }
 
+// failure of a block operation: its message becomes the context's
+int opsfail(dla_ctx* c, dla::BlockOps* ops, int code)
+{
+  if (code != 0 && c) c->err = ops->err;
+  return code;
+}
+
 }  // namespace
 
 extern "C" {
@@ -375,7 +382,7 @@ int dla_fill_guess(dla_ctx* c, int n, int m, double* evec, unsigned long long se
 // going to project U against X next anyway (always = force_defer, or only when growth*eps >= tol_ortho,
 // i.e. when ortho_vs_x will do another pass), W = Linv^T is returned in w_defer with *deferred = true and
 // the panel in memory still holds U before that update.  The caller folds W into its next sweep.
-static int ortho_cd_impl(dla_ctx* c, int n, int k, double* u, double* growth, int* ok, const double* g_in,
+static int ortho_cd_impl(dla_ctx* c, dla::BlockOps* ops, int n, int k, double* u, double* growth, int* ok, const double* g_in,
                          double* w_defer = nullptr, bool* deferred = nullptr, bool force_defer = false)
 {
   *growth = 1.0;
@@ -387,7 +394,7 @@ static int ortho_cd_impl(dla_ctx* c, int n, int k, double* u, double* growth, in
   if (have_g) gnext.assign(g_in, g_in + (size_t)k * k);
   int it = 0;
   bool macro_done = false;
-  const int kMaxIt = c->eng->ortho_maxit;    // maxit, diaglib.f90:3224
+  const int kMaxIt = ops->ortho_maxit;    // maxit, diaglib.f90:3224
   while (!macro_done) {
     if (++it > kMaxIt) {
       // reference prints and returns with ok=.false. (:3252-3254)
@@ -398,8 +405,8 @@ static int ortho_cd_impl(dla_ctx* c, int n, int k, double* u, double* growth, in
     if (have_g) {
       metric = gnext;
     } else {
-      int st = c->eng->gram(n, k, u, k, u, metric.data(), k);   // :3256
-      if (st) return engfail(c, st);
+      int st = ops->gram(n, k, u, k, u, metric.data(), k);   // :3256
+      if (st) return opsfail(c, ops, st);
     }
     msave = metric;
     int info = dla_potrf_lower(k, metric.data(), k);
@@ -443,12 +450,12 @@ static int ortho_cd_impl(dla_ctx* c, int n, int k, double* u, double* growth, in
       *deferred = true;
       st = DLA_OK;
     } else if (macro_done) {
-      st = c->eng->trmm(n, k, u, w.data(), k);                                        // last pass: no further Gram needed
+      st = ops->trmm(n, k, u, w.data(), k);                                        // last pass: no further Gram needed
     } else {
-      st = c->eng->trmm_gram(n, k, u, w.data(), k, gnext.data(), k);
+      st = ops->trmm_gram(n, k, u, w.data(), k, gnext.data(), k);
       have_g = true;
     }
-    if (st) return engfail(c, st);
+    if (st) return opsfail(c, ops, st);
   }
   if (c->verbose_ortho) std::printf("  [dla] ortho_cd: %d macro iterations, growth %.3e\n", it, *growth);
   *ok = 1;
@@ -474,7 +481,7 @@ int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
       return DLA_OK;
     }
   }
-  return ortho_cd_impl(c, n, k, u, growth, ok, nullptr);
+  return ortho_cd_impl(c, c->eng, n, k, u, growth, ok, nullptr);
 }
 
 // The reference's fallback `ortho` (diaglib.f90:3052-3092): Householder QR of a copy (dgeqrf), then U <- U R^-1 (dtrsm).
@@ -486,7 +493,7 @@ int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
 //      M holds the columns of U in an orthonormal basis [e_1..e_k, Z] of span(U) + span(e_1..e_k); every Householder
 //      vector of U lies in that span, so the reflections of M are those of U and diag(R) has the same signs.
 // r (k x k, column-major): the triangular factor, U_in = Q r, accumulated from the projection coefficients
-static int mgs2_device(dla_ctx* c, int n, int k, double* u, double* r)
+static int gram_schmidt2(dla_ctx* c, dla::BlockOps* ops, int n, int k, double* u, double* r)
 {
   std::fill(r, r + (size_t)k * k, 0.0);
   // column by column, each column projected against the finished ones TWICE before it is normalised ("twice is
@@ -495,20 +502,20 @@ static int mgs2_device(dla_ctx* c, int n, int k, double* u, double* r)
     double* uj = u + (size_t)n * j;
     for (int rep = 0; rep < 2 && j > 0; ++rep) {
       std::vector<double> h(j);
-      int st = c->eng->gram(n, j, u, 1, uj, h.data(), j);
-      if (st) return engfail(c, st);
-      st = c->eng->gemm(n, j, u, 1, h.data(), j, uj, 1);
-      if (st) return engfail(c, st);
+      int st = ops->gram(n, j, u, 1, uj, h.data(), j);
+      if (st) return opsfail(c, ops, st);
+      st = ops->gemm(n, j, u, 1, h.data(), j, uj, 1);
+      if (st) return opsfail(c, ops, st);
       for (int p = 0; p < j; ++p) r[(size_t)p + (size_t)j * k] += h[p];
     }
     double g = 0.0;
-    int st = c->eng->gram(n, 1, uj, 1, uj, &g, 1);
-    if (st) return engfail(c, st);
+    int st = ops->gram(n, 1, uj, 1, uj, &g, 1);
+    if (st) return opsfail(c, ops, st);
     if (!(g > 0.0)) return fail(c, DLA_ERR_ORTHO, "ortho: zero column");
     r[(size_t)j + (size_t)j * k] = std::sqrt(g);
     double w = 1.0 / std::sqrt(g);
-    st = c->eng->trmm(n, 1, uj, &w, 1);
-    if (st) return engfail(c, st);
+    st = ops->trmm(n, 1, uj, &w, 1);
+    if (st) return opsfail(c, ops, st);
   }
   return DLA_OK;
 }
@@ -544,31 +551,19 @@ static void householder_diag_signs(int rows, int cols, std::vector<double>& m, s
   }
 }
 
-static int ortho_qr_impl(dla_ctx* c, int n, int k, double* u)
+static int ortho_qr_impl(dla_ctx* c, dla::BlockOps* ops, long long row0, long long n_rows_global, int n, int k, double* u)
 {
   if (k <= 0) return DLA_OK;
-  const long long ng = global_rows(c, n);
-  if (ng < k) return fail(c, DLA_ERR_ARG, "ortho: more columns than rows");
+  if (n_rows_global < k) return fail(c, DLA_ERR_ARG, "ortho: more columns than rows");
   // 1. U = Q+ R+ on the device (Q+ replaces U)
   std::vector<double> rp((size_t)k * k);
-  int st = mgs2_device(c, n, k, u, rp.data());
+  int st = gram_schmidt2(c, ops, n, k, u, rp.data());
   if (st) return st;
-  // 2. top k (global) rows of Q+: Qt = E^T Q+ through the Gram door, so a row-sharded panel needs nothing new
+  // 2. top k (global) rows of Q+ (the device engine gets them as E^T Q+ through the Gram door, so a row-sharded panel
+  //    needs nothing new; host-size blocks are read directly)
   std::vector<double> qt((size_t)k * k);
-  {
-    void* ev = nullptr;
-    st = c->eng->alloc(sizeof(double) * (size_t)n * k, &ev);
-    if (st) return engfail(c, st);
-    st = c->eng->zero(ev, sizeof(double) * (size_t)n * k);
-    const double unit = 1.0;
-    for (int j = 0; j < k && !st; ++j) {
-      const long long lr = (long long)j - c->row0;             // global row j on this shard?
-      if (lr >= 0 && lr < n) st = c->eng->h2d((double*)ev + (size_t)j * n + lr, &unit, sizeof(double));
-    }
-    if (!st) st = c->eng->gram(n, k, (const double*)ev, k, u, qt.data(), k);
-    int stf = c->eng->free_(ev);
-    if (st || stf) return engfail(c, st ? st : stf);
-  }
+  st = ops->top_rows(n, k, u, row0, qt.data());
+  if (st) return opsfail(c, ops, st);
   // 3. the isometric small matrix.  With Q_low = Q+ without its top k rows, Q_low^T Q_low = I - Qt^T Qt = C C^T and
   //    Z = Q_low C^-T has orthonormal columns, so  U = [e_1..e_k, Z] [Qt; C^T] R+ :  M = [Qt; C^T] R+.  (Formed from the
   //    well-conditioned pieces Qt, C and the triangular R+, column by column -- the small singular directions of an
@@ -601,24 +596,25 @@ static int ortho_qr_impl(dla_ctx* c, int n, int k, double* u)
   if (!any) return DLA_OK;
   std::vector<double> w((size_t)k * k, 0.0);
   for (int j = 0; j < k; ++j) w[(size_t)j + (size_t)j * k] = sign[j];
-  return engfail(c, c->eng->trmm(n, k, u, w.data(), k));
+  return engfail(c, ops->trmm(n, k, u, w.data(), k));
 }
 
 int dla_ortho_qr(dla_ctx* c, int n, int k, double* u)
 {
   DLA_T("dla_ortho_qr");
-  return ortho_qr_impl(c, n, k, u);
+  return ortho_qr_impl(c, c->eng, c->row0, global_rows(c, n), n, k, u);
 }
 
-static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, const double* bx, double* u)
+static int ortho_vs_x_impl(dla_ctx* c, dla::BlockOps* ops, long long row0, long long n_rows_global, int n, int m, int k,
+                           const double* x, const double* bx, double* u)
 {
   if (k <= 0) return DLA_OK;
-  const int kMaxIt = c->eng->ortho_maxit;    // maxit, diaglib.f90:3521
+  const int kMaxIt = ops->ortho_maxit;    // maxit, diaglib.f90:3521
   // device-driven chain first (one host wait per call); shapes / modes it does not take run the host-driven loop below
   {
     dla::OrthoReport rep;
-    int stc = c->eng->ortho_chain(n, m, k, x, bx, u, &rep);
-    if (stc) return engfail(c, stc);
+    int stc = ops->ortho_chain(n, m, k, x, bx, u, &rep);
+    if (stc) return opsfail(c, ops, stc);
     if (rep.handled) {
       if (c->verbose_ortho)
         std::printf("  [dla] ortho_vs_x (device chain): %d outer iterations, %d macro iterations, status %d\n", rep.outer_its,
@@ -634,7 +630,7 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
       // steps have positive diagonals: they keep the column signs the Householder factor has set).
       if (rep.status == 2) {
         std::printf("  ortho_cd failed with the following error: maximum number of iterations reached.\n");
-        int stq = ortho_qr_impl(c, n, k, u);
+        int stq = ortho_qr_impl(c, ops, row0, n_rows_global, n, k, u);
         if (stq) return stq;
       }
       // (status 4, the outer loop ran out of iterations: the host-driven loop repeats it and reports the failure)
@@ -648,17 +644,17 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
   // space(:,1:ldu)), the last triangular update of an ortho_cd that is followed by a projection pass is not
   // applied on its own: with W = Linv^T pending,  X^T (U W) = (X^T U) W  and  U W - X (X^T U W) = [X | U] [-xu; W],
   // so the pass costs one Gram sweep and ONE sweep over [X | U] instead of a U sweep more (16 n k B).
-  const bool combo = m > 0 && u == x + (size_t)n * m && c->eng->can_combo(m, k);
+  const bool combo = m > 0 && u == x + (size_t)n * m && ops->can_combo(m, k);
   std::vector<double> wdef(combo ? (size_t)k * k : 1), cprime(combo ? (size_t)(m + k) * k : 1);
   bool pending = false;
-  int st = ortho_cd_impl(c, n, k, u, &growth, &ok, nullptr, combo ? wdef.data() : nullptr, &pending, true);   // :3533
+  int st = ortho_cd_impl(c, ops, n, k, u, &growth, &ok, nullptr, combo ? wdef.data() : nullptr, &pending, true);   // :3533
   if (st) return st;
-  if (!ok) { st = ortho_qr_impl(c, n, k, u); if (st) return st; }         // :3534
+  if (!ok) { st = ortho_qr_impl(c, ops, row0, n_rows_global, n, k, u); if (st) return st; }         // :3534
   while (!done) {
     ++it;
     if (m > 0) {
-      st = c->eng->gram(n, m, bx, k, u, xu.data(), m);     // xu = X^T U  (:3543) / (BX)^T U (:3632)
-      if (st) return engfail(c, st);
+      st = ops->gram(n, m, bx, k, u, xu.data(), m);     // xu = X^T U  (:3543) / (BX)^T U (:3632)
+      if (st) return opsfail(c, ops, st);
       if (pending) {
         // xu <- xu W ; C' = [-xu ; W]
         const int ldc = m + k;
@@ -670,23 +666,23 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
           }
           for (int p = 0; p < k; ++p) cprime[(size_t)(m + p) + (size_t)j * ldc] = wdef[(size_t)p + (size_t)j * k];
         }
-        st = c->eng->combo_gram(n, m, x, k, cprime.data(), ldc, u, gu.data(), k);
+        st = ops->combo_gram(n, m, x, k, cprime.data(), ldc, u, gu.data(), k);
         pending = false;
       } else {
-        st = c->eng->update_gram(n, m, x, k, xu.data(), m, u, gu.data(), k);   // U -= X xu (:3544) + U^T U for :3548
+        st = ops->update_gram(n, m, x, k, xu.data(), m, u, gu.data(), k);   // U -= X xu (:3544) + U^T U for :3548
       }
-      if (st) return engfail(c, st);
+      if (st) return opsfail(c, ops, st);
     }
-    st = ortho_cd_impl(c, n, k, u, &growth, &ok, m > 0 ? gu.data() : nullptr,
+    st = ortho_cd_impl(c, ops, n, k, u, &growth, &ok, m > 0 ? gu.data() : nullptr,
                        combo ? wdef.data() : nullptr, &pending, false);          // :3548
     if (st) return st;
     if (!ok) {
-      st = ortho_qr_impl(c, n, k, u);                      // :3549
+      st = ortho_qr_impl(c, ops, row0, n_rows_global, n, k, u);                      // :3549
       if (st) return st;
       double s = 0.0;
       if (m > 0) {
-        st = c->eng->gram(n, m, bx, k, u, xu.data(), m);   // :3559-3560
-        if (st) return engfail(c, st);
+        st = ops->gram(n, m, bx, k, u, xu.data(), m);   // :3559-3560
+        if (st) return opsfail(c, ops, st);
         for (size_t i = 0; i < (size_t)m * k; ++i) s += xu[i] * xu[i];
       }
       xu_norm = std::sqrt(s);
@@ -703,13 +699,13 @@ static int ortho_vs_x_impl(dla_ctx* c, int n, int m, int k, const double* x, con
 int dla_ortho_vs_x(dla_ctx* c, int n, int m, int k, const double* x, double* u)
 {
   DLA_T("dla_ortho_vs_x");
-  return ortho_vs_x_impl(c, n, m, k, x, x, u);
+  return ortho_vs_x_impl(c, c->eng, c->row0, global_rows(c, n), n, m, k, x, x, u);
 }
 
 int dla_b_ortho_vs_x(dla_ctx* c, int n, int m, int k, const double* x, const double* bx, double* u)
 {
   DLA_T("dla_b_ortho_vs_x");
-  return ortho_vs_x_impl(c, n, m, k, x, bx, u);
+  return ortho_vs_x_impl(c, c->eng, c->row0, global_rows(c, n), n, m, k, x, bx, u);
 }
 
 // b_ortho, diaglib.f90:3094-3183 (use_svd=.false.): M = U^T BU, L = chol(M) (no failure
@@ -757,19 +753,11 @@ int dla_check_guess(dla_ctx* c, int n, int m, double* evec)
   return DLA_OK;
 }
 
-// Plain host loops for the host-size coefficient blocks of get_coeffs (column-major, ld = rows).  This is not
-// a device engine: it cannot be selected for a context, and everything that touches n-length panels is absent.
+// Plain host loops for the host-size coefficient blocks of get_coeffs (column-major, ld = rows): the few block
+// operations the orthogonalisation control flow needs (dla::BlockOps), nothing else -- no memory management, no
+// reductions over ranks (the coefficient blocks are replicated on every rank).
 namespace {
-struct CoeffAlgebra final : dla::Engine {
-  const char* name() const override { return "coeff-host"; }
-  void* stream() override { return nullptr; }
-  int alloc(size_t, void**) override { return DLA_ERR_ARG; }
-  int free_(void*) override { return DLA_ERR_ARG; }
-  int zero(void*, size_t) override { return DLA_ERR_ARG; }
-  int h2d(void*, const void*, size_t) override { return DLA_ERR_ARG; }
-  int d2h(void*, const void*, size_t) override { return DLA_ERR_ARG; }
-  int d2d(void*, const void*, size_t) override { return DLA_ERR_ARG; }
-  int sync() override { return DLA_OK; }
+struct CoeffOps final : dla::BlockOps {
   int gram(int n, int l, const double* x, int k, const double* u, double* ch, int ldc) override
   {
     for (int j = 0; j < k; ++j)
@@ -813,27 +801,12 @@ struct CoeffAlgebra final : dla::Engine {
     std::memcpy(u, out.data(), sizeof(double) * (size_t)n * k);
     return DLA_OK;
   }
-  int ritz_residual(int, int, int, const double*, const double*, const double*, int, const double*, int, const int*,
-                    double*, double*, double*, double*) override { return DLA_ERR_ARG; }
-  int axpy(size_t len, double alpha, const double* x, double* y) override
+  int top_rows(int n, int k, const double* u, long long, double* qt) override
   {
-    for (size_t i = 0; i < len; ++i) y[i] += alpha * x[i];
+    for (int j = 0; j < k; ++j)
+      for (int i = 0; i < k; ++i) qt[(size_t)i + (size_t)j * k] = (i < n) ? u[(size_t)i + (size_t)j * n] : 0.0;
     return DLA_OK;
   }
-  int sumsq(size_t len, const double* x, double* out) override
-  {
-    double acc = 0.0;
-    for (size_t i = 0; i < len; ++i) acc += x[i] * x[i];
-    *out = acc;
-    return DLA_OK;
-  }
-  int random_fill(int, int, double*, long long, unsigned long long, double, long long) override { return DLA_ERR_ARG; }
-  int synth_setup(long long, long long, int, int, double) override { return DLA_ERR_ARG; }
-  int synth_matvec(int, int, const double*, double*) override { return DLA_ERR_ARG; }
-  int synth_precnd(int, int, double, const double*, double*) override { return DLA_ERR_ARG; }
-  int host_alloc(size_t, void**) override { return DLA_ERR_ARG; }
-  int host_free(void*) override { return DLA_ERR_ARG; }
-  int comm_init(int, int, const char*) override { return DLA_ERR_ARG; }
 };
 }  // namespace
 
@@ -852,14 +825,9 @@ int dla_get_coeffs(dla_ctx* c, int len_a, int len_u, int n_max, int n_act, const
   // u_x / u_p are len_u x n_max coefficient blocks (len_u <= 3 n_max rows, O(1) in n), identical on every
   // rank: like the Cholesky factors and the projected eigenproblem they are host-size data, so the same
   // ortho_vs_x control flow runs on them through the coefficient algebra below -- no launches, no reductions.
-  CoeffAlgebra small;
-  dla_ctx local;
-  local.eng = &small;
-  local.verbose_ortho = c->verbose_ortho;
-  int st = ortho_vs_x_impl(&local, len_u, n_max, n_act, u_x, u_x, u_p);
-  if (st) c->err = local.err.empty() ? small.err : local.err;
-  local.eng = nullptr;
-  return st;
+  CoeffOps small;
+  small.ortho_maxit = c->eng->ortho_maxit;
+  return ortho_vs_x_impl(c, &small, 0, len_u, len_u, n_max, n_act, u_x, u_x, u_p);
 }
 
 // ------------------------------------------------------------------ callbacks

@@ -42,6 +42,11 @@ if world > 1 and spec.get("transport", "hook") == "p2p":
     dist.all_gather_object(everyone, mine)
     ctx.p2p_attach(world, rank, everyone)
     ctx.set_shard(n, row0)
+elif world > 1 and spec.get("transport") == "rccl":
+    uid = [ctx.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    ctx.comm_init(world, rank, uid[0])
+    ctx.set_shard(n, row0)
 elif world > 1:
     ctx.set_allreduce_hook(hook, world, rank)
     ctx.set_shard(n, row0)
@@ -65,20 +70,20 @@ st = ctx.stats()
 np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), eig=eig, ok=ok, iters=info["iters"], cols=info["matvec_cols"],
          row0=row0, vec=ev.download(), allreduces=st["allreduces"], host_syncs=st["host_syncs"])
 dist.barrier()
-if world > 1 and spec.get("transport", "hook") == "p2p":
+if world > 1 and spec.get("transport", "hook") in ("p2p", "rccl"):
     ctx.comm_finalize()
 dist.destroy_process_group()
 """
 
 
-def _run_world(tmp_path, spec, world):
+def _run_world(tmp_path, spec, world, one_gpu_each=False):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, spec=json.dumps(spec), out=str(tmp_path)))
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   LOCAL_RANK="0")
+                   LOCAL_RANK=str(r) if one_gpu_each else "0")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
@@ -117,3 +122,23 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, solver, guess, transport)
     sgn = np.sign((v1 * v2).sum(0))
     assert np.abs(v2 * sgn - v1)[:, :t].max() < 1e-6
     assert np.abs(v2[:, :t].T @ v2[:, :t] - np.eye(t)).max() < 1e-12
+
+
+def test_two_gpus_rccl_equal_one_rank(tmp_path):
+    """the RCCL data path with more than one rank -- one rank per GPU, ncclAllReduce on the engines' streams,
+    device-driven chains with the collective between reduction and tail.  Needs two visible GPUs (skipped on the
+    one-GPU boxes this suite normally runs on)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    spec = dict(n=400_000, n_targ=8, n_max=13, tol=1e-10, solver="davidson", guess="unit", transport="rccl")
+    d1 = tmp_path / "w1"; d1.mkdir()
+    d2 = tmp_path / "w2"; d2.mkdir()
+    one = _run_world(d1, spec, 1)[0]
+    two = _run_world(d2, spec, 2, one_gpu_each=True)
+    t = spec["n_targ"]
+    assert bool(one["ok"]) and all(bool(r["ok"]) for r in two)
+    assert np.array_equal(two[0]["eig"], two[1]["eig"])
+    assert np.allclose(two[0]["eig"][:t], one["eig"][:t], rtol=1e-11, atol=0)
+    assert int(two[0]["iters"]) == int(two[1]["iters"])
+    assert abs(int(two[0]["iters"]) - int(one["iters"])) <= max(1, int(one["iters"]) // 5)
