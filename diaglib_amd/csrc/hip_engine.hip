@@ -95,6 +95,7 @@ struct GramArgs {
   int lower;         // 1: only tile pairs on or below the block diagonal are needed (symmetric result, 'l' consumer)
   const int* phase;  // device-driven chains (ortho_chain): run only if *phase == want; nullptr = always
   int want;
+  int noskip;        // A/B: issue the loads of fully padded column groups too (gram_lds_kernel)
 };
 
 // A launch of a device-driven chain is speculative: the step it belongs to may not be the one the device-side state
@@ -103,6 +104,17 @@ struct GramArgs {
 
 // (NT stays 0 here: the two 64-byte halves of a line are fetched by consecutive instructions and rely on
 // the cache to merge; non-temporal loads measured -10 %)
+// Quarter tiles.  v_mfma_f64_4x4x4 multiplies four independent 4x4x4 blocks in a quarter of the cycles of the 16x16x4 form
+// (15 vs 60 measured, tools/mfma_probe.hip).  Lane (kk = lane>>4, blk = (lane>>2)&3, t = lane&3) supplies A[blk][t][kk] and
+// B[blk][kk][t]; D[blk][i][j] comes back in lane 16 i + 4 blk + j.  With the SAME A value in all four blocks and the
+// usual 16-wide fragment as B this is "4 columns of a 16x16x4 product": lane L receives D[4 qq + (L>>4)][L&15], exactly
+// component qq of the 16x16x4 accumulator.  A block whose last 16-column tile holds only 4*QT live columns (37 = 32 + 5,
+// 21 = 16 + 5) pays QT quarter instructions for that tile instead of a full one.
+__device__ __forceinline__ double mfma_quarter(double a4, double b16, double acc)
+{
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a4, b16, acc, 0, 0, 0);
+}
+
 template <int TLW, int KT, int VEC, int RSTEP, int NT = 0, int PF = -1>
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 {
@@ -246,7 +258,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 // Even n only (16-byte row pairs).
 // SELF: U is X itself (Gram matrix of one block, TLW == KT, a single pass): the tiles are loaded and staged once and serve as
 // both operands -- half the load instructions and LDS traffic of the general kernel on the same algorithmic bytes.
-template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0>
+// QT > 0 (single U pass only): the last U tile -- for SELF the last tile of the block -- has 4*QT live columns and is multiplied
+// by quarter instructions (mfma_quarter).  SELF puts the narrow tile on the A side, which lands in the standard
+// accumulator layout; the general kernel has it on the B side, where lane L receives
+// D[4 ((L>>2)&3) + (L>>4)][4 qq + (L&3)] -- put back in place when the accumulators go through LDS at the end.
+template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0, int QT = 0>
 __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
 {
   DLA_PREDICATED(a);
@@ -265,55 +281,99 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   const int xg = blockIdx.y % a.passes_x, ug = blockIdx.y / a.passes_x;
   const long long n = a.n;
 
-  // staged column j*CPI + lc of this lane -> panel column (clamped: garbage only reaches unused rows/columns of D)
-  const double* cp[NI];
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int sc = CPI * j + lc;
-    if (sc < 16 * TLW) {
-      int col = xg * TLW * 16 + sc;
-      col = col < a.l ? col : a.l - 1;
-      cp[j] = a.x + (size_t)col * (size_t)n + 2 * li;
-    } else {
-      int col = ug * KT * 16 + (sc - 16 * TLW);
-      col = col < a.k ? col : a.k - 1;
-      cp[j] = a.u + (size_t)col * (size_t)n + 2 * li;
-    }
-  }
+  // tile pairs this pass forms: both tiles must hold columns of their block, and with `lower` the pair must lie on or
+  // below the block diagonal
   v4d acc[TLW][KT];
   bool want[TLW][KT];
   bool any_want = false;
+  unsigned tile_used = 0;                  // staged tiles some wanted pair reads (bit = staged tile index)
 #pragma unroll
   for (int t = 0; t < TLW; ++t)
 #pragma unroll
     for (int q = 0; q < KT; ++q) {
       acc[t][q] = (v4d){0.0, 0.0, 0.0, 0.0};
-      want[t][q] = !a.lower || (xg * TLW + t >= ug * KT + q);
+      const int xt = xg * TLW + t, ut = ug * KT + q;
+      want[t][q] = (16 * xt < a.l) && (16 * ut < a.k) && (!a.lower || xt >= ut);
       any_want = any_want || want[t][q];
+      if (want[t][q]) tile_used |= (1u << t) | (1u << (SELF ? q : TLW + q));
     }
+  // staged column j*CPI + lc of this lane -> panel column (clamped: garbage only reaches unused rows/columns of D).
+  // Load instructions whose columns all lie beyond the block (40..47 of a 37-column block), or in a tile no wanted pair
+  // reads (the tiles above the diagonal of a `lower` pass), are never issued: their staged columns hold zeros from the start
+  const double* cp[NI];
+  unsigned skip = 0;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int sc = CPI * j + lc;
+    if (!(tile_used & (1u << ((CPI * j) / 16)))) skip |= 1u << j;
+    if (sc < 16 * TLW) {
+      int col = xg * TLW * 16 + sc;
+      if (xg * TLW * 16 + CPI * j >= a.l) skip |= 1u << j;
+      col = col < a.l ? col : a.l - 1;
+      cp[j] = a.x + (size_t)col * (size_t)n + 2 * li;
+    } else {
+      int col = ug * KT * 16 + (sc - 16 * TLW);
+      if (ug * KT * 16 + (CPI * j - 16 * TLW) >= a.k) skip |= 1u << j;
+      col = col < a.k ? col : a.k - 1;
+      cp[j] = a.u + (size_t)col * (size_t)n + 2 * li;
+    }
+  }
+  if (a.noskip) skip = 0;
+  if (skip) {
+    for (int idx = 2 * lane; idx < NC * RS; idx += 128) lds_store2(my + idx, vzero<2>());
+  }
+  const int i4 = lane & 3;
+  // quarter tiles' accumulators, scalars of their own (see gemm_kernel): SELF [U tile][quarter], else [X tile][quarter]
+  double accq[SELF ? KT : TLW][QT > 0 ? QT : 1];
+#pragma unroll
+  for (int t = 0; t < (SELF ? KT : TLW); ++t)
+#pragma unroll
+    for (int qq = 0; qq < (QT > 0 ? QT : 1); ++qq) accq[t][qq] = 0.0;
   typedef VecOf<2>::type vec_t;
   vec_t stg[NI];
   auto load_tile = [&](long long tile) {
     const long long r0 = tile * R;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) stg[j] = pload<2, NT>(cp[j] + r0);
+    for (int j = 0; j < NI; ++j)
+      if (!(skip & (1u << j))) stg[j] = pload<2, NT>(cp[j] + r0);
   };
   auto stage_tile = [&]() {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) lds_store2(my + (size_t)(CPI * j + lc) * RS + 2 * li, stg[j]);
+    for (int j = 0; j < NI; ++j)
+      if (!(skip & (1u << j))) lds_store2(my + (size_t)(CPI * j + lc) * RS + 2 * li, stg[j]);
   };
+  constexpr int KF = (QT > 0 && !SELF) ? KT - 1 : KT;     // U tiles multiplied by full instructions
+  constexpr int TF = (QT > 0 && SELF) ? TLW - 1 : TLW;    // X tiles ...
   auto mfma_tile = [&]() {
 #pragma unroll
     for (int s4 = 0; s4 < R / 4; ++s4) {
       double uf[KT];
 #pragma unroll
-      for (int q = 0; q < KT; ++q) uf[q] = lds_load1(my + (size_t)(UOFF + 16 * q + c) * RS + 4 * s4 + g);
+      for (int q = 0; q < (SELF ? KT : KF); ++q) uf[q] = lds_load1(my + (size_t)(UOFF + 16 * q + c) * RS + 4 * s4 + g);
+      double uq[QT > 0 ? QT : 1];
+      if constexpr (QT > 0 && !SELF) {
 #pragma unroll
-      for (int t = 0; t < TLW; ++t) {
+        for (int qq = 0; qq < QT; ++qq) uq[qq] = lds_load1(my + (size_t)(UOFF + 16 * KF + 4 * qq + i4) * RS + 4 * s4 + g);
+      }
+#pragma unroll
+      for (int t = 0; t < TF; ++t) {
         const double xf = lds_load1(my + (size_t)(16 * t + c) * RS + 4 * s4 + g);
 #pragma unroll
-        for (int q = 0; q < KT; ++q)
+        for (int q = 0; q < KF; ++q)
           if (want[t][q]) acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf, uf[q], acc[t][q], 0, 0, 0);
+        if constexpr (QT > 0 && !SELF) {
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq)
+            if (want[t][KT - 1]) accq[t][qq] = mfma_quarter(xf, uq[qq], accq[t][qq]);
+        }
+      }
+      if constexpr (QT > 0 && SELF) {
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) {
+          const double xq = lds_load1(my + (size_t)(16 * TF + 4 * qq + i4) * RS + 4 * s4 + g);
+#pragma unroll
+          for (int q = 0; q < KT; ++q) accq[q][qq] = mfma_quarter(xq, uf[q], accq[q][qq]);
+        }
       }
     }
   };
@@ -357,8 +417,19 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   for (int t = 0; t < TLW; ++t)
 #pragma unroll
     for (int q = 0; q < KT; ++q) {
+      if (QT > 0 && !SELF && q == KT - 1) {
+        // quarter results back to the standard layout: (row 4 blk + i', column 4 qq + j) lives in component blk of lane 16 i' + 4 qq + j
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = acc[t][q][r];
+        for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = 0.0;
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) red[wave * 256 + ((lane >> 2) & 3) * 64 + 16 * g + 4 * qq + i4] = accq[t][qq];
+      } else if (QT > 0 && SELF && t == TLW - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = r < QT ? accq[q][r < QT ? r : 0] : 0.0;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = acc[t][q][r];
+      }
       __syncthreads();
       double sum = ((red[threadIdx.x] + red[256 + threadIdx.x]) + red[512 + threadIdx.x]) + red[768 + threadIdx.x];
       pout[(size_t)(t * KT + q) * 256 + threadIdx.x] = sum;
@@ -383,6 +454,7 @@ struct GemmArgs {
   int l, l4, k;
   const int* phase;    // see DLA_PREDICATED
   int want;
+  int xpf;             // 1: the first column stage of a wave's next row tile is loaded before the epilogue of the current one
 };
 
 // small C (l <= 16, k <= 16) travels inside the kernel arguments: no staging copy, no extra launch
@@ -394,6 +466,7 @@ struct GemmArgsInl {
   int l, l4, k;
   const int* phase;
   int want;
+  int xpf;
   double cin[256];     // packed C: [l4 <= 16][16]
 };
 __device__ __forceinline__ const double* packed_c(const GemmArgs& a) { return a.cpk; }
@@ -410,25 +483,35 @@ __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return
 // column steps are processed PIPE at a time through a two-stage register pipeline -- the loads of the next
 // stage are in flight while the MFMAs of the current one issue.  For KT == 1 occupancy hides the latency
 // better than registers do (A/B: batching there costs 5-10 %).
-template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1), int PIPE = (KT >= 2 ? 2 : 0), int ZPAD = 9>
+// QT > 0: the last tile has only 4*QT live columns and is formed by quarter instructions (see mfma_quarter).
+template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1), int PIPE = (KT >= 2 ? 2 : 0), int ZPAD = 9,
+          int QT = 0, int RTP = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 {
   DLA_PREDICATED(a);
-  constexpr int RT = 2;                    // row groups per wave tile
+  constexpr int RT = RTP;                  // row groups per wave tile
   constexpr int RG = 16 * VEC;             // rows per group
   constexpr int WT = RT * RG;              // rows per wave tile (64 for VEC=2)
   extern __shared__ __attribute__((aligned(16))) double cs[];  // [KT][l4][16]
   typedef typename VecOf<VEC>::type vec_t;
   const long long n = a.n;
   const int l = a.l, l4 = a.l4;
+  constexpr int KF = QT > 0 ? KT - 1 : KT;   // tiles formed by full 16x16x4 instructions
+  // LDS copy of C: the full tiles as packed, [KF][l4][16]; of a quarter-tile block's last tile only the 8 leading columns,
+  // [l4][8] (a 148-row C' of the [X | U] sweep at k = 37 then leaves room for two blocks per CU)
+  const int csz = KF * l4 * 16 + (QT > 0 ? l4 * 8 : 0);
   {
     const double* csrc = packed_c(a);
-    for (int idx = threadIdx.x; idx < KT * l4 * 16; idx += 256) cs[idx] = csrc[idx];
+    for (int idx = threadIdx.x; idx < KF * l4 * 16; idx += 256) cs[idx] = csrc[idx];
+    if constexpr (QT > 0) {
+      for (int idx = threadIdx.x; idx < l4 * 8; idx += 256) cs[KF * l4 * 16 + idx] = csrc[KF * l4 * 16 + (idx >> 3) * 16 + (idx & 7)];
+    }
   }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
+  const int i4 = lane & 3;                  // quarter tiles: column of the 4-column group this lane's A value belongs to
   const long long ntiles = (n + WT - 1) / WT;
   const int nsteps = l4 / 4;
   // LDS row stride of the transpose tile (doubles).  The fragment reads run along a row (16 lanes, 128 contiguous
@@ -436,13 +519,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
   // column, ZS doubles apart: an odd ZS spreads them over all banks.  (The first version used 16*KT + 8 with rows
   // 2 apart: all 16 lanes on one bank, measured as 25 % LDS-issue stall in the 13-column TRMM+Gram sweep.)
   constexpr int ZS = 16 * KT + ZPAD;
-  double* zs = cs + (size_t)KT * l4 * 16 + (size_t)wave * 16 * ZS;   // [16 rows][ZS] per wave (GRAM only)
+  double* zs = cs + (size_t)csz + (size_t)wave * 16 * ZS;            // [16 rows][ZS] per wave (GRAM only)
   v4d gacc[KT][KT];                                        // tile (qa, qb) of Z^T Z, qa >= qb only
 #pragma unroll
   for (int qa = 0; qa < KT; ++qa)
 #pragma unroll
     for (int qb = 0; qb < KT; ++qb) gacc[qa][qb] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double gaccq[KT][QT > 0 ? QT : 1];                       // quarter rows of the last block row of G
+#pragma unroll
+  for (int qb = 0; qb < KT; ++qb)
+#pragma unroll
+    for (int qq = 0; qq < (QT > 0 ? QT : 1); ++qq) gaccq[qb][qq] = 0.0;
 
+  // PIPE > 0: the first column stage of this wave's NEXT row tile, in flight while the epilogue of the current one
+  // (stores, and for GRAM the transposes and 4..6 more MFMAs per row group) runs
+  vec_t xnext[PIPE > 0 ? PIPE : 1][RT];
+  bool have_next = false;
   for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
     const long long r0 = tile * WT;
     v4d acc[RT][VEC][KT];
@@ -452,6 +544,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
       for (int e = 0; e < VEC; ++e)
 #pragma unroll
         for (int q = 0; q < KT; ++q) acc[rt][e][q] = (v4d){0.0, 0.0, 0.0, 0.0};
+    // the quarter tiles' accumulators are scalars of their own (as components of a v4d the compiler shuttles the whole
+    // tuple between AGPRs and VGPRs around every quarter instruction)
+    double accq[RT][VEC][QT > 0 ? QT : 1];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+#pragma unroll
+        for (int qq = 0; qq < (QT > 0 ? QT : 1); ++qq) accq[rt][e][qq] = 0.0;
+    auto accv = [&](int rt, int e, int q, int reg) -> double {
+      if (QT > 0 && q == KF) return reg < QT ? accq[rt][e][reg < QT ? reg : 0] : 0.0;
+      return acc[rt][e][q][reg];
+    };
 
     long long row[RT];
     bool rok[RT];
@@ -477,19 +582,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
         for (int u4 = 0; u4 < PIPE; ++u4) {
           double cfu[KT];
 #pragma unroll
-          for (int q = 0; q < KT; ++q) cfu[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * (c0 + u4) + g) * 16 + i];
+          for (int q = 0; q < KF; ++q) cfu[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * (c0 + u4) + g) * 16 + i];
+          double cfq[QT > 0 ? QT : 1];
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) cfq[qq] = cs[(size_t)KF * l4 * 16 + (size_t)(4 * (c0 + u4) + g) * 8 + 4 * qq + i4];
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e)
+            for (int e = 0; e < VEC; ++e) {
 #pragma unroll
-              for (int q = 0; q < KT; ++q)
+              for (int q = 0; q < KF; ++q)
                 acc[rt][e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(xs[u4][rt], e), acc[rt][e][q], 0, 0, 0);
+#pragma unroll
+              for (int qq = 0; qq < QT; ++qq)
+                accq[rt][e][qq] = mfma_quarter(cfq[qq], vget<VEC>(xs[u4][rt], e), accq[rt][e][qq]);
+            }
         }
       };
       if (PIPE <= nfull4) {
         vec_t xa[PIPE][RT];
-        load_stage(0, xa);
+        if (have_next) {
+#pragma unroll
+          for (int u4 = 0; u4 < PIPE; ++u4)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) xa[u4][rt] = xnext[u4][rt];
+        } else {
+          load_stage(0, xa);
+        }
         for (; cs4 + 2 * PIPE <= nfull4; cs4 += PIPE) {
           vec_t xb[PIPE][RT];
           load_stage(cs4 + PIPE, xb);
@@ -516,15 +635,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
       }
       double cf[KT];
 #pragma unroll
-      for (int q = 0; q < KT; ++q) cf[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * cs4 + g) * 16 + i];
+      for (int q = 0; q < KF; ++q) cf[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * cs4 + g) * 16 + i];
+      double cfq[QT > 0 ? QT : 1];
+#pragma unroll
+      for (int qq = 0; qq < QT; ++qq) cfq[qq] = cs[(size_t)KF * l4 * 16 + (size_t)(4 * cs4 + g) * 8 + 4 * qq + i4];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e)
+        for (int e = 0; e < VEC; ++e) {
 #pragma unroll
-          for (int q = 0; q < KT; ++q) {
+          for (int q = 0; q < KF; ++q)
             acc[rt][e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[q], vget<VEC>(xv[rt], e), acc[rt][e][q], 0, 0, 0);
-          }
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq)
+            accq[rt][e][qq] = mfma_quarter(cfq[qq], vget<VEC>(xv[rt], e), accq[rt][e][qq]);
+        }
+    }
+    if constexpr (PIPE > 0) {
+      have_next = false;
+      const long long ntile = tile + (long long)gridDim.x * 4;
+      if (a.xpf && PIPE <= l / 4 && ntile < ntiles) {
+        // (in place, MODE 2: the next tile's rows are not this tile's rows, nothing stored below is read here)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          long long nr = ntile * WT + rt * RG + VEC * i;
+          if (nr >= n) nr = 0;
+#pragma unroll
+          for (int u4 = 0; u4 < PIPE; ++u4) xnext[u4][rt] = pload<VEC, NT>(a.x + (size_t)(4 * u4 + g) * (size_t)n + nr);
+        }
+        have_next = true;
+      }
     }
     // epilogue
 #pragma unroll
@@ -539,7 +679,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
           vec_t v = vzero<VEC>();
           if (rok[rt] && j < a.k) {
             double* zp = a.z + (size_t)j * (size_t)n + row[rt];
-            v = vmake<VEC>(acc[rt][0][q][reg], acc[rt][VEC - 1][q][reg]);
+            v = vmake<VEC>(accv(rt, 0, q, reg), accv(rt, VEC - 1, q, reg));
             // (loading the old values ahead of the sweep costs 32 VGPRs = 3 waves per SIMD and is slower)
             if constexpr (MODE == 1) { vec_t old = *(const vec_t*)zp; v = old - v; }
             if constexpr (MODE == 3) { vec_t old = *(const vec_t*)zp; v = old + v; }
@@ -563,10 +703,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 #pragma unroll
             for (int q = 0; q < KT; ++q) zv[q] = zs[(4 * s4 + g) * ZS + 16 * q + i];
 #pragma unroll
-            for (int qa = 0; qa < KT; ++qa)
+            for (int qa = 0; qa < KF; ++qa)
 #pragma unroll
               for (int qb = 0; qb <= qa; ++qb)
                 gacc[qa][qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[qa], zv[qb], gacc[qa][qb], 0, 0, 0);
+            // rows 4 qq .. 4 qq + 3 of the last block row of G: 4 columns of Z as A, the usual fragments as B
+#pragma unroll
+            for (int qq = 0; qq < QT; ++qq) {
+              const double za = zs[(4 * s4 + g) * ZS + 16 * KF + 4 * qq + i4];
+#pragma unroll
+              for (int qb = 0; qb < KT; ++qb) gaccq[qb][qq] = mfma_quarter(za, zv[qb], gaccq[qb][qq]);
+            }
           }
           __builtin_amdgcn_wave_barrier();
         }
@@ -584,7 +731,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
       for (int qb = 0; qb < KT; ++qb) {
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = gacc[qa][qb][r];
+        for (int r = 0; r < 4; ++r)
+          red[wave * 256 + r * 64 + lane] = (QT > 0 && qa == KF) ? (r < QT ? gaccq[qb][r < QT ? r : 0] : 0.0) : gacc[qa][qb][r];
         __syncthreads();
         a.gpart[((size_t)blockIdx.x * (KT * KT) + (qa * KT + qb)) * 256 + t] =
             ((red[t] + red[256 + t]) + red[512 + t]) + red[768 + t];
@@ -612,7 +760,7 @@ struct RitzArgs {
 
 // NT = 3: V / AV are read once and evec / r written once per sweep -> non-temporal loads and stores
 // (+6 % measured, tools/tune_ab.py)
-template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 2 ? 2 : 0)>
+template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 2 ? 2 : 0), int QT = 0>
 __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 {
   constexpr int RG = 16 * VEC;             // rows per wave tile (one row group)
@@ -620,7 +768,11 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
   typedef typename VecOf<VEC>::type vec_t;
   const long long n = a.n;
   const int l = a.l, l4 = a.l4;
-  for (int idx = threadIdx.x; idx < KT * l4 * 16; idx += 256) cs[idx] = a.cpk[idx];
+  constexpr int KF = QT > 0 ? KT - 1 : KT;   // full tiles; the last tile has 4*QT live columns (see mfma_quarter)
+  for (int idx = threadIdx.x; idx < KF * l4 * 16; idx += 256) cs[idx] = a.cpk[idx];
+  if constexpr (QT > 0) {                    // ... and keeps only its 8 leading columns in LDS, [l4][8] (see gemm_kernel)
+    for (int idx = threadIdx.x; idx < l4 * 8; idx += 256) cs[KF * l4 * 16 + idx] = a.cpk[KF * l4 * 16 + (idx >> 3) * 16 + (idx & 7)];
+  }
   __shared__ double s_theta[48];
   __shared__ int s_active[48];
   if (threadIdx.x < 48) { s_theta[threadIdx.x] = a.theta[threadIdx.x]; s_active[threadIdx.x] = a.active[threadIdx.x]; }
@@ -628,6 +780,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
+  const int i4 = lane & 3;
   const long long ntiles = (n + RG - 1) / RG;
   const int nsteps = l4 / 4;
 
@@ -654,6 +807,19 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
     for (int e = 0; e < VEC; ++e)
 #pragma unroll
       for (int q = 0; q < KT; ++q) { av[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; aav[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+    double avq[VEC][QT > 0 ? QT : 1], aavq[VEC][QT > 0 ? QT : 1];   // quarter tiles: scalars of their own (see gemm_kernel)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+      for (int qq = 0; qq < (QT > 0 ? QT : 1); ++qq) { avq[e][qq] = 0.0; aavq[e][qq] = 0.0; }
+    auto avv = [&](int e, int q, int reg) -> double {
+      if (QT > 0 && q == KF) return reg < QT ? avq[e][reg < QT ? reg : 0] : 0.0;
+      return av[e][q][reg];
+    };
+    auto aavv = [&](int e, int q, int reg) -> double {
+      if (QT > 0 && q == KF) return reg < QT ? aavq[e][reg < QT ? reg : 0] : 0.0;
+      return aav[e][q][reg];
+    };
     int cs4 = 0;
     if constexpr (PIPE > 0) {
       // two-stage register pipeline over column steps (see gemm_kernel)
@@ -671,14 +837,23 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
         for (int u4 = 0; u4 < PIPE; ++u4) {
           double cfu[KT];
 #pragma unroll
-          for (int q = 0; q < KT; ++q) cfu[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * (c0 + u4) + g) * 16 + i];
+          for (int q = 0; q < KF; ++q) cfu[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * (c0 + u4) + g) * 16 + i];
+          double cfq[QT > 0 ? QT : 1];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e)
+          for (int qq = 0; qq < QT; ++qq) cfq[qq] = cs[(size_t)KF * l4 * 16 + (size_t)(4 * (c0 + u4) + g) * 8 + 4 * qq + i4];
 #pragma unroll
-            for (int q = 0; q < KT; ++q) {
+          for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+            for (int q = 0; q < KF; ++q) {
               av[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(xs[u4], e), av[e][q], 0, 0, 0);
               aav[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(ys[u4], e), aav[e][q], 0, 0, 0);
             }
+#pragma unroll
+            for (int qq = 0; qq < QT; ++qq) {
+              avq[e][qq] = mfma_quarter(cfq[qq], vget<VEC>(xs[u4], e), avq[e][qq]);
+              aavq[e][qq] = mfma_quarter(cfq[qq], vget<VEC>(ys[u4], e), aavq[e][qq]);
+            }
+          }
         }
       };
       if (PIPE <= nfull4) {
@@ -705,14 +880,23 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
       yv = cok ? yv : vzero<VEC>();
       double cf[KT];
 #pragma unroll
-      for (int q = 0; q < KT; ++q) cf[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * cs4 + g) * 16 + i];
+      for (int q = 0; q < KF; ++q) cf[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * cs4 + g) * 16 + i];
+      double cfq[QT > 0 ? QT : 1];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e)
+      for (int qq = 0; qq < QT; ++qq) cfq[qq] = cs[(size_t)KF * l4 * 16 + (size_t)(4 * cs4 + g) * 8 + 4 * qq + i4];
 #pragma unroll
-        for (int q = 0; q < KT; ++q) {
+      for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+        for (int q = 0; q < KF; ++q) {
           av[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[q], vget<VEC>(xv, e), av[e][q], 0, 0, 0);
           aav[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[q], vget<VEC>(yv, e), aav[e][q], 0, 0, 0);
         }
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) {
+          avq[e][qq] = mfma_quarter(cfq[qq], vget<VEC>(xv, e), avq[e][qq]);
+          aavq[e][qq] = mfma_quarter(cfq[qq], vget<VEC>(yv, e), aavq[e][qq]);
+        }
+      }
     }
     if (rok) {
 #pragma unroll
@@ -721,8 +905,8 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
         for (int reg = 0; reg < 4; ++reg) {
           const int j = 16 * q + g + 4 * reg;
           if (j >= a.k) continue;
-          const double e0 = av[0][q][reg], e1 = av[VEC - 1][q][reg];
-          double r0 = aav[0][q][reg], r1 = aav[VEC - 1][q][reg];
+          const double e0 = avv(0, q, reg), e1 = avv(VEC - 1, q, reg);
+          double r0 = aavv(0, q, reg), r1 = aavv(VEC - 1, q, reg);
           if (a.avy) pstore<VEC, NT>(a.avy + (size_t)j * (size_t)n + row, vmake<VEC>(r0, r1));
           if (act[q][reg]) {
             r0 = r0 - th[q][reg] * e0;   // daxpy(-eig), reference diaglib.f90:1729
@@ -2275,26 +2459,29 @@ struct HipEngine : dla::Engine {
   template <int TLW, int KT, int R>
   int launch_gram_lds(const GramArgs& a, dim3 grid)
   {
+#define GLK(SELF_, Q)                                                                                          \
+    do {                                                                                                      \
+      auto kfn = gram_lds_kernel<TLW, KT, 1, R, SELF_, Q>;                                                    \
+      const size_t lds = sizeof(double) * 4 * 16 * (SELF_ ? TLW : TLW + KT) * (R + 2);                        \
+      if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;                                          \
+      hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);                                                   \
+      return DLA_OK;                                                                                          \
+    } while (0)
     if constexpr (TLW == KT) {
       if (cur_self) {
-        auto kfs = gram_lds_kernel<TLW, KT, 1, R, 1>;
-        const size_t ldss = sizeof(double) * 4 * 16 * TLW * (R + 2);
-        if (!raise_lds((const void*)kfs, ldss)) return DLA_ERR_RUNTIME;
-        hipLaunchKernelGGL(kfs, grid, dim3(256), ldss, st, a);
-        return DLA_OK;
+        if constexpr (KT >= 2) { if (cur_qt == 1) GLK(1, 1); if (cur_qt == 2) GLK(1, 2); }
+        GLK(1, 0);
       }
     }
-    auto kfn = gram_lds_kernel<TLW, KT, 1, R>;
-    const size_t lds = sizeof(double) * 4 * 16 * (TLW + KT) * (R + 2);
-    if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
-    return DLA_OK;
+    if constexpr (KT >= 2) { if (cur_qt == 1) GLK(0, 1); if (cur_qt == 2) GLK(0, 2); }
+    GLK(0, 0);
+#undef GLK
   }
   // tile rows of the LDS-staged kernel: 32 for narrow passes (few loads per tile otherwise) and for 3-tile U blocks,
   // 16 elsewhere (A/B at n = 2e6, tools/tune_gram.py)
   int lds_rows(int tlw, int kt) const
   {
-    const int r = (tlw <= 2 || kt == 3) ? 32 : 16;
+    const int r = ((tlw <= 2 || kt == 3) && tlw + kt <= 7) ? 32 : 16;   // (more than 7 tiles of 32 rows: too many staging registers)
     return (r == 32 && sizeof(double) * 4 * 16 * (size_t)(tlw + kt) * 34 > lds_limit) ? 16 : r;
   }
   // (a pass narrower than one tile, e.g. the 4-column W^T x of the benchmark operator, would stage mostly
@@ -2302,17 +2489,19 @@ struct HipEngine : dla::Engine {
   bool use_lds_gram(bool vec2, int l, int kt) const { return vec2 && kt <= 3 && l > 8 && tune[5] != 2; }
   bool cur_lds = false;   // decision of the Gram being launched
   bool cur_self = false;  // ... a block against itself in one pass: staged once (gram_lds_kernel SELF)
+  int cur_qt = 0;         // ... quarter tiles of its last U tile (gram_lds_kernel QT)
   template <int TLW, int KT>
   int launch_gram(const GramArgs& a, dim3 grid, bool vec2)
   {
     if constexpr (KT <= 3) {
       if (cur_lds) {
-        constexpr bool can32 = sizeof(double) * 4 * 16 * (TLW + KT) * 34 <= 150 * 1024;
+        constexpr bool can32 = sizeof(double) * 4 * 16 * (TLW + KT) * 34 <= 150 * 1024 && TLW + KT <= 7;
         if constexpr (can32) { if (lds_rows(TLW, KT) == 32) return launch_gram_lds<TLW, KT, 32>(a, grid); }
         return launch_gram_lds<TLW, KT, 16>(a, grid);
       }
     }
-    if constexpr (TLW == 5 || TLW == 7 || TLW == 10 || (TLW == 12 && KT > 1) || (TLW == 3 && KT >= 2 && KT <= 3)) {
+    if constexpr (TLW == 5 || TLW == 7 || TLW == 10 || (TLW == 12 && KT > 1) || (TLW == 3 && KT >= 2 && KT <= 3) || (TLW >= 5 && KT == 3) ||
+                  (TLW >= 7 && KT == 2)) {
       err = "gram: width without a direct-load instance";
       return DLA_ERR_RUNTIME;
     } else {
@@ -2342,7 +2531,11 @@ struct HipEngine : dla::Engine {
     // widest pass: the direct-load kernel loses its register prefetch stage beyond 8 tiles (measured); the LDS-staged
     // one keeps all of X's columns of up to 12 tiles in one pass, so U is read once for L <= 192
     static const int maxtl[5] = {0, 8, 6, 4, 3};
-    int mt = (ldsk && kt == 1) ? 12 : maxtl[kt];
+    // (the LDS-staged kernel runs at one wave per SIMD for wide passes anyway; its accumulators spill over into the
+    // AGPRs, up to 21 tiles: fewer passes = fewer re-reads of U, and `lower` passes skip the tiles above the diagonal)
+    static const int maxtl_lds[4] = {0, 12, 8, 7};
+    int mt = ldsk ? maxtl_lds[kt] : maxtl[kt];
+    if (tune[7] == 3) mt = (ldsk && kt == 1) ? 12 : maxtl[kt];       // A/B: the narrower passes
     // the LDS-staged kernel stages 16 (tlw + kt) columns of 18 doubles per wave: keep the pass inside lds_limit
     if (ldsk) mt = std::max(1, std::min(mt, (int)(lds_limit / (sizeof(double) * 4 * 16 * 18)) - kt));
     const int passes_x = (tx + mt - 1) / mt;
@@ -2352,8 +2545,8 @@ struct HipEngine : dla::Engine {
     static const int avail1l[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
     if (kt == 1 && ldsk) { for (int v : avail1l) if (v >= tlw) { tlw = v; break; } }
     else if (kt == 1) { for (int v : avail1) if (v >= tlw) { tlw = v; break; } }
-    else if (kt == 2 && ldsk) { tlw = std::min(tlw, 6); }                       // 1..6 all instantiated
-    else if (kt == 3 && ldsk) { tlw = std::min(tlw, 4); }                       // 1..4
+    else if (kt == 2 && ldsk) { tlw = std::min(tlw, 8); }                       // 1..8 all instantiated
+    else if (kt == 3 && ldsk) { tlw = std::min(tlw, 7); }                       // 1..7
     else if (kt == 2) { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : tlw <= 4 ? 4 : 6; }
     else if (kt == 3) { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : 4; }
     else { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : 3; }
@@ -2363,6 +2556,7 @@ struct HipEngine : dla::Engine {
     // below the diagonal are formed (the host side mirrors, see gram())
     cur_self = ldsk && x == u && l == k && passes == 1 && tlw == kt;
     if (cur_self) lower = true;
+    cur_qt = (ldsk && passes_u == 1 && kt >= 2) ? quarter_tiles(k, vec2) : 0;
     const int ch = vec2 ? 32 : 16;
     long long nchunks = ((long long)n + ch - 1) / ch;
     long long want = (nchunks + 4 * 4 - 1) / (4 * 4);   // >= 4 chunks per wave
@@ -2377,22 +2571,23 @@ struct HipEngine : dla::Engine {
     if (stc) return stc;
     stc = ensure_small(sizeof(double) * (size_t)l * k);
     if (stc) return stc;
-    GramArgs a{x, u, d_partial, (long long)n, l, k, px, lower ? 1 : 0, pred_phase, pred_want};
+    GramArgs a{x, u, d_partial, (long long)n, l, k, px, lower ? 1 : 0, pred_phase, pred_want, tune[7] == 2 ? 1 : 0};
     dim3 grid(blocks_per_pass, passes);
     {
       const bool same = (x == u) && (l == k);
       const int rs = (tlw * kt >= 6) ? 2 : 4;
       char kn[64];
       if (cur_lds) {
-        const bool can32 = sizeof(double) * 4 * 16 * (tlw + kt) * 34 <= 150 * 1024;
-        std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d, %d>", tlw, kt, (can32 && lds_rows(tlw, kt) == 32) ? 32 : 16, cur_self ? 1 : 0);
+        const bool can32 = sizeof(double) * 4 * 16 * (tlw + kt) * 34 <= 150 * 1024 && tlw + kt <= 7;
+        std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d, %d, %d>", tlw, kt, (can32 && lds_rows(tlw, kt) == 32) ? 32 : 16, cur_self ? 1 : 0,
+                      cur_qt);
       }
       else std::snprintf(kn, sizeof kn, "gram_kernel<%d, %d, %d, %d, 0, -1>", tlw, kt, vec2 ? 2 : 1, rs);
       Scope s(this, cls, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k, kn);
 #define GL(T, K) if (tlw == T && kt == K) { int r_ = launch_gram<T, K>(a, grid, vec2); if (r_) return r_; } else
       GL(1, 1) GL(2, 1) GL(3, 1) GL(4, 1) GL(5, 1) GL(6, 1) GL(7, 1) GL(8, 1) GL(10, 1) GL(12, 1)
-      GL(1, 2) GL(2, 2) GL(3, 2) GL(4, 2) GL(5, 2) GL(6, 2)
-      GL(1, 3) GL(2, 3) GL(3, 3) GL(4, 3)
+      GL(1, 2) GL(2, 2) GL(3, 2) GL(4, 2) GL(5, 2) GL(6, 2) GL(7, 2) GL(8, 2)
+      GL(1, 3) GL(2, 3) GL(3, 3) GL(4, 3) GL(5, 3) GL(6, 3) GL(7, 3)
       GL(1, 4) GL(2, 4) GL(3, 4)
       { err = "gram: no kernel instance"; return DLA_ERR_RUNTIME; }
 #undef GL
@@ -2582,31 +2777,52 @@ struct HipEngine : dla::Engine {
     return stage_to_device(pk.data(), sizeof(double) * cnt, d_cpk);
   }
 
-  template <int KT, typename ARGS>
-  int launch_gemm_gram(const ARGS& a, int blocks, size_t lds, bool vec2, int mode)
+  // quarter tiles of the last 16-column tile (0: none): blocks of 17..24 and 33..40 columns on the 16-byte path
+  int quarter_tiles(int k, bool vec2) const
   {
-#define GG(V, M)                                                                                              \
+    const int kt = (k + 15) / 16, rem = k - 16 * (kt - 1);
+    return (vec2 && kt >= 2 && kt <= 3 && rem <= 8 && tune[7] != 1) ? (rem + 3) / 4 : 0;
+  }
+
+  template <int KT, typename ARGS>
+  int launch_gemm_gram(const ARGS& a, int blocks, size_t lds, bool vec2, int mode, int qt, int rtp)
+  {
+#define GGQR(V, M, Q, R)                                                                                      \
     do {                                                                                                      \
-      auto kfn = gemm_kernel<KT, V, M, ARGS, true>;                                                           \
+      auto kfn = gemm_kernel<KT, V, M, ARGS, true, (M == 2 ? 0 : 1), (KT >= 2 ? 2 : 0), 9, Q, R>;             \
       if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;                                          \
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);                                           \
     } while (0)
+#define GGQ(V, M, Q) do { if (KT == 3 && V == 2 && rtp == 1) GGQR(V, M, Q, 1); else GGQR(V, M, Q, 2); } while (0)
+#define GG(V, M) GGQ(V, M, 0)
+    if constexpr (KT >= 2) {
+      if (vec2 && qt == 1) { if (mode == 1) GGQ(2, 1, 1); else if (mode == 2) GGQ(2, 2, 1); else GGQ(2, 0, 1); return DLA_OK; }
+      if (vec2 && qt == 2) { if (mode == 1) GGQ(2, 1, 2); else if (mode == 2) GGQ(2, 2, 2); else GGQ(2, 0, 2); return DLA_OK; }
+    }
     if (vec2) { if (mode == 1) GG(2, 1); else if (mode == 2) GG(2, 2); else GG(2, 0); }
     else      { if (mode == 1) GG(1, 1); else if (mode == 2) GG(1, 2); else GG(1, 0); }
 #undef GG
+#undef GGQ
+#undef GGQR
     return DLA_OK;
   }
 
   template <int KT, typename ARGS>
-  void launch_gemm(const ARGS& a, int blocks, size_t lds, bool vec2, int mode)
+  void launch_gemm(const ARGS& a, int blocks, size_t lds, bool vec2, int mode, int qt)
   {
 #define GM(V, M) hipLaunchKernelGGL((gemm_kernel<KT, V, M, ARGS>), dim3(blocks), dim3(256), lds, st, a)
+#define GMQ(M, Q) hipLaunchKernelGGL((gemm_kernel<KT, 2, M, ARGS, false, (M == 2 ? 0 : 1), 2, 9, Q>), dim3(blocks), dim3(256), lds, st, a)
 #define GMP(M, P) hipLaunchKernelGGL((gemm_kernel<KT, 2, M, ARGS, false, 1, P>), dim3(blocks), dim3(256), lds, st, a)
     if (vec2 && KT >= 2 && (mode == 0 || mode == 1) && (tune[2] == 1 || tune[2] == 4)) {
       if (tune[2] == 1) { if (mode == 0) GMP(0, 0); else GMP(1, 0); }
       else              { if (mode == 0) GMP(0, 4); else GMP(1, 4); }
       return;
     }
+    if constexpr (KT >= 2) {
+      if (vec2 && qt == 1) { if (mode == 0) GMQ(0, 1); else if (mode == 1) GMQ(1, 1); else if (mode == 2) GMQ(2, 1); else GMQ(3, 1); return; }
+      if (vec2 && qt == 2) { if (mode == 0) GMQ(0, 2); else if (mode == 1) GMQ(1, 2); else if (mode == 2) GMQ(2, 2); else GMQ(3, 2); return; }
+    }
+#undef GMQ
     if (vec2) { if (mode == 0) GM(2, 0); else if (mode == 1) GM(2, 1); else if (mode == 2) GM(2, 2); else GM(2, 3); }
     else      { if (mode == 0) GM(1, 0); else if (mode == 1) GM(1, 1); else if (mode == 2) GM(1, 2); else GM(1, 3); }
 #undef GM
@@ -2625,13 +2841,22 @@ struct HipEngine : dla::Engine {
       if (stc) return stc;
     }
     const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)z) % 16 == 0);
-    const int wt = vec2 ? 64 : 32;
-    const long long ntiles = ((long long)n + wt - 1) / wt;
-    // fused variant: + 4 wave tiles of (16*VEC rows) x 24 doubles, and >= 8 KiB for the final reduction
-    const size_t lds_c = sizeof(double) * (size_t)kt * l4 * 16;
+    int qt = (tune[2] == 1 || tune[2] == 4) && !fuse ? 0 : quarter_tiles(k, vec2);
+    // (the plain two-tile update is the one sweep that measured slower with quarter tiles, -9 % at L = 63, k = 21:
+    // tools/quarter_tile_ab.py)
+    if (!fuse && mode == 1 && kt == 2) qt = 0;
+    // LDS copy of C (a quarter-tile kernel keeps 8 columns of the last tile); the fused variant adds 4 wave tiles of
+    // 16 rows x (16 kt + 9) doubles, and needs >= 8 KiB for the final reduction
+    const size_t lds_c = sizeof(double) * (size_t)l4 * (qt > 0 ? 16 * (kt - 1) + 8 : 16 * kt);
     const size_t lds = fuse ? std::max(lds_c + sizeof(double) * 4 * 16 * (16 * kt + 9), (size_t)8192) : lds_c;
     int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
     if (tune[3] > 0) per_cu = (int)std::max((size_t)1, std::min((size_t)tune[3], (size_t)(156 * 1024) / std::max(lds, (size_t)4096)));
+    // row groups per wave tile (gemm_kernel RTP): the fused three-tile sweeps need > 256 registers with two groups, one
+    // wave per SIMD; with one group two fit -- when the LDS leaves room for a second block per CU (measured +9..20 %,
+    // and -26 % when it does not)
+    const int rtp = (fuse && kt == 3 && vec2 && per_cu >= 2 && tune[7] != 5) ? 1 : 2;
+    const int wt = (vec2 ? 32 : 16) * rtp;
+    const long long ntiles = ((long long)n + wt - 1) / wt;
     const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu, (ntiles + 3) / 4));
     if (fuse) {
       int stp = ensure_partial(sizeof(double) * (size_t)blocks * kt * kt * 256);
@@ -2640,12 +2865,12 @@ struct HipEngine : dla::Engine {
     }
     GemmArgs a{};
     a.x = x + (size_t)l0 * n; a.cpk = cpk_dev ? cpk_dev : d_cpk; a.z = z; a.n = n; a.l = l; a.l4 = l4; a.k = k; a.gpart = d_partial;
-    a.phase = pred_phase; a.want = pred_want;
+    a.phase = pred_phase; a.want = pred_want; a.xpf = tune[7] == 4 ? 0 : 1;
     const double rd = (mode == 0) ? 8.0 * n * (double)l : (mode == 2 ? 8.0 * n * (double)k : 8.0 * n * (double)(l + k));
     char kn[96];
-    std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, %d, %d, 9>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
+    std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, %d, %d, 9, %d, %d>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
                   fuse ? "true" : "false", mode == 2 ? 0 : 1,
-                  kt >= 2 ? 2 : 0);
+                  kt >= 2 ? 2 : 0, qt, rtp);
     Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k, kn);
     if (inl) {
       GemmArgsInl ai{};
@@ -2653,25 +2878,25 @@ struct HipEngine : dla::Engine {
       for (int j = 0; j < k; ++j)
         for (int p = 0; p < l; ++p) ai.cin[p * 16 + j] = c_host[(size_t)(l0 + p) + (size_t)j * ldc];
       int stl = DLA_OK;
-      if (fuse) stl = launch_gemm_gram<1>(ai, blocks, lds, vec2, mode);
-      else launch_gemm<1>(ai, blocks, lds, vec2, mode);
+      if (fuse) stl = launch_gemm_gram<1>(ai, blocks, lds, vec2, mode, 0, 2);
+      else launch_gemm<1>(ai, blocks, lds, vec2, mode, 0);
       if (stl) return stl;
       HIPCHK(hipGetLastError());
       return DLA_OK;
     }
     if (fuse) {
       int stl;
-      if (kt == 1) stl = launch_gemm_gram<1>(a, blocks, lds, vec2, mode);
-      else if (kt == 2) stl = launch_gemm_gram<2>(a, blocks, lds, vec2, mode);
-      else stl = launch_gemm_gram<3>(a, blocks, lds, vec2, mode);
+      if (kt == 1) stl = launch_gemm_gram<1>(a, blocks, lds, vec2, mode, 0, 2);
+      else if (kt == 2) stl = launch_gemm_gram<2>(a, blocks, lds, vec2, mode, qt, 2);
+      else stl = launch_gemm_gram<3>(a, blocks, lds, vec2, mode, qt, rtp);
       if (stl) return stl;
       HIPCHK(hipGetLastError());
       return DLA_OK;
     }
     switch (kt) {
-      case 1: launch_gemm<1>(a, blocks, lds, vec2, mode); break;
-      case 2: launch_gemm<2>(a, blocks, lds, vec2, mode); break;
-      case 3: launch_gemm<3>(a, blocks, lds, vec2, mode); break;
+      case 1: launch_gemm<1>(a, blocks, lds, vec2, mode, 0); break;
+      case 2: launch_gemm<2>(a, blocks, lds, vec2, mode, qt); break;
+      case 3: launch_gemm<3>(a, blocks, lds, vec2, mode, qt); break;
       default: err = "gemm: k > 48 not supported in one call"; return DLA_ERR_ARG;
     }
     HIPCHK(hipGetLastError());
@@ -2763,7 +2988,11 @@ struct HipEngine : dla::Engine {
     }
     const int kt = (m + 15) / 16;
     const int l4 = ((l + 3) / 4) * 4;
-    const size_t lds_c = sizeof(double) * (size_t)kt * l4 * 16;
+    uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy;
+    const bool vec2 = (n % 2 == 0) && (al % 16 == 0);
+    const int qt = (tune[0] == 1 || tune[0] == 4) ? 0 : quarter_tiles(m, vec2);
+    // LDS copy of Y (a quarter-tile kernel keeps 8 columns of the last tile)
+    const size_t lds_c = sizeof(double) * (size_t)l4 * (qt > 0 ? 16 * (kt - 1) + 8 : 16 * kt);
     if (lds_c > std::min((size_t)150 * 1024, lds_limit)) {
       // Y does not fit the LDS copy in one piece (wide block times deep subspace, e.g. 37 columns x 20 blocks): form the
       // two products with the chunked panel GEMM, then run the fused sweep on the n x m results with Y = identity
@@ -2790,8 +3019,6 @@ struct HipEngine : dla::Engine {
       if (skip && skip[j]) continue;
       a.theta[j] = eig[j]; a.active[j] = 1; ++nact;
     }
-    uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy;
-    const bool vec2 = (n % 2 == 0) && (al % 16 == 0);
     const int rg = vec2 ? 32 : 16;
     const long long ntiles = ((long long)n + rg - 1) / rg;
     const size_t lds = std::max(lds_c, sizeof(double) * 4 * 16 * kt * 2);
@@ -2807,7 +3034,7 @@ struct HipEngine : dla::Engine {
     const int ncol = 16 * kt;
     {
       char kn[64];
-      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d>", kt, vec2 ? 2 : 1, kt >= 2 ? 2 : 0);
+      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d>", kt, vec2 ? 2 : 1, kt >= 2 ? 2 : 0, qt);
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
 #define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME; hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
       if (vec2 && kt >= 2 && tune[0] == 1) {
@@ -2816,6 +3043,12 @@ struct HipEngine : dla::Engine {
       } else if (vec2 && kt >= 2 && tune[0] == 4) {
         if (kt == 2) RZ((ritz_kernel<2, 2, 3, 4>));
         else RZ((ritz_kernel<3, 2, 3, 4>));
+      } else if (vec2 && qt == 1) {
+        if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 1>));
+        else RZ((ritz_kernel<3, 2, 3, 2, 1>));
+      } else if (vec2 && qt == 2) {
+        if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 2>));
+        else RZ((ritz_kernel<3, 2, 3, 2, 2>));
       } else if (vec2) {
         if (kt == 1) RZ((ritz_kernel<1, 2>));
         else if (kt == 2) RZ((ritz_kernel<2, 2>));
