@@ -229,9 +229,22 @@ def main() -> None:
                 flag = torch.tensor([okf], dtype=torch.float64)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if float(flag[0]) > 0:
+                    # self-test of the transport before anything is timed: a 2 x 2 product whose sum over ranks is known
+                    try:
+                        probe = ctx.panel(np.full((64, 2), float(rank + 1), order="F"))
+                        got = ctx.gram(probe, probe)
+                        probe.free()
+                        okf = 1.0 if abs(got[0, 0] - 64.0 * sum((r + 1) ** 2 for r in range(world))) < 1e-9 else 0.0
+                    except capi.DlaError:
+                        okf = 0.0
+                    flag = torch.tensor([okf], dtype=torch.float64)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag[0]) > 0:
                     transport = "p2p"
                 elif shared:
                     raise SystemExit("peer-to-peer mailboxes could not be attached")
+                else:
+                    ctx.p2p_detach()              # RCCL everywhere
         ctx.set_shard(n, row0)
     elif os.environ.get("DIAGLIB_BENCH_FORCE_COMM"):
         # latency rehearsal of one shard of an N-GPU run: every small product goes through a 1-rank RCCL all-reduce

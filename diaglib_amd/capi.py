@@ -30,7 +30,7 @@ OP_NAMES = ["gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd"]
 EXPORTS = [
     "dla_create", "dla_destroy", "dla_default_ctx", "dla_set_option", "dla_get_option", "dla_last_error",
     "dla_backend_name", "dla_get_stats", "dla_reset_stats", "dla_get_kernel_stats", "dla_stream",
-    "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_p2p_export", "dla_p2p_attach", "dla_set_allreduce_hook", "dla_set_shard",
+    "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_p2p_export", "dla_p2p_attach", "dla_p2p_detach", "dla_set_allreduce_hook", "dla_set_shard",
     "dla_alloc", "dla_free", "dla_trim", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
     "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_trmm_gram", "dla_update_gram", "dla_combo_gram", "dla_ritz_residual", "dla_axpy",
     "dla_nrm2", "dla_stream_triad", "dla_random_fill", "dla_fill_guess",
@@ -93,7 +93,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_get_kernel_stats": (i, [vp, C.POINTER(KernelStat), i]),
         "dla_comm_unique_id": (i, [C.c_char_p]), "dla_comm_init": (i, [vp, i, i, C.c_char_p]),
         "dla_comm_info": (i, [vp, c_ip, c_ip]), "dla_comm_finalize": (i, [vp]),
-        "dla_p2p_export": (i, [vp, i, C.c_char_p]), "dla_p2p_attach": (i, [vp, i, i, C.c_char_p]),
+        "dla_p2p_export": (i, [vp, i, C.c_char_p]), "dla_p2p_attach": (i, [vp, i, i, C.c_char_p]), "dla_p2p_detach": (i, [vp]),
         "dla_set_allreduce_hook": (i, [vp, vp, vp, i, i]), "dla_set_shard": (i, [vp, C.c_longlong, C.c_longlong]),
         "dla_alloc": (i, [vp, sz, C.POINTER(vp)]), "dla_free": (i, [vp, vp]), "dla_zero": (i, [vp, vp, sz]),
         "dla_upload": (i, [vp, vp, vp, sz]), "dla_download": (i, [vp, vp, vp, sz]), "dla_copy": (i, [vp, vp, vp, sz]),
@@ -275,6 +275,10 @@ class Context:
         blob = b"".join(handles)
         assert len(blob) == 128 * nranks
         self._chk(self.lib.dla_p2p_attach(self.h, nranks, rank, blob))
+
+    def p2p_detach(self) -> None:
+        """close the mailboxes; the small products go back to the RCCL communicator / the hook"""
+        self._chk(self.lib.dla_p2p_detach(self.h))
 
     def comm_finalize(self) -> None:
         self._chk(self.lib.dla_comm_finalize(self.h))

@@ -142,6 +142,7 @@ struct Engine : BlockOps {
   // attach all ranks' handles (rank order)
   virtual int p2p_export(int /*nranks*/, void* /*handles*/) { return DLA_ERR_COMM; }
   virtual int p2p_attach(int /*nranks*/, int /*rank*/, const void* /*handles*/) { return DLA_ERR_COMM; }
+  virtual int p2p_detach() { return DLA_OK; }
   int nranks = 1, rank = 0;
   bool local_only = false;   // true while working on data that is replicated on every rank (no reductions)
   dla_allreduce_fn hook = nullptr;

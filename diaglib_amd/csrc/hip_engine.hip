@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 // by quarter instructions (mfma_quarter).  SELF puts the narrow tile on the A side, which lands in the standard
 // accumulator layout; the general kernel has it on the B side, where lane L receives
 // D[4 ((L>>2)&3) + (L>>4)][4 qq + (L&3)] -- put back in place when the accumulators go through LDS at the end.
-template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0, int QT = 0>
+template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0, int QT = 0, int DBG = 0>
 __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
 {
   DLA_PREDICATED(a);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
       cp[j] = a.u + (size_t)col * (size_t)n + 2 * li;
     }
   }
-  if (a.noskip) skip = 0;
+  if (a.noskip & 1) skip = 0;
   if (skip) {
     for (int idx = 2 * lane; idx < NC * RS; idx += 128) lds_store2(my + idx, vzero<2>());
   }
@@ -384,11 +384,15 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   if (tile < nfull) {
     load_tile(tile);
     for (;;) {
-      stage_tile();
+      if constexpr (!(DBG & 4)) stage_tile();
+      else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[0][0][0] += stg[j].x + stg[j].y;
+      }
       __builtin_amdgcn_wave_barrier();
       const long long next = tile + stride;
       if (next < nfull) load_tile(next);
-      mfma_tile();
+      if constexpr (!(DBG & 2)) mfma_tile();
       __builtin_amdgcn_wave_barrier();
       tile = next;
       if (next >= nfull) break;
@@ -2211,6 +2215,7 @@ struct HipEngine : dla::Engine {
     if (p2p.h_status) (void)hipHostFree(p2p.h_status);
     p2p = P2P{};
   }
+  int p2p_detach() override { p2p_release(); return DLA_OK; }
   int p2p_check()
   {
     if (p2p.on && *(volatile int*)p2p.h_status) { err = "p2p all-reduce: a peer did not arrive within 5 s"; return DLA_ERR_COMM; }
@@ -2294,6 +2299,7 @@ struct HipEngine : dla::Engine {
   std::map<long long, std::vector<int>> ortho_history;   // (k, m) -> the sweeps the last call of that shape executed
 
   bool chain_armed = false;          // the device state machine stands at its initial state
+  const bool chain_debug = std::getenv("DIAGLIB_AMD_CHAIN_DEBUG") != nullptr;   // print every chain's plan and outcome
   bool fuse_tail = false;            // the reduction being enqueued may run the tail in its last block
   bool tail_fused = false;           // ... and did
   OrthoTailArgs pending_tail{};
@@ -2426,6 +2432,11 @@ struct HipEngine : dla::Engine {
     }
     if (sres.status == OST_RUNNING) { err = "ortho_chain: no progress"; return DLA_ERR_RUNTIME; }
     chain_armed = true;              // a terminal tail has put the machine back to its initial state
+    if (chain_debug) {
+      std::printf("  [dla] chain k=%d m=%d: %zu launches enqueued, executed:", k, m, launched.size());
+      for (int i = 0; i < std::min(sres.nops, 48); ++i) std::printf(" %d", sres.log[i]);
+      std::printf("  (host waits so far %lld)\n", (long long)stats.host_syncs);
+    }
     // account for the launches the device executed: they are the greedy match of its log inside the launch sequence
     {
       const int nlog = std::min(sres.nops, 48);
@@ -2474,6 +2485,15 @@ struct HipEngine : dla::Engine {
       }
     }
     if constexpr (KT >= 2) { if (cur_qt == 1) GLK(0, 1); if (cur_qt == 2) GLK(0, 2); }
+    if constexpr (KT == 1 && R == 16 && (TLW == 5 || TLW == 7 || TLW == 8)) {
+      if (tune[7] == 6 || tune[7] == 7) {
+        auto kfn = tune[7] == 6 ? gram_lds_kernel<TLW, KT, 1, R, 0, 0, 2> : gram_lds_kernel<TLW, KT, 1, R, 0, 0, 6>;
+        const size_t lds = sizeof(double) * 4 * 16 * (TLW + KT) * (R + 2);
+        if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+        return DLA_OK;
+      }
+    }
     GLK(0, 0);
 #undef GLK
   }

@@ -225,6 +225,12 @@ int dla_p2p_attach(dla_ctx* c, int nranks, int rank, const char* all_handles)
   return engfail(c, c->eng->p2p_attach(nranks, rank, all_handles));
 }
 
+int dla_p2p_detach(dla_ctx* c)
+{
+  if (!c) return DLA_ERR_ARG;
+  return engfail(c, c->eng->p2p_detach());
+}
+
 int dla_comm_info(dla_ctx* c, int* nranks, int* rank)
 {
   if (!c) return DLA_ERR_ARG;

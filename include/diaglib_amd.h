@@ -139,9 +139,11 @@ int  dla_comm_info(dla_ctx* ctx, int* nranks, int* rank);
  *   1. every rank: dla_p2p_export(ctx, nranks, h)   -> 128 bytes (two hipIpcMemHandle_t)
  *   2. the caller's control plane (MPI, torch.distributed, ...) gathers the nranks x 128 bytes in rank order
  *   3. every rank: dla_p2p_attach(ctx, nranks, rank, all)
- * dla_comm_finalize detaches.  Larger buffers and contexts without mailboxes use the RCCL communicator / the hook. */
+ * dla_p2p_detach closes the mailboxes and hands the small products back to the RCCL communicator / the hook (rank count and
+ * rank stay); dla_comm_finalize detaches too.  Larger buffers and contexts without mailboxes use the communicator / the hook. */
 int  dla_p2p_export(dla_ctx* ctx, int nranks, char handles[128]);
 int  dla_p2p_attach(dla_ctx* ctx, int nranks, int rank, const char* all_handles);
+int  dla_p2p_detach(dla_ctx* ctx);
 /* host-buffer reduction hook (op 0 = sum, 1 = max); lets a caller supply the collective
  * (e.g. MPI or torch.distributed/gloo).  Used when no RCCL communicator is attached. */
 typedef void (*dla_allreduce_fn)(void* user, double* buf, int count, int op);

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Per-kernel time and inter-kernel gaps of one timed solve from a rocprofv3 --kernel-trace CSV.
-    python tools/kt_gaps.py <run_kernel_trace.csv> [solve-index-from-end]
+    python tools/kt_gaps.py <run_kernel_trace.csv> [solve-index-from-end] [--timeline]
 Prints: per kernel name launches / total / avg, the GPU-busy sum, the gap sum and the span of the selected solve
 (solves are delimited by random_fill/memcpy-free heuristics: the `synth_apply_kernel` that follows a long idle)."""
 import csv, sys, re
 from collections import defaultdict
-rows = list(csv.DictReader(open(sys.argv[1])))
+rows = list(csv.DictReader(open([a for a in sys.argv[1:] if a != "--timeline"][0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(nm):
     nm = nm.replace("(anonymous namespace)::", "").replace("void ", "")
@@ -22,7 +22,9 @@ for e in ev:
     cur.append(e)
 solves.append(cur)
 solves = [s for s in solves if len(s) > 100]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+timeline = "--timeline" in sys.argv
+args = [a for a in sys.argv[1:] if a != "--timeline"]
+k = int(args[1]) if len(args) > 1 else 1
 s = solves[-k]
 tot = defaultdict(lambda: [0, 0])
 for st, en, nm in s:
@@ -38,3 +40,10 @@ for g, a, b in gaps[-12:]:
     print(f"  {g/1e3:8.1f}  after {a[:40]:40s} before {b[:40]}")
 import statistics
 print("median gap", statistics.median(g for g, _, _ in gaps) / 1e3, "us; gaps > 5us:", sum(1 for g, _, _ in gaps if g > 5000))
+if timeline:
+    # every launch of the selected solve: start offset, duration, idle time before it
+    print("timeline (us): start  dur  gap-before  kernel")
+    t0, prev = s[0][0], s[0][0]
+    for st, en, nm in s:
+        print(f"  {(st - t0) / 1e3:9.1f} {(en - st) / 1e3:8.1f} {(st - prev) / 1e3:8.1f}  {nm[:70]}")
+        prev = en
