@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <cstring>
 #include <ctime>
 #include <map>
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 // by quarter instructions (mfma_quarter).  SELF puts the narrow tile on the A side, which lands in the standard
 // accumulator layout; the general kernel has it on the B side, where lane L receives
 // D[4 ((L>>2)&3) + (L>>4)][4 qq + (L&3)] -- put back in place when the accumulators go through LDS at the end.
-template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0, int QT = 0, int DBG = 0>
+template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0, int QT = 0>
 __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
 {
   DLA_PREDICATED(a);
@@ -299,7 +300,9 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
     }
   // staged column j*CPI + lc of this lane -> panel column (clamped: garbage only reaches unused rows/columns of D).
   // Load instructions whose columns all lie beyond the block (40..47 of a 37-column block), or in a tile no wanted pair
-  // reads (the tiles above the diagonal of a `lower` pass), are never issued: their staged columns hold zeros from the start
+  // reads (the tiles above the diagonal of a `lower` pass), fetch nothing new: all their lanes read one fixed 16-byte
+  // word (a single request instead of eight 128-byte lines).  No control flow: a test per instruction splits the load
+  // clause and cost the narrow passes 5-20 %.
   const double* cp[NI];
   unsigned skip = 0;
 #pragma unroll
@@ -319,8 +322,11 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
     }
   }
   if (a.noskip & 1) skip = 0;
-  if (skip) {
-    for (int idx = 2 * lane; idx < NC * RS; idx += 128) lds_store2(my + idx, vzero<2>());
+  long long rmul[NI];                      // row advance of the instruction: 1, or 0 for the pinned ones
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    rmul[j] = 1;
+    if (skip & (1u << j)) { rmul[j] = 0; cp[j] = a.x; }
   }
   const int i4 = lane & 3;
   // quarter tiles' accumulators, scalars of their own (see gemm_kernel): SELF [U tile][quarter], else [X tile][quarter]
@@ -334,13 +340,11 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   auto load_tile = [&](long long tile) {
     const long long r0 = tile * R;
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-      if (!(skip & (1u << j))) stg[j] = pload<2, NT>(cp[j] + r0);
+    for (int j = 0; j < NI; ++j) stg[j] = pload<2, NT>(cp[j] + r0 * rmul[j]);
   };
   auto stage_tile = [&]() {
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-      if (!(skip & (1u << j))) lds_store2(my + (size_t)(CPI * j + lc) * RS + 2 * li, stg[j]);
+    for (int j = 0; j < NI; ++j) lds_store2(my + (size_t)(CPI * j + lc) * RS + 2 * li, stg[j]);
   };
   constexpr int KF = (QT > 0 && !SELF) ? KT - 1 : KT;     // U tiles multiplied by full instructions
   constexpr int TF = (QT > 0 && SELF) ? TLW - 1 : TLW;    // X tiles ...
@@ -384,15 +388,11 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   if (tile < nfull) {
     load_tile(tile);
     for (;;) {
-      if constexpr (!(DBG & 4)) stage_tile();
-      else {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[0][0][0] += stg[j].x + stg[j].y;
-      }
+      stage_tile();
       __builtin_amdgcn_wave_barrier();
       const long long next = tile + stride;
       if (next < nfull) load_tile(next);
-      if constexpr (!(DBG & 2)) mfma_tile();
+      mfma_tile();
       __builtin_amdgcn_wave_barrier();
       tile = next;
       if (next >= nfull) break;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       stg[j] = vzero<2>();
-      if (ok) stg[j] = *(const vec_t*)(cp[j] + r0);
+      if (ok) stg[j] = *(const vec_t*)(cp[j] + r0 * rmul[j]);
     }
     stage_tile();
     __builtin_amdgcn_wave_barrier();
@@ -2485,15 +2485,6 @@ struct HipEngine : dla::Engine {
       }
     }
     if constexpr (KT >= 2) { if (cur_qt == 1) GLK(0, 1); if (cur_qt == 2) GLK(0, 2); }
-    if constexpr (KT == 1 && R == 16 && (TLW == 5 || TLW == 7 || TLW == 8)) {
-      if (tune[7] == 6 || tune[7] == 7) {
-        auto kfn = tune[7] == 6 ? gram_lds_kernel<TLW, KT, 1, R, 0, 0, 2> : gram_lds_kernel<TLW, KT, 1, R, 0, 0, 6>;
-        const size_t lds = sizeof(double) * 4 * 16 * (TLW + KT) * (R + 2);
-        if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;
-        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
-        return DLA_OK;
-      }
-    }
     GLK(0, 0);
 #undef GLK
   }
