@@ -263,7 +263,9 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 // by quarter instructions (mfma_quarter).  SELF puts the narrow tile on the A side, which lands in the standard
 // accumulator layout; the general kernel has it on the B side, where lane L receives
 // D[4 ((L>>2)&3) + (L>>4)][4 qq + (L&3)] -- put back in place when the accumulators go through LDS at the end.
-template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0, int QT = 0>
+// LOW: the whole lower block triangle of X^T U (l == k, x != u: the S^T A S of LOBPCG) in ONE pass -- the tile pairs above
+// the diagonal are compiled out, so up to 7 x 7 tiles fit the accumulator registers (28 pairs) and both panels are read once.
+template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0, int QT = 0, int LOW = 0>
 __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
 {
   DLA_PREDICATED(a);
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
     for (int q = 0; q < KT; ++q) {
       acc[t][q] = (v4d){0.0, 0.0, 0.0, 0.0};
       const int xt = xg * TLW + t, ut = ug * KT + q;
-      want[t][q] = (16 * xt < a.l) && (16 * ut < a.k) && (!a.lower || xt >= ut);
+      want[t][q] = (16 * xt < a.l) && (16 * ut < a.k) && (LOW ? (t >= q) : (!a.lower || xt >= ut));
       any_want = any_want || want[t][q];
       if (want[t][q]) tile_used |= (1u << t) | (1u << (SELF ? q : TLW + q));
     }
@@ -339,8 +341,23 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   vec_t stg[NI];
   auto load_tile = [&](long long tile) {
     const long long r0 = tile * R;
+    if constexpr (LOW) {
+      // 28 load instructions per tile: their 56 address registers are recomputed instead of kept (the accumulators of the
+      // 28 tile pairs need the room); l == k, one pass, nothing pinned except whole padding groups
 #pragma unroll
-    for (int j = 0; j < NI; ++j) stg[j] = pload<2, NT>(cp[j] + r0 * rmul[j]);
+      for (int j = 0; j < NI; ++j) {
+        const int sc = CPI * j + lc;
+        const bool isx = sc < 16 * TLW;
+        int col = isx ? sc : sc - 16 * TLW;
+        col = col < a.l ? col : a.l - 1;
+        const double* base = isx ? a.x : a.u;
+        const bool pin = (isx ? CPI * j : CPI * j - 16 * TLW) >= a.l;
+        stg[j] = pload<2, NT>(pin ? a.x : base + (size_t)col * (size_t)n + 2 * li + r0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) stg[j] = pload<2, NT>(cp[j] + r0 * rmul[j]);
+    }
   };
   auto stage_tile = [&]() {
 #pragma unroll
@@ -421,6 +438,10 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   for (int t = 0; t < TLW; ++t)
 #pragma unroll
     for (int q = 0; q < KT; ++q) {
+      if (LOW && t < q) {                       // never formed: zeros go out
+        pout[(size_t)(t * KT + q) * 256 + threadIdx.x] = 0.0;
+        continue;
+      }
       if (QT > 0 && !SELF && q == KT - 1) {
         // quarter results back to the standard layout: (row 4 blk + i', column 4 qq + j) lives in component blk of lane 16 i' + 4 qq + j
 #pragma unroll
@@ -482,7 +503,8 @@ __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return
 // rows of a 16*VEC-row group are transposed through a wave-private LDS tile (row stride 24 doubles:
 // conflict-free for the fragment reads) into MFMA operands: lane (c, g) reads Z[row(g)][c].
 // NT: X is read once per sweep -> non-temporal loads (+16..25 % measured on Z = XC / U -= XC, tools/tune_ab.py);
-// the in-place triangular update (MODE 2) re-reads a panel that still sits in the Infinity Cache, so it stays plain.
+// the in-place triangular update (MODE 2) stays plain: non-temporal loads there measured +1..9 % right behind a projection
+// sweep over the whole basis and -0.4..+0.7 % on whole solves, where it mostly follows a sweep over the same block.
 // PIPE > 0 (used for KT >= 2, where 4*KT MFMAs follow every load and the kernel runs at 1-2 waves per SIMD):
 // column steps are processed PIPE at a time through a two-stage register pipeline -- the loads of the next
 // stage are in flight while the MFMAs of the current one issue.  For KT == 1 occupancy hides the latency
@@ -2488,6 +2510,16 @@ struct HipEngine : dla::Engine {
     GLK(0, 0);
 #undef GLK
   }
+  // single-pass lower triangle (gram_lds_kernel LOW): T x T tiles, 16-row wave tiles
+  template <int T>
+  int launch_gram_low(const GramArgs& a, dim3 grid)
+  {
+    auto kfn = gram_lds_kernel<T, T, 1, 16, 0, 0, 1>;
+    const size_t lds = sizeof(double) * 4 * 16 * (2 * T) * 18;
+    if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    return DLA_OK;
+  }
   // tile rows of the LDS-staged kernel: 32 for narrow passes (few loads per tile otherwise) and for 3-tile U blocks,
   // 16 elsewhere (A/B at n = 2e6, tools/tune_gram.py)
   int lds_rows(int tlw, int kt) const
@@ -2561,13 +2593,18 @@ struct HipEngine : dla::Engine {
     else if (kt == 2) { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : tlw <= 4 ? 4 : 6; }
     else if (kt == 3) { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : 4; }
     else { tlw = tlw <= 1 ? 1 : tlw <= 2 ? 2 : 3; }
-    const int px = (tx + tlw - 1) / tlw;
-    const int passes = px * passes_u;
+    int px = (tx + tlw - 1) / tlw;
+    int passes = px * passes_u;
     // a block against itself in a single pass: one staged image serves both operands, and only the tile pairs on or
     // below the diagonal are formed (the host side mirrors, see gram())
     cur_self = ldsk && x == u && l == k && passes == 1 && tlw == kt;
     if (cur_self) lower = true;
     cur_qt = (ldsk && passes_u == 1 && kt >= 2) ? quarter_tiles(k, vec2) : 0;
+    // the lower triangle of X^T U for two different panels of 49..112 columns (S^T A S of LOBPCG at n_max = 21 / 37):
+    // one pass over both panels with the 10..28 tile pairs on or below the diagonal (gram_lds_kernel LOW)
+    const bool low_single = lower && ldsk && !cur_self && l == k && tx >= 4 && tx <= 7 && passes > 1 && tune[7] != 8 &&
+                            sizeof(double) * 4 * 16 * (size_t)(2 * tx) * 18 <= lds_limit;
+    if (low_single) { kt = tlw = tx; px = 1; passes = 1; cur_qt = 0; }
     const int ch = vec2 ? 32 : 16;
     long long nchunks = ((long long)n + ch - 1) / ch;
     long long want = (nchunks + 4 * 4 - 1) / (4 * 4);   // >= 4 chunks per wave
@@ -2590,11 +2627,16 @@ struct HipEngine : dla::Engine {
       char kn[64];
       if (cur_lds) {
         const bool can32 = sizeof(double) * 4 * 16 * (tlw + kt) * 34 <= 150 * 1024 && tlw + kt <= 7;
-        std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d, %d, %d>", tlw, kt, (can32 && lds_rows(tlw, kt) == 32) ? 32 : 16, cur_self ? 1 : 0,
-                      cur_qt);
+        std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d, %d, %d, %d>", tlw, kt,
+                      (!low_single && can32 && lds_rows(tlw, kt) == 32) ? 32 : 16, cur_self ? 1 : 0, cur_qt, low_single ? 1 : 0);
       }
       else std::snprintf(kn, sizeof kn, "gram_kernel<%d, %d, %d, %d, 0, -1>", tlw, kt, vec2 ? 2 : 1, rs);
       Scope s(this, cls, 8.0 * (double)n * (same ? (double)k : (double)(l + k)), 2.0 * (double)n * l * k, kn);
+      if (low_single) {
+        int r_ = tx == 4 ? launch_gram_low<4>(a, grid) : tx == 5 ? launch_gram_low<5>(a, grid) : tx == 6 ? launch_gram_low<6>(a, grid)
+                                                                                                       : launch_gram_low<7>(a, grid);
+        if (r_) return r_;
+      } else
 #define GL(T, K) if (tlw == T && kt == K) { int r_ = launch_gram<T, K>(a, grid, vec2); if (r_) return r_; } else
       GL(1, 1) GL(2, 1) GL(3, 1) GL(4, 1) GL(5, 1) GL(6, 1) GL(7, 1) GL(8, 1) GL(10, 1) GL(12, 1)
       GL(1, 2) GL(2, 2) GL(3, 2) GL(4, 2) GL(5, 2) GL(6, 2) GL(7, 2) GL(8, 2)

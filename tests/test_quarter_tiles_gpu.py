@@ -135,3 +135,22 @@ def test_ritz_step(ctx, rng, n, l, m):
             assert np.isclose(rn0[1, i], np.abs(r0[:, i]).max(), rtol=1e-15)
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("l", [49, 63, 64, 65, 80, 89, 96, 100, 111, 112])
+@pytest.mark.parametrize("n", [64, 2000, 4110])
+def test_lower_triangle_of_two_panels_single_pass(ctx, rng, n, l):
+    """S^T A S of LOBPCG: the lower triangle of X^T U for two different panels of 4..7 column tiles is formed in one pass
+    (tile pairs above the diagonal compiled out); knob 8 = the multi-pass kernel it replaces."""
+    x = np.asfortranarray(rng.standard_normal((n, l)))
+    u = np.asfortranarray(rng.standard_normal((n, l)))
+    px = ctx.panel(np.asfortranarray(np.hstack([np.full((n, 1), 1e30), x, np.full((n, 1), 1e30)])))
+    pu = ctx.panel(np.asfortranarray(np.hstack([np.full((n, 1), 1e30), u, np.full((n, 1), 1e30)])))
+    low = np.tril(np.ones((l, l), bool))
+    want = x.T @ u
+    for knob in (0, 8):
+        ctx.set_option(TUNE0 + 7, knob)
+        got = ctx.gram_lower(px.col(1, l), pu.col(1, l))
+        ctx.set_option(TUNE0 + 7, 0)
+        assert np.all(np.abs(got - want)[low] <= _gb(np.abs(x), np.abs(u))[low]), knob
+        assert np.all(np.isfinite(got))

@@ -28,13 +28,13 @@ def timeit(cls, f, reps=4):
     return st["alg_bytes"] / st["ms"] / 1e6
 
 
-LABEL = {0: "default", 1: "full tiles", 2: "pads loaded", 3: "narrow passes", 4: "no next-tile prefetch", 5: "64-row tiles"}
+LABEL = {0: "default", 1: "full tiles", 2: "pads loaded", 3: "narrow passes", 4: "no next-tile prefetch", 5: "64-row tiles", 8: "multi-pass lower"}
 
 
 def ab(title, cls, f, values=(1, 0)):
     # knob 7: 1 = full 16x16x4 tiles only, 2 = Gram loads its padded / unused column groups too, 3 = Gram passes of at most
     # 12 accumulator tiles, 4 = no next-tile prefetch in the row products, 5 = 64-row wave tiles in the fused three-tile
-    # sweeps, 0 = default
+    # sweeps, 8 = lower triangle of two panels in several passes, 0 = default
     res = {v: [] for v in values}
     for _ in range(rounds):
         for v in values:
@@ -59,8 +59,8 @@ for (l, kw) in ((111, 37), (63, 21)):
     ab(f"gram self {kw}x{kw}", "gram", lambda: ctx.gram(blk, blk), (1, 2, 0))
     ab(f"gram L={l} x {kw}", "gram", lambda: ctx.gram(x, blk), (1, 2, 3, 0))
     ab(f"gram L={2 * kw} x {kw}", "gram", lambda: ctx.gram(x.col(0, 2 * kw), blk), (1, 2, 3, 0))
-    ab(f"gram lower {l} x {l} (S^T AS)", "gram", lambda: ctx.gram_lower(x, x2), (2, 3, 0))
-    ab(f"gram lower {l - 22} x {l - 22}", "gram", lambda: ctx.gram_lower(x.col(0, l - 22), x2.col(0, l - 22)), (2, 3, 0))
+    ab(f"gram lower {l} x {l} (S^T AS)", "gram", lambda: ctx.gram_lower(x, x2), (8, 0))
+    ab(f"gram lower {l - 22} x {l - 22}", "gram", lambda: ctx.gram_lower(x.col(0, l - 22), x2.col(0, l - 22)), (8, 0))
     ab(f"gemm L={l} k={kw}", "gemm", lambda: ctx.panel_gemm(x, c, ow1))
     ab(f"update L={l} k={kw}", "gemm", lambda: ctx.panel_update(x, c, ow1))
     ab(f"trmm k={kw}", "trmm", lambda: ctx.trmm_linvt(blk, np.asfortranarray(w.T)))
