@@ -100,7 +100,9 @@ def test_hostsim_single_rank_matches_oracle(sim, oracle, tmp_path):
             eo, vo, oko, tr = oracle.lobpcg(n, t, m, 200, 1e-9, 0.0, mv, pc, g)
         assert bool(res["ok"]) and oko
         assert np.allclose(res["eig"][:t], eo[:t], rtol=1e-11, atol=0)
-        assert abs(int(res["iters"]) - tr.iters) <= 1
+        # unit guess: the history is robust to rounding; the random guess of check_guess runs ~110 iterations with 5 restarts,
+        # and its count moves by a few iterations with the last bits of the small eigensolver (108 / 110 / 111 seen)
+        assert abs(int(res["iters"]) - tr.iters) <= (1 if guess == "unit" else max(2, tr.iters // 20))
         v = res["vec"]; sgn = np.sign((v * vo).sum(0))
         assert np.abs(v * sgn - vo)[:, :t].max() < 1e-6
 
