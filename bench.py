@@ -145,7 +145,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=2_000_000)
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=2_000_000,
+                    help="global rows (--rows: the spelling that survives torch.distributed.run's own option parser)")
     ap.add_argument("--roots", type=int, default=8)
     ap.add_argument("--solver", default="davidson", choices=["davidson", "lobpcg"])
     ap.add_argument("--tol", type=float, default=2e-13)
