@@ -1640,7 +1640,11 @@ struct P2PArgs {
   double* buf_host;                        // optional pinned mirror of the result
   int count, op;                           // op 0 sum, 1 max
   int nranks, rank;
-  unsigned long long seq;                  // 1, 2, 3, ... identical on all ranks
+  unsigned long long* executed;            // device word: exchanges this rank has completed.  The sequence number of a call
+                                           // is taken from it, not from the host: launches of a device-driven chain that find
+                                           // it is not their turn must not consume a number, or two consecutive exchanges
+                                           // could fall on the same mailbox set (all ranks execute the same exchanges, so
+                                           // the counters agree)
   double* data[P2P_MAX_RANKS];             // mailbox of rank r: [2][nranks][P2P_MAX_DOUBLES]
   unsigned long long* flags[P2P_MAX_RANKS];//                    [2][nranks][P2P_FLAG_STRIDE]
   int* status;                             // device word: != 0 after a timeout
@@ -1650,7 +1654,8 @@ struct P2PArgs {
 __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a)
 {
   DLA_PREDICATED(a);
-  const int tid = threadIdx.x, par = (int)(a.seq & 1ULL);
+  const unsigned long long seq = *a.executed + 1;
+  const int tid = threadIdx.x, par = (int)(seq & 1ULL);
   const size_t slot = ((size_t)par * a.nranks + a.rank) * P2P_MAX_DOUBLES;
   // 1. my contribution into every mailbox (my own included)
   for (int r = 0; r < a.nranks; ++r) {
@@ -1664,11 +1669,11 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a)
   if (tid == 0) s_bad = 0;
   __syncthreads();
   if (tid < a.nranks) {
-    __hip_atomic_store(a.flags[tid] + ((size_t)par * a.nranks + a.rank) * P2P_FLAG_STRIDE, a.seq, __ATOMIC_RELEASE,
+    __hip_atomic_store(a.flags[tid] + ((size_t)par * a.nranks + a.rank) * P2P_FLAG_STRIDE, seq, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long* mine = a.flags[a.rank] + ((size_t)par * a.nranks + tid) * P2P_FLAG_STRIDE;
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
       if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { s_bad = 1; break; }
       __builtin_amdgcn_s_sleep(8);
     }
@@ -1689,6 +1694,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a)
     a.buf[i] = v;
     if (a.buf_host) a.buf_host[i] = v;
   }
+  if (tid == 0) *a.executed = seq;         // (every thread read the old value before the first barrier above)
 }
 
 // ======================================================================================
@@ -2152,7 +2158,7 @@ struct HipEngine : dla::Engine {
     if (p2p.on && count <= P2P_MAX_DOUBLES) {
       P2PArgs pa{};
       pa.buf = dev; pa.buf_host = nullptr; pa.count = count; pa.op = op; pa.nranks = nranks; pa.rank = rank;
-      pa.seq = ++p2p.seq;
+      pa.executed = p2p.d_executed;
       for (int r = 0; r < nranks; ++r) { pa.data[r] = p2p.data[r]; pa.flags[r] = p2p.flags[r]; }
       pa.status = p2p.d_status; pa.phase = pred_phase; pa.want = pred_want;
       Scope s(this, DLA_OP_ELEM, 0.0, 0.0, "p2p_allreduce_kernel");
@@ -2183,7 +2189,7 @@ struct HipEngine : dla::Engine {
     double* data[P2P_MAX_RANKS] = {nullptr}; unsigned long long* flags[P2P_MAX_RANKS] = {nullptr};
     int* h_status = nullptr;             // pinned, device-mapped: a timed-out kernel sets it, the host reads it at its waits
     int* d_status = nullptr;
-    unsigned long long seq = 0;
+    unsigned long long* d_executed = nullptr;   // see P2PArgs::executed
     int slots = 0;                       // ranks the local mailbox was sized for
   } p2p;
   static size_t p2p_data_bytes(int nr) { return sizeof(double) * 2 * (size_t)nr * P2P_MAX_DOUBLES; }
@@ -2202,6 +2208,8 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipHostMalloc((void**)&p2p.h_status, sizeof(int), hipHostMallocMapped));
     *p2p.h_status = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&p2p.d_status, p2p.h_status, 0));
+    HIPCHK(hipMalloc((void**)&p2p.d_executed, sizeof(unsigned long long)));
+    HIPCHK(hipMemset(p2p.d_executed, 0, sizeof(unsigned long long)));
     HIPCHK(hipDeviceSynchronize());
     p2p.slots = nr;
     hipIpcMemHandle_t* h = (hipIpcMemHandle_t*)handles;
@@ -2221,7 +2229,8 @@ struct HipEngine : dla::Engine {
       HIPCHK(hipIpcOpenMemHandle((void**)&p2p.flags[r], h[2 * r + 1], hipIpcMemLazyEnablePeerAccess));
     }
     nranks = nr; rank = rk;
-    p2p.seq = 0;
+    HIPCHK(hipMemset(p2p.d_executed, 0, sizeof(unsigned long long)));
+    HIPCHK(hipDeviceSynchronize());
     p2p.on = true;
     return DLA_OK;
   }
@@ -2235,6 +2244,7 @@ struct HipEngine : dla::Engine {
     if (p2p.my_data) (void)hipFree(p2p.my_data);
     if (p2p.my_flags) (void)hipFree(p2p.my_flags);
     if (p2p.h_status) (void)hipHostFree(p2p.h_status);
+    if (p2p.d_executed) (void)hipFree(p2p.d_executed);
     p2p = P2P{};
   }
   int p2p_detach() override { p2p_release(); return DLA_OK; }
