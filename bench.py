@@ -192,6 +192,9 @@ def main() -> None:
     from diaglib_amd import capi
     ctx = capi.Context()
     assert ctx.backend.startswith("hip:"), ctx.backend
+    for kv in filter(None, os.environ.get("DIAGLIB_BENCH_TUNE", "").split(",")):     # A/B of engine knobs: "6=4,7=1"
+        knob, val = kv.split("=")
+        ctx.set_option(100 + int(knob), int(val))
 
     transport = None
     n, n_targ = args.n, args.roots

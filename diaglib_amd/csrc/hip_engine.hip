@@ -1493,6 +1493,94 @@ __global__ __launch_bounds__(64) void ortho_tail_kernel(OrthoTailArgs a)
 // result does not depend on arrival order) and writes C to the device buffer and to its pinned
 // host mirror.  Hand-off = agent-scope release / acquire around a relaxed ticket
 // (cdna_hip_programming.md guideline 16); the ticket is reset by its last arriver.
+// ======================================================================================
+// One-shot all-reduce of a small buffer over peer mailboxes (SURVEY 8f row 2)
+// ======================================================================================
+// Every reduction of this library is latency-bound (<= 64 KB: a k x k Gram matrix, an L x k projection block, a handful of
+// norms).  Instead of a ring collective every rank writes its contribution straight into a slot of every peer's
+// mailbox (one xGMI hop), raises a flag there, waits until all flags of its OWN mailbox are up and adds the slots in
+// RANK ORDER -- the same sum, bit for bit, on every rank, whatever the arrival order.
+//   * mailboxes are fine-grained device allocations shared through hipIpc handles (dla_p2p_export / dla_p2p_attach);
+//   * two mailbox sets alternate (parity of the sequence number): a peer can write for call s+2 only after it has seen
+//     this rank's flag for call s+1, which this rank raises only after it has finished reading call s;
+//   * the wait is bounded (P2P_TIMEOUT_TICKS of the 100 MHz wall clock): a missing peer sets a status word, the kernel
+//     ends and the host reports DLA_ERR_COMM at its next wait -- the grid always drains;
+//   * a launch belongs to the device-driven chains like any other: when it is not its turn (DLA_PREDICATED) it returns
+//     before touching a mailbox, on every rank alike (all ranks hold the same phase).
+#define P2P_MAX_RANKS 8
+#define P2P_MAX_DOUBLES 16384              // 128 KB per slot (the widest projection block of BASELINE cfg 4/5 fits)
+#define P2P_FLAG_STRIDE 16                 // one flag per 128-byte line
+#define P2P_TIMEOUT_TICKS 500000000ULL     // 5 s
+struct P2PArgs {
+  double* buf;                             // in: this rank's contribution, out: the reduced values
+  double* buf_host;                        // optional pinned mirror of the result
+  int count, op;                           // op 0 sum, 1 max
+  int nranks, rank;
+  unsigned long long* executed;            // device word: exchanges this rank has completed.  The sequence number of a call
+                                           // is taken from it, not from the host: launches of a device-driven chain that find
+                                           // it is not their turn must not consume a number, or two consecutive exchanges
+                                           // could fall on the same mailbox set (all ranks execute the same exchanges, so
+                                           // the counters agree)
+  double* data[P2P_MAX_RANKS];             // mailbox of rank r: [2][nranks][P2P_MAX_DOUBLES]
+  unsigned long long* flags[P2P_MAX_RANKS];//                    [2][nranks][P2P_FLAG_STRIDE]
+  int* status;                             // device word: != 0 after a timeout
+  const int* phase; int want;
+};
+
+// the exchange itself, executed by the 256 threads of ONE block (ends with a block barrier); false: a peer timed out
+__device__ bool p2p_exchange(const P2PArgs& a)
+{
+  const unsigned long long seq = *a.executed + 1;
+  const int tid = threadIdx.x, par = (int)(seq & 1ULL);
+  const size_t slot = ((size_t)par * a.nranks + a.rank) * P2P_MAX_DOUBLES;
+  // 1. my contribution into every mailbox (my own included)
+  for (int r = 0; r < a.nranks; ++r) {
+    double* dst = a.data[r] + slot;
+    for (int i = tid; i < a.count; i += 256) __hip_atomic_store(dst + i, a.buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  // 2. raise my flag everywhere, 3. wait for everyone's flag in my mailbox
+  __shared__ int s_bad;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  if (tid < a.nranks) {
+    __hip_atomic_store(a.flags[tid] + ((size_t)par * a.nranks + a.rank) * P2P_FLAG_STRIDE, seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long* mine = a.flags[a.rank] + ((size_t)par * a.nranks + tid) * P2P_FLAG_STRIDE;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { s_bad = 1; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (tid == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return false;
+  }
+  // 4. combine the slots of my mailbox in rank order
+  const double* mine = a.data[a.rank] + (size_t)par * a.nranks * P2P_MAX_DOUBLES;
+  for (int i = tid; i < a.count; i += 256) {
+    double v = __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int r = 1; r < a.nranks; ++r) {
+      const double x = __hip_atomic_load(mine + (size_t)r * P2P_MAX_DOUBLES + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v = a.op == 0 ? v + x : fmax(v, x);
+    }
+    a.buf[i] = v;
+    if (a.buf_host) a.buf_host[i] = v;
+  }
+  if (tid == 0) *a.executed = seq;         // (every thread read the old value before the first barrier above)
+  __syncthreads();
+  return true;
+}
+
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a)
+{
+  DLA_PREDICATED(a);
+  (void)p2p_exchange(a);
+}
+
 struct GramReduceArgs {
   const double* partial;
   double* lvl2;        // [passes*slots][groups][256]
@@ -1508,6 +1596,9 @@ struct GramReduceArgs {
   int n_ps;            // passes * slots = number of output tiles
   unsigned* gticket;   // zero between launches
   OrthoTailArgs tail;
+  // ... and with several ranks on the peer-to-peer transport the same block first exchanges the reduced matrix with
+  // its peers (p2p.nranks > 1), so that sweep -> [reduce, cross-rank sum, k x k step] is still one launch
+  P2PArgs p2p;
 };
 
 // TAIL: the block that completes the last output tile also runs the state machine's step
@@ -1585,7 +1676,8 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
   }
   if constexpr (!TAIL) return;
   __shared__ __attribute__((aligned(16))) double tail_lds[TAIL ? TAIL_LDS_DOUBLES : 1];
-  if (a.n_ps == 1 && a.tail.after != OP_XU) {
+  const bool exchange = a.p2p.nranks > 1;
+  if (!exchange && a.n_ps == 1 && a.tail.after != OP_XU) {
     // a single 16 x 16 tile, complete in this block's registers: it reaches the tail through LDS, no fences
     const int gi = (lane >> 4) + 4 * reg, gj = lane & 15;
     tail_lds[gi * TLD + gj] = tot;
@@ -1613,88 +1705,15 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
     s_last = last;
   }
   __syncthreads();
-  if (!s_last || threadIdx.x >= 64) return;
+  if (!s_last) return;
+  if (exchange) {
+    // the whole reduced matrix is in a.c now (acquired above); sum it over the ranks in place, then run the step on it
+    if (!p2p_exchange(a.p2p)) return;      // a peer timed out: the status word tells the host
+    __threadfence();
+    __syncthreads();
+  }
+  if (threadIdx.x >= 64) return;
   ortho_tail(a.tail, tail_lds, threadIdx.x, &pre);
-}
-
-// ======================================================================================
-// One-shot all-reduce of a small buffer over peer mailboxes (SURVEY 8f row 2)
-// ======================================================================================
-// Every reduction of this library is latency-bound (<= 64 KB: a k x k Gram matrix, an L x k projection block, a handful of
-// norms).  Instead of a ring collective every rank writes its contribution straight into a slot of every peer's
-// mailbox (one xGMI hop), raises a flag there, waits until all flags of its OWN mailbox are up and adds the slots in
-// RANK ORDER -- the same sum, bit for bit, on every rank, whatever the arrival order.
-//   * mailboxes are fine-grained device allocations shared through hipIpc handles (dla_p2p_export / dla_p2p_attach);
-//   * two mailbox sets alternate (parity of the sequence number): a peer can write for call s+2 only after it has seen
-//     this rank's flag for call s+1, which this rank raises only after it has finished reading call s;
-//   * the wait is bounded (P2P_TIMEOUT_TICKS of the 100 MHz wall clock): a missing peer sets a status word, the kernel
-//     ends and the host reports DLA_ERR_COMM at its next wait -- the grid always drains;
-//   * a launch belongs to the device-driven chains like any other: when it is not its turn (DLA_PREDICATED) it returns
-//     before touching a mailbox, on every rank alike (all ranks hold the same phase).
-#define P2P_MAX_RANKS 8
-#define P2P_MAX_DOUBLES 16384              // 128 KB per slot (the widest projection block of BASELINE cfg 4/5 fits)
-#define P2P_FLAG_STRIDE 16                 // one flag per 128-byte line
-#define P2P_TIMEOUT_TICKS 500000000ULL     // 5 s
-struct P2PArgs {
-  double* buf;                             // in: this rank's contribution, out: the reduced values
-  double* buf_host;                        // optional pinned mirror of the result
-  int count, op;                           // op 0 sum, 1 max
-  int nranks, rank;
-  unsigned long long* executed;            // device word: exchanges this rank has completed.  The sequence number of a call
-                                           // is taken from it, not from the host: launches of a device-driven chain that find
-                                           // it is not their turn must not consume a number, or two consecutive exchanges
-                                           // could fall on the same mailbox set (all ranks execute the same exchanges, so
-                                           // the counters agree)
-  double* data[P2P_MAX_RANKS];             // mailbox of rank r: [2][nranks][P2P_MAX_DOUBLES]
-  unsigned long long* flags[P2P_MAX_RANKS];//                    [2][nranks][P2P_FLAG_STRIDE]
-  int* status;                             // device word: != 0 after a timeout
-  const int* phase; int want;
-};
-
-__global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a)
-{
-  DLA_PREDICATED(a);
-  const unsigned long long seq = *a.executed + 1;
-  const int tid = threadIdx.x, par = (int)(seq & 1ULL);
-  const size_t slot = ((size_t)par * a.nranks + a.rank) * P2P_MAX_DOUBLES;
-  // 1. my contribution into every mailbox (my own included)
-  for (int r = 0; r < a.nranks; ++r) {
-    double* dst = a.data[r] + slot;
-    for (int i = tid; i < a.count; i += 256) __hip_atomic_store(dst + i, a.buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  __threadfence_system();
-  __syncthreads();
-  // 2. raise my flag everywhere, 3. wait for everyone's flag in my mailbox
-  __shared__ int s_bad;
-  if (tid == 0) s_bad = 0;
-  __syncthreads();
-  if (tid < a.nranks) {
-    __hip_atomic_store(a.flags[tid] + ((size_t)par * a.nranks + a.rank) * P2P_FLAG_STRIDE, seq, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-    const unsigned long long* mine = a.flags[a.rank] + ((size_t)par * a.nranks + tid) * P2P_FLAG_STRIDE;
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { s_bad = 1; break; }
-      __builtin_amdgcn_s_sleep(8);
-    }
-  }
-  __syncthreads();
-  if (s_bad) {
-    if (tid == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return;
-  }
-  // 4. combine the slots of my mailbox in rank order
-  const double* mine = a.data[a.rank] + (size_t)par * a.nranks * P2P_MAX_DOUBLES;
-  for (int i = tid; i < a.count; i += 256) {
-    double v = __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    for (int r = 1; r < a.nranks; ++r) {
-      const double x = __hip_atomic_load(mine + (size_t)r * P2P_MAX_DOUBLES + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      v = a.op == 0 ? v + x : fmax(v, x);
-    }
-    a.buf[i] = v;
-    if (a.buf_host) a.buf_host[i] = v;
-  }
-  if (tid == 0) *a.executed = seq;         // (every thread read the old value before the first barrier above)
 }
 
 // ======================================================================================
@@ -2156,11 +2175,8 @@ struct HipEngine : dla::Engine {
     if (local_only || (nranks <= 1 && !comm && !p2p.on)) return DLA_OK;
     stats.allreduces++;
     if (p2p.on && count <= P2P_MAX_DOUBLES) {
-      P2PArgs pa{};
-      pa.buf = dev; pa.buf_host = nullptr; pa.count = count; pa.op = op; pa.nranks = nranks; pa.rank = rank;
-      pa.executed = p2p.d_executed;
-      for (int r = 0; r < nranks; ++r) { pa.data[r] = p2p.data[r]; pa.flags[r] = p2p.flags[r]; }
-      pa.status = p2p.d_status; pa.phase = pred_phase; pa.want = pred_want;
+      if (exchange_fused) { exchange_fused = false; return DLA_OK; }   // the reduction kernel did it (launch_reduce)
+      P2PArgs pa = p2p_args(dev, count, op);
       Scope s(this, DLA_OP_ELEM, 0.0, 0.0, "p2p_allreduce_kernel");
       hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(256), 0, st, pa);
       HIPCHK(hipGetLastError());
@@ -2182,6 +2198,16 @@ struct HipEngine : dla::Engine {
     err = "nranks > 1 but neither an RCCL communicator nor a reduction hook is attached";
     return DLA_ERR_COMM;
   }
+  P2PArgs p2p_args(double* dev, int count, int op)
+  {
+    P2PArgs pa{};
+    pa.buf = dev; pa.buf_host = nullptr; pa.count = count; pa.op = op; pa.nranks = nranks; pa.rank = rank;
+    pa.executed = p2p.d_executed;
+    for (int r = 0; r < nranks; ++r) { pa.data[r] = p2p.data[r]; pa.flags[r] = p2p.flags[r]; }
+    pa.status = p2p.d_status; pa.phase = pred_phase; pa.want = pred_want;
+    return pa;
+  }
+  bool exchange_fused = false;       // the reduction just enqueued carries the cross-rank sum (gram_reduce_kernel<true>)
   // ---- one-shot peer-to-peer all-reduce (p2p_allreduce_kernel)
   struct P2P {
     bool on = false;
@@ -2351,8 +2377,11 @@ struct HipEngine : dla::Engine {
 
   void launch_reduce(GramReduceArgs& ra, dim3 grid)
   {
+    if (fuse_tail && p2p.on && ra.l * ra.k > P2P_MAX_DOUBLES) fuse_tail = false;   // beyond a mailbox slot: separate launches
     if (fuse_tail) {
       ra.do_tail = 1; ra.tail = pending_tail; tail_fused = true;
+      ra.p2p = P2PArgs{};
+      if (p2p.on) { ra.p2p = p2p_args(ra.c, ra.l * ra.k, 0); exchange_fused = true; }
       hipLaunchKernelGGL(gram_reduce_kernel<true>, grid, dim3(256), 0, st, ra);
     } else {
       hipLaunchKernelGGL(gram_reduce_kernel<false>, grid, dim3(256), 0, st, ra);
@@ -2369,7 +2398,7 @@ struct HipEngine : dla::Engine {
   int launch_op(int op, int n, int m, int k, const double* x, const double* bx, double* u, bool publish)
   {
     pending_tail = OrthoTailArgs{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, op, m, k, m > 0 ? 1 : 0, ortho_maxit, publish ? 1 : 0};
-    fuse_tail = (nranks <= 1 && !comm && !p2p.on);
+    fuse_tail = p2p.on ? tune[6] != 4 : (nranks <= 1 && !comm);     // (knob 6 = 4: the exchange as a launch of its own)
     tail_fused = false;
     pred_phase = &d_ost->phase; pred_want = op;
     int stc = DLA_OK;
