@@ -1852,10 +1852,18 @@ struct HipEngine : dla::Engine {
   }
 
   // ---- timing helpers
+  // The engine's allocations, events and launches belong to `device`; a host application that switches the calling thread's
+  // current device between calls (torch does) must not redirect them: every allocating or launching path starts here.
+  void bind()
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device) (void)hipSetDevice(device);
+  }
   struct Scope {
     HipEngine* e; int cls; hipEvent_t a = nullptr, b = nullptr; std::string kname;
     Scope(HipEngine* e_, int cls_, double bytes, double flops, const std::string& kname_ = std::string()) : e(e_), cls(cls_), kname(kname_)
     {
+      e->bind();
       if (e->spec_rec) {
         // speculative launch of a device-driven chain: counted after the read-back, if the device executed it
         e->spec_rec->push_back({e->spec_tag, cls_, kname_, bytes, flops});
@@ -1927,6 +1935,7 @@ struct HipEngine : dla::Engine {
   int alloc(size_t bytes, void** dev) override
   {
     *dev = nullptr;
+    bind();
     const size_t gran = (size_t)2 << 20;
     bytes = ((std::max(bytes, (size_t)8) + gran - 1) / gran) * gran;
     for (size_t i = 0; i < cache.size(); ++i)
@@ -2084,12 +2093,13 @@ struct HipEngine : dla::Engine {
     stage_pending = true;
     return DLA_OK;
   }
-  int host_alloc(size_t bytes, void** p) override { HIPCHK(hipHostMalloc(p, bytes, hipHostMallocDefault)); return DLA_OK; }
+  int host_alloc(size_t bytes, void** p) override { bind(); HIPCHK(hipHostMalloc(p, bytes, hipHostMallocDefault)); return DLA_OK; }
   int host_free(void* p) override { if (p) HIPCHK(hipHostFree(p)); return DLA_OK; }
 
   int ensure_partial(size_t bytes)
   {
     if (bytes <= partial_bytes) return DLA_OK;
+    bind();
     if (d_partial) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(d_partial)); d_partial = nullptr; }
     HIPCHK(hipMalloc((void**)&d_partial, bytes));
     partial_bytes = bytes;
@@ -2098,6 +2108,7 @@ struct HipEngine : dla::Engine {
   int ensure_small(size_t bytes)
   {
     if (bytes <= small_bytes) return DLA_OK;
+    bind();
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipFree(d_small)); HIPCHK(hipHostFree(h_small));
     small_bytes = bytes;
@@ -2150,6 +2161,7 @@ struct HipEngine : dla::Engine {
   // stage a small host matrix to the device through a ring of pinned buffers (no host sync)
   int stage_to_device(const double* host_packed, size_t bytes, double* dev)
   {
+    bind();
     if (bytes > ring_bytes) {
       HIPCHK(hipStreamSynchronize(st));
       for (int i = 0; i < RING; ++i) {
@@ -2365,6 +2377,7 @@ struct HipEngine : dla::Engine {
   int ensure_chain_buffers()
   {
     if (d_ost) return DLA_OK;
+    bind();
     HIPCHK(hipMalloc((void**)&d_ost, sizeof(OrthoDev)));
     HIPCHK(hipHostMalloc((void**)&h_ost, sizeof(OrthoDev), hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&h_ost_dev, h_ost, 0));
@@ -2854,6 +2867,7 @@ struct HipEngine : dla::Engine {
   // ---- packed C upload: [KT][l4][16], zero padded
   int upload_packed(const double* c_host, int ldc, int l0, int l, int k, int kt, int l4)
   {
+    bind();
     const size_t cnt = (size_t)kt * l4 * 16;
     if (sizeof(double) * cnt > cpk_bytes) {
       HIPCHK(hipStreamSynchronize(st));
@@ -3043,6 +3057,7 @@ struct HipEngine : dla::Engine {
     // wide block (cold path: the drivers never exceed n_max columns): W is upper triangular, so column
     // block J of U W needs columns <= max(J) only; go right to left through a scratch panel
     double* tmp = nullptr;
+    bind();
     HIPCHK(hipMalloc((void**)&tmp, sizeof(double) * (size_t)n * 48));
     int stc = DLA_OK;
     for (int j1 = k; j1 > 0 && stc == DLA_OK; j1 -= 48) {
@@ -3305,6 +3320,7 @@ struct HipEngine : dla::Engine {
   {
     (void)n_global;
     if (rank_w != 4) { err = "synth operator: rank_w must be 4"; return DLA_ERR_ARG; }
+    bind();
     HIPCHK(hipStreamSynchronize(st));
     if (d_w) HIPCHK(hipFree(d_w));
     if (d_diag) HIPCHK(hipFree(d_diag));
