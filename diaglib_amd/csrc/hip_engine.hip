@@ -2149,9 +2149,12 @@ struct HipEngine : dla::Engine {
 
   // reduced small result -> host: single rank reads the pinned mirror the kernel wrote,
   // multi-rank copies the all-reduced device buffer
+  bool mirror_fresh = false;         // the last cross-rank sum already wrote h_small (peer-to-peer exchange)
   int small_to_host(size_t count)
   {
-    if (!local_only && (nranks > 1 || comm || p2p.on)) HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    if (!local_only && (nranks > 1 || comm || p2p.on) && !mirror_fresh)
+      HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    mirror_fresh = false;
     int stw = wait_stream();
     if (stw) return stw;
     stats.host_syncs++;
@@ -2186,9 +2189,12 @@ struct HipEngine : dla::Engine {
   {
     if (local_only || (nranks <= 1 && !comm && !p2p.on)) return DLA_OK;
     stats.allreduces++;
+    mirror_fresh = false;
     if (p2p.on && count <= P2P_MAX_DOUBLES) {
       if (exchange_fused) { exchange_fused = false; return DLA_OK; }   // the reduction kernel did it (launch_reduce)
       P2PArgs pa = p2p_args(dev, count, op);
+      // outside the device-driven chains the host reads the result next: the exchange writes the pinned mirror itself
+      if (!pred_phase && dev == d_small && host_mirror == h_small) { pa.buf_host = h_small_dev; mirror_fresh = true; }
       Scope s(this, DLA_OP_ELEM, 0.0, 0.0, "p2p_allreduce_kernel");
       hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(256), 0, st, pa);
       HIPCHK(hipGetLastError());
