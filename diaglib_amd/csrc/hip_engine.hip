@@ -2396,6 +2396,7 @@ struct HipEngine : dla::Engine {
 
   void launch_reduce(GramReduceArgs& ra, dim3 grid)
   {
+    exchange_fused = false;
     if (fuse_tail && p2p.on && ra.l * ra.k > P2P_MAX_DOUBLES) fuse_tail = false;   // beyond a mailbox slot: separate launches
     if (fuse_tail) {
       ra.do_tail = 1; ra.tail = pending_tail; tail_fused = true;
@@ -3180,6 +3181,7 @@ struct HipEngine : dla::Engine {
     }
     HIPCHK(hipGetLastError());
     // sums and all ranks' maxima in one collective (reference :1730-1731 are two reductions)
+    exchange_fused = false;
     stc = allreduce_dev(d_small, ncol * (1 + nslots), 0, h_small);
     if (stc) return stc;
     stc = small_to_host((size_t)ncol * (1 + nslots));
@@ -3246,6 +3248,7 @@ struct HipEngine : dla::Engine {
       hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const double*)d_partial, blocks, d_small, h_small_dev);
     }
     HIPCHK(hipGetLastError());
+    exchange_fused = false;
     stc = allreduce_dev(d_small, 1, 0, h_small);
     if (stc) return stc;
     stc = small_to_host(1);
