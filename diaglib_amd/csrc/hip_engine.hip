@@ -505,12 +505,13 @@ __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return
 // NT: X is read once per sweep -> non-temporal loads (+16..25 % measured on Z = XC / U -= XC, tools/tune_ab.py);
 // the in-place triangular update (MODE 2) stays plain: non-temporal loads there measured +1..9 % right behind a projection
 // sweep over the whole basis and -0.4..+0.7 % on whole solves, where it mostly follows a sweep over the same block.
-// PIPE > 0 (used for KT >= 2, where 4*KT MFMAs follow every load and the kernel runs at 1-2 waves per SIMD):
+// PIPE > 0 (used for KT >= 2, where 4*KT MFMAs follow every load and the kernel runs at 1-2 waves per SIMD; 2 steps for
+// two-tile blocks, 3 for three-tile ones: +6 % on the fused 37-column sweeps, +3 % on the Ritz step against 2):
 // column steps are processed PIPE at a time through a two-stage register pipeline -- the loads of the next
 // stage are in flight while the MFMAs of the current one issue.  For KT == 1 occupancy hides the latency
 // better than registers do (A/B: batching there costs 5-10 %).
 // QT > 0: the last tile has only 4*QT live columns and is formed by quarter instructions (see mfma_quarter).
-template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1), int PIPE = (KT >= 2 ? 2 : 0), int ZPAD = 9,
+template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1), int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int ZPAD = 9,
           int QT = 0, int RTP = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 {
@@ -786,7 +787,7 @@ struct RitzArgs {
 
 // NT = 3: V / AV are read once and evec / r written once per sweep -> non-temporal loads and stores
 // (+6 % measured, tools/tune_ab.py)
-template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 2 ? 2 : 0), int QT = 0>
+template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int QT = 0>
 __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 {
   constexpr int RG = 16 * VEC;             // rows per wave tile (one row group)
@@ -2900,12 +2901,13 @@ struct HipEngine : dla::Engine {
   template <int KT, typename ARGS>
   int launch_gemm_gram(const ARGS& a, int blocks, size_t lds, bool vec2, int mode, int qt, int rtp)
   {
-#define GGQR(V, M, Q, R)                                                                                      \
+#define GGQRP(V, M, Q, R, P)                                                                                  \
     do {                                                                                                      \
-      auto kfn = gemm_kernel<KT, V, M, ARGS, true, (M == 2 ? 0 : 1), (KT >= 2 ? 2 : 0), 9, Q, R>;             \
+      auto kfn = gemm_kernel<KT, V, M, ARGS, true, (M == 2 ? 0 : 1), P, 9, Q, R>;                             \
       if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;                                          \
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);                                           \
     } while (0)
+#define GGQR(V, M, Q, R) GGQRP(V, M, Q, R, (KT >= 3 ? 3 : KT >= 2 ? 2 : 0))
 #define GGQ(V, M, Q) do { if (KT == 3 && V == 2 && rtp == 1) GGQR(V, M, Q, 1); else GGQR(V, M, Q, 2); } while (0)
 #define GG(V, M) GGQ(V, M, 0)
     if constexpr (KT >= 2) {
@@ -2917,6 +2919,7 @@ struct HipEngine : dla::Engine {
 #undef GG
 #undef GGQ
 #undef GGQR
+#undef GGQRP
     return DLA_OK;
   }
 
@@ -2924,7 +2927,8 @@ struct HipEngine : dla::Engine {
   void launch_gemm(const ARGS& a, int blocks, size_t lds, bool vec2, int mode, int qt)
   {
 #define GM(V, M) hipLaunchKernelGGL((gemm_kernel<KT, V, M, ARGS>), dim3(blocks), dim3(256), lds, st, a)
-#define GMQ(M, Q) hipLaunchKernelGGL((gemm_kernel<KT, 2, M, ARGS, false, (M == 2 ? 0 : 1), 2, 9, Q>), dim3(blocks), dim3(256), lds, st, a)
+#define GMQP(M, Q, P) hipLaunchKernelGGL((gemm_kernel<KT, 2, M, ARGS, false, (M == 2 ? 0 : 1), P, 9, Q>), dim3(blocks), dim3(256), lds, st, a)
+#define GMQ(M, Q) GMQP(M, Q, (KT >= 3 ? 3 : 2))
 #define GMP(M, P) hipLaunchKernelGGL((gemm_kernel<KT, 2, M, ARGS, false, 1, P>), dim3(blocks), dim3(256), lds, st, a)
     if (vec2 && KT >= 2 && (mode == 0 || mode == 1) && (tune[2] == 1 || tune[2] == 4)) {
       if (tune[2] == 1) { if (mode == 0) GMP(0, 0); else GMP(1, 0); }
@@ -2936,6 +2940,7 @@ struct HipEngine : dla::Engine {
       if (vec2 && qt == 2) { if (mode == 0) GMQ(0, 2); else if (mode == 1) GMQ(1, 2); else if (mode == 2) GMQ(2, 2); else GMQ(3, 2); return; }
     }
 #undef GMQ
+#undef GMQP
     if (vec2) { if (mode == 0) GM(2, 0); else if (mode == 1) GM(2, 1); else if (mode == 2) GM(2, 2); else GM(2, 3); }
     else      { if (mode == 0) GM(1, 0); else if (mode == 1) GM(1, 1); else if (mode == 2) GM(1, 2); else GM(1, 3); }
 #undef GM
@@ -2983,7 +2988,7 @@ struct HipEngine : dla::Engine {
     char kn[96];
     std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, %d, %d, 9, %d, %d>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
                   fuse ? "true" : "false", mode == 2 ? 0 : 1,
-                  kt >= 2 ? 2 : 0, qt, rtp);
+                  kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt, rtp);
     Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k, kn);
     if (inl) {
       GemmArgsInl ai{};
@@ -3148,7 +3153,7 @@ struct HipEngine : dla::Engine {
     const int ncol = 16 * kt;
     {
       char kn[64];
-      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d>", kt, vec2 ? 2 : 1, kt >= 2 ? 2 : 0, qt);
+      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d>", kt, vec2 ? 2 : 1, kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt);
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
 #define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME; hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
       if (vec2 && kt >= 2 && tune[0] == 1) {
@@ -3159,10 +3164,10 @@ struct HipEngine : dla::Engine {
         else RZ((ritz_kernel<3, 2, 3, 4>));
       } else if (vec2 && qt == 1) {
         if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 1>));
-        else RZ((ritz_kernel<3, 2, 3, 2, 1>));
+        else RZ((ritz_kernel<3, 2, 3, 3, 1>));
       } else if (vec2 && qt == 2) {
         if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 2>));
-        else RZ((ritz_kernel<3, 2, 3, 2, 2>));
+        else RZ((ritz_kernel<3, 2, 3, 3, 2>));
       } else if (vec2) {
         if (kt == 1) RZ((ritz_kernel<1, 2>));
         else if (kt == 2) RZ((ritz_kernel<2, 2>));

@@ -31,18 +31,19 @@ def timeit(cls, f, reps=4):
 LABEL = {0: "default", 1: "full tiles", 2: "pads loaded", 3: "narrow passes", 4: "no next-tile prefetch", 5: "64-row tiles", 8: "multi-pass lower"}
 
 
-def ab(title, cls, f, values=(1, 0)):
+def ab(title, cls, f, values=(1, 0), knob=7, labels=None):
     # knob 7: 1 = full 16x16x4 tiles only, 2 = Gram loads its padded / unused column groups too, 3 = Gram passes of at most
     # 12 accumulator tiles, 4 = no next-tile prefetch in the row products, 5 = 64-row wave tiles in the fused three-tile
     # sweeps, 8 = lower triangle of two panels in several passes, 0 = default
     res = {v: [] for v in values}
     for _ in range(rounds):
         for v in values:
-            ctx.set_option(TUNE0 + 7, v)
+            ctx.set_option(TUNE0 + knob, v)
             res[v].append(timeit(cls, f))
-    ctx.set_option(TUNE0 + 7, 0)
+    ctx.set_option(TUNE0 + knob, 0)
     base = np.median(res[values[0]])
-    print(f"{title:34s} " + "   ".join(f"{LABEL[v]} {np.median(res[v]):7.1f}" for v in values) +
+    lab = labels or LABEL
+    print(f"{title:34s} " + "   ".join(f"{lab[v]} {np.median(res[v]):7.1f}" for v in values) +
           f" GB/s   ({np.median(res[0]) / base - 1:+.1%})", flush=True)
 
 
