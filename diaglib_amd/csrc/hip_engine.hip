@@ -506,7 +506,8 @@ __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return
 // the in-place triangular update (MODE 2) stays plain: non-temporal loads there measured +1..9 % right behind a projection
 // sweep over the whole basis and -0.4..+0.7 % on whole solves, where it mostly follows a sweep over the same block.
 // PIPE > 0 (used for KT >= 2, where 4*KT MFMAs follow every load and the kernel runs at 1-2 waves per SIMD; 2 steps for
-// two-tile blocks, 3 for three-tile ones: +6 % on the fused 37-column sweeps, +3 % on the Ritz step against 2):
+// two-tile blocks -- 3 and 4 measured equal or worse there -- and 3 for three-tile ones: +6 % on the fused 37-column
+// sweeps, +3 % on the Ritz step against 2):
 // column steps are processed PIPE at a time through a two-stage register pipeline -- the loads of the next
 // stage are in flight while the MFMAs of the current one issue.  For KT == 1 occupancy hides the latency
 // better than registers do (A/B: batching there costs 5-10 %).
