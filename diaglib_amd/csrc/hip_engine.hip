@@ -506,13 +506,14 @@ __device__ __forceinline__ const double* packed_c(const GemmArgsInl& a) { return
 // the in-place triangular update (MODE 2) stays plain: non-temporal loads there measured +1..9 % right behind a projection
 // sweep over the whole basis and -0.4..+0.7 % on whole solves, where it mostly follows a sweep over the same block.
 // PIPE > 0 (used for KT >= 2, where 4*KT MFMAs follow every load and the kernel runs at 1-2 waves per SIMD; 2 steps for
-// two-tile blocks -- 3 and 4 measured equal or worse there -- and 3 for three-tile ones: +6 % on the fused 37-column
-// sweeps, +3 % on the Ritz step against 2):
+// two-tile blocks -- 3 and 4 measured equal or worse there -- and for the plain three-tile products, which would lose
+// their second wave per SIMD to a third step; 3 for the fused three-tile sweeps and the three-tile Ritz step, which run
+// one wave per SIMD anyway: +6 % and +3 % against 2):
 // column steps are processed PIPE at a time through a two-stage register pipeline -- the loads of the next
 // stage are in flight while the MFMAs of the current one issue.  For KT == 1 occupancy hides the latency
 // better than registers do (A/B: batching there costs 5-10 %).
 // QT > 0: the last tile has only 4*QT live columns and is formed by quarter instructions (see mfma_quarter).
-template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1), int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int ZPAD = 9,
+template <int KT, int VEC, int MODE, typename ARGS, bool GRAM = false, int NT = (MODE == 2 ? 0 : 1), int PIPE = (KT >= 2 ? 2 : 0), int ZPAD = 9,
           int QT = 0, int RTP = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(ARGS a)
 {
@@ -2929,7 +2930,7 @@ struct HipEngine : dla::Engine {
   {
 #define GM(V, M) hipLaunchKernelGGL((gemm_kernel<KT, V, M, ARGS>), dim3(blocks), dim3(256), lds, st, a)
 #define GMQP(M, Q, P) hipLaunchKernelGGL((gemm_kernel<KT, 2, M, ARGS, false, (M == 2 ? 0 : 1), P, 9, Q>), dim3(blocks), dim3(256), lds, st, a)
-#define GMQ(M, Q) GMQP(M, Q, (KT >= 3 ? 3 : 2))
+#define GMQ(M, Q) GMQP(M, Q, 2)      /* (a third step per stage costs these kernels their second wave per SIMD: update -22 %) */
 #define GMP(M, P) hipLaunchKernelGGL((gemm_kernel<KT, 2, M, ARGS, false, 1, P>), dim3(blocks), dim3(256), lds, st, a)
     if (vec2 && KT >= 2 && (mode == 0 || mode == 1) && (tune[2] == 1 || tune[2] == 4)) {
       if (tune[2] == 1) { if (mode == 0) GMP(0, 0); else GMP(1, 0); }
@@ -2989,7 +2990,7 @@ struct HipEngine : dla::Engine {
     char kn[96];
     std::snprintf(kn, sizeof kn, "gemm_kernel<%d, %d, %d, %s, %s, %d, %d, 9, %d, %d>", kt, vec2 ? 2 : 1, mode, inl ? "GemmArgsInl" : "GemmArgs",
                   fuse ? "true" : "false", mode == 2 ? 0 : 1,
-                  kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt, rtp);
+                  (fuse && kt >= 3) ? 3 : kt >= 2 ? 2 : 0, qt, rtp);
     Scope s(this, cls, rd + 8.0 * n * (double)k, (cls == DLA_OP_TRMM ? 1.0 : 2.0) * (double)n * l * k, kn);
     if (inl) {
       GemmArgsInl ai{};
