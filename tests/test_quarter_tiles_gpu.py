@@ -20,7 +20,7 @@ def _gb(ax, au):
 
 
 @pytest.mark.parametrize("k", WIDTHS)
-@pytest.mark.parametrize("n", [64, 2000, 4110])
+@pytest.mark.parametrize("n", [2, 18, 64, 2000, 4110])
 def test_gram_shapes(ctx, rng, n, k):
     u = np.asfortranarray(rng.standard_normal((n, k)))
     pu = ctx.panel(np.asfortranarray(np.hstack([np.full((n, 1), 1e30), u, np.full((n, 1), 1e30)])))
@@ -40,7 +40,7 @@ def test_gram_shapes(ctx, rng, n, k):
 
 
 @pytest.mark.parametrize("k", WIDTHS)
-@pytest.mark.parametrize("n,l", [(2000, 111), (4110, 50), (64, 7)])
+@pytest.mark.parametrize("n,l", [(2000, 111), (4110, 50), (64, 7), (2, 40), (30, 111)])
 def test_row_products(ctx, rng, n, l, k):
     x = np.asfortranarray(rng.standard_normal((n, l)))
     c = np.asfortranarray(rng.standard_normal((l, k)))
@@ -71,7 +71,7 @@ def test_row_products(ctx, rng, n, l, k):
 
 @pytest.mark.parametrize("knob", [0, 1, 5])
 @pytest.mark.parametrize("k", WIDTHS + [41, 48])
-@pytest.mark.parametrize("n,m", [(2000, 74), (4110, 20), (1998, 111)])
+@pytest.mark.parametrize("n,m", [(2000, 74), (4110, 20), (1998, 111), (6, 30), (34, 74)])
 def test_fused_sweeps(ctx, rng, n, m, k, knob):
     """knob 1: full tiles only; knob 5: 64-row wave tiles in the three-tile sweeps (default: 32 rows when two blocks fit a CU)"""
     x = np.asfortranarray(rng.standard_normal((n, m)))
@@ -106,7 +106,7 @@ def test_fused_sweeps(ctx, rng, n, m, k, knob):
 
 
 @pytest.mark.parametrize("m", WIDTHS)
-@pytest.mark.parametrize("n,l", [(2000, 111), (4110, 40)])
+@pytest.mark.parametrize("n,l", [(2000, 111), (4110, 40), (10, 60)])
 def test_ritz_step(ctx, rng, n, l, m):
     v = np.asfortranarray(rng.standard_normal((n, l)))
     av = np.asfortranarray(rng.standard_normal((n, l)))
@@ -138,7 +138,7 @@ def test_ritz_step(ctx, rng, n, l, m):
 
 
 @pytest.mark.parametrize("l", [49, 63, 64, 65, 80, 89, 96, 100, 111, 112])
-@pytest.mark.parametrize("n", [64, 2000, 4110])
+@pytest.mark.parametrize("n", [2, 14, 30, 64, 2000, 4110])
 def test_lower_triangle_of_two_panels_single_pass(ctx, rng, n, l):
     """S^T A S of LOBPCG: the lower triangle of X^T U for two different panels of 4..7 column tiles is formed in one pass
     (tile pairs above the diagonal compiled out); knob 8 = the multi-pass kernel it replaces."""
