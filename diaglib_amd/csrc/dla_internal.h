@@ -94,6 +94,17 @@ struct Engine : BlockOps {
                             const double* eig, int n_res, const int* skip, double* evec, double* r,
                             double* avy /* optional n x m: uncorrected AV*Y */,
                             double* sumsq_max /* 2*n_res: sum r^2, max|r| */) = 0;
+  // the same sweep also forms P = V C2 and AP = AV C2 (k2 columns; LOBPCG's new P block, reference diaglib.f90:495-501,
+  // whose products read the same two panels as the Ritz step).  Default: the Ritz step, then two panel products.
+  virtual int ritz_residual_p(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
+                              const double* eig, int n_res, const int* skip, double* evec, double* r, double* avy,
+                              double* sumsq_max, int k2, const double* c2_host, int ldc2, double* p, double* ap)
+  {
+    int st = ritz_residual(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, sumsq_max);
+    if (!st && k2 > 0) st = gemm(n, l, v, k2, c2_host, ldc2, p, 0);
+    if (!st && k2 > 0) st = gemm(n, l, av, k2, c2_host, ldc2, ap, 0);
+    return st;
+  }
   virtual int axpy(size_t len, double alpha, const double* x, double* y) = 0;
   virtual int sumsq(size_t len, const double* x, double* out) = 0;
   virtual int stream_triad(size_t /*len*/, int /*reps*/, double* gbps) { *gbps = 0.0; return DLA_ERR_ARG; }

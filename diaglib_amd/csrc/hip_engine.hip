@@ -783,6 +783,11 @@ struct RitzArgs {
   double* red;         // block partials [nblk][16*KT][2]
   long long n;
   int l, l4, k;
+  // extra products of the same sweep (LOBPCG's P block): columns k .. k+k2-1 of the packed coefficient block give
+  // p2 = V C2 and ap2 = AV C2 -- no residual correction, no norms
+  double* p2;
+  double* ap2;
+  int k2;
   double theta[48];
   int active[48];
 };
@@ -813,11 +818,12 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
   const long long ntiles = (n + RG - 1) / RG;
   const int nsteps = l4 / 4;
 
-  double th[KT][4];
-  int act[KT][4];
-  double ssq[KT][4], smx[KT][4];
+  constexpr int KR = KT < 3 ? KT : 3;     // tiles that can hold residual columns (m <= 48); further tiles: extra products only
+  double th[KR][4];
+  int act[KR][4];
+  double ssq[KR][4], smx[KR][4];
 #pragma unroll
-  for (int q = 0; q < KT; ++q)
+  for (int q = 0; q < KR; ++q)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int j = 16 * q + g + 4 * reg;
@@ -933,18 +939,25 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int j = 16 * q + g + 4 * reg;
-          if (j >= a.k) continue;
+          if (j >= a.k + a.k2) continue;
           const double e0 = avv(0, q, reg), e1 = avv(VEC - 1, q, reg);
           double r0 = aavv(0, q, reg), r1 = aavv(VEC - 1, q, reg);
+          if (j >= a.k) {                  // a column of the extra block: two plain products
+            pstore<VEC, NT>(a.p2 + (size_t)(j - a.k) * (size_t)n + row, vmake<VEC>(e0, e1));
+            pstore<VEC, NT>(a.ap2 + (size_t)(j - a.k) * (size_t)n + row, vmake<VEC>(r0, r1));
+            continue;
+          }
+          constexpr int KRm = KR - 1;
+          const int qr = q < KR ? q : KRm;  // (j < k <= 48 implies q < 3; the clamp only keeps the unrolled indices in range)
           if (a.avy) pstore<VEC, NT>(a.avy + (size_t)j * (size_t)n + row, vmake<VEC>(r0, r1));
-          if (act[q][reg]) {
-            r0 = r0 - th[q][reg] * e0;   // daxpy(-eig), reference diaglib.f90:1729
-            ssq[q][reg] += r0 * r0;
-            smx[q][reg] = fmax(smx[q][reg], fabs(r0));
+          if (act[qr][reg]) {
+            r0 = r0 - th[qr][reg] * e0;   // daxpy(-eig), reference diaglib.f90:1729
+            ssq[qr][reg] += r0 * r0;
+            smx[qr][reg] = fmax(smx[qr][reg], fabs(r0));
             if constexpr (VEC == 2) {
-              r1 = r1 - th[q][reg] * e1;
-              ssq[q][reg] += r1 * r1;
-              smx[q][reg] = fmax(smx[q][reg], fabs(r1));
+              r1 = r1 - th[qr][reg] * e1;
+              ssq[qr][reg] += r1 * r1;
+              smx[qr][reg] = fmax(smx[qr][reg], fabs(r1));
             }
           }
           pstore<VEC, NT>(a.evec + (size_t)j * (size_t)n + row, vmake<VEC>(e0, e1));
@@ -956,7 +969,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
   __syncthreads();   // everyone is done with cs as the copy of Y
   double* sred = cs; // [4 waves][16*KT][2]
 #pragma unroll
-  for (int q = 0; q < KT; ++q)
+  for (int q = 0; q < KR; ++q)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       double s = ssq[q][reg], m = smx[q][reg];
@@ -975,7 +988,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
   if (threadIdx.x < 16 * KT) {
     const int j = threadIdx.x;
     double s = 0.0, m = 0.0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < 4 && j < 16 * KR; ++w) {
       s += sred[(w * 16 * KT + j) * 2 + 0];
       m = fmax(m, sred[(w * 16 * KT + j) * 2 + 1]);
     }
@@ -3090,9 +3103,33 @@ struct HipEngine : dla::Engine {
   {
     return with_lds_retry([&]() { return ritz_residual_once(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, out); });
   }
+  bool ritz_p_declined = false;
+  // the sweep with k2 extra products (Engine::ritz_residual_p): one pass when [Y | C2] fits five column tiles and the LDS copy,
+  // otherwise the Ritz step and two panel products
+  int ritz_residual_p(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
+                      const double* eig, int n_res, const int* skip, double* evec, double* r, double* avy,
+                      double* out, int k2, const double* c2_host, int ldc2, double* p2, double* ap2) override
+  {
+    if (k2 <= 0) return ritz_residual(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, out);
+    const uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy | (uintptr_t)p2 | (uintptr_t)ap2;
+    const int ktot = (m + k2 + 15) / 16, l4 = ((l + 3) / 4) * 4;
+    const bool one_pass = (n % 2 == 0) && (al % 16 == 0) && m <= 48 && ktot <= 5 && tune[0] != 5 &&
+                          sizeof(double) * (size_t)l4 * 16 * ktot <= std::min((size_t)150 * 1024, lds_limit);
+    if (!one_pass) return Engine::ritz_residual_p(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, out, k2, c2_host, ldc2, p2, ap2);
+    // [Y | C2] as one coefficient block
+    std::vector<double> yc((size_t)l * (m + k2));
+    for (int j = 0; j < m; ++j) std::memcpy(&yc[(size_t)j * l], y_host + (size_t)j * ldy, sizeof(double) * l);
+    for (int j = 0; j < k2; ++j) std::memcpy(&yc[(size_t)(m + j) * l], c2_host + (size_t)j * ldc2, sizeof(double) * l);
+    ritz_p_declined = false;
+    int st = with_lds_retry([&]() { return ritz_residual_once(n, l, m, v, av, yc.data(), l, eig, n_res, skip, evec, r, avy, out, k2, p2, ap2); });
+    if (st != DLA_OK && ritz_p_declined)      // (the LDS request was refused and the retry found the block too large: nothing ran)
+      return Engine::ritz_residual_p(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, out, k2, c2_host, ldc2, p2, ap2);
+    if (st == DLA_OK) stats.flops[DLA_OP_GEMM] += 4.0 * (double)n * l * k2;    // reference-schedule flops of the two products it replaces
+    return st;
+  }
   int ritz_residual_once(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
                          const double* eig, int n_res, const int* skip, double* evec, double* r, double* avy,
-                         double* out)
+                         double* out, int k2 = 0, double* p2 = nullptr, double* ap2 = nullptr)
   {
     if (m > 48) {
       // more than three 16-column tiles: blocks of 48 columns, each a sweep of its own over V and AV
@@ -3107,14 +3144,15 @@ struct HipEngine : dla::Engine {
       }
       return DLA_OK;
     }
-    const int kt = (m + 15) / 16;
+    const int kt = (m + k2 + 15) / 16;      // column tiles of [Y | C2]
     const int l4 = ((l + 3) / 4) * 4;
-    uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy;
+    uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy | (uintptr_t)p2 | (uintptr_t)ap2;
     const bool vec2 = (n % 2 == 0) && (al % 16 == 0);
-    const int qt = (tune[0] == 1 || tune[0] == 4) ? 0 : quarter_tiles(m, vec2);
+    const int qt = (tune[0] == 1 || tune[0] == 4) ? 0 : quarter_tiles(m + k2, vec2);
     // LDS copy of Y (a quarter-tile kernel keeps 8 columns of the last tile)
     const size_t lds_c = sizeof(double) * (size_t)l4 * (qt > 0 ? 16 * (kt - 1) + 8 : 16 * kt);
     if (lds_c > std::min((size_t)150 * 1024, lds_limit)) {
+      if (k2 > 0) { ritz_p_declined = true; err = "ritz sweep with extra products: coefficient block beyond the LDS limit"; return DLA_ERR_RUNTIME; }
       // Y does not fit the LDS copy in one piece (wide block times deep subspace, e.g. 37 columns x 20 blocks): form the
       // two products with the chunked panel GEMM, then run the fused sweep on the n x m results with Y = identity
       // for the residual correction and the norms (same arithmetic for r; evec and AV Y are plain products)
@@ -3132,9 +3170,10 @@ struct HipEngine : dla::Engine {
       int stq = free_(tmp);
       return stf ? stf : stq;
     }
-    int stc = upload_packed(y_host, ldy, 0, l, m, kt, l4);
+    int stc = upload_packed(y_host, ldy, 0, l, m + k2, kt, l4);
     if (stc) return stc;
     RitzArgs a{};
+    a.p2 = p2; a.ap2 = ap2; a.k2 = k2;
     int nact = 0;
     for (int j = 0; j < n_res && j < 48; ++j) {
       if (skip && skip[j]) continue;
@@ -3156,7 +3195,7 @@ struct HipEngine : dla::Engine {
     {
       char kn[64];
       std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d>", kt, vec2 ? 2 : 1, kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt);
-      Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
+      Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m + 2.0 * k2), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
 #define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME; hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
       if (vec2 && kt >= 2 && tune[0] == 1) {
         if (kt == 2) RZ((ritz_kernel<2, 2, 3, 0>));
@@ -3173,7 +3212,9 @@ struct HipEngine : dla::Engine {
       } else if (vec2) {
         if (kt == 1) RZ((ritz_kernel<1, 2>));
         else if (kt == 2) RZ((ritz_kernel<2, 2>));
-        else RZ((ritz_kernel<3, 2>));
+        else if (kt == 3) RZ((ritz_kernel<3, 2>));
+        else if (kt == 4) RZ((ritz_kernel<4, 2>));
+        else RZ((ritz_kernel<5, 2>));
       } else {
         if (kt == 1) RZ((ritz_kernel<1, 1>));
         else if (kt == 2) RZ((ritz_kernel<2, 1>));

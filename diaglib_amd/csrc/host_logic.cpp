@@ -347,6 +347,24 @@ int dla_ritz_residual(dla_ctx* c, int n, int l, int m, const double* v, const do
   return DLA_OK;
 }
 
+int dla_ritz_residual_p(dla_ctx* c, int n, int l, int m, const double* v, const double* av, const double* y, int ldy,
+                        const double* eig, int n_res, const int* skip, double* evec, double* r, double* avy,
+                        double* rnorm, int k2, const double* c2, int ldc2, double* p, double* ap)
+{
+  DLA_T("dla_ritz_residual_p");
+  if (k2 < 0 || (k2 > 0 && (!c2 || !p || !ap || ldc2 < l))) return fail(c, DLA_ERR_ARG, "ritz_residual_p: bad extra block");
+  std::vector<double> sm((size_t)2 * (n_res > 0 ? n_res : 1), 0.0);
+  int st = c->eng->ritz_residual_p(n, l, m, v, av, y, ldy, eig, n_res, skip, evec, r, avy, sm.data(), k2, c2, ldc2, p, ap);
+  if (st) return engfail(c, st);
+  double sqrtn = std::sqrt((double)global_rows(c, n));
+  for (int i = 0; i < n_res; ++i) {
+    if (skip && skip[i]) continue;
+    rnorm[2 * i] = std::sqrt(sm[2 * i]) / sqrtn;
+    rnorm[2 * i + 1] = sm[2 * i + 1];
+  }
+  return DLA_OK;
+}
+
 int dla_axpy(dla_ctx* c, size_t len, double alpha, const double* x, double* y)
 {
   DLA_T("dla_axpy");

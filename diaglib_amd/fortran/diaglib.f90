@@ -167,6 +167,15 @@ module diaglib
       integer(c_int) :: skip(*)
       integer(c_int) :: st
     end function
+    function dla_ritz_residual_p(ctx,n,l,m,v,av,y,ldy,eig,n_res,skip,evec,r,avy,rnorm,k2,c2,ldc2,p,ap) &
+             bind(C,name='dla_ritz_residual_p') result(st)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, v, av, evec, r, avy, p, ap
+      integer(c_int), value :: n, l, m, ldy, n_res, k2, ldc2
+      real(c_double) :: y(*), eig(*), rnorm(*), c2(*)
+      integer(c_int) :: skip(*)
+      integer(c_int) :: st
+    end function
     function dla_axpy(ctx,len,alpha,x,y) bind(C,name='dla_axpy') result(st)
       import :: c_ptr, c_int, c_double, c_size_t
       type(c_ptr), value :: ctx, x, y
@@ -796,9 +805,9 @@ contains
     type(c_funptr)  :: op, prec, metric
     type(c_ptr)     :: sp(2), asp(2), bsp(2), resid, latest
     integer         :: rd, wr              ! the copy the basis is read from / the copy that receives the new X and P
-    real(dp), allocatable :: h(:,:), theta(:), cx(:,:), cp(:,:)
+    real(dp), allocatable :: h(:,:), theta(:), cx(:,:), cp(:,:), seen(:,:,:)
     real(dp)        :: t_begin(2), t_end(2)
-    integer         :: it, sweeps, width, live, c_x, c_p, c_w, wide
+    integer         :: it, sweeps, width, live, c_x, c_p, c_w, wide, bet
 !
     op     = c_funloc(matvec)
     prec   = c_funloc(precnd)
@@ -816,9 +825,10 @@ contains
     resid = dev_panel(e%ctx, n, n_max, 'r')
     rd = 1
     wr = 2
-    allocate (h(wide,wide), theta(wide))
-    h  = zero
-    ok = .false.
+    allocate (h(wide,wide), theta(wide), seen(2,n_max,2))
+    h    = zero
+    seen = zero
+    ok   = .false.
     call clock_now(t_begin)
 !
 !   guess (:295), for the generalised problem made B-orthonormal (:299-302)
@@ -866,10 +876,27 @@ contains
       call lap_charge(w, w%diag)
       eig = theta(1:n_max)
 !
-!     new X, A X [, B X], residuals and norms in one sweep (:420-442)
+!     new X, A X [, B X], residuals and norms in one sweep (:420-442).  Standard problem: the P block of this sweep
+!     (P = S cp, A P = AS cp, :485-503) reads the same two panels, so the sweep forms it as well -- for the number of open
+!     roots the previous sweep left (`bet`); the coefficients only need the eigenvectors in h.  When a root locks in this
+!     sweep the bet is lost and the block is formed again below, as before.
 !
       call sub_refresh_mask(s)
-      call ritz_step(width)
+      bet = 0
+      if (.not.gen_eig) then
+        bet = open_roots_expected()
+        allocate (cx(width,n_max), cp(width,bet))
+        call chk(e%ctx, dla_get_coeffs(e%ctx, wide, width, n_max, bet, h, cx, cp), 'get_coeffs')
+        call chk(e%ctx, dla_ritz_residual_p(e%ctx, n, width, n_max, sp(rd), asp(rd), h, wide, eig, n_max, s%mask, &
+                                            sp(wr), resid, asp(wr), s%rnorm, bet, cp, width, &
+                                            colp(sp(wr),n,n_max+1), colp(asp(wr),n,n_max+1)), 'ritz/residual + p block')
+        latest = sp(wr)
+        deallocate (cx, cp)
+      else
+        call ritz_step(width)
+      end if
+      seen(:,:,1) = seen(:,:,2)
+      seen(:,:,2) = s%rnorm(1:2,1:n_max)
 !
       call sub_lock(s, it, n_max)                                 ! LOBPCG scans all n_max roots (:446-455)
       if (verbose) call print_table_rows(s, it, eig - shift)      ! the returned eig keeps the shift (:416,461)
@@ -887,12 +914,14 @@ contains
 !     coefficients of the new P block (:485-488); P = S cp, A P = AS cp [, B P = BS cp] (:495-503) go straight into
 !     the P block of the other copy, whose X block already holds the new Ritz vectors (:510-514)
 !
-      allocate (cx(width,n_max), cp(width,max(live,1)))
-      call chk(e%ctx, dla_get_coeffs(e%ctx, wide, width, n_max, live, h, cx, cp), 'get_coeffs')
-      call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, sp(rd),  live, cp, width, colp(sp(wr),n,c_p)), 'p block')
-      call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, asp(rd), live, cp, width, colp(asp(wr),n,c_p)), 'ap block')
-      if (gen_eig) call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, bsp(rd), live, cp, width, colp(bsp(wr),n,c_p)), 'bp block')
-      deallocate (cx, cp)
+      if (bet.ne.live) then
+        allocate (cx(width,n_max), cp(width,max(live,1)))
+        call chk(e%ctx, dla_get_coeffs(e%ctx, wide, width, n_max, live, h, cx, cp), 'get_coeffs')
+        call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, sp(rd),  live, cp, width, colp(sp(wr),n,c_p)), 'p block')
+        call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, asp(rd), live, cp, width, colp(asp(wr),n,c_p)), 'ap block')
+        if (gen_eig) call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, bsp(rd), live, cp, width, colp(bsp(wr),n,c_p)), 'bp block')
+        deallocate (cx, cp)
+      end if
       call turn_over()
 !
 !     new W block: preconditioned open residuals, orthogonalised against [X | P] (:518-528)
@@ -946,6 +975,37 @@ contains
       end if
       latest = sp(wr)
     end subroutine ritz_step
+!
+!   how many roots will still be open after the sweep that is about to run: the locking rule (sub_lock) applied to the
+!   residual norms extrapolated from the last two sweeps (each root's norms shrink by about the same factor per sweep).
+!   Only a bet -- the sweep forms the P block for this many roots, and the driver re-forms it when the bet is lost.
+!
+    function open_roots_expected() result(open)
+      integer  :: open, r, front
+      real(dp) :: guess(2), ratio
+      front = 0
+      do r = 1, n_max
+        if (.not.s%locked(r)) exit
+        front = front + 1
+      end do
+      if (it.gt.2) then
+        do r = front + 1, n_max
+          guess = seen(:,r,2)
+          if (seen(1,r,1).gt.zero .and. seen(2,r,1).gt.zero) then
+            ratio = min(one, seen(1,r,2)/seen(1,r,1))
+            guess(1) = seen(1,r,2)*ratio
+            ratio = min(one, seen(2,r,2)/seen(2,r,1))
+            guess(2) = seen(2,r,2)*ratio
+          end if
+          if (guess(1).lt.s%tol_rms .and. guess(2).lt.s%tol_max) then
+            front = front + 1
+          else
+            exit
+          end if
+        end do
+      end if
+      open = max(1, n_max - front)
+    end function open_roots_expected
 !
     subroutine turn_over()
       integer :: keep

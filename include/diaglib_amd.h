@@ -189,6 +189,13 @@ int  dla_trmm_linvt(dla_ctx* ctx, int n, int k, double* u_dev, const double* lin
 int  dla_ritz_residual(dla_ctx* ctx, int n, int l, int m, const double* v_dev, const double* av_dev,
                        const double* y_host, int ldy, const double* eig, int n_res, const int* skip,
                        double* evec_dev, double* r_dev, double* avy_dev, double* rnorm);
+/* The same sweep with k2 extra products: p_dev = V C2, ap_dev = AV C2 (C2: l x k2, host).  LOBPCG forms its new P block
+ * from the same two panels the Ritz step reads (diaglib.f90:495-501: P = S cp, AP = AS cp); with this entry they are read
+ * once.  k2 = 0: exactly dla_ritz_residual. */
+int  dla_ritz_residual_p(dla_ctx* ctx, int n, int l, int m, const double* v_dev, const double* av_dev,
+                         const double* y_host, int ldy, const double* eig, int n_res, const int* skip,
+                         double* evec_dev, double* r_dev, double* avy_dev, double* rnorm,
+                         int k2, const double* c2_host, int ldc2, double* p_dev, double* ap_dev);
 /* y += alpha x over len contiguous doubles.  daxpy at diaglib.f90:312,397 (LOBPCG shift). */
 int  dla_axpy(dla_ctx* ctx, size_t len, double alpha, const double* x_dev, double* y_dev);
 /* sqrt(sum x^2) over len contiguous doubles (all ranks).  dnrm2 at diaglib.f90:3749, 3268. */

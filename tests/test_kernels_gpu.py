@@ -248,3 +248,37 @@ def test_fused_sweeps_against_their_blas_pairs(ctx, oracle, rng, n, m, k):
     xu = np.asfortranarray(np.hstack([x, u]))
     check(big.col(m, k).download(), g, oracle.gemm_nn(xu, cp), np.abs(xu) @ np.abs(cp))
     assert np.array_equal(big.col(0, m).download(), x)              # X untouched
+
+
+@pytest.mark.parametrize("n,l,m,k2", [(2000, 39, 13, 13), (4110, 78, 13, 9), (2000, 111, 37, 37), (2001, 111, 37, 30), (3000, 63, 21, 21),
+                                      (1000, 26, 13, 1), (64, 111, 37, 37), (2000, 260, 48, 48), (2000, 111, 37, 0)])
+def test_ritz_sweep_with_extra_products(ctx, rng, n, l, m, k2):
+    """LOBPCG's new P block (reference diaglib.f90:495-501: P = S cp, AP = AS cp) formed by the Ritz sweep itself: the same
+    pass over V and AV yields evec, r, AV Y, the norms AND V C2, AV C2.  Everything must equal the separate calls bit for bit
+    (same contraction order), also where the engine falls back to them (odd n, more than five column tiles)."""
+    v = np.asfortranarray(rng.standard_normal((n, l)))
+    av = np.asfortranarray(rng.standard_normal((n, l)))
+    y = np.asfortranarray(rng.standard_normal((l + 2, m)))
+    c2 = np.asfortranarray(rng.standard_normal((l + 1, k2))) if k2 else np.zeros((l, 0), order="F")
+    eig = rng.standard_normal(m)
+    n_res = m
+    skip = np.zeros(m, np.int32); skip[m // 2] = 1
+    pv, pav = ctx.panel(v), ctx.panel(av)
+    pe, pr, pa = ctx.panel(n, m), ctx.panel(n, m), ctx.panel(n, m)
+    rn_ref = ctx.ritz_residual(pv, pav, y, eig, n_res, skip, pe, pr, pa)
+    ref = (pe.download(), pr.download(), pa.download())
+    pe2, pr2, pa2 = ctx.panel(n, m), ctx.panel(n, m), ctx.panel(n, m)
+    pp = ctx.panel(np.full((n, max(k2, 1) + 2), 7.0, order="F")); pap = ctx.panel(np.full((n, max(k2, 1) + 2), 7.0, order="F"))
+    rn = ctx.ritz_residual_p(pv, pav, y, eig, n_res, skip, pe2, pr2, pa2, c2[:l] if k2 else c2, pp.col(1, max(k2, 1)), pap.col(1, max(k2, 1)))
+    for a, b in zip(ref, (pe2.download(), pr2.download(), pa2.download())):
+        assert np.array_equal(a, b)
+    assert np.array_equal(rn, rn_ref)
+    gp, gap = pp.download(), pap.download()
+    assert np.all(gp[:, 0] == 7.0) and np.all(gp[:, k2 + 1:] == 7.0) and np.all(gap[:, 0] == 7.0) and np.all(gap[:, k2 + 1:] == 7.0)
+    if k2:
+        zp, zap = ctx.panel(n, k2), ctx.panel(n, k2)
+        ctx.panel_gemm(pv, c2[:l], zp); ctx.panel_gemm(pav, c2[:l], zap)
+        assert np.array_equal(gp[:, 1:k2 + 1], zp.download())
+        assert np.array_equal(gap[:, 1:k2 + 1], zap.download())
+        bound = 64 * EPS * (np.abs(v) @ np.abs(c2[:l])) + 1e-300
+        assert np.all(np.abs(gp[:, 1:k2 + 1] - v @ c2[:l]) <= bound)
