@@ -794,7 +794,9 @@ struct RitzArgs {
 
 // NT = 3: V / AV are read once and evec / r written once per sweep -> non-temporal loads and stores
 // (+6 % measured, tools/tune_ab.py)
-template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int QT = 0>
+// XP: the coefficient block carries extra product columns behind the k Ritz columns (RitzArgs::k2); a template argument so
+// that the plain Ritz step keeps its code (the same tests as run-time branches cost the one-tile kernel 37 %)
+template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int QT = 0, bool XP = false>
 __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 {
   constexpr int RG = 16 * VEC;             // rows per wave tile (one row group)
@@ -939,13 +941,15 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int j = 16 * q + g + 4 * reg;
-          if (j >= a.k + a.k2) continue;
+          if (j >= a.k + (XP ? a.k2 : 0)) continue;
           const double e0 = avv(0, q, reg), e1 = avv(VEC - 1, q, reg);
           double r0 = aavv(0, q, reg), r1 = aavv(VEC - 1, q, reg);
-          if (j >= a.k) {                  // a column of the extra block: two plain products
-            pstore<VEC, NT>(a.p2 + (size_t)(j - a.k) * (size_t)n + row, vmake<VEC>(e0, e1));
-            pstore<VEC, NT>(a.ap2 + (size_t)(j - a.k) * (size_t)n + row, vmake<VEC>(r0, r1));
-            continue;
+          if constexpr (XP) {
+            if (j >= a.k) {                // a column of the extra block: two plain products
+              pstore<VEC, NT>(a.p2 + (size_t)(j - a.k) * (size_t)n + row, vmake<VEC>(e0, e1));
+              pstore<VEC, NT>(a.ap2 + (size_t)(j - a.k) * (size_t)n + row, vmake<VEC>(r0, r1));
+              continue;
+            }
           }
           constexpr int KRm = KR - 1;
           const int qr = q < KR ? q : KRm;  // (j < k <= 48 implies q < 3; the clamp only keeps the unrolled indices in range)
@@ -3194,10 +3198,19 @@ struct HipEngine : dla::Engine {
     const int ncol = 16 * kt;
     {
       char kn[64];
-      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d>", kt, vec2 ? 2 : 1, kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt);
+      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d, %s>", kt, vec2 ? 2 : 1, kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt, k2 > 0 ? "true" : "false");
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m + 2.0 * k2), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
 #define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME; hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
-      if (vec2 && kt >= 2 && tune[0] == 1) {
+      if (k2 > 0) {
+        // [Y | C2]: vec2 guaranteed by the caller (ritz_residual_p)
+        if (qt == 1) { if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 1, true>)); else RZ((ritz_kernel<3, 2, 3, 3, 1, true>)); }
+        else if (qt == 2) { if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 2, true>)); else RZ((ritz_kernel<3, 2, 3, 3, 2, true>)); }
+        else if (kt == 1) RZ((ritz_kernel<1, 2, 3, 0, 0, true>));
+        else if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 0, true>));
+        else if (kt == 3) RZ((ritz_kernel<3, 2, 3, 3, 0, true>));
+        else if (kt == 4) RZ((ritz_kernel<4, 2, 3, 3, 0, true>));
+        else RZ((ritz_kernel<5, 2, 3, 3, 0, true>));
+      } else if (vec2 && kt >= 2 && tune[0] == 1) {
         if (kt == 2) RZ((ritz_kernel<2, 2, 3, 0>));
         else RZ((ritz_kernel<3, 2, 3, 0>));
       } else if (vec2 && kt >= 2 && tune[0] == 4) {
@@ -3212,9 +3225,7 @@ struct HipEngine : dla::Engine {
       } else if (vec2) {
         if (kt == 1) RZ((ritz_kernel<1, 2>));
         else if (kt == 2) RZ((ritz_kernel<2, 2>));
-        else if (kt == 3) RZ((ritz_kernel<3, 2>));
-        else if (kt == 4) RZ((ritz_kernel<4, 2>));
-        else RZ((ritz_kernel<5, 2>));
+        else RZ((ritz_kernel<3, 2>));
       } else {
         if (kt == 1) RZ((ritz_kernel<1, 1>));
         else if (kt == 2) RZ((ritz_kernel<2, 1>));

@@ -16,6 +16,7 @@ cp $OUT/kt5/run_kernel_stats.csv $OUT/kernel_stats_lobpcg_cfg5shape.csv
 rm -rf $OUT/kt5
 echo "cfg5 stats done"
 python3 bench.py --solver davidson --n 2000000 --roots 16 --steps 5 --warmup 1 --no-cpu-baseline --no-random-leg > $OUT/bench_davidson_cfg4shape_1gpu.json 2> $OUT/cfg4.err
+python3 bench.py --solver lobpcg --steps 5 --warmup 1 --no-cpu-baseline --no-random-leg > $OUT/bench_lobpcg_cfg3.json 2> $OUT/cfg3.err
 echo "cfg4 bench done"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt250 -o run -- python3 bench.py --n 250000 --steps 4 --warmup 2 --no-cpu-baseline --no-random-leg > $OUT/kt250.log 2>&1
 python3 tools/kt_gaps.py $OUT/kt250/run_kernel_trace.csv 3 > $OUT/kernel_trace_one_solve_250k_rows.txt
