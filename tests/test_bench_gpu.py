@@ -56,3 +56,19 @@ def test_bench_two_ranks_as_the_driver_launches_them():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
     assert d["host"]["allreduce_transport"] == "p2p" and d["host"]["allreduces"] > 0
     assert d["config"]["converged"] is True and d["config"]["rows_per_gpu"] in (100000, 100032, 99968)
+
+
+def test_headline_line_finds_its_counters():
+    """On the headline workload the dominant kernel's HBM traffic must come from profiles/pmc_traffic.json: the file is keyed by
+    workload and by the kernel name with every template argument, so a kernel whose template list changed without a new PMC
+    pass shows up here as traffic = null."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-random-leg"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _line(p.stdout)
+    _check(d, 1, 2, 1, 2000000)
+    r = d["roofline"]
+    assert r["traffic"] is not None, r["kernel"]
+    assert 0.9 < r["traffic"] / r["alg_bytes_per_launch"] < 1.1          # no wasted re-reads
+    assert d["config"]["iters"] == 9 and d["host"]["host_syncs"] / (d["steps"] + d["warmup"]) <= 35
+    assert r["step"]["sweeps_only"]["frac"] > r["step"]["frac"]
