@@ -56,7 +56,8 @@ class Stats(C.Structure):
 
 
 class KernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 96), ("launches", C.c_longlong), ("alg_bytes", C.c_double), ("ms", C.c_double)]
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_longlong), ("alg_bytes", C.c_double), ("ms", C.c_double),
+                ("flops", C.c_double)]
 
 
 class DlaError(RuntimeError):
@@ -243,7 +244,7 @@ class Context:
         buf = (KernelStat * 128)()
         n = self.lib.dla_get_kernel_stats(self.h, buf, 128)
         return {buf[j].name.decode(): {"launches": int(buf[j].launches), "alg_bytes": float(buf[j].alg_bytes),
-                                       "ms": float(buf[j].ms)} for j in range(n)}
+                                       "ms": float(buf[j].ms), "flops": float(buf[j].flops)} for j in range(n)}
 
     def reset_stats(self) -> None:
         self._chk(self.lib.dla_reset_stats(self.h))

@@ -1767,7 +1767,7 @@ struct HipEngine : dla::Engine {
   int tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void set_tune(int i, int v) override { if (i >= 0 && i < 8) tune[i] = v; }
   // per-kernel statistics (names as rocprofv3 prints them, without namespace / argument list)
-  struct KStat { long long launches = 0; double alg_bytes = 0.0, ms = 0.0; };
+  struct KStat { long long launches = 0; double alg_bytes = 0.0, ms = 0.0, flops = 0.0; };
   std::map<std::string, KStat> kstats;
   int kernel_stats(dla_kernel_stat* out, int cap) override
   {
@@ -1778,6 +1778,7 @@ struct HipEngine : dla::Engine {
       std::memset(&out[i], 0, sizeof(out[i]));
       std::strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
       out[i].launches = kv.second.launches; out[i].alg_bytes = kv.second.alg_bytes; out[i].ms = kv.second.ms;
+      out[i].flops = kv.second.flops;
       ++i;
     }
     return i;
@@ -1890,7 +1891,7 @@ struct HipEngine : dla::Engine {
         if (e->profile) { a = e->get_event(); b = e->get_event(); (void)hipEventRecord(a, e->st); }
         return;
       }
-      if (!kname.empty()) { auto& ks = e->kstats[kname]; ks.launches += 1; ks.alg_bytes += bytes; }
+      if (!kname.empty()) { auto& ks = e->kstats[kname]; ks.launches += 1; ks.alg_bytes += bytes; ks.flops += flops; }
       if (e->trace) {
         timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
         std::fprintf(stderr, "[dla] %ld.%06ld launch class %d, %.3e alg bytes\n", (long)ts.tv_sec, ts.tv_nsec / 1000, cls_, bytes);
@@ -2548,7 +2549,7 @@ struct HipEngine : dla::Engine {
       for (auto& r : recs) {
         if (!ran[r.tag]) continue;
         stats.launches[r.cls] += 1; stats.alg_bytes[r.cls] += r.bytes; stats.flops[r.cls] += r.flops;
-        if (!r.kname.empty()) { auto& ks = kstats[r.kname]; ks.launches += 1; ks.alg_bytes += r.bytes; }
+        if (!r.kname.empty()) { auto& ks = kstats[r.kname]; ks.launches += 1; ks.alg_bytes += r.bytes; ks.flops += r.flops; }
       }
       // reference-schedule flops of what the fused sweeps fold in (same bookkeeping as trmm_gram / combo_gram)
       for (size_t i = 0; i < launched.size(); ++i) {
@@ -3128,7 +3129,6 @@ struct HipEngine : dla::Engine {
     int st = with_lds_retry([&]() { return ritz_residual_once(n, l, m, v, av, yc.data(), l, eig, n_res, skip, evec, r, avy, out, k2, p2, ap2); });
     if (st != DLA_OK && ritz_p_declined)      // (the LDS request was refused and the retry found the block too large: nothing ran)
       return Engine::ritz_residual_p(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, out, k2, c2_host, ldc2, p2, ap2);
-    if (st == DLA_OK) stats.flops[DLA_OP_GEMM] += 4.0 * (double)n * l * k2;    // reference-schedule flops of the two products it replaces
     return st;
   }
   int ritz_residual_once(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
@@ -3199,7 +3199,9 @@ struct HipEngine : dla::Engine {
     {
       char kn[64];
       std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d, %s>", kt, vec2 ? 2 : 1, kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt, k2 > 0 ? "true" : "false");
-      Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m + 2.0 * k2), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
+      // (flops: the two Ritz products and, with extra columns, the two panel products they replace)
+      Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m + 2.0 * k2),
+              4.0 * (double)n * l * (m + k2) + 5.0 * (double)n * nact, kn);
 #define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME; hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
       if (k2 > 0) {
         // [Y | C2]: vec2 guaranteed by the caller (ritz_residual_p)

@@ -109,6 +109,7 @@ typedef struct {
   long long launches;
   double    alg_bytes;
   double    ms;
+  double    flops;       /* reference-schedule flops of the launches (what the BLAS calls they replace would execute) */
 } dla_kernel_stat;
 
 /* ---------------------------------------------------------------- context */
