@@ -821,6 +821,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
   const int nsteps = l4 / 4;
 
   constexpr int KR = KT < 3 ? KT : 3;     // tiles that can hold residual columns (m <= 48); further tiles: extra products only
+  constexpr bool TH_LDS = KT >= 4;
   double th[KR][4];
   int act[KR][4];
   double ssq[KR][4], smx[KR][4];
@@ -954,12 +955,15 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
           constexpr int KRm = KR - 1;
           const int qr = q < KR ? q : KRm;  // (j < k <= 48 implies q < 3; the clamp only keeps the unrolled indices in range)
           if (a.avy) pstore<VEC, NT>(a.avy + (size_t)j * (size_t)n + row, vmake<VEC>(r0, r1));
-          if (act[qr][reg]) {
-            r0 = r0 - th[qr][reg] * e0;   // daxpy(-eig), reference diaglib.f90:1729
+          // (the four- and five-tile kernels sit at the register limit: they read theta / active from LDS per tile)
+          const double thv = TH_LDS ? s_theta[j] : th[qr][reg];
+          const int actv = TH_LDS ? s_active[j] : act[qr][reg];
+          if (actv) {
+            r0 = r0 - thv * e0;            // daxpy(-eig), reference diaglib.f90:1729
             ssq[qr][reg] += r0 * r0;
             smx[qr][reg] = fmax(smx[qr][reg], fabs(r0));
             if constexpr (VEC == 2) {
-              r1 = r1 - th[qr][reg] * e1;
+              r1 = r1 - thv * e1;
               ssq[qr][reg] += r1 * r1;
               smx[qr][reg] = fmax(smx[qr][reg], fabs(r1));
             }
