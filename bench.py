@@ -383,7 +383,7 @@ def main() -> None:
     # ... and the same classes without the launches that move no panel bytes (reductions of per-block partials, the k x k
     # steps of the device-driven chains, the cross-rank exchange): the rate of the sweeps themselves
     small_ms = sum(v["ms"] for k, v in kst.items()
-                   if k.startswith(("gram_reduce_kernel", "ortho_tail_kernel", "p2p_allreduce_kernel")))
+                   if k.startswith(("gram_reduce_kernel", "ortho_tail_kernel", "ortho_tail16_kernel", "p2p_allreduce_kernel")))
     roofline["step"] = {"what": "ortho/matvec step = classes " + "+".join(step_cls) + " (HIP-event time, reductions included)",
                         "achieved": round(step_b / max(step_ms, 1e-9) / 1e6, 1),
                         "frac": round(step_b / max(step_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),

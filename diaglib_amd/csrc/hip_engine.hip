@@ -97,6 +97,8 @@ struct GramArgs {
   const int* phase;  // device-driven chains (ortho_chain): run only if *phase == want; nullptr = always
   int want;
   int noskip;        // A/B: issue the loads of fully padded column groups too (gram_lds_kernel)
+  const double* wp;  // gram_lds_kernel WP: pending factor of the U block, packed [16][16] (wp[16 p + j] = W(p, j)); nullptr = identity
+  double* uw;        // gram_lds_kernel WP: when set, the transformed tiles U W are also written back (the panel address of U)
 };
 
 // A launch of a device-driven chain is speculative: the step it belongs to may not be the one the device-side state
@@ -265,10 +267,22 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 // D[4 ((L>>2)&3) + (L>>4)][4 qq + (L&3)] -- put back in place when the accumulators go through LDS at the end.
 // LOW: the whole lower block triangle of X^T U (l == k, x != u: the S^T A S of LOBPCG) in ONE pass -- the tile pairs above
 // the diagonal are compiled out, so up to 7 x 7 tiles fit the accumulator registers (28 pairs) and both panels are read once.
-template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0, int QT = 0, int LOW = 0>
+// WP (one U tile, k <= 16): the U block in memory carries a PENDING right factor W (the triangular updates of the
+// Cholesky-QR loop that have not been written back, see "pending factor" at ortho_tail16): every staged U tile is replaced
+// by U W in LDS (4 MFMAs per 16 rows: D^T = W^T U^T, lane (c, g) reads U[row c][4 s + g] and writes (U W)[row c][g + 4 r]
+// -- the same four LDS words, so no lane touches a word another lane reads) before the products are formed.  The values
+// are those a triangular-update sweep would have stored (same instruction, same order); they are just never rounded to
+// memory.  Without SELF the pass also forms (U W)^T (U W) as one extra output slot behind the TLW x KT slots of X^T (U W):
+// X^T U and the Gram matrix of U in one sweep over [X | U].  With GramArgs::uw the transformed tiles are written back as well
+// (full 128-byte column segments, straight from the staged image): the triangular update, the Gram matrix of its result
+// and X^T of its result in ONE sweep, all three taken from the very values that reach memory.
+template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0, int QT = 0, int LOW = 0, int WP = 0>
 __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
 {
   DLA_PREDICATED(a);
+  static_assert(!WP || (KT == 1 && QT == 0 && LOW == 0), "pending factor: one U tile");
+  constexpr int UU = (WP && !SELF) ? 1 : 0;   // extra output slot (U W)^T (U W)
+  constexpr int NSLOT = TLW * KT + UU;
   // R rows per wave tile (16 or 32): R/2 lanes cover one column segment, 128/R columns per load instruction
   constexpr int RS = R + 2;                // doubles per staged column (+2 keeps 16-byte alignment)
   constexpr int LPC = R / 2;               // lanes per column
@@ -337,6 +351,12 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   for (int t = 0; t < (SELF ? KT : TLW); ++t)
 #pragma unroll
     for (int qq = 0; qq < (QT > 0 ? QT : 1); ++qq) accq[t][qq] = 0.0;
+  v4d accuu = (v4d){0.0, 0.0, 0.0, 0.0};
+  double wa[WP ? 4 : 1];                     // A operands of the tile transform: W(4 s + g, c)
+  if constexpr (WP) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wa[s] = a.wp ? a.wp[(4 * s + g) * 16 + c] : ((4 * s + g) == c ? 1.0 : 0.0);
+  }
   typedef VecOf<2>::type vec_t;
   vec_t stg[NI];
   auto load_tile = [&](long long tile) {
@@ -365,12 +385,46 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   };
   constexpr int KF = (QT > 0 && !SELF) ? KT - 1 : KT;     // U tiles multiplied by full instructions
   constexpr int TF = (QT > 0 && SELF) ? TLW - 1 : TLW;    // X tiles ...
+  // WP: staged U tile <- (U tile) W, 16 rows at a time
+  auto apply_w = [&](long long r0w, bool rows_ok) {
+    if constexpr (WP) {
+      if (a.wp == nullptr && a.uw == nullptr) return;      // nothing pending: the staged tile is the block itself
+      // (all fragment reads first, then the MFMA chains of the R / 16 row groups side by side, then the stores)
+      double* ut = my + (size_t)UOFF * RS + c;
+      double uin[R / 16][4];
+#pragma unroll
+      for (int h = 0; h < R / 16; ++h)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) uin[h][s] = lds_load1(ut + (size_t)(4 * s + g) * RS + 16 * h);
+      v4d d[R / 16];
+#pragma unroll
+      for (int h = 0; h < R / 16; ++h) d[h] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int h = 0; h < R / 16; ++h) d[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], uin[h][s], d[h], 0, 0, 0);
+#pragma unroll
+      for (int h = 0; h < R / 16; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds_store1(ut + (size_t)(g + 4 * r) * RS + 16 * h, d[h][r]);
+      __builtin_amdgcn_wave_barrier();
+      if (a.uw != nullptr && rows_ok) {
+        // the wave's own rows of the block: 128-byte segments of CPI columns per instruction
+#pragma unroll
+        for (int j = (16 * (SELF ? 0 : TLW)) / CPI; j < NI; ++j) {
+          const int uc = CPI * j + lc - UOFF;
+          if (uc < a.k) pstore<2, 0>(a.uw + (size_t)uc * (size_t)n + r0w + 2 * li, *(const lds_v2f64*)(my + (size_t)(CPI * j + lc) * RS + 2 * li));
+        }
+      }
+    }
+  };
   auto mfma_tile = [&]() {
 #pragma unroll
     for (int s4 = 0; s4 < R / 4; ++s4) {
       double uf[KT];
 #pragma unroll
       for (int q = 0; q < (SELF ? KT : KF); ++q) uf[q] = lds_load1(my + (size_t)(UOFF + 16 * q + c) * RS + 4 * s4 + g);
+      if constexpr (UU) accuu = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[0], uf[0], accuu, 0, 0, 0);
       double uq[QT > 0 ? QT : 1];
       if constexpr (QT > 0 && !SELF) {
 #pragma unroll
@@ -409,6 +463,7 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
       __builtin_amdgcn_wave_barrier();
       const long long next = tile + stride;
       if (next < nfull) load_tile(next);
+      apply_w(tile * R, true);
       mfma_tile();
       __builtin_amdgcn_wave_barrier();
       tile = next;
@@ -426,6 +481,7 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
     }
     stage_tile();
     __builtin_amdgcn_wave_barrier();
+    apply_w(r0, ok);
     mfma_tile();
     __builtin_amdgcn_wave_barrier();
   }
@@ -433,7 +489,14 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   // deterministic in-block reduction over the 4 waves, one slot at a time (the staging area is free now)
   __syncthreads();
   double* red = glds;   // [4][256]
-  double* pout = a.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(TLW * KT) * 256;
+  double* pout = a.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)NSLOT * 256;
+  if constexpr (UU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = accuu[r];
+    __syncthreads();
+    pout[(size_t)(TLW * KT) * 256 + threadIdx.x] = ((red[threadIdx.x] + red[256 + threadIdx.x]) + red[512 + threadIdx.x]) + red[768 + threadIdx.x];
+    __syncthreads();
+  }
 #pragma unroll
   for (int t = 0; t < TLW; ++t)
 #pragma unroll
@@ -1263,7 +1326,9 @@ __global__ void diag_precnd_kernel(int n, int m, double fac, const double* __res
 // (OrthoDev::phase).  The host enqueues the sequence of sweeps it expects (the one the previous call took); every
 // sweep and every tail kernel checks the phase and leaves at once when it is not its turn (DLA_PREDICATED), so a
 // wrong guess costs empty launches, never a wrong result.  One host wait at the end reads the state back.
-enum { OP_NONE = 0, OP_GRAM_UU = 1, OP_TRMMG = 2, OP_XU = 3, OP_COMBO = 4, OP_FINAL = 5 };
+// OP_GRAMX / OP_GRAMW / OP_XW belong to the pending-factor schedule (k <= 16, even n; see ortho_tail16): X^T U and U^T U in one
+// sweep over [X | U]; the Gram matrix of U W formed on the fly; both at once
+enum { OP_NONE = 0, OP_GRAM_UU = 1, OP_TRMMG = 2, OP_XU = 3, OP_COMBO = 4, OP_FINAL = 5, OP_GRAMX = 6, OP_GRAMW = 7, OP_XW = 8 };
 enum { OST_RUNNING = 0, OST_DONE = 1, OST_CD_MAXIT = 2, OST_FACTOR_FAIL = 3, OST_VSX_MAXIT = 4 };
 
 struct OrthoDev {
@@ -1274,8 +1339,10 @@ struct OrthoDev {
   int nops;           // sweeps executed so far
   int macro_total;    // macro-iterations over all ortho_cd passes (report)
   int shifts;         // level shifts taken (report)
-  int pad_;
+  int have_xu;        // pending-factor schedule: X^T U of the block in memory is known (xug) up to the factors in wst
   double growth;      // prod ||L^-1||_est of the current ortho_cd pass
+  int sloppy;         // pending-factor schedule: the last projection used an X^T U carried through ill-conditioned factors
+  int pad2_;
   int log[48];        // the sweeps executed, in order
 };
 
@@ -1291,7 +1358,13 @@ struct OrthoTailArgs {
   int can_defer;       // 1: ortho_vs_x on the block that follows X (combined sweep available); 0: plain ortho_cd
   int maxit;           // maxit, diaglib.f90:3224,3521
   int publish;         // 1: last launch of the host's plan -- leave the state in the host mirror whatever happened
+  // pending-factor schedule (ortho_tail16)
+  int fold;            // 1: this chain runs it; 2: ortho_tail16 with the sweep-per-update schedule (odd n)
+  const double* xug;   // X^T U and U^T U of the last OP_GRAMX / OP_XW sweep: (m + k) x k, ld m + k
+  double* wst;         // pending factors between launches, accumulator layout: [0,256) Wp^T, [256,512) Wd^T, [512,768) Wp
+  unsigned long long* dbg;   // $DIAGLIB_AMD_CHAIN_DEBUG: time stamps of the step (100 MHz ticks), 16 per executed sweep
 };
+#define TSTAMP(a, nops, i) do { if ((a).dbg != nullptr && (nops) < 48) (a).dbg[(nops) * 16 + (i)] = wall_clock64(); } while (0)
 
 // The k x k work is done by ONE wave on LDS images (row-major, row stride TLD): lane i owns row i (k <= 48 < 64).  LDS
 // operations of a wave complete in order, so no workgroup barrier is needed (the routine can run at the end of a kernel
@@ -1363,8 +1436,37 @@ __device__ __forceinline__ double lds_norm_est(int k, const double* A, int lane)
   return dn + sqrt(on);
 }
 
-struct TailState { int it_macro, it_outer, macro_total, shifts, nops, phase, status; double growth; };
+struct TailState { int it_macro, it_outer, macro_total, shifts, nops, phase, status; double growth; int have_xu, sloppy; };
 #define TAIL_LDS_DOUBLES (48 * TLD + 48 * 64)   // image A, then image S (also used as 48 x 64 scratch)
+
+// what one lane does at the end of a step: log the sweep, report to the host when the chain ends (or the plan does), leave the
+// new state -- or the initial one, ready for the next chain -- in device memory
+__device__ __forceinline__ void tail_publish(const OrthoTailArgs& a, const TailState& t)
+{
+  OrthoDev* st = a.st;
+  const int ph_out = (t.status == OST_RUNNING) ? t.phase : OP_NONE;
+  const int nops = t.nops;
+  if (nops < 48) st->log[nops] = a.after;
+  if (t.status != OST_RUNNING || a.publish) {
+    // report to the host: scalars from registers, the log from device memory
+    a.st_host->phase = ph_out; a.st_host->status = t.status; a.st_host->it_macro = t.it_macro;
+    a.st_host->it_outer = t.it_outer; a.st_host->nops = nops + 1; a.st_host->macro_total = t.macro_total;
+    a.st_host->shifts = t.shifts; a.st_host->growth = t.growth;
+    const int nl = nops + 1 < 48 ? nops + 1 : 48;
+    for (int q = 0; q < nl; ++q) a.st_host->log[q] = (q == nops) ? a.after : st->log[q];
+  }
+  if (t.status != OST_RUNNING) {
+    // finished (or failed): re-arm the machine for the next chain, so that no initial state has to be copied in
+    st->it_macro = 0; st->it_outer = 0; st->nops = 0; st->macro_total = 0; st->shifts = 0; st->growth = 1.0; st->have_xu = 0; st->sloppy = 0;
+    st->status = OST_RUNNING;
+    __hip_atomic_store(&st->phase, (int)OP_GRAM_UU, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    st->it_macro = t.it_macro; st->it_outer = t.it_outer; st->nops = nops + 1; st->macro_total = t.macro_total;
+    st->shifts = t.shifts; st->growth = t.growth; st->status = t.status; st->have_xu = t.have_xu; st->sloppy = t.sloppy;
+    __hip_atomic_store(&st->phase, ph_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 
 // One step of the state machine, executed by the 64 lanes of one wave; lds: TAIL_LDS_DOUBLES doubles.
 // pre != nullptr: the caller has checked the phase and read the state already (fused into a reduction kernel);
@@ -1480,28 +1582,353 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
       }
     }
   }
-  if (lane == 0) {
-    const int ph_out = (t.status == OST_RUNNING) ? t.phase : OP_NONE;
-    const int nops = t.nops;
-    if (nops < 48) st->log[nops] = a.after;
-    if (t.status != OST_RUNNING || a.publish) {
-      // report to the host: scalars from registers, the log from device memory
-      a.st_host->phase = ph_out; a.st_host->status = t.status; a.st_host->it_macro = t.it_macro;
-      a.st_host->it_outer = t.it_outer; a.st_host->nops = nops + 1; a.st_host->macro_total = t.macro_total;
-      a.st_host->shifts = t.shifts; a.st_host->growth = t.growth;
-      const int nl = nops + 1 < 48 ? nops + 1 : 48;
-      for (int q = 0; q < nl; ++q) a.st_host->log[q] = (q == nops) ? a.after : st->log[q];
+  if (lane == 0) tail_publish(a, t);
+}
+
+
+// ======================================================================================
+// k <= 16: the k x k step on the matrix cores, and the pending-factor schedule
+// ======================================================================================
+// Pending factor.  A macro-iteration of ortho_cd (reference diaglib.f90:3246-3332) ends with U <- U W, W = L^-T, and the next
+// one starts with the Gram matrix of the result.  The update need not reach memory in between: a sweep can form U W tile by
+// tile on the fly (gram_lds_kernel WP: same instruction sequence as the update sweep, so the same values -- just not rounded to
+// memory), and the projection sweep applies the pending factors together with its own coefficients (the identity the
+// pending-W folding already used: X^T (U W) = (X^T U) W).  The chain carries Wp, the product of the factors not yet applied to
+// the block in memory U_mem, and Wd, the product of the factors since X^T U was last formed (X^T of the current block is
+// xu Wd).  What may stay pending is decided by what the RESULT's accuracy rests on.  The reference ends every call with a
+// pass in which X^T U and U^T U are measured on the stored block and only a near-identity factor (the one of the converged
+// macro-iteration) is still to be applied: that pass is kept exactly.  Everything before it -- the ortho_cd in front of the
+// loop and the first projection -- only has to hand a well-conditioned block with a small X component to that pass, so there
+// products are carried on the small side:
+//     OP_GRAMX  X^T U and U^T U in one sweep over [X | U]                                  (dgemm :3256 and dgemm :3543)
+//     OP_GRAMW  Gram matrix of U Wp on the fly, reads U, writes nothing                    (dtrmm :3327 + dgemm :3256)
+//               (after a level shift, :3265-3295, the block is numerically rank deficient and the next Gram matrix would see a
+//                fresh realisation of the rounding noise every time: there the update is written, OP_TRMMG)
+//     OP_COMBO  U <- [X | U] [-xu Wd ; Wp] + Gram matrix of the result                     (dgemm :3544 + the pending dtrmm + :3256)
+//     OP_XW     U <- U W written back, X^T U and U^T U of the stored result, one sweep     (dtrmm + dgemm :3256 + dgemm :3543)
+//     OP_COMBO  with the measured xu and the converged factor, OP_FINAL
+// = 4 L + 10 k columns of traffic and 5 k x k steps per ortho_vs_x call with the usual decisions, against
+// 4 L + 13 k and 7 for the sweep-per-update schedule above.  When the first projection used an X^T U carried through
+// ill-conditioned factors (growth of the leading ortho_cd times eps above tol_ortho) the closing pass is run even where the
+// reference would stop after one (:3562-3564 decide on the growth of the last ortho_cd only): never less orthogonal than the
+// reference.  Plain ortho_cd calls write every update (the result's accuracy rests on each of them).
+// Wp and Wd live in device memory between launches in the accumulator layout of v_mfma_f64_16x16x4 ("C-layout": lane
+// (c = lane & 15, g = lane >> 4) keeps M[g + 4 r][c] in register r), transposed, because a C-layout register quadruple is
+// directly the B operand of M and the A operand of M^T.
+//
+// The k x k work itself (diaglib.f90:3261-3332) runs on ONE wave with the matrices in registers:
+//   * Cholesky factorisation G = R^T R, right-looking, one row per step: the pivot comes from a readlane, the row is scaled,
+//     and the rank-1 update of the trailing matrix is ONE v_mfma_f64_16x16x4 whose A and B operands are the same register
+//     (row j of R sits in the 16 lanes g = j & 3 of register j >> 2, which is where both operand layouts want it);
+//   * L^-1 (L = R^T) by forward substitution on the identity, row operations X[i] -= L[i][j] X[j]: the same A operand, one
+//     more MFMA per step, interleaved with the factorisation (two independent dependency chains);
+//   * products of 16 x 16 matrices: 4 MFMAs each; one transpose of X through LDS gives W = X^T in C-layout.
+// 13 steps of ~0.1 us replace the ~7.4 us of LDS-latency-bound loops of ortho_tail.  Operation order differs from the host
+// routines (outer-product instead of dot-product form); results agree to rounding, decisions are taken on all-reduced
+// numbers and are identical on every rank.
+__device__ __forceinline__ double sel4(const v4d& m, int r) { return r == 0 ? m[0] : (r == 1 ? m[1] : (r == 2 ? m[2] : m[3])); }
+__device__ __forceinline__ v4d mfma16(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// a: Gram matrix in C-layout (identity beyond k).  Out: R (upper triangle of a), X = L^-1 (lower), the largest diagonal
+// entries of both.  Returns 0 or the 1-based index of the first non-positive pivot.
+// One step, row j = 4 RR + gj: the register index RR is a template argument (the loop below branches to one of four copies of
+// the step; a register picked by a run-time index costs a dozen selects per access, and this loop is pure issue latency).
+template <int RR>
+__device__ __forceinline__ void chol_inv_step(int j, double d, v4d& a, v4d& x, double& dmax, double& xmax, int c, int g)
+{
+  const int gj = j & 3;
+  // 1 / sqrt(d): hardware estimate + two Newton steps (a correctly rounded sqrt and a division are ~50 dependent FP64
+  // instructions, and every step waits for them)
+  double inv = __builtin_amdgcn_rsq(d);
+  inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+  inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+  const double sd = d * inv;
+  const bool rowj = (g == gj);
+  const double arow = a[RR];
+  const double scaled = c > j ? arow * inv : (c == j ? sd : arow);
+  const double v = (rowj && c > j) ? scaled : 0.0;           // R[j][c], c > j
+  const double xrow = x[RR] * inv;                           // X[j][c] (row j is final once divided by R[j][j])
+  const double vb = rowj ? xrow : 0.0;
+  if (rowj) { a[RR] = scaled; x[RR] = xrow; }
+  a = mfma16(-v, v, a);      // A[i][c'] -= R[j][i] R[j][c'],  i, c' > j
+  x = mfma16(-v, vb, x);     // X[i][c'] -= L[i][j] X[j][c'],  i > j
+  dmax = fmax(dmax, sd); xmax = fmax(xmax, inv);
+}
+
+__device__ __forceinline__ int chol_inv16(int k, v4d& a, v4d& x, double& dmax, double& xmax, int lane)
+{
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) x[r] = (g + 4 * r == c) ? 1.0 : 0.0;
+  dmax = 0.0; xmax = 0.0;
+  int info = 0;
+#pragma unroll 1
+  for (int j = 0; j < k; ++j) {
+    const int src = 16 * (j & 3) + j;                        // the lane that holds A[j][j], in register j >> 2
+    double d;
+    switch (j >> 2) {
+      case 0: d = rlane(a[0], src); break;
+      case 1: d = rlane(a[1], src); break;
+      case 2: d = rlane(a[2], src); break;
+      default: d = rlane(a[3], src); break;
     }
-    if (t.status != OST_RUNNING) {
-      // finished (or failed): re-arm the machine for the next chain, so that no initial state has to be copied in
-      st->it_macro = 0; st->it_outer = 0; st->nops = 0; st->macro_total = 0; st->shifts = 0; st->growth = 1.0;
-      st->status = OST_RUNNING;
-      __hip_atomic_store(&st->phase, (int)OP_GRAM_UU, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(d > 0.0) || !isfinite(d)) { info = j + 1; break; }
+    switch (j >> 2) {
+      case 0: chol_inv_step<0>(j, d, a, x, dmax, xmax, c, g); break;
+      case 1: chol_inv_step<1>(j, d, a, x, dmax, xmax, c, g); break;
+      case 2: chol_inv_step<2>(j, d, a, x, dmax, xmax, c, g); break;
+      default: chol_inv_step<3>(j, d, a, x, dmax, xmax, c, g); break;
+    }
+  }
+  return info;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// LDS use of ortho_tail16 (doubles): [0,256) G hand-over / transpose scratch (16 x 17), [272,528) Wd for the assembly,
+// [528,784) Wp for the assembly
+#define T16_LDS_DOUBLES 784
+
+// One step of the state machine for k <= 16, called by ALL 256 threads of a block (wave 0 does the serial part, all four
+// waves assemble the coefficient block of a projection sweep).  g_in_lds: lds[64 r + lane] already holds the Gram matrix
+// in C-layout (a single-tile reduction hands it over from its registers).
+__device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailState* pre, bool g_in_lds, unsigned long long t_entry = 0)
+{
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  OrthoDev* st = a.st;
+  __shared__ int s_go;
+  if (pre == nullptr) {
+    const int ph = __hip_atomic_load(&st->phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int need = a.after == OP_GRAMX ? (int)OP_GRAM_UU : a.after;     // (the first sweep of any chain answers the start phase)
+    if (ph != need) {
+      if (a.publish && tid == 0 && st->nops > 0) *a.st_host = *st;
+      return;
+    }
+  }
+  const int k = a.k, m = a.m;
+  const double eps = 2.220446049250313e-16, tol = 2.0 * eps;
+  const int maxit = a.maxit, can_defer = a.can_defer;
+  const int after = a.after;
+  const bool sweep_xu = (after == OP_GRAMX || after == OP_XW);          // this sweep formed xu (and G) in xug, on the stored block
+  // coefficient source of a possible assembly: rows of xu, prefetched by every wave (tiles wave, wave + 4, ...)
+  const double* xsrc = (after == OP_XU || sweep_xu) ? a.gsrc : a.xug;
+  const int ldx = (after == OP_XU) ? m : m + k;
+  const bool may_assemble = m > 0 && (after == OP_XU || sweep_xu || after == OP_GRAMW || after == OP_TRMMG);
+  double xa[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int row = 16 * (wave + 4 * q) + c, col = 4 * s + g;
+      xa[q][s] = 0.0;
+      if (may_assemble && row < m && col < k)
+        xa[q][s] = __hip_atomic_load(xsrc + (size_t)row + (size_t)col * ldx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  double* lds_d = lds + 272;
+  double* lds_p = lds + 528;
+  if (wave == 0) {
+    TailState t = pre ? *pre : TailState{st->it_macro, st->it_outer, st->macro_total, st->shifts, st->nops, OP_NONE, OST_RUNNING, st->growth, st->have_xu, st->sloppy};
+    t.phase = OP_NONE; t.status = OST_RUNNING;
+    const int force_defer = can_defer && t.it_outer == 0;
+    int go = 0;
+    v4d pnew, dnew;
+    const int dslot = t.nops;
+    if (lane == 0 && a.dbg != nullptr && dslot < 48) { a.dbg[dslot * 16 + 8] = t_entry; a.dbg[dslot * 16 + 9] = (unsigned long long)after; }
+    if (lane == 0) TSTAMP(a, dslot, 0);
+    if (after == OP_FINAL) {
+      t.status = OST_DONE;
+    } else if (after == OP_XU) {
+      // the block in memory is U_mem with Wp pending: C' = [-(X^T U_mem) Wp ; Wp]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pnew[r] = a.wst[512 + 64 * r + lane]; dnew[r] = pnew[r]; }
+      t.it_macro = 0; t.growth = 1.0; t.have_xu = 0; t.sloppy = 0;
+      t.phase = OP_COMBO;
+      go = 1;
     } else {
-      st->it_macro = t.it_macro; st->it_outer = t.it_outer; st->nops = nops + 1; st->macro_total = t.macro_total;
-      st->shifts = t.shifts; st->growth = t.growth; st->status = t.status;
-      __hip_atomic_store(&st->phase, ph_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ++t.it_macro;
+      if (t.it_macro > maxit) {
+        t.status = OST_CD_MAXIT;
+      } else {
+        ++t.macro_total;
+        // the sweep left the block itself in memory (nothing pending), or its Gram matrix belongs to U_mem Wp formed on the fly
+        const bool fresh = (after != OP_GRAMW);
+        const bool stage0 = can_defer && t.it_outer == 0;       // the ortho_cd in front of the loop (:3533)
+        if (after == OP_TRMMG && !stage0) t.have_xu = 0;        // (closing passes use a measured X^T U only)
+        v4d ptold, dtold;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double id = (g + 4 * r == c) ? 1.0 : 0.0;
+          ptold[r] = fresh ? id : a.wst[64 * r + lane];
+          dtold[r] = (sweep_xu || !t.have_xu) ? id : a.wst[256 + 64 * r + lane];
+        }
+        // Gram matrix, lower triangle mirrored, identity beyond k
+        v4d g0;
+        const int roff = sweep_xu ? m : 0, ldg = sweep_xu ? m + k : k;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = g + 4 * r, hi = i > c ? i : c, lo = i > c ? c : i;
+          double v = (i == c) ? 1.0 : 0.0;
+          if (i < k && c < k) {
+            if (g_in_lds) v = lds_load1(lds + 64 * (hi >> 2) + 16 * (hi & 3) + lo);     // register hi >> 2, lane 16 (hi & 3) + lo
+            else v = __hip_atomic_load(a.gsrc + (size_t)(roff + hi) + (size_t)lo * ldg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          g0[r] = v;
+        }
+        v4d am = g0, x;
+        double dmax, xmax;
+        if (lane == 0 && g0[0] == g0[0]) TSTAMP(a, dslot, 1);
+        // factorisation; on a non-positive pivot the level-shift ladder (:3265-3295): shift = max(eps alpha ||U||_F, 2 eps),
+        // alpha = 100, 1000, ...  (one call site: the factorisation loop exists once in the code)
+        int info, it_micro = 0;
+        double alpha = 100.0, unorm = -1.0;
+        for (;;) {
+          info = chol_inv16(k, am, x, dmax, xmax, lane);
+          if (info == 0) break;
+          if (unorm < 0.0) {
+            double trp = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (g + 4 * r == c && c < k) trp += g0[r];
+            const double tr = wave_sum(trp);
+            unorm = sqrt(tr > 0.0 ? tr : 0.0);       // ||U||_F = sqrt(trace(U^T U)), dnrm2 at :3268
+          }
+          if (++it_micro > maxit) break;
+          const double shift = fmax(eps * alpha * unorm, tol);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) am[r] = g0[r] + ((g + 4 * r == c && c < k) ? shift : 0.0);
+          alpha *= 10.0;
+          ++t.shifts;
+        }
+        if (info != 0) {
+          t.status = OST_FACTOR_FAIL;
+        } else {
+          // norm_est (:3447-3479) of L = R^T and of L^-1: largest diagonal entry + Frobenius norm of the strict triangle
+          double fr = 0.0, fx = 0.0;
+          if (lane == 0 && x[0] == x[0]) TSTAMP(a, dslot, 2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = g + 4 * r;
+            if (i < k && c < k) { if (c > i) fr += am[r] * am[r]; if (c < i) fx += x[r] * x[r]; }
+          }
+          fr = wave_sum(fr); fx = wave_sum(fx);
+          const double l_norm = dmax + sqrt(fr), linv_norm = xmax + sqrt(fx);
+          if (lane == 0 && l_norm == l_norm) TSTAMP(a, dslot, 3);
+          // W = X^T in C-layout (transpose through LDS; the wave's LDS operations complete in order)
+          TSYNC();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds_store1(lds + (g + 4 * r) * 17 + c, x[r]);
+          TSYNC();
+          v4d w;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w[r] = lds_load1(lds + c * 17 + (g + 4 * r));
+          TSYNC();
+          // Wp <- Wp W, Wd <- Wd W and their transposes (X M^T = (M W)^T)
+          v4d ptnew = (v4d){0.0, 0.0, 0.0, 0.0}, dtnew = ptnew;
+          pnew = ptnew; dnew = ptnew;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            pnew = mfma16(ptold[s], w[s], pnew);
+            ptnew = mfma16(w[s], ptold[s], ptnew);
+            dnew = mfma16(dtold[s], w[s], dnew);
+            dtnew = mfma16(w[s], dtold[s], dtnew);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            a.wst[64 * r + lane] = ptnew[r];
+            a.wst[256 + 64 * r + lane] = dtnew[r];
+            a.wst[512 + 64 * r + lane] = pnew[r];
+            const int pp = g + 4 * r;
+            a.wpk[pp * 16 + c] = (pp < k && c < k) ? pnew[r] : 0.0;      // packed for the sweeps: [16][16], zero padded
+          }
+          if (lane == 0 && pnew[0] == pnew[0]) TSTAMP(a, dslot, 4);
+          if (sweep_xu) t.have_xu = 1;
+          const double rcond = l_norm * linv_norm;
+          if (lane == 0 && a.dbg != nullptr && dslot < 48) a.dbg[dslot * 16 + 10] = (unsigned long long)__double_as_longlong(rcond);
+          t.growth *= linv_norm;
+          const bool macro_done = eps * rcond * rcond < tol;      // :3331-3332
+          if (!macro_done) {
+            // another macro-iteration.  In front of the loop its Gram matrix comes from U_mem Wp on the fly -- unless the
+            // factorisation needed a level shift (rank-deficient block: the update is written); inside the loop the update is
+            // written, together with X^T U and U^T U of what is stored (OP_XW) when it is expected to be the last one
+            if (!can_defer || a.fold != 1) t.phase = OP_TRMMG;           // (fold == 2: odd n, no on-the-fly sweeps)
+            else if (stage0) t.phase = (it_micro > 0) ? OP_TRMMG : OP_GRAMW;
+            // (a Cholesky-QR step without a level shift almost always leaves a block that passes the test -- measured on the
+            //  benchmark: every time -- while a shifted one never does: without a shift the update sweep measures X^T U of
+            //  what it stores on its way, a wrong guess costs one more sweep over X)
+            else if (!t.have_xu && it_micro == 0) t.phase = OP_XW;
+            else { t.phase = OP_TRMMG; t.have_xu = 0; }
+          } else if (can_defer && (force_defer || t.sloppy || t.growth * eps >= tol)) {
+            // ortho_vs_x goes on with a projection pass (xu_norm = growth eps >= tol, :3562-3564)
+            if (!force_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;     // :3568
+            else {
+              ++t.it_outer;
+              if (t.have_xu) {
+                t.sloppy = (stage0 && t.growth * eps >= tol) ? 1 : 0;
+                t.it_macro = 0; t.growth = 1.0; t.have_xu = 0; t.phase = OP_COMBO; go = 1;
+              }
+              else t.phase = OP_XU;
+            }
+          } else {
+            if (can_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;
+            else t.phase = OP_FINAL;
+          }
+        }
+      }
     }
+    if (go) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { lds_store1(lds_d + 64 * r + lane, dnew[r]); lds_store1(lds_p + 64 * r + lane, pnew[r]); }
+    }
+    if (lane == 0) { TSTAMP(a, dslot, 5); s_go = go; tail_publish(a, t); TSTAMP(a, dslot, 6); }
+  }
+  __syncthreads();
+  if (!s_go) return;
+  // C' = [-(xu Wd) ; Wp ; 0], packed [l4][16] for the projection sweep; 16 rows of xu per MFMA quadruple
+  const int l = m + k, l4 = ((l + 3) / 4) * 4;
+  double db[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) db[s] = lds_load1(lds_d + 64 * s + lane);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t0 = 16 * (wave + 4 * q);
+    if (t0 >= m) break;
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma16(xa[q][s], db[s], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p_ = t0 + g + 4 * r;
+      if (p_ < m) a.cpk[(size_t)p_ * 16 + c] = (c < k) ? -acc[r] : 0.0;
+    }
+  }
+  // (m > 256: the tiles beyond the prefetched ones)
+  for (int t0 = 16 * (wave + 16); t0 < m; t0 += 64) {
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int row = t0 + c, col = 4 * s + g;
+      const double v = (row < m && col < k) ? __hip_atomic_load(xsrc + (size_t)row + (size_t)col * ldx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      acc = mfma16(v, db[s], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p_ = t0 + g + 4 * r;
+      if (p_ < m) a.cpk[(size_t)p_ * 16 + c] = (c < k) ? -acc[r] : 0.0;
+    }
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int pp = g + 4 * r;
+      if (pp < k) a.cpk[(size_t)(m + pp) * 16 + c] = (c < k) ? lds_load1(lds_p + 64 * r + lane) : 0.0;
+    }
+    for (int idx = lane; idx < (l4 - l) * 16; idx += 64) a.cpk[(size_t)l * 16 + idx] = 0.0;
+    if (lane == 0 && pre != nullptr) TSTAMP(a, pre->nops, 7);
   }
 }
 
@@ -1511,12 +1938,12 @@ __global__ __launch_bounds__(64) void ortho_tail_kernel(OrthoTailArgs a)
   ortho_tail(a, lds, threadIdx.x);
 }
 
-// second stage: sum the block partials in a fixed order and scatter into column-major C (ld = l).
-// One launch, two levels: block (ps, grp) sums its share of the partials into lvl2[ps][grp]; the
-// block that draws the last ticket for ps adds the `groups` level-2 rows in index order (so the
-// result does not depend on arrival order) and writes C to the device buffer and to its pinned
-// host mirror.  Hand-off = agent-scope release / acquire around a relaxed ticket
-// (cdna_hip_programming.md guideline 16); the ticket is reset by its last arriver.
+__global__ __launch_bounds__(256) void ortho_tail16_kernel(OrthoTailArgs a)
+{
+  __shared__ __attribute__((aligned(16))) double lds[T16_LDS_DOUBLES];
+  ortho_tail16(a, lds, nullptr, false);
+}
+
 // ======================================================================================
 // One-shot all-reduce of a small buffer over peer mailboxes
 // ======================================================================================
@@ -1607,32 +2034,45 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a)
 
 struct GramReduceArgs {
   const double* partial;
-  double* lvl2;        // [passes*slots][groups][256]
-  unsigned* ticket;    // [passes*slots], zero between launches
-  double* c;           // l x k, ld = l (device)
+  double* lvl2;        // [output tiles][groups][256]
+  unsigned* ticket;    // [output tiles], zero between launches
+  double* c;           // l x k, ld = ldc (device)
   double* c_host;      // same, pinned host mirror (device-visible address)
   int nblk, l, k, tlw, kt, passes_x;
   const int* phase;
   int want;
   // device-driven chains on one rank: the block that completes the LAST output tile also runs the state machine's
-  // step (ortho_tail) on the reduced matrix, so that no further launch stands between two sweeps
+  // step (ortho_tail / ortho_tail16) on the reduced matrix, so that no further launch stands between two sweeps
   int do_tail;
-  int n_ps;            // passes * slots = number of output tiles
+  int n_ps;            // number of output tiles = passes * tlw * kt + extra
   unsigned* gticket;   // zero between launches
   OrthoTailArgs tail;
   // ... and with several ranks on the peer-to-peer transport the same block first exchanges the reduced matrix with
   // its peers (p2p.nranks > 1), so that sweep -> [reduce, cross-rank sum, k x k step] is still one launch
   P2PArgs p2p;
+  int extra;           // 1: one more output tile, slot tlw * kt of pass 0 (gram_lds_kernel WP: the Gram matrix of the U block);
+                       // it lands in rows l .. l + k - 1 of c
+  int ldc;             // leading dimension of c: l, or l + k with the extra tile
 };
 
+// Second stage of every reduction: sum the block partials in a fixed order and scatter into column-major C.
+// One launch, two levels: block (tile, grp) sums its share of the partials into lvl2[tile][grp]; the block that draws the last
+// ticket of the tile adds the `groups` level-2 rows in index order (so the result does not depend on arrival order) and
+// writes C to the device buffer and to its pinned host mirror.  The level-2 rows are handed over WITHOUT cache
+// maintenance: write-through (sc1) stores, drained, then one agent-scope ticket per block; the last arriver reads them
+// with sc1 loads (MI355X_MICROARCH.md, "Valid forms": one signalling lane per storing workgroup, one workgroup per CU --
+// this grid has at most a few dozen blocks).  An agent-scope release + acquire pair in their place costs 3.4 us per launch.
 // TAIL: the block that completes the last output tile also runs the state machine's step
 template <bool TAIL>
 __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
 {
   DLA_PREDICATED(a);
-  const int slots = a.tlw * a.kt;
+  const unsigned long long t_entry = (TAIL && a.tail.dbg != nullptr) ? wall_clock64() : 0ULL;
+  const int nsl = a.tlw * a.kt;              // output tiles of one pass
+  const int slots = nsl + a.extra;           // partial slots per (pass, block)
   const int ps = blockIdx.x, grp = blockIdx.y, G = gridDim.y;
-  const int pass = ps / slots, slot = ps % slots;
+  const bool is_extra = ps >= a.n_ps - a.extra;
+  const int pass = is_extra ? 0 : ps / nsl, slot = is_extra ? nsl : ps % nsl;
   const int e = threadIdx.x;
   const double* p = a.partial + ((size_t)pass * a.nblk) * (size_t)slots * 256 + (size_t)slot * 256 + e;
   const int per = (a.nblk + G - 1) / G;
@@ -1643,7 +2083,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
   if constexpr (TAIL) {
     if (threadIdx.x < 64)
       pre = TailState{a.tail.st->it_macro, a.tail.st->it_outer, a.tail.st->macro_total, a.tail.st->shifts, a.tail.st->nops,
-                      OP_NONE, OST_RUNNING, a.tail.st->growth};
+                      OP_NONE, OST_RUNNING, a.tail.st->growth, a.tail.st->have_xu, a.tail.st->sloppy};
   }
   // loads are issued in batches of 32 / 8 (independent), the adds stay in index order
   double s = 0.0;
@@ -1663,46 +2103,54 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
     for (int q = 0; q < 8; ++q) s += v[q];
   }
   for (; b < b1; ++b) s += p[(size_t)b * slots * 256];
-  a.lvl2[((size_t)ps * G + grp) * 256 + e] = s;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
   __shared__ int s_last;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  double tot = s;
+  if (G > 1) {
+    __hip_atomic_store(&a.lvl2[((size_t)ps * G + grp) * 256 + e], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(&a.ticket[ps], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == (unsigned)(G - 1));
-    if (last) {
-      __hip_atomic_store(&a.ticket[ps], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned t = __hip_atomic_fetch_add(&a.ticket[ps], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == (unsigned)(G - 1));
+      if (last) __hip_atomic_store(&a.ticket[ps], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = last;
     }
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  double tot = 0.0;
-  {
+    __syncthreads();
+    if (!s_last) return;
+    tot = 0.0;
     double v[32];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) v[q] = (q < G) ? a.lvl2[((size_t)ps * G + q) * 256 + e] : 0.0;
+    for (int q = 0; q < 32; ++q)
+      v[q] = (q < G) ? __hip_atomic_load(&a.lvl2[((size_t)ps * G + q) * 256 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
     for (int q = 0; q < 32; ++q) tot += v[q];   // G <= 32; padding zeros do not change the sum
   }
   const int xg = pass % a.passes_x, ug = pass / a.passes_x;
   const int t = slot / a.kt, q = slot % a.kt;
   const int reg = e >> 6, lane = e & 63;
-  const int xcol = (xg * a.tlw + t) * 16 + (lane >> 4) + 4 * reg;
-  const int ucol = (ug * a.kt + q) * 16 + (lane & 15);
-  if (xcol < a.l && ucol < a.k) {
-    a.c[(size_t)xcol + (size_t)ucol * a.l] = tot;
-    if (a.c_host) a.c_host[(size_t)xcol + (size_t)ucol * a.l] = tot;
+  const int xcol = is_extra ? a.l + (lane >> 4) + 4 * reg : (xg * a.tlw + t) * 16 + (lane >> 4) + 4 * reg;
+  const int ucol = is_extra ? (lane & 15) : (ug * a.kt + q) * 16 + (lane & 15);
+  const bool live = (is_extra ? xcol < a.l + a.k : xcol < a.l) && ucol < a.k;
+  const bool exchange = TAIL && a.p2p.nranks > 1;
+  // the chain's tail reads C in this same launch: for ortho_tail16 (sc1 loads) write-through stores, drained, and a ticket
+  // are the whole hand-over; the LDS-loop tail and the peer-to-peer exchange read with plain loads behind an acquire
+  const bool wt = TAIL && a.tail.fold && !exchange;
+  if (live) {
+    double* dst = a.c + (size_t)xcol + (size_t)ucol * a.ldc;
+    if (wt) __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *dst = tot;
+    if (a.c_host) a.c_host[(size_t)xcol + (size_t)ucol * a.ldc] = tot;
   }
   if constexpr (!TAIL) return;
   __shared__ __attribute__((aligned(16))) double tail_lds[TAIL ? TAIL_LDS_DOUBLES : 1];
-  const bool exchange = a.p2p.nranks > 1;
   if (!exchange && a.n_ps == 1 && a.tail.after != OP_XU) {
-    // a single 16 x 16 tile, complete in this block's registers: it reaches the tail through LDS, no fences
+    // a single 16 x 16 tile, complete in this block's registers: it reaches the tail through LDS, no hand-over
+    if (a.tail.fold) {
+      tail_lds[e] = tot;                     // wave w holds register w of the C-layout
+      __syncthreads();
+      ortho_tail16(a.tail, tail_lds, &pre, true, t_entry);
+      return;
+    }
     const int gi = (lane >> 4) + 4 * reg, gj = lane & 15;
     tail_lds[gi * TLD + gj] = tot;
     tail_lds[48 * TLD + gi * TLD + gj] = tot;
@@ -1710,22 +2158,18 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
     if (threadIdx.x < 64) ortho_tail(a.tail, tail_lds, threadIdx.x, &pre, true);
     return;
   }
-  // hand the finished tile(s) over to the one wave that runs the tail: same release / ticket / acquire pattern
+  // hand the finished tile(s) over to the block that runs the tail
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!wt) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     int last = 1;
     if (a.n_ps > 1) {
       const unsigned t2 = __hip_atomic_fetch_add(a.gticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       last = (t2 == (unsigned)(a.n_ps - 1));
       if (last) __hip_atomic_store(a.gticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (last && !wt) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     s_last = last;
   }
   __syncthreads();
@@ -1736,6 +2180,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
     __threadfence();
     __syncthreads();
   }
+  if (a.tail.fold) { ortho_tail16(a.tail, tail_lds, &pre, false, t_entry); return; }
   if (threadIdx.x >= 64) return;
   ortho_tail(a.tail, tail_lds, threadIdx.x, &pre);
 }
@@ -1826,6 +2271,8 @@ struct HipEngine : dla::Engine {
     if (d_wpk) (void)hipFree(d_wpk);
     if (d_wfull) (void)hipFree(d_wfull);
     if (d_cpk2) (void)hipFree(d_cpk2);
+    if (d_wst) (void)hipFree(d_wst);
+    if (d_xug) (void)hipFree(d_xug);
     for (int i = 0; i < RING; ++i) if (h_ring[i]) { (void)hipHostFree(h_ring[i]); (void)hipEventDestroy(ring_ev[i]); }
     if (d_cpk) (void)hipFree(d_cpk);
     if (d_w) (void)hipFree(d_w);
@@ -2397,6 +2844,10 @@ struct HipEngine : dla::Engine {
   OrthoDev* h_ost_dev = nullptr;
   OrthoDev* h_ost_init = nullptr;   // pinned source of the initial state
   double* d_wpk = nullptr; double* d_wfull = nullptr; double* d_cpk2 = nullptr;
+  unsigned long long* d_dbg = nullptr;   // $DIAGLIB_AMD_CHAIN_DEBUG: time stamps of the chain's steps
+  double* d_wst = nullptr;          // pending factors of ortho_tail16 (3 x 256 doubles)
+  double* d_xug = nullptr;          // X^T U | U^T U of the last OP_GRAMX / OP_XW sweep: (m + k) x k
+  static const int XUG_DOUBLES = 640 * 16;
   std::map<long long, std::vector<int>> ortho_history;   // (k, m) -> the sweeps the last call of that shape executed
 
   bool chain_armed = false;          // the device state machine stands at its initial state
@@ -2416,17 +2867,21 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipMalloc((void**)&d_wpk, sizeof(double) * 3 * 48 * 16));
     HIPCHK(hipMalloc((void**)&d_wfull, sizeof(double) * 48 * 48));
     HIPCHK(hipMalloc((void**)&d_cpk2, (size_t)80 * 1024));
+    HIPCHK(hipMalloc((void**)&d_wst, sizeof(double) * 768));
+    if (chain_debug) { HIPCHK(hipMalloc((void**)&d_dbg, sizeof(unsigned long long) * 48 * 16)); HIPCHK(hipMemset(d_dbg, 0, sizeof(unsigned long long) * 48 * 16)); }
+    HIPCHK(hipMalloc((void**)&d_xug, sizeof(double) * XUG_DOUBLES));
     return DLA_OK;
   }
 
   void launch_reduce(GramReduceArgs& ra, dim3 grid)
   {
     exchange_fused = false;
-    if (fuse_tail && p2p.on && ra.l * ra.k > P2P_MAX_DOUBLES) fuse_tail = false;   // beyond a mailbox slot: separate launches
+    if (ra.ldc == 0) ra.ldc = ra.l;
+    if (fuse_tail && p2p.on && ra.ldc * ra.k > P2P_MAX_DOUBLES) fuse_tail = false;   // beyond a mailbox slot: separate launches
     if (fuse_tail) {
       ra.do_tail = 1; ra.tail = pending_tail; tail_fused = true;
       ra.p2p = P2PArgs{};
-      if (p2p.on) { ra.p2p = p2p_args(ra.c, ra.l * ra.k, 0); exchange_fused = true; }
+      if (p2p.on) { ra.p2p = p2p_args(ra.c, ra.ldc * ra.k, 0); exchange_fused = true; }
       hipLaunchKernelGGL(gram_reduce_kernel<true>, grid, dim3(256), 0, st, ra);
     } else {
       hipLaunchKernelGGL(gram_reduce_kernel<false>, grid, dim3(256), 0, st, ra);
@@ -2434,22 +2889,28 @@ struct HipEngine : dla::Engine {
   }
   void launch_tail_kernel(const OrthoTailArgs& ta)
   {
-    hipLaunchKernelGGL(ortho_tail_kernel, dim3(1), dim3(64), 0, st, ta);
+    if (ta.fold) hipLaunchKernelGGL(ortho_tail16_kernel, dim3(1), dim3(256), 0, st, ta);
+    else hipLaunchKernelGGL(ortho_tail_kernel, dim3(1), dim3(64), 0, st, ta);
   }
 
   // one speculative step: the sweep, its reduction (+ cross-rank sum) and the tail that takes the next decision.
   // On one rank the tail rides in the last block of the reduction kernel; with a communicator the all-reduce has to
   // come between the two, so the tail is a launch of its own.
-  int launch_op(int op, int n, int m, int k, const double* x, const double* bx, double* u, bool publish)
+  int launch_op(int op, int n, int m, int k, const double* x, const double* bx, double* u, bool publish, int fold)
   {
-    pending_tail = OrthoTailArgs{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, op, m, k, m > 0 ? 1 : 0, ortho_maxit, publish ? 1 : 0};
+    pending_tail = OrthoTailArgs{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, op, m, k, m > 0 ? 1 : 0, ortho_maxit, publish ? 1 : 0,
+                                 fold, d_xug, d_wst, d_dbg};
+    if (op == OP_GRAMX || op == OP_XW) pending_tail.gsrc = d_xug;
     fuse_tail = p2p.on ? tune[6] != 4 : (nranks <= 1 && !comm);     // (knob 6 = 4: the exchange as a launch of its own)
     tail_fused = false;
-    pred_phase = &d_ost->phase; pred_want = op;
+    pred_phase = &d_ost->phase; pred_want = (op == OP_GRAMX) ? (int)OP_GRAM_UU : op;   // the first sweep answers the start phase
     int stc = DLA_OK;
     switch (op) {
       case OP_GRAM_UU: stc = gram_dev_once(n, k, u, k, u, DLA_OP_GRAM, false); break;
       case OP_XU:      stc = gram_dev_once(n, m, bx, k, u, DLA_OP_GRAM, false); break;
+      case OP_GRAMX:   stc = gram_wp_once(n, m, bx, k, u, nullptr, nullptr); break;
+      case OP_XW:      stc = gram_wp_once(n, m, bx, k, u, d_wpk, u); break;
+      case OP_GRAMW:   stc = gram_wp_once(n, 0, nullptr, k, u, d_wpk, nullptr); break;
       case OP_TRMMG:
         stc = gemm_chunk(n, 0, k, u, k, nullptr, 0, u, 2, DLA_OP_TRMM, true, d_wpk);
         if (!stc) stc = fused_reduce(k);
@@ -2464,10 +2925,96 @@ struct HipEngine : dla::Engine {
     pred_phase = nullptr; pred_want = 0;
     fuse_tail = false;
     if (stc || tail_fused) return stc;
-    Scope s(this, DLA_OP_GRAM, 0.0, 0.0, "ortho_tail_kernel");
+    Scope s(this, DLA_OP_GRAM, 0.0, 0.0, fold ? "ortho_tail16_kernel" : "ortho_tail_kernel");
     launch_tail_kernel(pending_tail);
     HIPCHK(hipGetLastError());
     return DLA_OK;
+  }
+
+  // Sweeps of the pending-factor schedule (gram_lds_kernel WP; k <= 16, even n):
+  //   m > 0:  X^T (U W) and (U W)^T (U W) in one pass over [X | U] -> d_xug ((m + k) x k, the Gram matrix in rows m..);
+  //   m == 0: (U W)^T (U W) -> d_small (k x k).   wp == nullptr: W = identity.
+  template <int TLW, int R>
+  int launch_gram_wp(const GramArgs& a, dim3 grid, bool self)
+  {
+    if (self) {
+      if constexpr (TLW == 1) {
+        auto kfn = gram_lds_kernel<1, 1, 1, 32, 1, 0, 0, 1>;
+        const size_t lds = sizeof(double) * 4 * 16 * 34;
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+      }
+      return DLA_OK;
+    }
+    auto kfn = gram_lds_kernel<TLW, 1, 1, R, 0, 0, 0, 1>;
+    const size_t lds = sizeof(double) * 4 * 16 * (TLW + 1) * (R + 2);
+    if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    return DLA_OK;
+  }
+  int gram_wp_once(int n, int m, const double* x, int k, const double* u, const double* wp, double* uw)
+  {
+    const bool self = (m == 0);
+    const int tx = self ? 1 : (m + 15) / 16;
+    const int passes = self ? 1 : (tx + 11) / 12;
+    int tlw = (tx + passes - 1) / passes;
+    static const int avail[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
+    for (int v : avail) if (v >= tlw) { tlw = v; break; }
+    // the staged image of the widest pass: 13 tiles of 16 rows (4 waves x 13 x 16 x 18 doubles = 117 KiB); under a refused
+    // LDS raise the chain is not taken at all (ortho_chain)
+    const int R = tlw <= 2 ? 32 : 16;
+    const long long nchunks = ((long long)n + 31) / 32;
+    const long long want = (nchunks + 15) / 16;
+    int blocks = (int)std::max(1LL, std::min((long long)ncu * (self ? 2 : 1), want));
+    if (tune[4] > 0) blocks = (int)std::max(1LL, std::min((long long)tune[4], want));
+    const int slots = self ? 1 : tlw + 1;
+    int stc = ensure_partial(sizeof(double) * (size_t)passes * blocks * slots * 256);
+    if (stc) return stc;
+    stc = ensure_small(sizeof(double) * (size_t)k * k);
+    if (stc) return stc;
+    if (!self && (m + k) * k > XUG_DOUBLES) { err = "gram_wp: basis too wide for the chain's buffer"; return DLA_ERR_ARG; }
+    // (written-back tiles: every pass would transform the block again, and passes run side by side)
+    if (uw != nullptr && passes != 1) { err = "gram_wp: the storing sweep takes one pass"; return DLA_ERR_ARG; }
+    GramArgs a{self ? u : x, u, d_partial, (long long)n, self ? k : m, k, passes, 0, pred_phase, pred_want, 0, wp, uw};
+    dim3 grid(blocks, passes);
+    {
+      char kn[64];
+      std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, 1, 1, %d, %d, 0, 0, 1>", tlw, self ? 32 : R, self ? 1 : 0);
+      // reference-schedule flops: the Gram matrix (2 n k^2), X^T U (2 n m k), and the triangular update the sweep applies on the fly (n k^2)
+      Scope s(this, DLA_OP_GRAM, 8.0 * (double)n * (double)(m + k + (uw ? k : 0)), 2.0 * (double)n * (m + k) * k + (wp ? 1.0 * (double)n * k * k : 0.0), kn);
+      int r_ = DLA_ERR_RUNTIME;
+      switch (tlw) {
+        case 1: r_ = launch_gram_wp<1, 32>(a, grid, self); break;
+        case 2: r_ = launch_gram_wp<2, 32>(a, grid, self); break;
+        case 3: r_ = launch_gram_wp<3, 16>(a, grid, self); break;
+        case 4: r_ = launch_gram_wp<4, 16>(a, grid, self); break;
+        case 5: r_ = launch_gram_wp<5, 16>(a, grid, self); break;
+        case 6: r_ = launch_gram_wp<6, 16>(a, grid, self); break;
+        case 7: r_ = launch_gram_wp<7, 16>(a, grid, self); break;
+        case 8: r_ = launch_gram_wp<8, 16>(a, grid, self); break;
+        case 10: r_ = launch_gram_wp<10, 16>(a, grid, self); break;
+        case 12: r_ = launch_gram_wp<12, 16>(a, grid, self); break;
+        default: err = "gram_wp: no kernel instance";
+      }
+      if (r_) return r_;
+    }
+    const int n_out = self ? 1 : passes * tlw + 1;
+    double* cdst = self ? d_small : d_xug;
+    {
+      Scope s2(this, DLA_OP_GRAM, 0.0, 0.0, "gram_reduce_kernel");
+      const int groups = std::max(1, std::min(32, (blocks + 31) / 32));
+      const size_t need2 = sizeof(double) * (size_t)n_out * groups * 256;
+      if (need2 > lvl2_bytes) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (d_lvl2) HIPCHK(hipFree(d_lvl2));
+        lvl2_bytes = std::max(need2, (size_t)1 << 20);
+        HIPCHK(hipMalloc((void**)&d_lvl2, lvl2_bytes));
+      }
+      GramReduceArgs ra{d_partial, d_lvl2, d_ticket, cdst, nullptr, blocks, self ? k : m, k, tlw, 1, passes,
+                        pred_phase, pred_want, 0, n_out, d_ticket + 4096, OrthoTailArgs{}, P2PArgs{}, self ? 0 : 1, self ? k : m + k};
+      launch_reduce(ra, dim3(n_out, groups));
+    }
+    HIPCHK(hipGetLastError());
+    return allreduce_dev(cdst, (self ? k : m + k) * k, 0, h_small);
   }
 
   int ortho_chain(int n, int m, int k, const double* x, const double* bx, double* u, dla::OrthoReport* rep) override
@@ -2478,6 +3025,11 @@ struct HipEngine : dla::Engine {
     const bool vsx = m > 0;
     if (vsx && !(u == x + (size_t)n * m && can_combo(m, k))) return DLA_OK;
     if (!vsx && fused_lds(k, k) > lds_limit) return DLA_OK;
+    // k x k steps on the matrix cores (ortho_tail16) for one-tile blocks; with them, on the 16-byte path and while X^T U fits one
+    // pass of the storing sweep (12 tiles), the pending-factor schedule (fold = 1); otherwise the sweep-per-update one (fold = 2)
+    const bool vec2 = (n % 2 == 0) && (((uintptr_t)u | (uintptr_t)x | (uintptr_t)bx) % 16 == 0);
+    int fold = (k <= 16 && tune[6] != 5) ? 2 : 0;
+    if (fold && vsx && vec2 && m <= 192 && tune[6] != 6 && lds_limit > (size_t)128 * 1024) fold = 1;
     int stc = ensure_chain_buffers();
     if (stc) return stc;
     // the widest reductions of the chain: make sure nothing reallocates (and drains the stream) half way
@@ -2497,14 +3049,15 @@ struct HipEngine : dla::Engine {
     h_ost->nops = 0;
 
     // the schedule depends on how much of the new block already lies in span(X): remembered per basis width
-    const long long key = (long long)k * 1000000 + m;
+    const long long key = (long long)k * 1000000 + m + fold * 500000000000LL;
     std::vector<int>& hist = ortho_history[key];
     std::vector<int> plan = hist;
-    std::vector<int>& last_k = ortho_history[-(long long)(2 * k + (vsx ? 1 : 0)) - 1];   // most recent call of this kind and width
+    std::vector<int>& last_k = ortho_history[-(long long)(8 * k + (vsx ? 1 : 0) + 2 * fold) - 1];   // most recent call of this kind and width
     if (plan.empty()) plan = last_k;
     if (plan.empty()) {
       // the schedule measured on the reference: cd x2, [projection, cd x2], [projection, cd x1]
-      if (vsx) plan = {OP_GRAM_UU, OP_TRMMG, OP_XU, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
+      if (fold == 1) plan = {OP_GRAMX, OP_GRAMW, OP_COMBO, OP_XW, OP_COMBO, OP_FINAL};
+      else if (vsx) plan = {OP_GRAM_UU, OP_TRMMG, OP_XU, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
       else plan = {OP_GRAM_UU, OP_TRMMG, OP_FINAL};
     }
     std::vector<SpecRec> recs;
@@ -2515,7 +3068,7 @@ struct HipEngine : dla::Engine {
       for (size_t pi = 0; pi < plan.size(); ++pi) {
         spec_tag = (int)launched.size();
         launched.push_back(plan[pi]);
-        stc = launch_op(plan[pi], n, m, k, x, bx, u, pi + 1 == plan.size());
+        stc = launch_op(plan[pi], n, m, k, x, bx, u, pi + 1 == plan.size(), fold);
         if (stc) break;
       }
       spec_rec = nullptr;
@@ -2527,12 +3080,27 @@ struct HipEngine : dla::Engine {
       if (sres.status < 0) { err = "ortho_chain: the device reported nothing"; return DLA_ERR_RUNTIME; }
       if (sres.status != OST_RUNNING) break;
       // the device went another way than expected: continue from where it stands with the most likely tail
-      switch (sres.phase) {
-        case OP_TRMMG: plan = vsx ? std::vector<int>{OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL} : std::vector<int>{OP_TRMMG, OP_FINAL}; break;
-        case OP_XU:    plan = {OP_XU, OP_COMBO, OP_FINAL}; break;
-        case OP_COMBO: plan = {OP_COMBO, OP_FINAL}; break;
-        case OP_FINAL: plan = {OP_FINAL}; break;
-        default: err = "ortho_chain: device state machine in an unexpected phase"; return DLA_ERR_RUNTIME;
+      // (a launch whose turn it is not costs ~2 us, a host round trip ~25: the continuation lists what may follow, in order)
+      if (fold == 1) {
+        switch (sres.phase) {
+          case OP_TRMMG: plan = sres.it_outer == 0 ? std::vector<int>{OP_TRMMG, OP_GRAMW, OP_COMBO, OP_XW, OP_COMBO, OP_FINAL}
+                                                   : std::vector<int>{OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL}; break;
+          case OP_GRAMW: plan = {OP_GRAMW, OP_GRAMW, OP_COMBO, OP_XW, OP_COMBO, OP_FINAL}; break;
+          case OP_COMBO: plan = sres.it_outer <= 1 ? std::vector<int>{OP_COMBO, OP_XW, OP_COMBO, OP_FINAL}
+                                                   : std::vector<int>{OP_COMBO, OP_XW, OP_XU, OP_COMBO, OP_FINAL}; break;
+          case OP_XW:    plan = {OP_XW, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL}; break;
+          case OP_XU:    plan = {OP_XU, OP_COMBO, OP_FINAL}; break;
+          case OP_FINAL: plan = {OP_FINAL}; break;
+          default: err = "ortho_chain: device state machine in an unexpected phase"; return DLA_ERR_RUNTIME;
+        }
+      } else {
+        switch (sres.phase) {
+          case OP_TRMMG: plan = vsx ? std::vector<int>{OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL} : std::vector<int>{OP_TRMMG, OP_FINAL}; break;
+          case OP_XU:    plan = {OP_XU, OP_COMBO, OP_FINAL}; break;
+          case OP_COMBO: plan = {OP_COMBO, OP_FINAL}; break;
+          case OP_FINAL: plan = {OP_FINAL}; break;
+          default: err = "ortho_chain: device state machine in an unexpected phase"; return DLA_ERR_RUNTIME;
+        }
       }
       h_ost->status = -1;
     }
@@ -2542,6 +3110,18 @@ struct HipEngine : dla::Engine {
       std::printf("  [dla] chain k=%d m=%d: %zu launches enqueued, executed:", k, m, launched.size());
       for (int i = 0; i < std::min(sres.nops, 48); ++i) std::printf(" %d", sres.log[i]);
       std::printf("  (host waits so far %lld)\n", (long long)stats.host_syncs);
+      if (d_dbg && fold) {
+        std::vector<unsigned long long> hs(48 * 16);
+        (void)hipMemcpy(hs.data(), d_dbg, sizeof(unsigned long long) * 48 * 16, hipMemcpyDeviceToHost);
+        for (int i = 0; i < std::min(sres.nops, 48); ++i) {
+          const unsigned long long* q = &hs[i * 16];
+          auto us = [&](int a_, int b_) { return (q[a_] && q[b_]) ? (double)(long long)(q[b_] - q[a_]) * 0.01 : -1.0; };
+          double rc; std::memcpy(&rc, &q[10], 8);
+          std::printf("    op %llu (err est %.2e): kernel entry->tail %.2f us | G load %.2f | chol+inv %.2f | norms %.2f | products+stores %.2f | decide %.2f | publish %.2f | assemble %.2f\n",
+                      q[9], 2.2e-16 * rc * rc, us(8, 0), us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7));
+        }
+        (void)hipMemset(d_dbg, 0, sizeof(unsigned long long) * 48 * 16);
+      }
     }
     // account for the launches the device executed: they are the greedy match of its log inside the launch sequence
     {
@@ -2711,7 +3291,7 @@ struct HipEngine : dla::Engine {
       char kn[64];
       if (cur_lds) {
         const bool can32 = sizeof(double) * 4 * 16 * (tlw + kt) * 34 <= 150 * 1024 && tlw + kt <= 7;
-        std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d, %d, %d, %d>", tlw, kt,
+        std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d, %d, %d, %d, 0>", tlw, kt,
                       (!low_single && can32 && lds_rows(tlw, kt) == 32) ? 32 : 16, cur_self ? 1 : 0, cur_qt, low_single ? 1 : 0);
       }
       else std::snprintf(kn, sizeof kn, "gram_kernel<%d, %d, %d, %d, 0, -1>", tlw, kt, vec2 ? 2 : 1, rs);
