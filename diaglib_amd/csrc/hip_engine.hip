@@ -1360,6 +1360,7 @@ struct OrthoTailArgs {
   int publish;         // 1: last launch of the host's plan -- leave the state in the host mirror whatever happened
   // pending-factor schedule (ortho_tail16)
   int fold;            // 1: this chain runs it; 2: ortho_tail16 with the sweep-per-update schedule (odd n)
+  int lead_once;       // 1: the ortho_cd in front of the loop (:3533) takes ONE factorisation step (see ortho_tail16)
   const double* xug;   // X^T U and U^T U of the last OP_GRAMX / OP_XW sweep: (m + k) x k, ld m + k
   double* wst;         // pending factors between launches, accumulator layout: [0,256) Wp^T, [256,512) Wd^T, [512,768) Wp
   unsigned long long* dbg;   // $DIAGLIB_AMD_CHAIN_DEBUG: time stamps of the step (100 MHz ticks), 16 per executed sweep
@@ -1850,7 +1851,13 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
           const double rcond = l_norm * linv_norm;
           if (lane == 0 && a.dbg != nullptr && dslot < 48) a.dbg[dslot * 16 + 10] = (unsigned long long)__double_as_longlong(rcond);
           t.growth *= linv_norm;
-          const bool macro_done = eps * rcond * rcond < tol;      // :3331-3332
+          // The ortho_cd in front of the loop is not iterated (lead_once): its result feeds the first projection, which is
+          // linear in the block and does not care how orthonormal it is, and every later decision is taken on Gram matrices
+          // measured after that projection.  The reference's second macro-iteration there (its first one leaves condition
+          // 1 + O(eps c^2), the second one confirms it) costs a sweep and a k x k step per call and changes nothing the closing
+          // passes do not re-measure; with a carried X^T U of that quality (growth eps >= tol_ortho) the closing pass is
+          // mandatory (sloppy), as for every carried product.
+          const bool macro_done = (eps * rcond * rcond < tol) || (stage0 && a.lead_once && a.fold == 1 && after == OP_GRAMX);      // :3331-3332
           if (!macro_done) {
             // another macro-iteration.  In front of the loop its Gram matrix comes from U_mem Wp on the fly -- unless the
             // factorisation needed a level shift (rank-deficient block: the update is written); inside the loop the update is
@@ -1860,7 +1867,7 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
             // (a Cholesky-QR step without a level shift almost always leaves a block that passes the test -- measured on the
             //  benchmark: every time -- while a shifted one never does: without a shift the update sweep measures X^T U of
             //  what it stores on its way, a wrong guess costs one more sweep over X)
-            else if (!t.have_xu && it_micro == 0) t.phase = OP_XW;
+            else if (it_micro == 0) t.phase = OP_XW;
             else { t.phase = OP_TRMMG; t.have_xu = 0; }
           } else if (can_defer && (force_defer || t.sloppy || t.growth * eps >= tol)) {
             // ortho_vs_x goes on with a projection pass (xu_norm = growth eps >= tol, :3562-3564)
@@ -2899,7 +2906,7 @@ struct HipEngine : dla::Engine {
   int launch_op(int op, int n, int m, int k, const double* x, const double* bx, double* u, bool publish, int fold)
   {
     pending_tail = OrthoTailArgs{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, op, m, k, m > 0 ? 1 : 0, ortho_maxit, publish ? 1 : 0,
-                                 fold, d_xug, d_wst, d_dbg};
+                                 fold, tune[6] == 7 ? 0 : 1, d_xug, d_wst, d_dbg};
     if (op == OP_GRAMX || op == OP_XW) pending_tail.gsrc = d_xug;
     fuse_tail = p2p.on ? tune[6] != 4 : (nranks <= 1 && !comm);     // (knob 6 = 4: the exchange as a launch of its own)
     tail_fused = false;
@@ -3056,7 +3063,7 @@ struct HipEngine : dla::Engine {
     if (plan.empty()) plan = last_k;
     if (plan.empty()) {
       // the schedule measured on the reference: cd x2, [projection, cd x2], [projection, cd x1]
-      if (fold == 1) plan = {OP_GRAMX, OP_GRAMW, OP_COMBO, OP_XW, OP_COMBO, OP_FINAL};
+      if (fold == 1) plan = {OP_GRAMX, OP_COMBO, OP_TRMMG, OP_XW, OP_COMBO, OP_FINAL};
       else if (vsx) plan = {OP_GRAM_UU, OP_TRMMG, OP_XU, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
       else plan = {OP_GRAM_UU, OP_TRMMG, OP_FINAL};
     }
