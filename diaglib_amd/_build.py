@@ -23,6 +23,7 @@ FLANG = os.path.join(ROCM, "lib", "llvm", "bin", "flang")
 ARCH = "gfx950"
 
 CXX_SOURCES = ["csrc/host_logic.cpp", "csrc/smalldense.cpp"]
+WIDE_SIMD_SOURCES = ["csrc/smalldense.cpp"]
 HIP_SOURCES = ["csrc/hip_engine.hip"]
 F90_SOURCES = ["fortran/real_precision.f90", "fortran/diaglib.f90", "fortran/diaglib_cbind.f90"]  # order matters
 HEADERS = ["csrc/dla_internal.h", os.path.join(ROOT, "include", "diaglib_amd.h")]
@@ -74,6 +75,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
             # host-size dense kernels want AVX2/FMA (every x86 host of an MI355X node has them)
             _run([HIPCC, "-x", "c++", "-O3", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-c", src, "-o", o], verbose)
         objs.append(o)
+        if s in WIDE_SIMD_SOURCES:
+            # the same file once more for AVX-512 hosts (EPYC Zen 4 / 5), picked at run time (smalldense.cpp)
+            o4 = os.path.join(OBJ, os.path.basename(s) + ".v4.o")
+            if force or _newer([src] + hdrs, o4):
+                _run([HIPCC, "-x", "c++", "-O3", "-march=x86-64-v4", "-mprefer-vector-width=512", "-std=c++17", "-fPIC",
+                      "-DSD_NS=sd_v4", "-DSD_IMPL_ONLY", "-c", src, "-o", o4], verbose)
+            objs.append(o4)
     f_objs = []
     rebuild_f = force
     for s in F90_SOURCES:

@@ -7,12 +7,20 @@
 // algorithms so that the library needs no LAPACK at run time.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "../../include/diaglib_amd.h"
 #include "dla_internal.h"
 
-namespace {
+// The eigensolvers below are compiled twice -- for AVX2 (every x86 host of an MI355X node has it) and for AVX-512 (EPYC Zen 4 / 5:
+// twice the vector width in the reduction and the back-transformation, which run on the critical path of every iteration while
+// the GPU waits) -- into two namespaces; the C entry points at the end of this file pick one at run time.
+#ifndef SD_NS
+#define SD_NS sd_v3
+#endif
+
+namespace SD_NS {
 
 // sqrt(a^2+b^2); the matrices handled here are projected operators (|entries| << 1e150), so the
 // plain form is safe and several times faster than std::hypot
@@ -148,11 +156,19 @@ int sym_eig(int n, std::vector<double>& s, std::vector<double>& d, std::vector<d
 // Cost 4/3 n^3 + O(m n^2) instead of ~9 n^3.  This runs on the critical path of every iteration
 // while the GPU waits, so the loops are laid out for the host's SIMD units.
 // ---------------------------------------------------------------------------------------
+#if defined(__AVX512F__)
+constexpr int VW = 8;
+typedef double v4 __attribute__((vector_size(64)));     // ("v4": the SIMD vector of this build, 4 or 8 doubles)
+inline v4 bc4(double x) { return (v4){x, x, x, x, x, x, x, x}; }
+inline double hsum4(v4 a) { return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])); }
+#else
+constexpr int VW = 4;
 typedef double v4 __attribute__((vector_size(32)));
-inline v4 ld4(const double* q) { v4 r; std::memcpy(&r, q, sizeof r); return r; }
-inline void st4(double* q, v4 r) { std::memcpy(q, &r, sizeof r); }
 inline v4 bc4(double x) { return (v4){x, x, x, x}; }
 inline double hsum4(v4 a) { return (a[0] + a[1]) + (a[2] + a[3]); }
+#endif
+inline v4 ld4(const double* q) { v4 r; std::memcpy(&r, q, sizeof r); return r; }
+inline void st4(double* q, v4 r) { std::memcpy(q, &r, sizeof r); }
 
 struct Tridiag {
   int n;
@@ -176,7 +192,7 @@ inline double row_pass(double* row, int len, double vi, double wi, const double*
   int j = 1;
   v4 acc = bc4(0.0);
   const v4 vvi = bc4(vi), vwi = bc4(wi), vx0 = bc4(x0);
-  for (; j + 4 <= len; j += 4) {
+  for (; j + VW <= len; j += VW) {
     v4 r = ld4(row + j);
     if (UPD) { r -= vvi * ld4(w + j) + vwi * ld4(v + j); st4(row + j, r); }
     if (MV) { acc += r * ld4(x + j); st4(pn + j, ld4(pn + j) + r * vx0); }
@@ -207,7 +223,7 @@ inline void row_pass2(double* a, double* b, int la, double va, double wa, double
   int j = 2;
   v4 acca = bc4(0.0), accb = bc4(0.0);
   const v4 vva = bc4(va), vwa = bc4(wa), vvb = bc4(vb), vwb = bc4(wb), vx0 = bc4(x0), vx1 = bc4(x1);
-  for (; j + 4 <= la; j += 4) {
+  for (; j + VW <= la; j += VW) {
     const v4 wj = ld4(w + j), vj = ld4(v + j), xj = ld4(x + j);
     v4 ra = ld4(a + j), rb = ld4(b + j - 1);
     ra -= vva * wj + vwa * vj; st4(a + j, ra);
@@ -259,8 +275,8 @@ void tridiagonalize(int n, std::vector<double>& s, Tridiag& t)
   t.n = n;
   t.d.assign(n, 0.0); t.e.assign(n, 0.0);
   t.hv.assign((size_t)n * n, 0.0); t.hbeta.assign(n, 0.0);
-  std::vector<double> vbuf[2], pbuf[2], w(n + 4, 0.0);
-  for (int q = 0; q < 2; ++q) { vbuf[q].assign(n + 4, 0.0); pbuf[q].assign(n + 4, 0.0); }
+  std::vector<double> vbuf[2], pbuf[2], w(n + VW, 0.0);
+  for (int q = 0; q < 2; ++q) { vbuf[q].assign(n + VW, 0.0); pbuf[q].assign(n + VW, 0.0); }
   if (n >= 3) {
     // step 0: reflector from row 0, plain product with the trailing matrix
     double sub;
@@ -326,49 +342,72 @@ void tridiagonalize(int n, std::vector<double>& s, Tridiag& t)
   for (int i = 0; i < n; ++i) t.d[i] = s[(size_t)i * n + i];
 }
 
-// (T - lam I) = P L U by Gaussian elimination with partial pivoting on the tridiagonal matrix; tiny pivots
-// are replaced by +-tiny (inverse iteration only needs the direction).  One factorisation serves all the
-// iterations of one eigenvector.
-struct TriLU {
-  std::vector<double> a, b, c, l;   // U: diagonal, first and second super-diagonal; multipliers
-  std::vector<int> piv;
-  explicit TriLU(int n) : a(n), b(n), c(n), l(n), piv(n) {}
-  void factor(int n, const std::vector<double>& d, const std::vector<double>& e, double lam, double tiny)
+// Inverse iteration for up to 16 eigenvectors AT ONCE.  (T - lam_j I) = P L U by Gaussian elimination with partial
+// pivoting on the tridiagonal matrix (tiny pivots are replaced by +-tiny: inverse iteration only needs the direction), one
+// shift per SIMD lane: the factorisation and the two triangular solves are first-order recurrences along the matrix index,
+// i.e. pure latency for one vector -- sixteen of them advance together at the price of one.  One factorisation serves
+// all the iterations of its lane.
+constexpr int LW = 16;                                 // lanes = shifts per batch
+typedef double v8 __attribute__((vector_size(64)));
+typedef long long v8i __attribute__((vector_size(64)));
+struct Lanes { v8 a, b; };                             // 16 doubles
+inline v8 bc8(double x) { return (v8){x, x, x, x, x, x, x, x}; }
+inline v8 abs8(v8 x) { return x < bc8(0.0) ? -x : x; }
+inline v8 sel8(v8i m, v8 x, v8 y) { return m ? x : y; }
+
+struct TriLU16 {
+  // U: diagonal, first and second super-diagonal; multipliers; pivot masks -- [index][lane]
+  std::vector<v8> a, b, c, l;
+  std::vector<v8i> piv;
+  explicit TriLU16(int n) : a(2 * n), b(2 * n), c(2 * n), l(2 * n), piv(2 * n) {}
+  void factor(int n, const std::vector<double>& d, const std::vector<double>& e, const double* lam, double tiny)
   {
-    for (int i = 0; i < n; ++i) { a[i] = d[i] - lam; b[i] = (i + 1 < n) ? e[i] : 0.0; c[i] = 0.0; }
-    for (int i = 0; i + 1 < n; ++i) {
-      const double sub = e[i];                 // T(i+1,i)
-      if (std::fabs(a[i]) >= std::fabs(sub)) {
-        piv[i] = 0;
-        if (a[i] == 0.0) a[i] = tiny;
-        const double mlt = sub / a[i];
-        l[i] = mlt;
-        a[i + 1] -= mlt * b[i];
-      } else {
-        piv[i] = 1;                            // swap rows i and i+1
-        const double mlt = a[i] / sub;
-        l[i] = mlt;
-        const double ai1 = a[i + 1], bi = b[i], bi1 = b[i + 1];
-        a[i] = sub; b[i] = ai1; c[i] = bi1;
-        a[i + 1] = bi - mlt * ai1;
-        b[i + 1] = -mlt * bi1;
+    for (int h = 0; h < 2; ++h) {
+      v8 lm; std::memcpy(&lm, lam + 8 * h, sizeof lm);
+      v8 ai = bc8(d[0]) - lm, bi = bc8(n > 1 ? e[0] : 0.0);
+      const v8 vt = bc8(tiny);
+      for (int i = 0; i + 1 < n; ++i) {
+        const v8 sub = bc8(e[i]);                          // T(i+1, i), the same in every lane
+        const v8 an = bc8(d[i + 1]) - lm, bn = bc8(i + 2 < n ? e[i + 1] : 0.0);
+        const v8i swp = abs8(ai) < abs8(sub);              // swap rows i and i+1
+        const v8 a0 = sel8(ai == bc8(0.0), vt, ai);        // (only used where no swap happens)
+        const v8 mlt = sel8(swp, ai / sub, sub / a0);
+        // no swap: U_i = (a0, bi, 0), next row (an - mlt bi, bn);  swap: U_i = (sub, an, bn), next row (bi - mlt an, -mlt bn)
+        a[2 * i + h] = sel8(swp, sub, a0);
+        b[2 * i + h] = sel8(swp, an, bi);
+        c[2 * i + h] = sel8(swp, bn, bc8(0.0));
+        l[2 * i + h] = mlt;
+        piv[2 * i + h] = swp;
+        const v8 na = sel8(swp, bi - mlt * an, an - mlt * bi);
+        const v8 nb = sel8(swp, -mlt * bn, bn);
+        ai = na; bi = nb;
+      }
+      a[2 * (n - 1) + h] = ai; b[2 * (n - 1) + h] = bc8(0.0); c[2 * (n - 1) + h] = bc8(0.0);
+      for (int i = 0; i < n; ++i) {
+        const v8 x = a[2 * i + h];
+        a[2 * i + h] = sel8(abs8(x) < vt, sel8(x < bc8(0.0), -vt, vt), x);
       }
     }
-    for (int i = 0; i < n; ++i) {
-      if (std::fabs(a[i]) < tiny) a[i] = (a[i] < 0.0 ? -tiny : tiny);
-    }
   }
-  void solve(int n, std::vector<double>& x) const
+  // x: [index][lane], 2 vectors per index
+  void solve(int n, v8* x) const
   {
-    for (int i = 0; i + 1 < n; ++i) {
-      if (piv[i]) std::swap(x[i], x[i + 1]);
-      x[i + 1] -= l[i] * x[i];
-    }
-    for (int i = n - 1; i >= 0; --i) {
-      double t = x[i];
-      if (i + 1 < n) t -= b[i] * x[i + 1];
-      if (i + 2 < n) t -= c[i] * x[i + 2];
-      x[i] = t / a[i];
+    for (int h = 0; h < 2; ++h) {
+      v8 xi = x[h];
+      for (int i = 0; i + 1 < n; ++i) {
+        const v8 xn = x[2 * (i + 1) + h];
+        const v8i swp = piv[2 * i + h];
+        const v8 top = sel8(swp, xn, xi), bot = sel8(swp, xi, xn);
+        x[2 * i + h] = top;
+        xi = bot - l[2 * i + h] * top;
+      }
+      x[2 * (n - 1) + h] = xi;
+      v8 x1 = bc8(0.0), x2 = bc8(0.0);
+      for (int i = n - 1; i >= 0; --i) {
+        const v8 t = (x[2 * i + h] - b[2 * i + h] * x1 - c[2 * i + h] * x2) / a[2 * i + h];
+        x[2 * i + h] = t;
+        x2 = x1; x1 = t;
+      }
     }
   }
 };
@@ -395,20 +434,20 @@ void bisect_lowest(int n, const std::vector<double>& d, const std::vector<double
   }
   const double pad = 4.0 * eps * n;
   gl -= pad; gu += pad;
-  constexpr int W = 16, NV = W / 4;
+  constexpr int W = 16, NV = W / VW;
   const int mp = ((m + W - 1) / W) * W;
   std::vector<double> lo(mp, gl), hi(mp, gu), mid(mp, 0.0);
   std::vector<int> cnt(mp, 0);
   const double BIG = 0x1p+300, SMALL = 0x1p-300, ZERO_REPL = 0x1p-900;
-  typedef long long v4i __attribute__((vector_size(32)));
+  typedef long long v4i __attribute__((vector_size(8 * VW)));
   auto sturm = [&](const double* x, int* c) {   // counts for W shifts at once
     v4 xs[NV], p0[NV], p1[NV];
     v4i neg[NV];
     for (int q = 0; q < NV; ++q) {
-      xs[q] = ld4(x + 4 * q);
+      xs[q] = ld4(x + VW * q);
       p0[q] = bc4(1.0);
       p1[q] = bc4(ds[0]) - xs[q];
-      neg[q] = (v4i){0, 0, 0, 0};
+      neg[q] = v4i{};
     }
     auto account = [&](int q) {
       // an exact zero takes the sign opposite to its predecessor (it counts as a negative pivot)
@@ -438,7 +477,7 @@ void bisect_lowest(int n, const std::vector<double>& d, const std::vector<double
       }
     }
     for (int q = 0; q < NV; ++q)
-      for (int r = 0; r < 4; ++r) c[4 * q + r] = (int)neg[q][r];
+      for (int r = 0; r < VW; ++r) c[VW * q + r] = (int)neg[q][r];
   };
   const double tol_abs = eps;   // scaled units: eps * ||T||
   for (int it = 0; it < 120; ++it) {
@@ -480,57 +519,94 @@ int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_
   const double ortol = 1.0e-3 * onenrm;     // cluster criterion (as LAPACK dstein)
   const double sep = 10.0 * eps * onenrm;   // minimal separation of the shifts inside a cluster
   const double tiny = eps * onenrm;
-  std::vector<double> x(n);
-  TriLU lu(n);
   unsigned long long seed = 0x243F6A8885A308D3ULL;
   auto rnd = [&]() {   // deterministic start vectors
     seed = seed * 6364136223846793005ULL + 1442695040888963407ULL;
     return ((double)(seed >> 11) * (1.0 / 9007199254740992.0)) - 0.5;
   };
-  int cluster_start = 0;
-  double lam_prev = 0.0;
-  for (int j = 0; j < m; ++j) {
-    double lam = w_all[j];
-    if (j > 0 && std::fabs(w_all[j] - w_all[j - 1]) >= ortol) cluster_start = j;
-    if (j > cluster_start && lam - lam_prev < sep) lam = lam_prev + sep;
-    lam_prev = lam;
-    double* z = &zt[(size_t)j * n];
-    for (int i = 0; i < n; ++i) x[i] = rnd();
-    lu.factor(n, t.d, t.e, lam, tiny);
-    for (int it = 0; it < 8; ++it) {
-      lu.solve(n, x);
-      // re-orthogonalise against the earlier members of the cluster (modified Gram-Schmidt);
-      // zt rows are still in tridiagonal coordinates here (back-transformation comes last)
-      for (int q = cluster_start; q < j; ++q) {
-        const double* zq = &zt[(size_t)q * n];
-        double dot = 0.0;
-        for (int i = 0; i < n; ++i) dot += zq[i] * x[i];
-        for (int i = 0; i < n; ++i) x[i] -= dot * zq[i];
-      }
-      double xinf = 0.0;
-      for (int i = 0; i < n; ++i) xinf = std::max(xinf, std::fabs(x[i]));
-      if (!(xinf > 0.0) || !std::isfinite(xinf)) { for (int i = 0; i < n; ++i) x[i] = rnd(); continue; }
-      double nrm = 0.0;
-      for (int i = 0; i < n; ++i) { x[i] /= xinf; nrm += x[i] * x[i]; }
-      nrm = std::sqrt(nrm);
-      for (int i = 0; i < n; ++i) x[i] /= nrm;
-      if (it >= 1) {
-        // converged when the eigen-residual is at rounding level (plus the shift perturbation)
-        double res = 0.0;
-        for (int i = 0; i < n; ++i) {
-          double ti = (t.d[i] - w_all[j]) * x[i];
-          if (i > 0) ti += t.e[i - 1] * x[i - 1];
-          if (i + 1 < n) ti += t.e[i] * x[i + 1];
-          res += ti * ti;
-        }
-        if (std::sqrt(res) <= 64.0 * eps * onenrm + 2.0 * std::fabs(lam - w_all[j])) break;
-      }
+  // shifts: the eigenvalues, pulled apart inside clusters (as LAPACK dstein)
+  std::vector<double> lam(m);
+  std::vector<int> cstart(m);
+  {
+    int cluster_start = 0;
+    double lam_prev = 0.0;
+    for (int j = 0; j < m; ++j) {
+      double lj = w_all[j];
+      if (j > 0 && std::fabs(w_all[j] - w_all[j - 1]) >= ortol) cluster_start = j;
+      if (j > cluster_start && lj - lam_prev < sep) lj = lam_prev + sep;
+      lam_prev = lj;
+      lam[j] = lj; cstart[j] = cluster_start;
     }
-    std::memcpy(z, x.data(), sizeof(double) * n);
+  }
+  TriLU16 lu(n);
+  std::vector<v8> xl(2 * (size_t)n);                  // iterates, [index][lane]
+  std::vector<double> cols((size_t)LW * n);           // the same, one contiguous column per lane
+  for (int j0 = 0; j0 < m; j0 += LW) {
+    const int nb = std::min(LW, m - j0);
+    double lm[LW];
+    for (int q = 0; q < LW; ++q) lm[q] = lam[j0 + std::min(q, nb - 1)];   // (idle lanes shadow the last shift)
+    for (int q = 0; q < nb; ++q)
+      for (int i = 0; i < n; ++i) cols[(size_t)q * n + i] = rnd();
+    for (int q = nb; q < LW; ++q)
+      for (int i = 0; i < n; ++i) cols[(size_t)q * n + i] = cols[(size_t)(nb - 1) * n + i];
+    lu.factor(n, t.d, t.e, lm, tiny);
+    bool conv[LW];
+    for (int q = 0; q < LW; ++q) conv[q] = false;
+    for (int it = 0; it < 8; ++it) {
+      double* xs = reinterpret_cast<double*>(xl.data());
+      for (int q = 0; q < LW; ++q)
+        for (int i = 0; i < n; ++i) xs[(size_t)i * LW + q] = cols[(size_t)q * n + i];
+      lu.solve(n, xl.data());
+      for (int q = 0; q < nb; ++q)
+        for (int i = 0; i < n; ++i) cols[(size_t)q * n + i] = xs[(size_t)i * LW + q];
+      bool all = true;
+      for (int q = 0; q < nb; ++q) {
+        const int j = j0 + q;
+        double* x = &cols[(size_t)q * n];
+        // re-orthogonalise against the earlier members of the cluster (modified Gram-Schmidt): finished vectors of earlier
+        // batches, then the lower lanes of this one (already orthonormalised in this iteration); zt rows are still in
+        // tridiagonal coordinates here (back-transformation comes last)
+        for (int p = cstart[j]; p < j; ++p) {
+          const double* zq = (p < j0) ? &zt[(size_t)p * n] : &cols[(size_t)(p - j0) * n];
+          double dot = 0.0;
+          for (int i = 0; i < n; ++i) dot += zq[i] * x[i];
+          for (int i = 0; i < n; ++i) x[i] -= dot * zq[i];
+        }
+        double xinf = 0.0;
+        for (int i = 0; i < n; ++i) xinf = std::max(xinf, std::fabs(x[i]));
+        if (!(xinf > 0.0) || !std::isfinite(xinf)) {
+          for (int i = 0; i < n; ++i) x[i] = rnd();
+          double nr = 0.0;
+          for (int i = 0; i < n; ++i) nr += x[i] * x[i];
+          nr = std::sqrt(nr);
+          for (int i = 0; i < n; ++i) x[i] /= nr;
+          conv[q] = false; all = false;
+          continue;
+        }
+        double nrm = 0.0;
+        for (int i = 0; i < n; ++i) { x[i] /= xinf; nrm += x[i] * x[i]; }
+        nrm = std::sqrt(nrm);
+        for (int i = 0; i < n; ++i) x[i] /= nrm;
+        if (it >= 1) {
+          // converged when the eigen-residual is at rounding level (plus the shift perturbation)
+          double res = 0.0;
+          for (int i = 0; i < n; ++i) {
+            double ti = (t.d[i] - w_all[j]) * x[i];
+            if (i > 0) ti += t.e[i - 1] * x[i - 1];
+            if (i + 1 < n) ti += t.e[i] * x[i + 1];
+            res += ti * ti;
+          }
+          conv[q] = std::sqrt(res) <= 64.0 * eps * onenrm + 2.0 * std::fabs(lam[j] - w_all[j]);
+        }
+        all = all && conv[q];
+      }
+      if (it >= 1 && all) break;
+    }
+    for (int q = 0; q < nb; ++q) std::memcpy(&zt[(size_t)(j0 + q) * n], &cols[(size_t)q * n], sizeof(double) * n);
   }
   // back-transformation: eigenvector of S = H_0 H_1 ... H_{n-3} z  (apply the last reflector first).
   // All m vectors advance together: zz[r][j] = component r of vector j, so both loops run along j.
-  const int mp = (m + 3) & ~3;
+  const int mp = (m + 7) & ~7;
   std::vector<double> zz((size_t)n * mp, 0.0), acc(mp);
   for (int j = 0; j < m; ++j)
     for (int r = 0; r < n; ++r) zz[(size_t)r * mp + j] = zt[(size_t)j * n + r];
@@ -556,6 +632,34 @@ int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_
   return 0;
 }
 
+}  // namespace SD_NS
+
+#ifndef SD_IMPL_ONLY
+namespace sd_v4 {   // the same routines, AVX-512 build of this file
+int sym_eig(int n, std::vector<double>& s, std::vector<double>& d, std::vector<double>& zt);
+int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_all, std::vector<double>& zt);
+}
+namespace {
+bool wide_simd()
+{
+#if defined(__x86_64__)
+  static const bool yes = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl") &&
+                          std::getenv("DIAGLIB_AMD_NO_AVX512") == nullptr;
+  return yes;
+#else
+  return false;
+#endif
+}
+int sym_eig(int n, std::vector<double>& s, std::vector<double>& d, std::vector<double>& zt)
+{
+  return wide_simd() ? sd_v4::sym_eig(n, s, d, zt) : sd_v3::sym_eig(n, s, d, zt);
+}
+int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_all, std::vector<double>& zt)
+{
+  return wide_simd() ? sd_v4::sym_eig_lowest(n, s, m, w_all, zt) : sd_v3::sym_eig_lowest(n, s, m, w_all, zt);
+}
+inline double& at(double* a, int ld, int i, int j) { return a[(size_t)i + (size_t)j * ld]; }
+inline double at(const double* a, int ld, int i, int j) { return a[(size_t)i + (size_t)j * ld]; }
 }  // namespace
 
 extern "C" {
@@ -674,3 +778,4 @@ double dla_norm_est(int m, const double* a, int lda)
 }
 
 }  // extern "C"
+#endif  // SD_IMPL_ONLY

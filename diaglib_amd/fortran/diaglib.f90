@@ -675,7 +675,7 @@ contains
 !
 !     Rayleigh-Ritz: the lowest n_max pairs of the upper triangle (:1703-1708)
 !
-      y = h
+      y(1:s%cols,1:s%cols) = h(1:s%cols,1:s%cols)       ! (only the leading block: the arrays are (ld,ld) = 0.5 MB at 20 blocks of 13)
       call lap_start(w)
       call need_eigensolver(dla_syev_lowest('u', s%cols, y, s%ld, theta, n_max))
       call lap_charge(w, w%diag)
