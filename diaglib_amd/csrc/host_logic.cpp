@@ -13,6 +13,8 @@
 #include <cstring>
 #include <functional>
 #include <vector>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include "dla_internal.h"
 
 using dla::Engine;
@@ -44,7 +46,16 @@ const double kTolOrtho = 2.0 * DBL_EPSILON;  // tol_ortho, diaglib.f90:151
 // the CALLING THREAD -- its own engine (stream, scratch, panel cache, statistics, options) -- so two host threads can
 // solve different problems with different operators at the same time.  It is created on the thread's first use and
 // lives until dla_destroy(dla_default_ctx()) or the end of the process.
-thread_local dla_ctx* g_default = nullptr;
+// The thread's context is released when the thread ends (the owner's destructor runs at thread exit): a caller that solves
+// from short-lived threads does not leave a stream, pinned buffers and a panel cache behind per thread.  The process' main
+// thread is the exception -- its thread-local destructors run during process exit, when the HIP runtime may already be
+// gone -- its context goes with the process (or through dla_destroy / diaglib_amd_config(release_context=.true.)).
+struct DefaultCtxOwner {
+  dla_ctx* c = nullptr;
+  ~DefaultCtxOwner();
+};
+thread_local DefaultCtxOwner g_default_owner;
+#define g_default (g_default_owner.c)
 // built-in operator callbacks have the reference's context-free shape; they act on the calling thread's setup
 thread_local dla_ctx* g_synth_ctx = nullptr;
 thread_local dla_ctx* g_spmm_ctx = nullptr;
@@ -94,6 +105,21 @@ int dla_create(dla_ctx** out, int device)
   *out = c;
   return DLA_OK;
 }
+
+}  // extern "C" (reopened below)
+
+namespace {
+DefaultCtxOwner::~DefaultCtxOwner()
+{
+  if (!c) return;
+  if ((long)syscall(SYS_gettid) == (long)getpid()) return;      // main thread: process exit, leave it to the process
+  dla_ctx* mine = c;
+  c = nullptr;
+  (void)dla_destroy(mine);
+}
+}  // namespace
+
+extern "C" {
 
 int dla_destroy(dla_ctx* c)
 {

@@ -78,6 +78,11 @@ module diaglib
       import :: c_ptr
       type(c_ptr) :: ctx
     end function
+    function dla_destroy(ctx) bind(C,name='dla_destroy') result(st)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx
+      integer(c_int)     :: st
+    end function
     function dla_set_option(ctx,opt,val) bind(C,name='dla_set_option') result(st)
       import :: c_ptr, c_int
       type(c_ptr), value :: ctx
@@ -293,7 +298,7 @@ contains
 ! ---------------------------------------------------------------------------------------
 ! configuration (extension; defaults reproduce the reference contract: host callbacks, host eig/evec)
 ! ---------------------------------------------------------------------------------------
-  subroutine diaglib_amd_config(callbacks_on_device, evec_on_device, release_cache, caslr_algorithm)
+  subroutine diaglib_amd_config(callbacks_on_device, evec_on_device, release_cache, caslr_algorithm, release_context)
     logical, intent(in), optional :: callbacks_on_device, evec_on_device
 !   release_cache = .true.: hand the panels the allocator keeps between solves back to the runtime (dla_trim)
     logical, intent(in), optional :: release_cache
@@ -301,6 +306,9 @@ contains
 !   1 = the Helmich-Paris route through the singular values of the scaled coupling block (the reference selects it
 !   with the harness variable i_alg of its module utils, diaglib.f90:560,675); a setting of the calling thread's context
     integer, intent(in), optional :: caslr_algorithm
+!   release_context = .true.: destroy the calling thread's engine context (stream, pinned buffers, cached panels); the next
+!   driver call of this thread creates a fresh one.  Contexts of threads that end are released by themselves.
+    logical, intent(in), optional :: release_context
     integer(c_size_t) :: released
     type(c_ptr)    :: ctx
     integer(c_int) :: st
@@ -311,6 +319,9 @@ contains
       if (release_cache) st = dla_trim(ctx, released)
     end if
     if (present(caslr_algorithm)) st = dla_set_option(ctx, opt_lr_alg, int(caslr_algorithm,c_int))
+    if (present(release_context)) then
+      if (release_context) st = dla_destroy(ctx)
+    end if
   end subroutine diaglib_amd_config
 !
 ! ---------------------------------------------------------------------------------------
