@@ -24,6 +24,7 @@ PRECND_T = C.CFUNCTYPE(None, c_ip, c_ip, c_dp, c_dp, c_dp)
 ALLREDUCE_T = C.CFUNCTYPE(None, C.c_void_p, c_dp, C.c_int, C.c_int)
 
 OPT_CALLBACKS_ON_DEVICE, OPT_EVEC_ON_DEVICE, OPT_PROFILE, OPT_VERBOSE_ORTHO, OPT_CALLBACK_ORDER, OPT_ORTHO_MAXIT, OPT_CASLR_ALGORITHM, OPT_STAGE_CHUNKS = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_P2P_TIMEOUT_MS = 9
 OP_NAMES = ["gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd"]
 
 # every symbol include/diaglib_amd.h declares (checked by tests/test_abi.py)

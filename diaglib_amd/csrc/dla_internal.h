@@ -154,6 +154,7 @@ struct Engine : BlockOps {
   virtual int p2p_export(int /*nranks*/, void* /*handles*/) { return DLA_ERR_COMM; }
   virtual int p2p_attach(int /*nranks*/, int /*rank*/, const void* /*handles*/) { return DLA_ERR_COMM; }
   virtual int p2p_detach() { return DLA_OK; }
+  virtual int set_p2p_timeout(int /*ms*/) { return DLA_OK; }      // DLA_OPT_P2P_TIMEOUT_MS
   int nranks = 1, rank = 0;
   bool local_only = false;   // true while working on data that is replicated on every rank (no reductions)
   dla_allreduce_fn hook = nullptr;
@@ -196,6 +197,7 @@ struct dla_ctx {
   int caslr_algorithm = 0;   // DLA_OPT_CASLR_ALGORITHM
   int stage_chunks = 0;      // DLA_OPT_STAGE_CHUNKS: 0 = automatic
   int callback_order = 1;    // DLA_OPT_CALLBACK_ORDER (default: host-synchronised, safe for callbacks on any stream)
+  int p2p_timeout_ms = 5000; // DLA_OPT_P2P_TIMEOUT_MS
   long long n_global = -1;   // -1: single shard, n_global == n
   long long row0 = 0;
   std::string err;

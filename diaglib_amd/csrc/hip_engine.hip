@@ -26,6 +26,7 @@
 #include <cstring>
 #include <ctime>
 #include <map>
+#include <set>
 #include <vector>
 #include "dla_internal.h"
 
@@ -1961,14 +1962,19 @@ __global__ __launch_bounds__(256) void ortho_tail16_kernel(OrthoTailArgs a)
 //   * mailboxes are fine-grained device allocations shared through hipIpc handles (dla_p2p_export / dla_p2p_attach);
 //   * two mailbox sets alternate (parity of the sequence number): a peer can write for call s+2 only after it has seen
 //     this rank's flag for call s+1, which this rank raises only after it has finished reading call s;
-//   * the wait is bounded (P2P_TIMEOUT_TICKS of the 100 MHz wall clock): a missing peer sets a status word, the kernel
-//     ends and the host reports DLA_ERR_COMM at its next wait -- the grid always drains;
+//   * the wait is bounded (DLA_OPT_P2P_TIMEOUT_MS, default 5 s of the 100 MHz wall clock; 0 = no limit): a rank that gives up
+//     writes the sequence number into the ERROR WORD of every mailbox (its own included), sets its status word and ends --
+//     the grid always drains.  Every exchange looks at its own error word first and while it waits, so a peer that arrives
+//     late -- it would find flag and data of the abandoned exchange in place and succeed alone -- fails the SAME exchange, and
+//     so does every later one: all ranks report DLA_ERR_COMM at their next host wait, the transport stays down until it is
+//     detached and exported again.  Ranks whose skew can exceed the limit (host-mode callbacks of unequal length, a paused
+//     process) raise it or use the RCCL / hook transports, which have none;
 //   * a launch belongs to the device-driven chains like any other: when it is not its turn (DLA_PREDICATED) it returns
 //     before touching a mailbox, on every rank alike (all ranks hold the same phase).
 #define P2P_MAX_RANKS 8
 #define P2P_MAX_DOUBLES 16384              // 128 KB per slot (the widest projection block of BASELINE cfg 4/5 fits)
 #define P2P_FLAG_STRIDE 16                 // one flag per 128-byte line
-#define P2P_TIMEOUT_TICKS 500000000ULL     // 5 s
+#define P2P_ERR_WORD(nr) ((size_t)2 * (nr) * P2P_FLAG_STRIDE)   // index of the error word behind a mailbox's flags
 struct P2PArgs {
   double* buf;                             // in: this rank's contribution, out: the reduced values
   double* buf_host;                        // optional pinned mirror of the result
@@ -1983,6 +1989,7 @@ struct P2PArgs {
   unsigned long long* flags[P2P_MAX_RANKS];//                    [2][nranks][P2P_FLAG_STRIDE]
   int* status;                             // device word: != 0 after a timeout
   const int* phase; int want;
+  unsigned long long timeout_ticks;        // 100 MHz ticks a rank waits for its peers; 0 = no limit
 };
 
 // the exchange itself, executed by the 256 threads of ONE block (ends with a block barrier); false: a peer timed out
@@ -2000,21 +2007,26 @@ __device__ bool p2p_exchange(const P2PArgs& a)
   __syncthreads();
   // 2. raise my flag everywhere, 3. wait for everyone's flag in my mailbox
   __shared__ int s_bad;
-  if (tid == 0) s_bad = 0;
+  unsigned long long* my_err = a.flags[a.rank] + P2P_ERR_WORD(a.nranks);
+  if (tid == 0) s_bad = __hip_atomic_load(my_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ULL;     // an earlier exchange was abandoned
   __syncthreads();
-  if (tid < a.nranks) {
+  if (!s_bad && tid < a.nranks) {
     __hip_atomic_store(a.flags[tid] + ((size_t)par * a.nranks + a.rank) * P2P_FLAG_STRIDE, seq, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long* mine = a.flags[a.rank] + ((size_t)par * a.nranks + tid) * P2P_FLAG_STRIDE;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { s_bad = 1; break; }
+      if (__hip_atomic_load(my_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ULL) { s_bad = 1; break; }   // a peer gave up
+      if (a.timeout_ticks != 0ULL && wall_clock64() - t0 > a.timeout_ticks) { s_bad = 2; break; }
       __builtin_amdgcn_s_sleep(8);
     }
   }
   __syncthreads();
   if (s_bad) {
+    // tell everyone (a peer that is late for this exchange must fail it too), then the host
+    if (tid < a.nranks) __hip_atomic_store(a.flags[tid] + P2P_ERR_WORD(a.nranks), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (tid == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
     return false;
   }
   // 4. combine the slots of my mailbox in rank order
@@ -2196,6 +2208,9 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
 // host side of the engine
 // ======================================================================================
 struct TimedLaunch { hipEvent_t a, b; int cls; std::string kname; };
+// every launch of the engine goes through here: a dry run (HipEngine::dry_launch) walks the launch paths -- shape decisions,
+// workspace growth, requests for more than 64 KiB of LDS -- without launching anything
+#define DLA_LAUNCH(...) do { if (!dry_launch) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 struct HipEngine : dla::Engine {
   int device = 0;
@@ -2251,6 +2266,7 @@ struct HipEngine : dla::Engine {
 
   const char* name() const override { return nm.c_str(); }
   void* stream() override { return (void*)st; }
+  bool dry_launch = false;           // see DLA_LAUNCH
 
   ~HipEngine() override
   {
@@ -2280,6 +2296,8 @@ struct HipEngine : dla::Engine {
     if (d_cpk2) (void)hipFree(d_cpk2);
     if (d_wst) (void)hipFree(d_wst);
     if (d_xug) (void)hipFree(d_xug);
+    if (d_red_small) (void)hipFree(d_red_small);
+    if (d_red_xug) (void)hipFree(d_red_xug);
     for (int i = 0; i < RING; ++i) if (h_ring[i]) { (void)hipHostFree(h_ring[i]); (void)hipEventDestroy(ring_ev[i]); }
     if (d_cpk) (void)hipFree(d_cpk);
     if (d_w) (void)hipFree(d_w);
@@ -2343,6 +2361,7 @@ struct HipEngine : dla::Engine {
     Scope(HipEngine* e_, int cls_, double bytes, double flops, const std::string& kname_ = std::string()) : e(e_), cls(cls_), kname(kname_)
     {
       e->bind();
+      if (e->dry_launch) return;
       if (e->spec_rec) {
         // speculative launch of a device-driven chain: counted after the read-back, if the device executed it
         e->spec_rec->push_back({e->spec_tag, cls_, kname_, bytes, flops});
@@ -2365,6 +2384,7 @@ struct HipEngine : dla::Engine {
     }
     ~Scope()
     {
+      if (e->dry_launch) return;
       if (e->trace) {
         hipError_t er = hipStreamSynchronize(e->st);
         timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -2667,6 +2687,7 @@ struct HipEngine : dla::Engine {
   int allreduce_dev(double* dev, int count, int op /*0 sum, 1 max*/, double* host_mirror)
   {
     if (local_only || (nranks <= 1 && !comm && !p2p.on)) return DLA_OK;
+    if (dry_launch) return DLA_OK;
     stats.allreduces++;
     mirror_fresh = false;
     if (p2p.on && count <= P2P_MAX_DOUBLES) {
@@ -2675,12 +2696,16 @@ struct HipEngine : dla::Engine {
       // outside the device-driven chains the host reads the result next: the exchange writes the pinned mirror itself
       if (!pred_phase && dev == d_small && host_mirror == h_small) { pa.buf_host = h_small_dev; mirror_fresh = true; }
       Scope s(this, DLA_OP_ELEM, 0.0, 0.0, "p2p_allreduce_kernel");
-      hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(256), 0, st, pa);
+      DLA_LAUNCH(p2p_allreduce_kernel, dim3(1), dim3(256), 0, st, pa);
       HIPCHK(hipGetLastError());
       return DLA_OK;
     }
     if (comm) {
-      ncclResult_t r = ncclAllReduce(dev, dev, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax, comm, st);
+      // inside a chain: out of place (see d_red_small), the tail reads the destination
+      double* dst = dev;
+      if (pred_phase && d_red_small && count <= RED_DOUBLES && (dev == d_small || dev == d_xug)) dst = (dev == d_xug) ? d_red_xug : d_red_small;
+      chain_reduced = (dst != dev);
+      ncclResult_t r = ncclAllReduce(dev, dst, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax, comm, st);
       if (r != ncclSuccess) { err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return DLA_ERR_COMM; }
       return DLA_OK;
     }
@@ -2702,9 +2727,11 @@ struct HipEngine : dla::Engine {
     pa.executed = p2p.d_executed;
     for (int r = 0; r < nranks; ++r) { pa.data[r] = p2p.data[r]; pa.flags[r] = p2p.flags[r]; }
     pa.status = p2p.d_status; pa.phase = pred_phase; pa.want = pred_want;
+    pa.timeout_ticks = (unsigned long long)std::max(0, p2p_timeout_ms) * 100000ULL;
     return pa;
   }
   bool exchange_fused = false;       // the reduction just enqueued carries the cross-rank sum (gram_reduce_kernel<true>)
+  bool chain_reduced = false;        // the last RCCL all-reduce of a chain went out of place (d_red_small / d_red_xug)
   // ---- one-shot peer-to-peer all-reduce (p2p_allreduce_kernel)
   struct P2P {
     bool on = false;
@@ -2716,7 +2743,8 @@ struct HipEngine : dla::Engine {
     int slots = 0;                       // ranks the local mailbox was sized for
   } p2p;
   static size_t p2p_data_bytes(int nr) { return sizeof(double) * 2 * (size_t)nr * P2P_MAX_DOUBLES; }
-  static size_t p2p_flag_bytes(int nr) { return sizeof(unsigned long long) * 2 * (size_t)nr * P2P_FLAG_STRIDE; }
+  static size_t p2p_flag_bytes(int nr) { return sizeof(unsigned long long) * (2 * (size_t)nr + 1) * P2P_FLAG_STRIDE; }   // flags + error word
+  int p2p_timeout_ms = 5000;           // DLA_OPT_P2P_TIMEOUT_MS
 
   // allocate this rank's mailbox (fine-grained: peers write into it while kernels of this rank poll it) and export it
   int p2p_export(int nr, void* handles /* 2 x hipIpcMemHandle_t */) override
@@ -2744,12 +2772,28 @@ struct HipEngine : dla::Engine {
   int p2p_attach(int nr, int rk, const void* handles) override
   {
     if (nr != p2p.slots || rk < 0 || rk >= nr) { err = "p2p_attach: export first, with the same rank count"; return DLA_ERR_ARG; }
+    // a second attach on the same export would start the sequence numbers at 1 again while the mailboxes still hold larger
+    // ones (every wait would pass at once, stale slots would be summed): a re-formed group exports again on every rank
+    if (p2p.on) { err = "p2p_attach: already attached; detach and export again on every rank"; return DLA_ERR_ARG; }
     HIPCHK(hipSetDevice(device));
     const hipIpcMemHandle_t* h = (const hipIpcMemHandle_t*)handles;
-    for (int r = 0; r < nr; ++r) {
+    for (int r = 0; r < P2P_MAX_RANKS; ++r) { p2p.data[r] = nullptr; p2p.flags[r] = nullptr; }
+    hipError_t e1 = hipSuccess;
+    for (int r = 0; r < nr && e1 == hipSuccess; ++r) {
       if (r == rk) { p2p.data[r] = p2p.my_data; p2p.flags[r] = p2p.my_flags; continue; }
-      HIPCHK(hipIpcOpenMemHandle((void**)&p2p.data[r], h[2 * r], hipIpcMemLazyEnablePeerAccess));
-      HIPCHK(hipIpcOpenMemHandle((void**)&p2p.flags[r], h[2 * r + 1], hipIpcMemLazyEnablePeerAccess));
+      e1 = hipIpcOpenMemHandle((void**)&p2p.data[r], h[2 * r], hipIpcMemLazyEnablePeerAccess);
+      if (e1 == hipSuccess) e1 = hipIpcOpenMemHandle((void**)&p2p.flags[r], h[2 * r + 1], hipIpcMemLazyEnablePeerAccess);
+    }
+    if (e1 != hipSuccess) {
+      // close what was opened so far: the mailbox set is all or nothing
+      for (int r = 0; r < nr; ++r) {
+        if (r == rk) continue;
+        if (p2p.data[r]) (void)hipIpcCloseMemHandle(p2p.data[r]);
+        if (p2p.flags[r]) (void)hipIpcCloseMemHandle(p2p.flags[r]);
+        p2p.data[r] = nullptr; p2p.flags[r] = nullptr;
+      }
+      err = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e1);
+      return DLA_ERR_RUNTIME;
     }
     nranks = nr; rank = rk;
     HIPCHK(hipMemset(p2p.d_executed, 0, sizeof(unsigned long long)));
@@ -2771,9 +2815,13 @@ struct HipEngine : dla::Engine {
     p2p = P2P{};
   }
   int p2p_detach() override { p2p_release(); return DLA_OK; }
+  int set_p2p_timeout(int ms) override { p2p_timeout_ms = ms; return DLA_OK; }
   int p2p_check()
   {
-    if (p2p.on && *(volatile int*)p2p.h_status) { err = "p2p all-reduce: a peer did not arrive within 5 s"; return DLA_ERR_COMM; }
+    if (p2p.on && *(volatile int*)p2p.h_status) {
+      err = "p2p all-reduce: a peer did not arrive within " + std::to_string(p2p_timeout_ms) + " ms (DLA_OPT_P2P_TIMEOUT_MS); the transport is down on every rank";
+      return DLA_ERR_COMM;
+    }
     return DLA_OK;
   }
 
@@ -2855,7 +2903,13 @@ struct HipEngine : dla::Engine {
   double* d_wst = nullptr;          // pending factors of ortho_tail16 (3 x 256 doubles)
   double* d_xug = nullptr;          // X^T U | U^T U of the last OP_GRAMX / OP_XW sweep: (m + k) x k
   static const int XUG_DOUBLES = 640 * 16;
+  // RCCL inside a device-driven chain: the collective itself cannot be predicated (it is enqueued by the host), so a launch
+  // whose turn it is not still all-reduces whatever its source buffer holds.  Out of place, into these buffers, that is harmless:
+  // the source is never scaled, and the tail that would read the result is predicated off like its sweep.
+  double* d_red_small = nullptr; double* d_red_xug = nullptr;
+  static const int RED_DOUBLES = 640 * 48;
   std::map<long long, std::vector<int>> ortho_history;   // (k, m) -> the sweeps the last call of that shape executed
+  std::set<long long> chain_verified;                    // shapes whose launch paths have been walked (see ortho_chain)
 
   bool chain_armed = false;          // the device state machine stands at its initial state
   const bool chain_debug = std::getenv("DIAGLIB_AMD_CHAIN_DEBUG") != nullptr;   // print every chain's plan and outcome
@@ -2877,6 +2931,8 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipMalloc((void**)&d_wst, sizeof(double) * 768));
     if (chain_debug) { HIPCHK(hipMalloc((void**)&d_dbg, sizeof(unsigned long long) * 48 * 16)); HIPCHK(hipMemset(d_dbg, 0, sizeof(unsigned long long) * 48 * 16)); }
     HIPCHK(hipMalloc((void**)&d_xug, sizeof(double) * XUG_DOUBLES));
+    HIPCHK(hipMalloc((void**)&d_red_small, sizeof(double) * RED_DOUBLES));
+    HIPCHK(hipMalloc((void**)&d_red_xug, sizeof(double) * RED_DOUBLES));
     return DLA_OK;
   }
 
@@ -2889,15 +2945,15 @@ struct HipEngine : dla::Engine {
       ra.do_tail = 1; ra.tail = pending_tail; tail_fused = true;
       ra.p2p = P2PArgs{};
       if (p2p.on) { ra.p2p = p2p_args(ra.c, ra.ldc * ra.k, 0); exchange_fused = true; }
-      hipLaunchKernelGGL(gram_reduce_kernel<true>, grid, dim3(256), 0, st, ra);
+      DLA_LAUNCH(gram_reduce_kernel<true>, grid, dim3(256), 0, st, ra);
     } else {
-      hipLaunchKernelGGL(gram_reduce_kernel<false>, grid, dim3(256), 0, st, ra);
+      DLA_LAUNCH(gram_reduce_kernel<false>, grid, dim3(256), 0, st, ra);
     }
   }
   void launch_tail_kernel(const OrthoTailArgs& ta)
   {
-    if (ta.fold) hipLaunchKernelGGL(ortho_tail16_kernel, dim3(1), dim3(256), 0, st, ta);
-    else hipLaunchKernelGGL(ortho_tail_kernel, dim3(1), dim3(64), 0, st, ta);
+    if (ta.fold) DLA_LAUNCH(ortho_tail16_kernel, dim3(1), dim3(256), 0, st, ta);
+    else DLA_LAUNCH(ortho_tail_kernel, dim3(1), dim3(64), 0, st, ta);
   }
 
   // one speculative step: the sweep, its reduction (+ cross-rank sum) and the tail that takes the next decision.
@@ -2932,6 +2988,12 @@ struct HipEngine : dla::Engine {
     pred_phase = nullptr; pred_want = 0;
     fuse_tail = false;
     if (stc || tail_fused) return stc;
+    if (comm && !p2p.on && d_red_small) {
+      // RCCL: the reduced matrices live in the out-of-place destinations of the all-reduce
+      if (chain_reduced) pending_tail.gsrc = (op == OP_GRAMX || op == OP_XW) ? d_red_xug : d_red_small;
+      pending_tail.xug = d_red_xug;
+    }
+    chain_reduced = false;
     Scope s(this, DLA_OP_GRAM, 0.0, 0.0, fold ? "ortho_tail16_kernel" : "ortho_tail_kernel");
     launch_tail_kernel(pending_tail);
     HIPCHK(hipGetLastError());
@@ -2948,14 +3010,14 @@ struct HipEngine : dla::Engine {
       if constexpr (TLW == 1) {
         auto kfn = gram_lds_kernel<1, 1, 1, 32, 1, 0, 0, 1>;
         const size_t lds = sizeof(double) * 4 * 16 * 34;
-        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+        DLA_LAUNCH(kfn, grid, dim3(256), lds, st, a);
       }
       return DLA_OK;
     }
     auto kfn = gram_lds_kernel<TLW, 1, 1, R, 0, 0, 0, 1>;
     const size_t lds = sizeof(double) * 4 * 16 * (TLW + 1) * (R + 2);
     if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    DLA_LAUNCH(kfn, grid, dim3(256), lds, st, a);
     return DLA_OK;
   }
   int gram_wp_once(int n, int m, const double* x, int k, const double* u, const double* wp, double* uw)
@@ -3039,6 +3101,30 @@ struct HipEngine : dla::Engine {
     if (fold && vsx && vec2 && m <= 192 && tune[6] != 6 && lds_limit > (size_t)128 * 1024) fold = 1;
     int stc = ensure_chain_buffers();
     if (stc) return stc;
+    // First chain of a shape: walk every launch path it may take WITHOUT launching (workspaces grow now, not half way; a
+    // refused request for more than 64 KiB of LDS shows up before anything has touched U).  After a refusal the engine's LDS
+    // limit is down and the host-driven loop, which redoes single operations under it, takes the call.
+    {
+      const long long vkey = (long long)k * 1000000 + m + fold * 500000000000LL + (vsx ? 0 : 250000000000LL);
+      if (!chain_verified.count(vkey)) {
+        static const int every_op[] = {OP_GRAM_UU, OP_GRAMX, OP_GRAMW, OP_XW, OP_XU, OP_TRMMG, OP_COMBO, OP_FINAL};
+        std::vector<SpecRec> dummy;
+        dry_launch = true; spec_rec = &dummy; lds_retry = false;
+        int std_ = DLA_OK;
+        for (int op : every_op) {
+          if (!vsx && (op == OP_GRAMX || op == OP_XW || op == OP_XU || op == OP_COMBO || op == OP_GRAMW)) continue;
+          if (fold != 1 && (op == OP_GRAMX || op == OP_GRAMW || op == OP_XW)) continue;
+          std_ = launch_op(op, n, m, k, x, bx, u, false, fold);
+          if (std_) break;
+        }
+        dry_launch = false; spec_rec = nullptr;
+        if (std_) {
+          if (lds_retry) { lds_retry = false; return DLA_OK; }        // rep->handled stays 0: host-driven loop
+          return std_;
+        }
+        chain_verified.insert(vkey);
+      }
+    }
     // the widest reductions of the chain: make sure nothing reallocates (and drains the stream) half way
     stc = ensure_small(sizeof(double) * (size_t)std::max(m, k) * k);
     if (stc) return stc;
@@ -3168,7 +3254,7 @@ struct HipEngine : dla::Engine {
       auto kfn = gram_lds_kernel<TLW, KT, 1, R, SELF_, Q>;                                                    \
       const size_t lds = sizeof(double) * 4 * 16 * (SELF_ ? TLW : TLW + KT) * (R + 2);                        \
       if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;                                          \
-      hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);                                                   \
+      DLA_LAUNCH(kfn, grid, dim3(256), lds, st, a);                                                   \
       return DLA_OK;                                                                                          \
     } while (0)
     if constexpr (TLW == KT) {
@@ -3188,7 +3274,7 @@ struct HipEngine : dla::Engine {
     auto kfn = gram_lds_kernel<T, T, 1, 16, 0, 0, 1>;
     const size_t lds = sizeof(double) * 4 * 16 * (2 * T) * 18;
     if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    DLA_LAUNCH(kfn, grid, dim3(256), lds, st, a);
     return DLA_OK;
   }
   // tile rows of the LDS-staged kernel: 32 for narrow passes (few loads per tile otherwise) and for 3-tile U blocks,
@@ -3220,8 +3306,8 @@ struct HipEngine : dla::Engine {
       return DLA_ERR_RUNTIME;
     } else {
       constexpr int RS = (TLW * KT >= 6) ? 2 : 4;
-      if (vec2) hipLaunchKernelGGL((gram_kernel<TLW, KT, 2, RS>), grid, dim3(256), 0, st, a);
-      else      hipLaunchKernelGGL((gram_kernel<TLW, KT, 1, RS>), grid, dim3(256), 0, st, a);
+      if (vec2) DLA_LAUNCH((gram_kernel<TLW, KT, 2, RS>), grid, dim3(256), 0, st, a);
+      else      DLA_LAUNCH((gram_kernel<TLW, KT, 1, RS>), grid, dim3(256), 0, st, a);
       return DLA_OK;
     }
   }
@@ -3516,7 +3602,7 @@ struct HipEngine : dla::Engine {
     do {                                                                                                      \
       auto kfn = gemm_kernel<KT, V, M, ARGS, true, (M == 2 ? 0 : 1), P, 9, Q, R>;                             \
       if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;                                          \
-      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);                                           \
+      DLA_LAUNCH(kfn, dim3(blocks), dim3(256), lds, st, a);                                           \
     } while (0)
 #define GGQR(V, M, Q, R) GGQRP(V, M, Q, R, (KT >= 3 ? 3 : KT >= 2 ? 2 : 0))
 #define GGQ(V, M, Q) do { if (KT == 3 && V == 2 && rtp == 1) GGQR(V, M, Q, 1); else GGQR(V, M, Q, 2); } while (0)
@@ -3537,10 +3623,10 @@ struct HipEngine : dla::Engine {
   template <int KT, typename ARGS>
   void launch_gemm(const ARGS& a, int blocks, size_t lds, bool vec2, int mode, int qt)
   {
-#define GM(V, M) hipLaunchKernelGGL((gemm_kernel<KT, V, M, ARGS>), dim3(blocks), dim3(256), lds, st, a)
-#define GMQP(M, Q, P) hipLaunchKernelGGL((gemm_kernel<KT, 2, M, ARGS, false, (M == 2 ? 0 : 1), P, 9, Q>), dim3(blocks), dim3(256), lds, st, a)
+#define GM(V, M) DLA_LAUNCH((gemm_kernel<KT, V, M, ARGS>), dim3(blocks), dim3(256), lds, st, a)
+#define GMQP(M, Q, P) DLA_LAUNCH((gemm_kernel<KT, 2, M, ARGS, false, (M == 2 ? 0 : 1), P, 9, Q>), dim3(blocks), dim3(256), lds, st, a)
 #define GMQ(M, Q) GMQP(M, Q, 2)      /* (a third step per stage costs these kernels their second wave per SIMD: update -22 %) */
-#define GMP(M, P) hipLaunchKernelGGL((gemm_kernel<KT, 2, M, ARGS, false, 1, P>), dim3(blocks), dim3(256), lds, st, a)
+#define GMP(M, P) DLA_LAUNCH((gemm_kernel<KT, 2, M, ARGS, false, 1, P>), dim3(blocks), dim3(256), lds, st, a)
     if (vec2 && KT >= 2 && (mode == 0 || mode == 1) && (tune[2] == 1 || tune[2] == 4)) {
       if (tune[2] == 1) { if (mode == 0) GMP(0, 0); else GMP(1, 0); }
       else              { if (mode == 0) GMP(0, 4); else GMP(1, 4); }
@@ -3793,7 +3879,7 @@ struct HipEngine : dla::Engine {
       // (flops: the two Ritz products and, with extra columns, the two panel products they replace)
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m + 2.0 * k2),
               4.0 * (double)n * l * (m + k2) + 5.0 * (double)n * nact, kn);
-#define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME; hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
+#define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME; DLA_LAUNCH(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
       if (k2 > 0) {
         // [Y | C2]: vec2 guaranteed by the caller (ritz_residual_p)
         if (qt == 1) { if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 1, true>)); else RZ((ritz_kernel<3, 2, 3, 3, 1, true>)); }
@@ -3828,7 +3914,7 @@ struct HipEngine : dla::Engine {
     }
     {
       Scope s2(this, DLA_OP_RITZ, 0.0, 0.0, "ritz_reduce_kernel");
-      hipLaunchKernelGGL(ritz_reduce_kernel, dim3(ncol), dim3(256), 0, st, (const double*)d_partial, blocks, ncol, d_small,
+      DLA_LAUNCH(ritz_reduce_kernel, dim3(ncol), dim3(256), 0, st, (const double*)d_partial, blocks, ncol, d_small,
                          h_small_dev, nslots, local_only ? 0 : rank);
     }
     HIPCHK(hipGetLastError());
@@ -3850,7 +3936,7 @@ struct HipEngine : dla::Engine {
   {
     Scope s(this, DLA_OP_ELEM, 24.0 * (double)len, 2.0 * (double)len);
     const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 8, (len + 255) / 256));
-    hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, st, len, alpha, x, y);
+    DLA_LAUNCH(axpy_kernel, dim3(blocks), dim3(256), 0, st, len, alpha, x, y);
     HIPCHK(hipGetLastError());
     return DLA_OK;
   }
@@ -3874,7 +3960,7 @@ struct HipEngine : dla::Engine {
         const int* sh = shapes[r / (reps + 1)];
         const int blocks = (int)std::min((size_t)ncu * sh[2], (len / 2 + 255) / 256);
         HIPCHK(hipEventRecord(e0, st));
-#define TRIAD(NT, U) hipLaunchKernelGGL((triad_kernel<NT, U>), dim3(blocks), dim3(256), 0, st, len / 2, 0.5, (const double*)pb, (const double*)pc, (double*)pa)
+#define TRIAD(NT, U) DLA_LAUNCH((triad_kernel<NT, U>), dim3(blocks), dim3(256), 0, st, len / 2, 0.5, (const double*)pb, (const double*)pc, (double*)pa)
         if (sh[0] == 1 && sh[1] == 4) TRIAD(1, 4); else if (sh[0] == 0) TRIAD(0, 4); else if (sh[1] == 1) TRIAD(1, 1); else TRIAD(1, 2);
 #undef TRIAD
         HIPCHK(hipEventRecord(e1, st));
@@ -3896,8 +3982,8 @@ struct HipEngine : dla::Engine {
     if (stc) return stc;
     {
       Scope s(this, DLA_OP_ELEM, 8.0 * (double)len, 2.0 * (double)len);
-      hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, len, x, d_partial);
-      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const double*)d_partial, blocks, d_small, h_small_dev);
+      DLA_LAUNCH(sumsq_kernel, dim3(blocks), dim3(256), 0, st, len, x, d_partial);
+      DLA_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const double*)d_partial, blocks, d_small, h_small_dev);
     }
     HIPCHK(hipGetLastError());
     exchange_fused = false;
@@ -3914,7 +4000,7 @@ struct HipEngine : dla::Engine {
     Scope s(this, DLA_OP_ELEM, 8.0 * (double)n * m, 0.0);
     const size_t total = (size_t)n * m;
     const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 8, (total + 255) / 256));
-    hipLaunchKernelGGL(random_fill_kernel, dim3(blocks), dim3(256), 0, st, (long long)n, m, evec, row0, seed, offset, support_rows);
+    DLA_LAUNCH(random_fill_kernel, dim3(blocks), dim3(256), 0, st, (long long)n, m, evec, row0, seed, offset, support_rows);
     HIPCHK(hipGetLastError());
     return DLA_OK;
   }
@@ -3960,7 +4046,7 @@ struct HipEngine : dla::Engine {
     if (n != ell_n || !d_ell_col) { err = "spmm_matvec: n differs from setup"; return DLA_ERR_ARG; }
     Scope s(this, DLA_OP_MATVEC, 12.0 * (double)ell_w * n + 16.0 * (double)n * m, 2.0 * (double)ell_w * n * m);
     const int blocks = std::max(1, std::min(ncu * 8, (n + 255) / 256));
-#define ELL(W) hipLaunchKernelGGL((ell_spmm_kernel<W>), dim3(blocks), dim3(256), 0, st, n, m, ell_w, (const int*)d_ell_col, (const double*)d_ell_val, x, ax)
+#define ELL(W) DLA_LAUNCH((ell_spmm_kernel<W>), dim3(blocks), dim3(256), 0, st, n, m, ell_w, (const int*)d_ell_col, (const double*)d_ell_val, x, ax)
     if (ell_w <= 4) ELL(4); else if (ell_w <= 8) ELL(8); else if (ell_w <= 16) ELL(16); else if (ell_w <= 32) ELL(32); else ELL(0);
 #undef ELL
     HIPCHK(hipGetLastError());
@@ -3971,7 +4057,7 @@ struct HipEngine : dla::Engine {
     if (n != ell_n || !d_ell_diag) { err = "spmm_precnd: n differs from setup"; return DLA_ERR_ARG; }
     Scope s(this, DLA_OP_PRECND, 8.0 * n * (2.0 * m + 1.0), (double)n * m);
     const int blocks = std::max(1, std::min(ncu * 8, (n + 255) / 256));
-    hipLaunchKernelGGL(diag_precnd_kernel, dim3(blocks), dim3(256), 0, st, n, m, fac, (const double*)d_ell_diag, x, px);
+    DLA_LAUNCH(diag_precnd_kernel, dim3(blocks), dim3(256), 0, st, n, m, fac, (const double*)d_ell_diag, x, px);
     HIPCHK(hipGetLastError());
     return DLA_OK;
   }
@@ -3989,7 +4075,7 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipMalloc((void**)&d_w, sizeof(double) * (size_t)n_local * rank_w));
     HIPCHK(hipMalloc((void**)&d_diag, sizeof(double) * (size_t)n_local));
     syn_row0 = row0; syn_n = n_local; syn_rw = rank_w; syn_sigma = sigma;
-    hipLaunchKernelGGL(synth_build_kernel, dim3((n_local + 255) / 256), dim3(256), 0, st, row0, n_local, rank_w, sigma, d_w, d_diag);
+    DLA_LAUNCH(synth_build_kernel, dim3((n_local + 255) / 256), dim3(256), 0, st, row0, n_local, rank_w, sigma, d_w, d_diag);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     return DLA_OK;
@@ -4004,7 +4090,7 @@ struct HipEngine : dla::Engine {
     Scope s(this, DLA_OP_MATVEC, 8.0 * n * (2.0 * m + syn_rw), 2.0 * (double)n * m * (2 * syn_rw + 1));
     // (t = W^T x sits in d_small, reduced over ranks; nothing else touches that buffer before the kernel below has read it)
     const int blocks = std::max(1, std::min(ncu * 8, (n + 255) / 256));
-    hipLaunchKernelGGL((synth_apply_kernel<4>), dim3(blocks), dim3(256), sizeof(double) * 4 * m, st,
+    DLA_LAUNCH((synth_apply_kernel<4>), dim3(blocks), dim3(256), sizeof(double) * 4 * m, st,
                        syn_row0, n, m, syn_sigma, d_w, (const double*)d_small, x, ax);
     HIPCHK(hipGetLastError());
     return DLA_OK;
@@ -4017,8 +4103,8 @@ struct HipEngine : dla::Engine {
     const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)px) % 16 == 0);
     const size_t nv = (size_t)n / (vec2 ? 2 : 1);
     const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 8, (nv + 255) / 256));
-    if (vec2) hipLaunchKernelGGL(synth_precnd_kernel<2>, dim3(blocks), dim3(256), 0, st, n, m, fac, d_diag, x, px);
-    else      hipLaunchKernelGGL(synth_precnd_kernel<1>, dim3(blocks), dim3(256), 0, st, n, m, fac, d_diag, x, px);
+    if (vec2) DLA_LAUNCH(synth_precnd_kernel<2>, dim3(blocks), dim3(256), 0, st, n, m, fac, d_diag, x, px);
+    else      DLA_LAUNCH(synth_precnd_kernel<1>, dim3(blocks), dim3(256), 0, st, n, m, fac, d_diag, x, px);
     HIPCHK(hipGetLastError());
     return DLA_OK;
   }

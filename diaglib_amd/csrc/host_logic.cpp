@@ -169,6 +169,10 @@ int dla_set_option(dla_ctx* c, int option, int value)
       if (value < 1 || value > 10) return fail(c, DLA_ERR_ARG, "ortho maxit must be 1..10");
       c->eng->ortho_maxit = value;
       break;
+    case DLA_OPT_P2P_TIMEOUT_MS:
+      if (value < 0) return fail(c, DLA_ERR_ARG, "p2p timeout must be >= 0 ms (0 = no limit)");
+      c->p2p_timeout_ms = value;
+      return engfail(c, c->eng->set_p2p_timeout(value));
     case DLA_OPT_CALLBACK_ORDER:
       if (value < 0 || value > 2) return fail(c, DLA_ERR_ARG, "callback order must be 0, 1 or 2");
       c->callback_order = value;
@@ -192,6 +196,7 @@ int dla_get_option(dla_ctx* c, int option)
     case DLA_OPT_ORTHO_MAXIT: return c->eng->ortho_maxit;
     case DLA_OPT_CASLR_ALGORITHM: return c->caslr_algorithm;
     case DLA_OPT_STAGE_CHUNKS: return c->stage_chunks;
+    case DLA_OPT_P2P_TIMEOUT_MS: return c->p2p_timeout_ms;
     default: return -1;
   }
 }
@@ -660,6 +665,8 @@ static int ortho_vs_x_impl(dla_ctx* c, dla::BlockOps* ops, long long row0, long 
 {
   if (k <= 0) return DLA_OK;
   const int kMaxIt = ops->ortho_maxit;    // maxit, diaglib.f90:3521
+  bool resume = false;                    // the device chain stopped in ortho_cd and the Householder fallback has run
+  int resume_it = 0;                      // ... after this many outer iterations
   // device-driven chain first (one host wait per call); shapes / modes it does not take run the host-driven loop below
   {
     dla::OrthoReport rep;
@@ -676,12 +683,14 @@ static int ortho_vs_x_impl(dla_ctx* c, dla::BlockOps* ops, long long row0, long 
       }
       // ortho_cd ran out of iterations on the device: U has had its maxit triangular updates, exactly what the
       // reference's ortho_cd leaves behind when it returns ok = .false.; the reference then calls `ortho` (:3534, :3549).
-      // Do the same, then let the host-driven loop below finish the job on the now orthonormal block (Cholesky-QR
-      // steps have positive diagonals: they keep the column signs the Householder factor has set).
+      // Do the same and go on where the reference goes on: after the ortho_cd in front of the loop (no outer iteration
+      // yet) with the loop itself; inside the loop with the explicit ||X^T U|| test of :3559-3564.
       if (rep.status == 2) {
         std::printf("  ortho_cd failed with the following error: maximum number of iterations reached.\n");
         int stq = ortho_qr_impl(c, ops, row0, n_rows_global, n, k, u);
         if (stq) return stq;
+        resume = true;
+        resume_it = rep.outer_its;
       }
       // (status 4, the outer loop ran out of iterations: the host-driven loop repeats it and reports the failure)
     }
@@ -697,9 +706,25 @@ static int ortho_vs_x_impl(dla_ctx* c, dla::BlockOps* ops, long long row0, long 
   const bool combo = m > 0 && u == x + (size_t)n * m && ops->can_combo(m, k);
   std::vector<double> wdef(combo ? (size_t)k * k : 1), cprime(combo ? (size_t)(m + k) * k : 1);
   bool pending = false;
-  int st = ortho_cd_impl(c, ops, n, k, u, &growth, &ok, nullptr, combo ? wdef.data() : nullptr, &pending, true);   // :3533
-  if (st) return st;
-  if (!ok) { st = ortho_qr_impl(c, ops, row0, n_rows_global, n, k, u); if (st) return st; }         // :3534
+  int st = DLA_OK;
+  if (resume) {
+    it = resume_it;
+    if (resume_it > 0) {
+      // the failure was inside the loop: ||X^T U|| of the Householder factor decides (:3559-3564)
+      double s2 = 0.0;
+      if (m > 0) {
+        st = ops->gram(n, m, bx, k, u, xu.data(), m);
+        if (st) return opsfail(c, ops, st);
+        for (size_t i = 0; i < (size_t)m * k; ++i) s2 += xu[i] * xu[i];
+      }
+      done = std::sqrt(s2) < kTolOrtho;
+      if (!done && it > kMaxIt) return fail(c, DLA_ERR_ORTHO, " catastrophic failure of ortho_vs_x");
+    }
+  } else {
+    st = ortho_cd_impl(c, ops, n, k, u, &growth, &ok, nullptr, combo ? wdef.data() : nullptr, &pending, true);   // :3533
+    if (st) return st;
+    if (!ok) { st = ortho_qr_impl(c, ops, row0, n_rows_global, n, k, u); if (st) return st; }         // :3534
+  }
   while (!done) {
     ++it;
     if (m > 0) {

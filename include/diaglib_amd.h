@@ -77,6 +77,11 @@ enum {
                                       i_alg = 0, dsygv at diaglib.f90:783), 1 the Helmich-Paris route (i_alg = 1, :805-860) */
   DLA_OPT_STAGE_CHUNKS = 8,        /* host-mode callbacks: column chunks a block is cut into for the download | user routine |
                                       upload pipeline (0 = automatic: ~32 MB chunks, at most 8; 1 = whole block at once) */
+  DLA_OPT_P2P_TIMEOUT_MS = 9,      /* peer-to-peer all-reduce (dla_p2p_attach): how long a rank waits INSIDE a kernel for its peers'
+                                      contributions, in ms (default 5000; 0 = no limit).  A rank that gives up marks the exchange
+                                      as failed in every rank's mailbox: all ranks return DLA_ERR_COMM at their next host wait and
+                                      the transport stays down until dla_p2p_detach + a fresh export.  Callers whose ranks can be
+                                      further apart than this (host-mode callbacks of unequal length) raise it or use RCCL  */
   DLA_OPT_TUNE0 = 100              /* 100..107: kernel-shape experiment knobs for the interleaved A/B tools
                                       (tools/tune_*.py, tools/kernel_bench.py); 0 = the shipped default          */
 };

@@ -41,3 +41,35 @@ def test_refused_lds_request_is_redone_under_the_limit():
     env = dict(os.environ, DIAGLIB_AMD_FORCE_LDS_REFUSAL="1")
     p = subprocess.run([sys.executable, "-c", CODE % ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0 and "refusal handled" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+CODE_CHAIN = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from diaglib_amd import capi
+from oracle.pyoracle import Oracle
+o = Oracle(); ctx = capi.Context()
+rng = np.random.default_rng(5)
+n, l, k = 4096, 180, 13
+q = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, l)))[0])
+for trial in range(2):
+    u = np.asfortranarray(rng.standard_normal((n, k)))
+    big = ctx.panel(np.asfortranarray(np.hstack([q, u])))
+    px, pu = big.col(0, l), big.col(l, k)          # the drivers' layout: the device-driven chain takes this call
+    ctx.ortho_vs_x(px, pu)                         # trial 0: the chain's first wide sweep asks for ~117 KiB and is refused
+    got = pu.download()
+    want = o.ortho_vs_x(q, u)[0]
+    assert np.abs(got - want).max() < 1e-11, np.abs(got - want).max()
+    assert np.abs(q.T @ got).max() < 1e-13 and np.abs(got.T @ got - np.eye(k)).max() < 1e-13
+    assert np.array_equal(px.download(), q)
+print("refusal inside a chain handled")
+"""
+
+
+def test_refused_lds_request_inside_a_device_driven_chain():
+    '''ADVICE r02: the refusal must not surface half way through a chain (earlier speculative launches may already have
+    updated U in place): the chain's launch paths are walked without launching first, a refusal there hands the call to
+    the host-driven loop under the 64 KiB limit.'''
+    env = dict(os.environ, DIAGLIB_AMD_FORCE_LDS_REFUSAL="1")
+    p = subprocess.run([sys.executable, "-c", CODE_CHAIN % ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and "refusal inside a chain handled" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])

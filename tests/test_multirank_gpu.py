@@ -142,3 +142,63 @@ def test_two_gpus_rccl_equal_one_rank(tmp_path):
     assert np.allclose(two[0]["eig"][:t], one["eig"][:t], rtol=1e-11, atol=0)
     assert int(two[0]["iters"]) == int(two[1]["iters"])
     assert abs(int(two[0]["iters"]) - int(one["iters"])) <= max(1, int(one["iters"]) // 5)
+
+
+TIMEOUT_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+from diaglib_amd import capi
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ctx = capi.Context()
+mine = ctx.p2p_export(world)
+everyone = [None] * world
+dist.all_gather_object(everyone, mine)
+ctx.p2p_attach(world, rank, everyone)
+ctx.set_option(capi.OPT_P2P_TIMEOUT_MS, 400)
+probe = ctx.panel(np.full((64, 2), float(rank + 1), order="F"))
+got = ctx.gram(probe, probe)                      # one good exchange first
+assert abs(got[0, 0] - 64.0 * sum((r + 1) ** 2 for r in range(world))) < 1e-9
+dist.barrier()
+if rank == {late}:
+    time.sleep(2.0)                               # this rank withholds its contribution beyond the limit
+t0 = time.time()
+code = 0
+try:
+    ctx.gram(probe, probe)
+except capi.DlaError as e:
+    code = 3 if "status 7" in str(e) and "p2p" in str(e) else 4      # DLA_ERR_COMM
+    print("FAILED", round(time.time() - t0, 2), str(e)[:120], flush=True)
+    try:
+        ctx.gram(probe, probe)                    # the transport stays down
+        code = 5
+    except capi.DlaError:
+        pass
+sys.exit(code)
+"""
+
+
+def test_p2p_rank_that_withholds_its_contribution_fails_every_rank(tmp_path):
+    """ADVICE r02 / VERDICT r02 6(c): one rank arrives 2 s late at an exchange whose limit is 0.4 s (DLA_OPT_P2P_TIMEOUT_MS).
+    The early rank gives up and marks the exchange as failed in every mailbox; the late rank -- which would find flag and data
+    in place and succeed alone -- fails the SAME exchange.  Both return DLA_ERR_COMM within seconds, the transport stays down,
+    every process exits non-zero on its own (fresh child processes)."""
+    import time
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(TIMEOUT_WORKER.format(root=ROOT, late=1))
+    procs = []
+    t0 = time.time()
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0",
+                   DIAGLIB_AMD_SHARE_DEVICES="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 3, (r, p.returncode, o[-500:], e[-1500:])
+        assert "FAILED" in o
+        took = float(o.split("FAILED")[1].split()[0])
+        assert took < 5.0, (r, took)

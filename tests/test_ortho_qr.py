@@ -120,5 +120,9 @@ def test_ortho_vs_x_takes_the_qr_fallback_when_ortho_cd_gives_up(ctx, oracle, rn
         ctx.set_option(capi.OPT_ORTHO_MAXIT, 10)
     assert np.abs(got.T @ got - np.eye(k)).max() < 50 * EPS
     assert np.abs(x.T @ got).max() < 50 * EPS
-    assert np.all(np.sign((got * want).sum(0)) == 1.0)
-    assert np.abs(got - want).max() < 2e3 * 1e10 * EPS          # Q of a block of condition 1e10
+    sgn = np.sign((got * want).sum(0))
+    if not contiguous:
+        assert np.all(sgn == 1.0)           # host-driven loop = the reference's flow: the Householder factor's signs (:3534)
+    # (the device chain takes ONE factorisation step in front of the loop -- DESIGN.md, "pending factors" -- so ortho_cd gives up
+    #  one projection later than in the reference and `ortho` sees another block: same span, column signs of its own)
+    assert np.abs(got * sgn - want).max() < 2e3 * 1e10 * EPS    # Q of a block of condition 1e10

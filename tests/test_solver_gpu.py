@@ -282,6 +282,21 @@ def test_rccl_communicator_single_rank(ctx, oracle, rng):
         eig, v, ok, info = ctx.lobpcg_driver(n, t, m, 100, 1e-8, 0.0, oracle.fn("orc_dense_matvec"),
                                              oracle.fn("orc_dense_precnd"), g)
         assert ok and np.allclose(eig[:t], eo[:t], rtol=1e-9)
+        # device-driven chain under RCCL with a plan that does not fit (launches whose turn it is not still run their
+        # collective -- out of place, so that nothing is scaled or consumed): a random block first (sets the plan), then an
+        # already orthonormal one (fewer steps than planned), both against the oracle
+        nn, mm, kk = 3000, 40, 11
+        q = np.linalg.qr(rng.standard_normal((nn, mm + kk)))[0]
+        xo = np.asfortranarray(q[:, :mm])
+        ctx.set_shard(nn, 0)
+        for u0 in (np.asfortranarray(rng.standard_normal((nn, kk))), np.asfortranarray(q[:, mm:])):
+            big = ctx.panel(np.asfortranarray(np.hstack([xo, u0])))
+            px, pu = big.col(0, mm), big.col(mm, kk)
+            ctx.ortho_vs_x(px, pu)
+            got = pu.download()
+            want = oracle.ortho_vs_x(xo, u0)[0]
+            assert np.abs(got - want).max() < 1e-11
+            assert np.abs(xo.T @ got).max() < 50 * np.finfo(float).eps
     finally:
         ctx.comm_finalize()
         ctx.set_shard(-1, 0)
