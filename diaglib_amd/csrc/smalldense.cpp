@@ -635,10 +635,14 @@ int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_
 }  // namespace SD_NS
 
 #ifndef SD_IMPL_ONLY
+#ifdef SD_SINGLE_ISA      // (builds that compile this file once: the AVX2 routines serve every host)
+namespace sd_v4 = sd_v3;
+#else
 namespace sd_v4 {   // the same routines, AVX-512 build of this file
 int sym_eig(int n, std::vector<double>& s, std::vector<double>& d, std::vector<double>& zt);
 int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_all, std::vector<double>& zt);
 }
+#endif
 namespace {
 bool wide_simd()
 {

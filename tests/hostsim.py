@@ -32,7 +32,7 @@ def build() -> str:
     objs = []
     for s in srcs_cxx:
         o = os.path.join(BUILD, os.path.basename(s) + ".o")
-        run(["g++", "-O2", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-c", s, "-o", o]); objs.append(o)
+        run(["g++", "-O2", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-DSD_SINGLE_ISA", "-Wno-psabi", "-c", s, "-o", o]); objs.append(o)
     for s in srcs_c:
         o = os.path.join(BUILD, os.path.basename(s) + ".o")
         run(["gcc", "-O3", "-march=x86-64-v3", "-fopenmp", "-fPIC", "-c", s, "-o", o]); objs.append(o)
