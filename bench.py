@@ -199,6 +199,7 @@ def main() -> None:
         ctx.set_option(100 + int(knob), int(val))
 
     transport = None
+    p2p_selftest = None                            # outcome of the mailbox self-test before anything is timed (N > 1)
     n, n_targ = args.n, args.roots
     n_max = min(2 * n_targ, n_targ + 5)            # harness convention, reference main.f90:354
     row0, n_loc = shard_rows(n, world, rank)
@@ -245,6 +246,7 @@ def main() -> None:
                         okf = 0.0
                     flag = torch.tensor([okf], dtype=torch.float64)
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                p2p_selftest = "passed" if float(flag[0]) > 0 else "failed on some rank: RCCL everywhere"
                 if float(flag[0]) > 0:
                     transport = "p2p"
                 elif shared:
@@ -325,6 +327,10 @@ def main() -> None:
         r2 = rt.numpy()
     rel_res = float((np.sqrt(r2[:n_targ]) / np.abs(eig[:n_targ])).max())
 
+    rows_per_rank = [n_loc]
+    if world > 1:
+        rows_per_rank = [None] * world
+        dist.all_gather_object(rows_per_rank, n_loc)
     # ---- flops / bytes (each rank counted its local rows; shards are equal up to 64 rows)
     classes = ["gram", "gemm", "trmm", "ritz", "elem"]
     flops_local = sum(stats[c]["flops"] for c in classes)
@@ -335,8 +341,10 @@ def main() -> None:
     main = {k: v for k, v in kst.items() if v["alg_bytes"] > 0 and v["ms"] > 0}
     if not main:                                    # DIAGLIB_BENCH_NOPROFILE: wall time only
         if rank == 0:
-            print(json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 3), "value": round(value, 2),
-                              "iters": info["iters"], "note": "kernel events disabled"}), flush=True)
+            print(json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 3), "value": round(value, 2), "n_gpus": world,
+                              "iters": info["iters"], "allreduces": stats["allreduces"], "host_syncs": stats["host_syncs"],
+                              "steps": args.steps, "allreduce_transport": transport, "p2p_selftest": p2p_selftest,
+                              "rows_per_rank": rows_per_rank, "note": "kernel events disabled"}), flush=True)
         return
     dom = max(main, key=lambda k: main[k]["ms"])
     dk = main[dom]
@@ -418,7 +426,8 @@ def main() -> None:
         "kernel_classes": kern,
         "kernels": per_kernel,
         "host": {"allreduces": stats["allreduces"], "host_syncs": stats["host_syncs"], "nproc": HOST_CPUS,
-                 "allreduce_transport": (transport if world > 1 and not rehearsal else None),
+                 "allreduce_transport": (transport if world > 1 and not rehearsal else ("gloo hook (rehearsal)" if rehearsal else None)),
+                 "p2p_selftest": p2p_selftest, "rows_per_rank": rows_per_rank,
                  "usable_cpus": CPU_THREADS},
     }
     if args.guess == "unit" and not args.no_random_leg:

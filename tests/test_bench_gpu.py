@@ -55,6 +55,7 @@ def test_bench_two_ranks_as_the_driver_launches_them():
     d = _line(p.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
     assert d["host"]["allreduce_transport"] == "p2p" and d["host"]["allreduces"] > 0
+    assert d["host"]["p2p_selftest"] == "passed" and sum(d["host"]["rows_per_rank"]) == 200000       # the line describes its own run
     assert d["config"]["converged"] is True and d["config"]["rows_per_gpu"] in (100000, 100032, 99968)
 
 
@@ -72,3 +73,30 @@ def test_headline_line_finds_its_counters():
     assert 0.9 < r["traffic"] / r["alg_bytes_per_launch"] < 1.1          # no wasted re-reads
     assert d["config"]["iters"] == 9 and d["host"]["host_syncs"] / (d["steps"] + d["warmup"]) <= 35
     assert r["step"]["sweeps_only"]["frac"] > r["step"]["frac"]
+
+
+def test_shard_rehearsal_exchange_cost_is_bounded():
+    """the latency floor of an N-GPU run, rehearsed on one GPU -- FOUR ranks share the device, every rank
+    holds n / 4 rows, every small product crosses ranks through the peer-to-peer mailboxes (the transport of the real run).
+    The ranks share one HBM, so the sweeps take what they take on one rank; what the 4-rank solve costs on top is the
+    exchanges (66 per solve, each inside a reduction kernel) and the skew of four processes that time-share one device.
+    Bound: 1.5 ms per solve (measured r03, events off: 9.50 ms on one rank, 10.62 ms on four at n = 1e6; 16.97 / 17.87 / 18.54 ms
+    on 1 / 2 / 4 ranks at n = 2e6; tools/shard_rehearsal.sh prints the same figures)."""
+    n = 1_000_000
+    env = dict(os.environ, DIAGLIB_BENCH_NOPROFILE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--rows", str(n), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-random-leg"]
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=600,
+                        cwd=ROOT, env=env)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    one = _line(p1.stdout)
+    env4 = dict(env, DIAGLIB_BENCH_SHARE_GPU="1")
+    p4 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                         "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "4"] + common,
+                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env4)
+    assert p4.returncode == 0, p4.stderr[-3000:]
+    four = _line(p4.stdout)
+    assert four["n_gpus"] == 4 and four["allreduce_transport"] == "p2p" and four["p2p_selftest"] == "passed"
+    assert sum(four["rows_per_rank"]) == n and four["iters"] == one["iters"]
+    per_solve_exchanges = four["allreduces"] / four["steps"]
+    assert per_solve_exchanges > 20
+    assert four["ms_per_step"] - one["ms_per_step"] <= 1.5, (four["ms_per_step"], one["ms_per_step"], per_solve_exchanges)
