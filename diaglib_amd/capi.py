@@ -38,7 +38,8 @@ EXPORTS = [
     "dla_ortho_cd", "dla_ortho_qr", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
     "dla_call_matvec", "dla_call_precnd",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
-    "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd", "dla_spmm_setup_csr", "dla_spmm_matvec", "dla_spmm_precnd",
+    "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd", "dla_synth_apbmul", "dla_synth_ambmul", "dla_synth_spdmul", "dla_synth_smdmul",
+    "dla_synth_metric", "dla_synth_lrprec1", "dla_synth_lrprec2", "dla_spmm_setup_csr", "dla_spmm_matvec", "dla_spmm_precnd",
     "dla_davidson_driver", "dla_gen_david_driver", "dla_lobpcg_driver", "dla_caslr_eff_driver", "dla_caslr_driver", "dla_call_lrprec",
     "dla_last_solve_info", "dla_set_solve_info",
 ]

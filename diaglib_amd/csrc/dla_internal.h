@@ -115,6 +115,10 @@ struct Engine : BlockOps {
 
   virtual int synth_setup(long long n_global, long long row0, int n_local, int rank_w, double sigma) = 0;
   virtual int synth_matvec(int n, int m, const double* x, double* ax) = 0;
+  // the sample operators of the linear-response / generalised drivers around the same W (hip_engine.hip SynthKind)
+  virtual int synth_apply(int /*kind*/, int /*n*/, int /*m*/, const double* /*x*/, double* /*y*/) { return DLA_ERR_ARG; }
+  virtual int synth_lrprec(int /*variant*/, int /*n*/, int /*m*/, double /*fac*/, const double* /*xp*/, const double* /*xm*/,
+                           double* /*yp*/, double* /*ym*/) { return DLA_ERR_ARG; }
   virtual int synth_precnd(int n, int m, double fac, const double* x, double* px) = 0;
 
   // Ordering of a DEVICE-mode callback against the engine's stream (the user's kernels may run on another stream):

@@ -1188,8 +1188,8 @@ __global__ void random_fill_kernel(long long n, int m, double* evec, long long r
   }
 }
 
-// built-in operator A = diag(i+1) + sigma W W^T
-__global__ void synth_build_kernel(long long row0, int n, int rw, double sigma, double* w, double* diag)
+// built-in operator A = diag(i+1) + sigma W W^T, and the family of sample operators around the same W (SynthKind)
+__global__ void synth_build_kernel(long long row0, int n, int rw, double sigma, double* w, double* diag, double* wsq)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1203,19 +1203,50 @@ __global__ void synth_build_kernel(long long row0, int n, int rw, double sigma, 
     s += v * v;
   }
   diag[i] = ((double)gi + 1.0) + sigma * s;
+  wsq[i] = s;
 }
 
-// ax = d x + sigma W t,  t = W^T x (rw x m, column-major, ld rw) already reduced
+// Sample operators of the linear-response and generalised drivers (reference callers main.f90:403-526,
+// 528-760 build dense SPD matrices A+B, A-B, S+D, S-D and a dense SPD metric): the same shape matrix-free,
+//     y = d(i) x + W C W^T x,   C a 4 x 4 coupling block,  i = 1-based global row,
+//   kind 0  A      d = i + 1,  C = sigma I                                (the benchmark operator)
+//   kind 1  A + B  d = i + 5,  C = sigma I                                (main.f90:563: apb(i,i) = 5 + i)
+//   kind 2  A - B  d = i + 2,  C = 0.2 sigma I                            (main.f90:570: amb(i,i) = 2 + i)
+//   kind 3  S + D  d = s(i),   C = tau J,  J = -J^T  (D antisymmetric: W J W^T)
+//   kind 4  S - D  d = s(i),   C = -tau J
+//   kind 5  metric d = s(i),   C = 0.1 I   (symmetric positive definite)
+// with s(i) = 1 + 0.5 / (1 + (i mod 7)) and tau = 0.05.  All of them need W^T x (4 x m, all-reduced over the shards) and one
+// elementwise pass: HBM-bound at 8 n (2 m + 4) bytes like the benchmark operator.
+enum { SYN_A = 0, SYN_APB = 1, SYN_AMB = 2, SYN_SPD = 3, SYN_SMD = 4, SYN_METRIC = 5 };
+__device__ __host__ inline double synth_s(unsigned long long gi) { return 1.0 + 0.5 / (1.0 + (double)(gi % 7ULL)); }
+__device__ __host__ inline double synth_d(int kind, unsigned long long gi)
+{
+  switch (kind) {
+    case SYN_A: return (double)gi + 1.0;
+    case SYN_APB: return (double)gi + 5.0;
+    case SYN_AMB: return (double)gi + 2.0;
+    default: return synth_s(gi);
+  }
+}
+struct SynthCoupling { double c[16]; };    // column-major 4 x 4
+
+// ax = d x + W (C t),  t = W^T x (rw x m, column-major, ld rw) already reduced
 template <int RW>
-__global__ __launch_bounds__(256) void synth_apply_kernel(long long row0, int n, int m, double sigma,
+__global__ __launch_bounds__(256) void synth_apply_kernel(long long row0, int n, int m, int kind, SynthCoupling cp,
                                                           const double* __restrict__ w, const double* __restrict__ t,
                                                           const double* __restrict__ x, double* __restrict__ ax)
 {
-  extern __shared__ double ts[];  // RW x m
-  for (int idx = threadIdx.x; idx < RW * m; idx += 256) ts[idx] = t[idx];
+  extern __shared__ double ts[];  // RW x m: C t
+  for (int idx = threadIdx.x; idx < RW * m; idx += 256) {
+    const int q = idx % RW, c = idx / RW;
+    double v = 0.0;
+#pragma unroll
+    for (int p = 0; p < RW; ++p) v += cp.c[q + RW * p] * t[p + c * RW];
+    ts[idx] = v;
+  }
   __syncthreads();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const double d = (double)(row0 + i + 1) + 1.0;
+    const double d = synth_d(kind, (unsigned long long)(row0 + i + 1));
     double wv[RW];
 #pragma unroll
     for (int q = 0; q < RW; ++q) wv[q] = w[(size_t)q * n + i];
@@ -1223,7 +1254,34 @@ __global__ __launch_bounds__(256) void synth_apply_kernel(long long row0, int n,
       double s = 0.0;
 #pragma unroll
       for (int q = 0; q < RW; ++q) s += wv[q] * ts[q + c * RW];
-      ax[(size_t)c * n + i] = d * x[(size_t)c * n + i] + sigma * s;
+      ax[(size_t)c * n + i] = d * x[(size_t)c * n + i] + s;
+    }
+  }
+}
+
+// Preconditioners of the linear-response drivers, the harness' lrprec_1 / lrprec_2 (main.f90:234-281) on the diagonals of
+// the sample operators: aa = ((A+B)_ii + (A-B)_ii) / 2, sigma = S_ii (J has a zero diagonal)
+//   variant 1: den = aa^2 - fac^2 sg^2,  yp = -(aa xp + fac sg xm) / den,  ym = -(aa xm + fac sg xp) / den
+//   variant 2: den = fac^2 aa^2 - sg^2,  yp = (fac aa xp + sg xm) / den,   ym = (fac aa xm + sg xp) / den
+__global__ void synth_lrprec_kernel(long long row0, int n, int m, int variant, double fac, double sigma, const double* __restrict__ wsq,
+                                    const double* __restrict__ xp, const double* __restrict__ xm, double* __restrict__ yp,
+                                    double* __restrict__ ym)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned long long gi = (unsigned long long)(row0 + i + 1);
+    const double aa = 0.5 * ((synth_d(SYN_APB, gi) + sigma * wsq[i]) + (synth_d(SYN_AMB, gi) + 0.2 * sigma * wsq[i]));
+    const double sg = synth_s(gi);
+    for (int c = 0; c < m; ++c) {
+      const double a = xp[(size_t)c * n + i], b = xm[(size_t)c * n + i];
+      if (variant == 1) {
+        const double den = -1.0 / (aa * aa - fac * fac * sg * sg);
+        yp[(size_t)c * n + i] = den * (aa * a + fac * sg * b);
+        ym[(size_t)c * n + i] = den * (aa * b + fac * sg * a);
+      } else {
+        const double den = 1.0 / (fac * fac * aa * aa - sg * sg);
+        yp[(size_t)c * n + i] = den * (fac * aa * a + sg * b);
+        ym[(size_t)c * n + i] = den * (fac * aa * b + sg * a);
+      }
     }
   }
 }
@@ -2228,7 +2286,7 @@ struct HipEngine : dla::Engine {
   double* h_ring[RING] = {nullptr}; hipEvent_t ring_ev[RING]; size_t ring_bytes = 0; int ring_pos = 0;
   double* d_cpk = nullptr; size_t cpk_bytes = 0;
     // built-in operator
-  double* d_w = nullptr; double* d_diag = nullptr; double* d_t = nullptr;
+  double* d_w = nullptr; double* d_diag = nullptr; double* d_t = nullptr; double* d_wsq = nullptr;
   long long syn_row0 = 0; int syn_n = 0, syn_rw = 0; double syn_sigma = 0.0;
   // rccl
   ncclComm_t comm = nullptr;
@@ -2302,6 +2360,7 @@ struct HipEngine : dla::Engine {
     if (d_cpk) (void)hipFree(d_cpk);
     if (d_w) (void)hipFree(d_w);
     if (d_diag) (void)hipFree(d_diag);
+    if (d_wsq) (void)hipFree(d_wsq);
     if (d_t) (void)hipFree(d_t);
     if (d_ell_col) (void)hipFree(d_ell_col);
     if (d_ell_val) (void)hipFree(d_ell_val);
@@ -4071,27 +4130,52 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipStreamSynchronize(st));
     if (d_w) HIPCHK(hipFree(d_w));
     if (d_diag) HIPCHK(hipFree(d_diag));
+    if (d_wsq) HIPCHK(hipFree(d_wsq));
     if (!d_t) HIPCHK(hipMalloc((void**)&d_t, sizeof(double) * 4 * 64));
     HIPCHK(hipMalloc((void**)&d_w, sizeof(double) * (size_t)n_local * rank_w));
     HIPCHK(hipMalloc((void**)&d_diag, sizeof(double) * (size_t)n_local));
+    HIPCHK(hipMalloc((void**)&d_wsq, sizeof(double) * (size_t)n_local));
     syn_row0 = row0; syn_n = n_local; syn_rw = rank_w; syn_sigma = sigma;
-    DLA_LAUNCH(synth_build_kernel, dim3((n_local + 255) / 256), dim3(256), 0, st, row0, n_local, rank_w, sigma, d_w, d_diag);
+    DLA_LAUNCH(synth_build_kernel, dim3((n_local + 255) / 256), dim3(256), 0, st, row0, n_local, rank_w, sigma, d_w, d_diag, d_wsq);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     return DLA_OK;
   }
 
-  int synth_matvec(int n, int m, const double* x, double* ax) override
+  int synth_matvec(int n, int m, const double* x, double* ax) override { return synth_apply(SYN_A, n, m, x, ax); }
+  // y = d x + W C W^T x for one of the sample operators (SynthKind)
+  int synth_apply(int kind, int n, int m, const double* x, double* ax) override
   {
-    if (n != syn_n) { err = "synth_matvec: n differs from setup"; return DLA_ERR_ARG; }
-    if (m > 64) { err = "synth_matvec: m > 64"; return DLA_ERR_ARG; }
+    if (n != syn_n) { err = "synth operator: n differs from setup"; return DLA_ERR_ARG; }
+    if (m > 64) { err = "synth operator: m > 64"; return DLA_ERR_ARG; }
+    if (kind < SYN_A || kind > SYN_METRIC) { err = "synth operator: unknown kind"; return DLA_ERR_ARG; }
     int stc = gram_dev(n, syn_rw, d_w, m, x, DLA_OP_MATVEC);   // t = W^T x (4 x m), reduced over ranks, on device
     if (stc) return stc;
+    SynthCoupling cp{};
+    const double tau = 0.05;
+    for (int q = 0; q < 4; ++q) {
+      if (kind == SYN_A || kind == SYN_APB) cp.c[q + 4 * q] = syn_sigma;
+      else if (kind == SYN_AMB) cp.c[q + 4 * q] = 0.2 * syn_sigma;
+      else if (kind == SYN_METRIC) cp.c[q + 4 * q] = 0.1;
+    }
+    if (kind == SYN_SPD || kind == SYN_SMD) {
+      const double tj = kind == SYN_SPD ? tau : -tau;       // J: (0,1) = 1, (1,0) = -1, (2,3) = 1, (3,2) = -1
+      cp.c[0 + 4 * 1] = tj; cp.c[1 + 4 * 0] = -tj; cp.c[2 + 4 * 3] = tj; cp.c[3 + 4 * 2] = -tj;
+    }
     Scope s(this, DLA_OP_MATVEC, 8.0 * n * (2.0 * m + syn_rw), 2.0 * (double)n * m * (2 * syn_rw + 1));
     // (t = W^T x sits in d_small, reduced over ranks; nothing else touches that buffer before the kernel below has read it)
     const int blocks = std::max(1, std::min(ncu * 8, (n + 255) / 256));
     DLA_LAUNCH((synth_apply_kernel<4>), dim3(blocks), dim3(256), sizeof(double) * 4 * m, st,
-                       syn_row0, n, m, syn_sigma, d_w, (const double*)d_small, x, ax);
+                       syn_row0, n, m, kind, cp, d_w, (const double*)d_small, x, ax);
+    HIPCHK(hipGetLastError());
+    return DLA_OK;
+  }
+  int synth_lrprec(int variant, int n, int m, double fac, const double* xp, const double* xm, double* yp, double* ym) override
+  {
+    if (n != syn_n) { err = "synth_lrprec: n differs from setup"; return DLA_ERR_ARG; }
+    Scope s(this, DLA_OP_PRECND, 8.0 * n * (4.0 * m + 1.0), 8.0 * (double)n * m);
+    const int blocks = std::max(1, std::min(ncu * 8, (n + 255) / 256));
+    DLA_LAUNCH(synth_lrprec_kernel, dim3(blocks), dim3(256), 0, st, syn_row0, n, m, variant, fac, syn_sigma, (const double*)d_wsq, xp, xm, yp, ym);
     HIPCHK(hipGetLastError());
     return DLA_OK;
   }

@@ -967,7 +967,10 @@ int dla_call_matvec(dla_ctx* c, dla_matvec_fn fn, int n, int m, const double* x,
   if (m <= 0) return DLA_OK;
   if (c->callbacks_on_device) {
     // the built-in operators run on the engine's own stream: nothing to order
-    const int order = ((void*)fn == (void*)&dla_synth_matvec || (void*)fn == (void*)&dla_spmm_matvec) ? 2 : c->callback_order;
+    const bool builtin = (void*)fn == (void*)&dla_synth_matvec || (void*)fn == (void*)&dla_spmm_matvec || (void*)fn == (void*)&dla_synth_apbmul ||
+                         (void*)fn == (void*)&dla_synth_ambmul || (void*)fn == (void*)&dla_synth_spdmul || (void*)fn == (void*)&dla_synth_smdmul ||
+                         (void*)fn == (void*)&dla_synth_metric;
+    const int order = builtin ? 2 : c->callback_order;
     int st = c->eng->callback_begin(order);
     if (st) return engfail(c, st);
     fn(&n, &m, x, ax);
@@ -998,10 +1001,11 @@ int dla_call_lrprec(dla_ctx* c, dla_lrprec_fn fn, int n, int m, double fac, cons
   DLA_T("dla_call_lrprec");
   if (m <= 0) return DLA_OK;
   if (c->callbacks_on_device) {
-    int st = c->eng->callback_begin(c->callback_order);
+    const int order = ((void*)fn == (void*)&dla_synth_lrprec1 || (void*)fn == (void*)&dla_synth_lrprec2) ? 2 : c->callback_order;
+    int st = c->eng->callback_begin(order);
     if (st) return engfail(c, st);
     fn(&n, &m, &fac, xp, xm, yp, ym);
-    return engfail(c, c->eng->callback_end(c->callback_order));
+    return engfail(c, c->eng->callback_end(order));
   }
   const size_t bytes = sizeof(double) * (size_t)n * m;
   int st = ensure_stage(c, 2 * bytes);
@@ -1048,6 +1052,27 @@ void dla_synth_precnd(const int* n, const int* m, const double* fac, const doubl
   if (!c) { std::fprintf(stderr, "diaglib_amd: dla_synth_precnd before dla_synth_setup\n"); std::abort(); }
   if (c->eng->synth_precnd(*n, *m, *fac, x, px)) { std::fprintf(stderr, "diaglib_amd: synth_precnd failed: %s\n", c->eng->err.c_str()); std::abort(); }
 }
+
+// sample operators of the linear-response / generalised drivers (hip_engine.hip SynthKind), reference callback shapes
+static void synth_kind(int kind, const char* what, const int* n, const int* m, const double* x, double* y)
+{
+  dla_ctx* c = g_synth_ctx;
+  if (!c) { std::fprintf(stderr, "diaglib_amd: %s before dla_synth_setup\n", what); std::abort(); }
+  if (c->eng->synth_apply(kind, *n, *m, x, y)) { std::fprintf(stderr, "diaglib_amd: %s failed: %s\n", what, c->eng->err.c_str()); std::abort(); }
+}
+void dla_synth_apbmul(const int* n, const int* m, const double* x, double* y) { synth_kind(1, "dla_synth_apbmul", n, m, x, y); }
+void dla_synth_ambmul(const int* n, const int* m, const double* x, double* y) { synth_kind(2, "dla_synth_ambmul", n, m, x, y); }
+void dla_synth_spdmul(const int* n, const int* m, const double* x, double* y) { synth_kind(3, "dla_synth_spdmul", n, m, x, y); }
+void dla_synth_smdmul(const int* n, const int* m, const double* x, double* y) { synth_kind(4, "dla_synth_smdmul", n, m, x, y); }
+void dla_synth_metric(const int* n, const int* m, const double* x, double* y) { synth_kind(5, "dla_synth_metric", n, m, x, y); }
+static void synth_lrp(int variant, const int* n, const int* m, const double* fac, const double* xp, const double* xm, double* yp, double* ym)
+{
+  dla_ctx* c = g_synth_ctx;
+  if (!c) { std::fprintf(stderr, "diaglib_amd: dla_synth_lrprec before dla_synth_setup\n"); std::abort(); }
+  if (c->eng->synth_lrprec(variant, *n, *m, *fac, xp, xm, yp, ym)) { std::fprintf(stderr, "diaglib_amd: synth_lrprec failed: %s\n", c->eng->err.c_str()); std::abort(); }
+}
+void dla_synth_lrprec1(const int* n, const int* m, const double* fac, const double* xp, const double* xm, double* yp, double* ym) { synth_lrp(1, n, m, fac, xp, xm, yp, ym); }
+void dla_synth_lrprec2(const int* n, const int* m, const double* fac, const double* xp, const double* xm, double* yp, double* ym) { synth_lrp(2, n, m, fac, xp, xm, yp, ym); }
 
 // ------------------------------------------------------------------ sample sparse operator
 int dla_spmm_setup_csr(dla_ctx* c, int n, const long long* rowptr, const int* colind, const double* values)

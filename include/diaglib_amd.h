@@ -271,6 +271,18 @@ double dla_norm_est(int m, const double* a, int lda);               /* norm_est:
 int  dla_synth_setup(dla_ctx* ctx, long long n_global, long long row0, int n_local, int rank_w, double sigma);
 void dla_synth_matvec(const int* n, const int* m, const double* x_dev, double* ax_dev);
 void dla_synth_precnd(const int* n, const int* m, const double* fac, const double* x_dev, double* px_dev);
+/* Sample operators for the linear-response and generalised drivers around the same W (after dla_synth_setup; device addresses,
+ * reference callback shapes: apbmul / ambmul / spdmul / smdmul of diaglib.f90:1024-1025, bvec of :1855, lrprec of :1317):
+ *   y = d(i) x + W C W^T x :  A+B: d = i+5, C = sigma I;  A-B: d = i+2, C = 0.2 sigma I (the harness' diagonals, main.f90:563,570);
+ *   S+D / S-D: d = s(i) = 1 + 0.5/(1 + i mod 7), C = +-0.05 J with J antisymmetric (D = 0.05 W J W^T);  metric: d = s(i), C = 0.1 I.
+ * lrprec1 / lrprec2 = the harness' lrprec_1 / lrprec_2 (main.f90:234-281) on the diagonals of these operators. */
+void dla_synth_apbmul(const int* n, const int* m, const double* x_dev, double* y_dev);
+void dla_synth_ambmul(const int* n, const int* m, const double* x_dev, double* y_dev);
+void dla_synth_spdmul(const int* n, const int* m, const double* x_dev, double* y_dev);
+void dla_synth_smdmul(const int* n, const int* m, const double* x_dev, double* y_dev);
+void dla_synth_metric(const int* n, const int* m, const double* x_dev, double* y_dev);
+void dla_synth_lrprec1(const int* n, const int* m, const double* fac, const double* xp_dev, const double* xm_dev, double* yp_dev, double* ym_dev);
+void dla_synth_lrprec2(const int* n, const int* m, const double* fac, const double* xp_dev, const double* xm_dev, double* yp_dev, double* ym_dev);
 
 /* ---------------------------------------------------------------- drivers (Fortran, bind(C) twins of the
  * module procedures davidson_driver / gen_david_driver / lobpcg_driver; argument meaning as reference
