@@ -1547,7 +1547,7 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
   const int kt = (k + 15) / 16, k4 = ((k + 3) / 4) * 4;
   const double eps = 2.220446049250313e-16, tol = 2.0 * eps;   // epsilon(one), tol_ortho (diaglib.f90:151)
   const int maxit = a.maxit, can_defer = a.can_defer;
-  TailState t = pre ? *pre : TailState{st->it_macro, st->it_outer, st->macro_total, st->shifts, st->nops, OP_NONE, OST_RUNNING, st->growth};
+  TailState t = pre ? *pre : TailState{st->it_macro, st->it_outer, st->macro_total, st->shifts, st->nops, OP_NONE, OST_RUNNING, st->growth, 0, st->sloppy};
   const int force_defer = can_defer && t.it_outer == 0;   // the ortho_cd that precedes the loop always leaves W pending
   double* A = lds;
   double* S = lds + 48 * TLD;
@@ -1628,13 +1628,21 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
         }
         const double rcond = l_norm * linv_norm;
         t.growth *= linv_norm;
-        const bool macro_done = eps * rcond * rcond < tol;      // :3331-3332
+        // (lead_once: the ortho_cd in front of the loop takes one factorisation step, see ortho_tail16; with a first
+        //  projection of that quality the closing pass is mandatory -- here it always is: the pass decision below looks at
+        //  growth eps, and a block that needed more than this one step has growth >= 2)
+        const bool macro_done = (eps * rcond * rcond < tol) || (force_defer && a.lead_once && a.after == OP_GRAM_UU);      // :3331-3332
         if (!macro_done) {
           t.phase = OP_TRMMG;
-        } else if (can_defer && (force_defer || t.growth * eps >= tol)) {
+        } else if (can_defer && (force_defer || t.sloppy || t.growth * eps >= tol)) {
           // the pass ends with W pending; ortho_vs_x goes on with a projection pass (xu_norm = growth eps >= tol)
           if (!force_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;     // :3568
-          else { ++t.it_outer; t.phase = OP_XU; }
+          else {
+            // (a first projection whose pending factor is not the near-identity one of a converged macro-iteration leaves
+            //  an X component of order eps cond(U): the closing pass is then mandatory)
+            t.sloppy = (force_defer && t.growth * eps >= tol) ? 1 : 0;
+            ++t.it_outer; t.phase = OP_XU;
+          }
         } else {
           if (can_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;
           else t.phase = OP_FINAL;
