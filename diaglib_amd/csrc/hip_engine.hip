@@ -1536,7 +1536,7 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
   OrthoDev* st = a.st;
   if (pre == nullptr) {
     const int ph = __hip_atomic_load(&st->phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ph != a.after) {
+    if (ph != (a.after == OP_GRAMX ? (int)OP_GRAM_UU : a.after)) {
       // not this step's turn.  The last launch of a plan still tells the host where the machine stands -- unless the
       // chain has already ended (a terminal step reported it and re-armed the machine: nops == 0)
       if (a.publish && lane == 0 && st->nops > 0) *a.st_host = *st;
@@ -1551,14 +1551,9 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
   const int force_defer = can_defer && t.it_outer == 0;   // the ortho_cd that precedes the loop always leaves W pending
   double* A = lds;
   double* S = lds + 48 * TLD;
-
-  if (a.after == OP_FINAL) {
-    t.status = OST_DONE;
-  } else if (a.after == OP_XU) {
-    // C' = [-(xu W) ; W]  (host_logic.cpp ortho_vs_x_impl, X^T (U W) = (X^T U) W), packed for the combined sweep
+  // C' = [-(xu W) ; W ; 0] packed for the combined sweep, W(pp, j) in the LDS image A (row pp), xu m x k with leading dimension ldx
+  auto assemble = [&](const double* xu, int ldx) {
     const int l = m + k, l4 = ((l + 3) / 4) * 4;
-    for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx % k) * TLD + idx / k, a.wfull[idx]);   // A[pp][j] = W(pp, j)
-    TSYNC();
     // rows that are not products: the W block, the zero padding of rows and columns
     for (int idx = lane; idx < kt * l4 * 16; idx += 64) {
       const int q = idx / (l4 * 16), p = (idx / 16) % l4, j = 16 * q + (idx % 16);
@@ -1566,7 +1561,7 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
     }
     for (int p = lane; p < m; p += 64) {
       // row p of xu into the lane's own LDS row (the S image is free here), then the k dot products
-      for (int pp = 0; pp < k; ++pp) lds_store1(S + pp * 64 + lane, a.gsrc[(size_t)p + (size_t)pp * m]);
+      for (int pp = 0; pp < k; ++pp) lds_store1(S + pp * 64 + lane, xu[(size_t)p + (size_t)pp * ldx]);
       for (int j = 0; j < k; ++j) {
         double sacc = 0.0;
 #pragma unroll 4
@@ -1574,6 +1569,15 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
         a.cpk[((size_t)(j / 16) * l4 + p) * 16 + (j % 16)] = -sacc;
       }
     }
+  };
+
+  if (a.after == OP_FINAL) {
+    t.status = OST_DONE;
+  } else if (a.after == OP_XU) {
+    // C' = [-(xu W) ; W]  (host_logic.cpp ortho_vs_x_impl, X^T (U W) = (X^T U) W), packed for the combined sweep
+    for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx % k) * TLD + idx / k, a.wfull[idx]);   // A[pp][j] = W(pp, j)
+    TSYNC();
+    assemble(a.gsrc, m);
     t.it_macro = 0;           // the ortho_cd that follows the combined sweep starts afresh (*growth = 1, it = 0)
     t.growth = 1.0;
     t.phase = OP_COMBO;
@@ -1585,9 +1589,11 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
     } else {
       ++t.macro_total;
       if (!g_in_lds) {
+        // (OP_GRAMX: [X | U]^T U in one sweep, (m + k) x k: the Gram matrix of U sits under X^T U)
+        const int roff = a.after == OP_GRAMX ? m : 0, ldg = a.after == OP_GRAMX ? m + k : k;
         for (int idx = lane; idx < k * k; idx += 64) {
           const int i = idx % k, j = idx / k;
-          if (i >= j) { const double v = a.gsrc[(size_t)i + (size_t)j * k]; lds_store1(A + i * TLD + j, v); lds_store1(S + i * TLD + j, v); }
+          if (i >= j) { const double v = a.gsrc[(size_t)(roff + i) + (size_t)j * ldg]; lds_store1(A + i * TLD + j, v); lds_store1(S + i * TLD + j, v); }
         }
       }
       int info = lds_potrf(k, A, lane);
@@ -1631,8 +1637,24 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
         // (lead_once: the ortho_cd in front of the loop takes one factorisation step, see ortho_tail16; with a first
         //  projection of that quality the closing pass is mandatory -- here it always is: the pass decision below looks at
         //  growth eps, and a block that needed more than this one step has growth >= 2)
-        const bool macro_done = (eps * rcond * rcond < tol) || (force_defer && a.lead_once && a.after == OP_GRAM_UU);      // :3331-3332
-        if (!macro_done) {
+        const bool macro_done = (eps * rcond * rcond < tol) || (force_defer && a.lead_once && (a.after == OP_GRAM_UU || a.after == OP_GRAMX));      // :3331-3332
+        if (a.after == OP_GRAMX) {
+          // X^T U came with the Gram matrix: the first projection follows at once, C' = [-(xu W) ; W] (one factorisation step
+          // in front of the loop, closing pass mandatory after a factor that is not near the identity: see lead_once above)
+          TSYNC();
+          for (int idx = lane; idx < k * k; idx += 64) {       // W image: S2[pp][j] = W(pp, j) = Linv(j, pp), through the free S image
+            const int pp = idx / k, j = idx % k;
+            lds_store1(S + pp * TLD + j, pp <= j ? lds_load1(A + j * TLD + pp) : 0.0);
+          }
+          TSYNC();
+          for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx / k) * TLD + idx % k, lds_load1(S + (idx / k) * TLD + idx % k));
+          TSYNC();
+          assemble(a.gsrc, m + k);
+          t.sloppy = (t.growth * eps >= tol) ? 1 : 0;
+          ++t.it_outer;
+          t.it_macro = 0; t.growth = 1.0;
+          t.phase = OP_COMBO;
+        } else if (!macro_done) {
           t.phase = OP_TRMMG;
         } else if (can_defer && (force_defer || t.sloppy || t.growth * eps >= tol)) {
           // the pass ends with W pending; ortho_vs_x goes on with a projection pass (xu_norm = growth eps >= tol)
@@ -3030,7 +3052,7 @@ struct HipEngine : dla::Engine {
   {
     pending_tail = OrthoTailArgs{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, op, m, k, m > 0 ? 1 : 0, ortho_maxit, publish ? 1 : 0,
                                  fold, tune[6] == 7 ? 0 : 1, d_xug, d_wst, d_dbg};
-    if (op == OP_GRAMX || op == OP_XW) pending_tail.gsrc = d_xug;
+    if (fold == 1 && (op == OP_GRAMX || op == OP_XW)) pending_tail.gsrc = d_xug;
     fuse_tail = p2p.on ? tune[6] != 4 : (nranks <= 1 && !comm);     // (knob 6 = 4: the exchange as a launch of its own)
     tail_fused = false;
     pred_phase = &d_ost->phase; pred_want = (op == OP_GRAMX) ? (int)OP_GRAM_UU : op;   // the first sweep answers the start phase
@@ -3038,7 +3060,10 @@ struct HipEngine : dla::Engine {
     switch (op) {
       case OP_GRAM_UU: stc = gram_dev_once(n, k, u, k, u, DLA_OP_GRAM, false); break;
       case OP_XU:      stc = gram_dev_once(n, m, bx, k, u, DLA_OP_GRAM, false); break;
-      case OP_GRAMX:   stc = gram_wp_once(n, m, bx, k, u, nullptr, nullptr); break;
+      case OP_GRAMX:
+        // one-tile blocks: the WP kernel family; wider blocks: the plain product with [X | U] as the left panel (U follows X)
+        stc = fold == 1 ? gram_wp_once(n, m, bx, k, u, nullptr, nullptr) : gram_dev_once(n, m + k, x, k, u, DLA_OP_GRAM, false);
+        break;
       case OP_XW:      stc = gram_wp_once(n, m, bx, k, u, d_wpk, u); break;
       case OP_GRAMW:   stc = gram_wp_once(n, 0, nullptr, k, u, d_wpk, nullptr); break;
       case OP_TRMMG:
@@ -3166,6 +3191,11 @@ struct HipEngine : dla::Engine {
     const bool vec2 = (n % 2 == 0) && (((uintptr_t)u | (uintptr_t)x | (uintptr_t)bx) % 16 == 0);
     int fold = (k <= 16 && tune[6] != 5) ? 2 : 0;
     if (fold && vsx && vec2 && m <= 192 && tune[6] != 6 && lds_limit > (size_t)128 * 1024) fold = 1;
+    // wider blocks (LDS-loop tail): X^T U and U^T U in ONE sweep when [X | U] fits one pass of the Gram kernel (the plain
+    // product with the contiguous panel [X | U] on the left: U follows X, bx == x) and the leading ortho_cd takes one step
+    const int ktw = (k + 15) / 16;
+    const bool wide_gramx = fold == 0 && vsx && vec2 && bx == x && tune[6] != 7 && tune[6] != 8 && ktw >= 2 && ktw <= 3 &&
+                            (m + k + 15) / 16 <= (ktw == 2 ? 8 : 7) && lds_limit > (size_t)128 * 1024;
     int stc = ensure_chain_buffers();
     if (stc) return stc;
     // First chain of a shape: walk every launch path it may take WITHOUT launching (workspaces grow now, not half way; a
@@ -3180,7 +3210,8 @@ struct HipEngine : dla::Engine {
         int std_ = DLA_OK;
         for (int op : every_op) {
           if (!vsx && (op == OP_GRAMX || op == OP_XW || op == OP_XU || op == OP_COMBO || op == OP_GRAMW)) continue;
-          if (fold != 1 && (op == OP_GRAMX || op == OP_GRAMW || op == OP_XW)) continue;
+          if (fold != 1 && (op == OP_GRAMW || op == OP_XW)) continue;
+          if (fold != 1 && op == OP_GRAMX && !wide_gramx) continue;
           std_ = launch_op(op, n, m, k, x, bx, u, false, fold);
           if (std_) break;
         }
@@ -3193,7 +3224,7 @@ struct HipEngine : dla::Engine {
       }
     }
     // the widest reductions of the chain: make sure nothing reallocates (and drains the stream) half way
-    stc = ensure_small(sizeof(double) * (size_t)std::max(m, k) * k);
+    stc = ensure_small(sizeof(double) * (size_t)(m + k) * k);
     if (stc) return stc;
 
     if (!chain_armed) {
@@ -3209,14 +3240,15 @@ struct HipEngine : dla::Engine {
     h_ost->nops = 0;
 
     // the schedule depends on how much of the new block already lies in span(X): remembered per basis width
-    const long long key = (long long)k * 1000000 + m + fold * 500000000000LL;
+    const long long key = (long long)k * 1000000 + m + fold * 500000000000LL + (wide_gramx ? 250000000000LL : 0LL);
     std::vector<int>& hist = ortho_history[key];
     std::vector<int> plan = hist;
-    std::vector<int>& last_k = ortho_history[-(long long)(8 * k + (vsx ? 1 : 0) + 2 * fold) - 1];   // most recent call of this kind and width
+    std::vector<int>& last_k = ortho_history[-(long long)(16 * k + (vsx ? 1 : 0) + 2 * fold + (wide_gramx ? 8 : 0)) - 1];   // most recent call of this kind and width
     if (plan.empty()) plan = last_k;
     if (plan.empty()) {
       // the schedule measured on the reference: cd x2, [projection, cd x2], [projection, cd x1]
       if (fold == 1) plan = {OP_GRAMX, OP_COMBO, OP_TRMMG, OP_XW, OP_COMBO, OP_FINAL};
+      else if (wide_gramx) plan = {OP_GRAMX, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
       else if (vsx) plan = {OP_GRAM_UU, OP_TRMMG, OP_XU, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
       else plan = {OP_GRAM_UU, OP_TRMMG, OP_FINAL};
     }
