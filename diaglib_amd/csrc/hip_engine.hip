@@ -1721,36 +1721,38 @@ __device__ __forceinline__ v4d mfma16(double a, double b, v4d c) { return __buil
 
 // a: Gram matrix in C-layout (identity beyond k).  Out: R (upper triangle of a), X = L^-1 (lower), the largest diagonal
 // entries of both.  Returns 0 or the 1-based index of the first non-positive pivot.
-// One step, row j = 4 RR + gj: the register index RR is a template argument (the loop below branches to one of four copies of
-// the step; a register picked by a run-time index costs a dozen selects per access, and this loop is pure issue latency).
+// The loop is pure issue latency for one wave, so it is written to the instruction: the factorisation runs in its
+// square-root-free form G = Lu D Lu^T (unit lower Lu), where a step needs NO write to the matrix registers besides the MFMA
+// itself -- row j of the working matrix is the unscaled row u_j = d_j Lu(:, j)^T, the trailing update is A -= (u_j / d_j) u_j^T
+// (one MFMA, A operand u_j / d_j, B operand u_j, both masked to the 16 lanes that hold row j), and Lu^-1 grows beside it by
+// X[i] -= (u_j[i] / d_j) X[j] (one more MFMA with the same A operand; its diagonal is 1, nothing to scale).  R = D^-1/2 U and
+// L^-1 = D^-1/2 Lu^-1 are two row scalings at the end, the square roots of all pivots taken at once.  A step is: two readlanes
+// (pivot), a reciprocal (hardware estimate + two Newton steps), three selects, one multiply, two MFMAs.
+// One step, row j = 4 RR + gj: the register index RR is a template argument (the loop branches to one of four copies of the step;
+// a register picked by a run-time index costs a dozen selects per access).
 template <int RR>
-__device__ __forceinline__ void chol_inv_step(int j, double d, v4d& a, v4d& x, double& dmax, double& xmax, int c, int g)
+__device__ __forceinline__ void ldl_inv_step(int j, double d, v4d& a, v4d& x, v4d& drow, int c, int g)
 {
   const int gj = j & 3;
-  // 1 / sqrt(d): hardware estimate + two Newton steps (a correctly rounded sqrt and a division are ~50 dependent FP64
-  // instructions, and every step waits for them)
-  double inv = __builtin_amdgcn_rsq(d);
-  inv = inv * fma(-0.5 * d * inv, inv, 1.5);
-  inv = inv * fma(-0.5 * d * inv, inv, 1.5);
-  const double sd = d * inv;
+  double inv = __builtin_amdgcn_rcp(d);
+  inv = fma(fma(-d, inv, 1.0), inv, inv);
+  inv = fma(fma(-d, inv, 1.0), inv, inv);
   const bool rowj = (g == gj);
-  const double arow = a[RR];
-  const double scaled = c > j ? arow * inv : (c == j ? sd : arow);
-  const double v = (rowj && c > j) ? scaled : 0.0;           // R[j][c], c > j
-  const double xrow = x[RR] * inv;                           // X[j][c] (row j is final once divided by R[j][j])
-  const double vb = rowj ? xrow : 0.0;
-  if (rowj) { a[RR] = scaled; x[RR] = xrow; }
-  a = mfma16(-v, v, a);      // A[i][c'] -= R[j][i] R[j][c'],  i, c' > j
-  x = mfma16(-v, vb, x);     // X[i][c'] -= L[i][j] X[j][c'],  i > j
-  dmax = fmax(dmax, sd); xmax = fmax(xmax, inv);
+  const double u = (rowj && c > j) ? a[RR] : 0.0;            // u_j[c], c > j
+  const double xb = rowj ? x[RR] : 0.0;                       // X[j][c] (unit diagonal: final as it stands)
+  if (rowj) drow[RR] = d;                                     // the pivot of this lane's row g + 4 RR
+  const double ua = -u * inv;
+  a = mfma16(ua, u, a);       // A[i][c'] -= u_j[i] u_j[c'] / d_j,  i, c' > j
+  x = mfma16(ua, xb, x);      // X[i][c'] -= Lu[i][j] X[j][c'],     i > j
 }
 
 __device__ __forceinline__ int chol_inv16(int k, v4d& a, v4d& x, double& dmax, double& xmax, int lane)
 {
   const int c = lane & 15, g = lane >> 4;
+  v4d drow;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) x[r] = (g + 4 * r == c) ? 1.0 : 0.0;
-  dmax = 0.0; xmax = 0.0;
+  for (int r = 0; r < 4; ++r) { x[r] = (g + 4 * r == c) ? 1.0 : 0.0; drow[r] = 1.0; }
+  double dlo = 1.0e300, dhi = 0.0;
   int info = 0;
 #pragma unroll 1
   for (int j = 0; j < k; ++j) {
@@ -1763,14 +1765,48 @@ __device__ __forceinline__ int chol_inv16(int k, v4d& a, v4d& x, double& dmax, d
       default: d = rlane(a[3], src); break;
     }
     if (!(d > 0.0) || !isfinite(d)) { info = j + 1; break; }
+    dlo = fmin(dlo, d); dhi = fmax(dhi, d);
     switch (j >> 2) {
-      case 0: chol_inv_step<0>(j, d, a, x, dmax, xmax, c, g); break;
-      case 1: chol_inv_step<1>(j, d, a, x, dmax, xmax, c, g); break;
-      case 2: chol_inv_step<2>(j, d, a, x, dmax, xmax, c, g); break;
-      default: chol_inv_step<3>(j, d, a, x, dmax, xmax, c, g); break;
+      case 0: ldl_inv_step<0>(j, d, a, x, drow, c, g); break;
+      case 1: ldl_inv_step<1>(j, d, a, x, drow, c, g); break;
+      case 2: ldl_inv_step<2>(j, d, a, x, drow, c, g); break;
+      default: ldl_inv_step<3>(j, d, a, x, drow, c, g); break;
     }
   }
-  return info;
+  if (info) return info;
+  // R = D^-1/2 U, L^-1 = D^-1/2 Lu^-1: every lane scales its four rows (1 / sqrt: hardware estimate + two Newton steps)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double d = drow[r];
+    double s = __builtin_amdgcn_rsq(d);
+    s = s * fma(-0.5 * d * s, s, 1.5);
+    s = s * fma(-0.5 * d * s, s, 1.5);
+    a[r] *= s; x[r] *= s;
+  }
+  dmax = sqrt(dhi);                  // max R[j][j] = sqrt(max d_j)
+  xmax = 1.0 / sqrt(dlo);            // max X[j][j] = 1 / sqrt(min d_j)
+  return 0;
+}
+
+// sums of two per-lane values over the wave: shifts inside the 16-lane rows (DPP row_shr, no LDS traffic), then the four row
+// totals through readlanes; every lane gets both sums
+__device__ __forceinline__ double dpp_row_shr(double v, int sh)     // sh: compile-time 1, 2, 4, 8
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  switch (sh) {
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); break;
+    case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); break;
+  }
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_sum2(double& p, double& q)
+{
+#pragma unroll
+  for (int sh = 1; sh < 16; sh <<= 1) { p += dpp_row_shr(p, sh); q += dpp_row_shr(q, sh); }     // lane 15 of each row: the row's sum
+  p = ((rlane(p, 15) + rlane(p, 31)) + rlane(p, 47)) + rlane(p, 63);
+  q = ((rlane(q, 15) + rlane(q, 31)) + rlane(q, 47)) + rlane(q, 63);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -1873,6 +1909,7 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
         v4d am = g0, x;
         double dmax, xmax;
         if (lane == 0 && g0[0] == g0[0]) TSTAMP(a, dslot, 1);
+        const unsigned long long cyc0 = a.dbg ? __builtin_readcyclecounter() : 0ULL;
         // factorisation; on a non-positive pivot the level-shift ladder (:3265-3295): shift = max(eps alpha ||U||_F, 2 eps),
         // alpha = 100, 1000, ...  (one call site: the factorisation loop exists once in the code)
         int info, it_micro = 0;
@@ -1900,12 +1937,13 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
           // norm_est (:3447-3479) of L = R^T and of L^-1: largest diagonal entry + Frobenius norm of the strict triangle
           double fr = 0.0, fx = 0.0;
           if (lane == 0 && x[0] == x[0]) TSTAMP(a, dslot, 2);
+          if (lane == 0 && a.dbg != nullptr && dslot < 48) a.dbg[dslot * 16 + 11] = __builtin_readcyclecounter() - cyc0;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = g + 4 * r;
             if (i < k && c < k) { if (c > i) fr += am[r] * am[r]; if (c < i) fx += x[r] * x[r]; }
           }
-          fr = wave_sum(fr); fx = wave_sum(fx);
+          wave_sum2(fr, fx);
           const double l_norm = dmax + sqrt(fr), linv_norm = xmax + sqrt(fx);
           if (lane == 0 && l_norm == l_norm) TSTAMP(a, dslot, 3);
           // W = X^T in C-layout (transpose through LDS; the wave's LDS operations complete in order)
@@ -3309,8 +3347,8 @@ struct HipEngine : dla::Engine {
           const unsigned long long* q = &hs[i * 16];
           auto us = [&](int a_, int b_) { return (q[a_] && q[b_]) ? (double)(long long)(q[b_] - q[a_]) * 0.01 : -1.0; };
           double rc; std::memcpy(&rc, &q[10], 8);
-          std::printf("    op %llu (err est %.2e): kernel entry->tail %.2f us | G load %.2f | chol+inv %.2f | norms %.2f | products+stores %.2f | decide %.2f | publish %.2f | assemble %.2f\n",
-                      q[9], 2.2e-16 * rc * rc, us(8, 0), us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7));
+          std::printf("    op %llu (err est %.2e, chol %llu cycles = %.2f GHz): kernel entry->tail %.2f us | G load %.2f | chol+inv %.2f | norms %.2f | products+stores %.2f | decide %.2f | publish %.2f | assemble %.2f\n",
+                      q[9], 2.2e-16 * rc * rc, q[11], us(1, 2) > 0 ? (double)q[11] / (us(1, 2) * 1e3) : 0.0, us(8, 0), us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7));
         }
         (void)hipMemset(d_dbg, 0, sizeof(unsigned long long) * 48 * 16);
       }
