@@ -1597,13 +1597,13 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
         }
       }
       int info = lds_potrf(k, A, lane);
+      int it_micro = 0;
       if (info != 0) {
         // level-shift ladder (:3265-3295): shift = max(eps alpha ||U||_F, 2 eps), alpha = 100, 1000, ...
         double tr = 0.0;
         for (int i = 0; i < k; ++i) tr += lds_load1(S + i * TLD + i);
         const double unorm = sqrt(tr > 0.0 ? tr : 0.0);
         double alpha = 100.0;
-        int it_micro = 0;
         while (info != 0) {
           if (++it_micro > maxit) break;
           const double shift = fmax(eps * alpha * unorm, tol);
@@ -1637,8 +1637,13 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
         // (lead_once: the ortho_cd in front of the loop takes one factorisation step, see ortho_tail16; with a first
         //  projection of that quality the closing pass is mandatory -- here it always is: the pass decision below looks at
         //  growth eps, and a block that needed more than this one step has growth >= 2)
-        const bool macro_done = (eps * rcond * rcond < tol) || (force_defer && a.lead_once && (a.after == OP_GRAM_UU || a.after == OP_GRAMX));      // :3331-3332
-        if (a.after == OP_GRAMX) {
+        // (a block that needed a level shift is numerically rank deficient: its weakest columns come out as amplified
+        //  rounding noise, WHICH noise depends on the order of the operations, and the solvers' convergence history can
+        //  depend on it -- the reference's dense test matrix with unit guesses does, tests/test_trace_text.py.  There the
+        //  reference's order is kept: ortho_cd in front of the loop runs to convergence before the first projection)
+        const bool lead = force_defer && a.lead_once && it_micro == 0 && (a.after == OP_GRAM_UU || a.after == OP_GRAMX);
+        const bool macro_done = (eps * rcond * rcond < tol) || lead;      // :3331-3332
+        if (a.after == OP_GRAMX && lead) {
           // X^T U came with the Gram matrix: the first projection follows at once, C' = [-(xu W) ; W] (one factorisation step
           // in front of the loop, closing pass mandatory after a factor that is not near the identity: see lead_once above)
           TSYNC();
@@ -1983,8 +1988,10 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
           // measured after that projection.  The reference's second macro-iteration there (its first one leaves condition
           // 1 + O(eps c^2), the second one confirms it) costs a sweep and a k x k step per call and changes nothing the closing
           // passes do not re-measure; with a carried X^T U of that quality (growth eps >= tol_ortho) the closing pass is
-          // mandatory (sloppy), as for every carried product.
-          const bool macro_done = (eps * rcond * rcond < tol) || (stage0 && a.lead_once && a.fold == 1 && after == OP_GRAMX);      // :3331-3332
+          // mandatory (sloppy), as for every carried product.  Not after a level shift: a numerically rank-deficient block
+          // keeps the reference's order of operations (see ortho_tail), because its weakest columns are amplified rounding
+          // noise whose realisation depends on that order and the solvers' convergence history on the noise.
+          const bool macro_done = (eps * rcond * rcond < tol) || (stage0 && a.lead_once && a.fold == 1 && after == OP_GRAMX && it_micro == 0);      // :3331-3332
           if (!macro_done) {
             // another macro-iteration.  In front of the loop its Gram matrix comes from U_mem Wp on the fly -- unless the
             // factorisation needed a level shift (rank-deficient block: the update is written); inside the loop the update is
