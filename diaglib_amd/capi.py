@@ -25,6 +25,7 @@ ALLREDUCE_T = C.CFUNCTYPE(None, C.c_void_p, c_dp, C.c_int, C.c_int)
 
 OPT_CALLBACKS_ON_DEVICE, OPT_EVEC_ON_DEVICE, OPT_PROFILE, OPT_VERBOSE_ORTHO, OPT_CALLBACK_ORDER, OPT_ORTHO_MAXIT, OPT_CASLR_ALGORITHM, OPT_STAGE_CHUNKS = 1, 2, 3, 4, 5, 6, 7, 8
 OPT_P2P_TIMEOUT_MS = 9
+OPT_RUN_AHEAD = 10
 OP_NAMES = ["gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd"]
 
 # every symbol include/diaglib_amd.h declares (checked by tests/test_abi.py)
@@ -36,7 +37,7 @@ EXPORTS = [
     "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_trmm_gram", "dla_update_gram", "dla_combo_gram", "dla_ritz_residual", "dla_ritz_residual_p", "dla_axpy",
     "dla_nrm2", "dla_stream_triad", "dla_random_fill", "dla_fill_guess",
     "dla_ortho_cd", "dla_ortho_qr", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
-    "dla_call_matvec", "dla_call_precnd",
+    "dla_call_matvec", "dla_call_precnd", "dla_expand_project",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
     "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd", "dla_synth_apbmul", "dla_synth_ambmul", "dla_synth_spdmul", "dla_synth_smdmul",
     "dla_synth_metric", "dla_synth_lrprec1", "dla_synth_lrprec2", "dla_spmm_setup_csr", "dla_spmm_matvec", "dla_spmm_precnd",
@@ -118,6 +119,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_b_ortho": (i, [vp, i, i, vp, vp]), "dla_b_ortho_vs_x": (i, [vp, i, i, i, vp, vp, vp]),
         "dla_check_guess": (i, [vp, i, i, vp]),
         "dla_get_coeffs": (i, [vp, i, i, i, i, c_dp, c_dp, c_dp]),
+        "dla_expand_project": (i, [vp, i, i, i, i, vp, vp, vp, d, c_dp, i]),
         "dla_call_matvec": (i, [vp, vp, i, i, vp, vp]), "dla_call_precnd": (i, [vp, vp, i, i, d, vp, vp]),
         "dla_syev": (i, [C.c_char, i, c_dp, i, c_dp]), "dla_syev_lowest": (i, [C.c_char, i, c_dp, i, c_dp, i]),
         "dla_potrf_lower": (i, [i, c_dp, i]),
@@ -400,6 +402,13 @@ class Context:
 
     def ortho_vs_x(self, x: DevPanel, u: DevPanel, m: Optional[int] = None) -> None:
         self._chk(self.lib.dla_ortho_vs_x(self.h, x.n, x.m if m is None else m, u.m, x.ptr, u.ptr))
+
+    def expand_project(self, mode: int, basis: DevPanel, abasis: DevPanel, m: int, k: int, matvec: int, shift: float = 0.0) -> np.ndarray:
+        """dla_expand_project on the leading m + k columns of the two panels: ortho_vs_x(X, U), AU = A U + shift U, then the
+        projection -- mode 0: [X | U]^T AU ((m+k) x k), mode 1: lower triangle of [X | U]^T [AX | AU]"""
+        h = np.zeros((m + k, k if mode == 0 else m + k), order="F")
+        self._chk(self.lib.dla_expand_project(self.h, mode, basis.n, m, k, basis.ptr, abasis.ptr, matvec, shift, _dp(h), m + k))
+        return h
 
     def b_ortho(self, u: DevPanel, bu: DevPanel) -> None:
         self._chk(self.lib.dla_b_ortho(self.h, u.n, u.m, u.ptr, bu.ptr))

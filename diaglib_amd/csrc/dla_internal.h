@@ -16,6 +16,7 @@ struct OrthoReport {
                         // 4 ortho_vs_x ran out of iterations
   int outer_its = 0, macro_its = 0, shifts = 0;
   double growth = 1.0;
+  int clean = 1;        // ortho_chain_finish: 1 when the launches enqueued by ortho_chain_begin were the whole chain
 };
 
 // The block operations the orthogonalisation control flow (ortho_cd / ortho_vs_x / ortho in host_logic.cpp) is written
@@ -49,6 +50,12 @@ struct BlockOps {
   // ortho_cd (m == 0) with the k x k factorisations and the loop decisions on the device: one host wait per call.
   virtual int ortho_chain(int /*n*/, int /*m*/, int /*k*/, const double* /*x*/, const double* /*bx*/, double* /*u*/,
                           OrthoReport* rep) { rep->handled = 0; return 0; }
+  // The same in two halves (dla_expand_project): begin enqueues the planned launches and returns with the chain in flight
+  // (rep->handled = 1, status 0); finish reads the device's report -- `waited`: the caller has waited for the stream in
+  // between -- and completes the chain when it went another way than planned (rep->clean = 0 then: whatever the caller
+  // enqueued in between has read an unfinished block).  Nothing but launches on the engine's stream may come in between.
+  virtual int ortho_chain_begin(int, int, int, const double*, const double*, double*, OrthoReport* rep) { rep->handled = 0; return 0; }
+  virtual int ortho_chain_finish(OrthoReport*, bool /*waited*/) { return DLA_ERR_ARG; }
   // the top k GLOBAL rows of the n x k block u (row0 = global index of local row 0), k x k to the host
   virtual int top_rows(int n, int k, const double* u, long long row0, double* qt_host) = 0;
   int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests
@@ -202,6 +209,7 @@ struct dla_ctx {
   int stage_chunks = 0;      // DLA_OPT_STAGE_CHUNKS: 0 = automatic
   int callback_order = 1;    // DLA_OPT_CALLBACK_ORDER (default: host-synchronised, safe for callbacks on any stream)
   int p2p_timeout_ms = 5000; // DLA_OPT_P2P_TIMEOUT_MS
+  int run_ahead = 1;         // DLA_OPT_RUN_AHEAD
   long long n_global = -1;   // -1: single shard, n_global == n
   long long row0 = 0;
   std::string err;

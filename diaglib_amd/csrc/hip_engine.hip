@@ -2543,6 +2543,7 @@ struct HipEngine : dla::Engine {
   }
   void collect_times() override
   {
+    account_chains();
     if (timed.empty()) return;
     (void)hipStreamSynchronize(st);
     for (auto& t : timed) {
@@ -3223,9 +3224,33 @@ struct HipEngine : dla::Engine {
     return allreduce_dev(cdst, (self ? k : m + k) * k, 0, h_small);
   }
 
+  // A chain runs in two halves: ortho_chain_begin enqueues the planned launches, ortho_chain_finish waits, reads what the
+  // device reports and continues from there when it went another way than planned.  ortho_chain is the two back to back;
+  // dla_expand_project (host_logic.cpp) puts the operator and the projection sweep of the new block between them, so that
+  // the chain's report is read at THEIR wait (one host wait per expansion instead of two; the speculated launches are
+  // simply repeated when the report is not the expected one).
+  struct ChainRun {
+    bool active = false;
+    int n = 0, m = 0, k = 0, fold = 0;
+    bool vsx = false;
+    const double *x = nullptr, *bx = nullptr;
+    double* u = nullptr;
+    long long key = 0, key_last = 0;
+    std::vector<int> plan, launched;
+    std::vector<SpecRec> recs;
+  } run;
+
   int ortho_chain(int n, int m, int k, const double* x, const double* bx, double* u, dla::OrthoReport* rep) override
   {
+    int stc = ortho_chain_begin(n, m, k, x, bx, u, rep);
+    if (stc || !rep->handled) return stc;
+    return ortho_chain_finish(rep, false);
+  }
+
+  int ortho_chain_begin(int n, int m, int k, const double* x, const double* bx, double* u, dla::OrthoReport* rep) override
+  {
     rep->handled = 0;
+    if (run.active) { err = "ortho_chain: a chain is already in flight"; return DLA_ERR_RUNTIME; }
     if (tune[6] == 3) return DLA_OK;                               // A/B: host-driven loop
     if (hook || local_only || k <= 0 || k > 48) return DLA_OK;     // hook reductions need the host between sweeps
     const bool vsx = m > 0;
@@ -3297,22 +3322,88 @@ struct HipEngine : dla::Engine {
       else if (vsx) plan = {OP_GRAM_UU, OP_TRMMG, OP_XU, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
       else plan = {OP_GRAM_UU, OP_TRMMG, OP_FINAL};
     }
-    std::vector<SpecRec> recs;
-    std::vector<int> launched;
+    run.n = n; run.m = m; run.k = k; run.fold = fold; run.vsx = vsx; run.x = x; run.bx = bx; run.u = u;
+    run.key = key;
+    run.key_last = -(long long)(16 * k + (vsx ? 1 : 0) + 2 * fold + (wide_gramx ? 8 : 0)) - 1;
+    run.plan = plan; run.launched.clear(); run.recs.clear();
+    stc = chain_enqueue();
+    if (stc) return stc;
+    account_chains();                // (the device has work now)
+    run.active = true;
+    rep->handled = 1;
+    rep->status = 0;                 // in flight
+    return DLA_OK;
+  }
+
+  // statistics of finished chains: the launches the device executed are the greedy match of its log inside the launch
+  // sequence.  Called with the device busy (behind the next chain's launches) or when somebody reads the statistics.
+  struct ChainDone { std::vector<int> launched; std::vector<SpecRec> recs; int log[48]; int nlog = 0, n = 0, k = 0; };
+  std::vector<ChainDone> unaccounted;
+  void account_chains()
+  {
+    for (auto& cd : unaccounted) {
+      std::vector<char> ran(cd.launched.size(), 0);
+      int j = 0;
+      for (size_t i = 0; i < cd.launched.size() && j < cd.nlog; ++i)
+        if (cd.launched[i] == cd.log[j]) { ran[i] = 1; ++j; }
+      for (auto& r : cd.recs) {
+        if (!ran[r.tag]) continue;
+        stats.launches[r.cls] += 1; stats.alg_bytes[r.cls] += r.bytes; stats.flops[r.cls] += r.flops;
+        if (!r.kname.empty()) { auto& ks = kstats[r.kname]; ks.launches += 1; ks.alg_bytes += r.bytes; ks.flops += r.flops; }
+      }
+      // reference-schedule flops of what the fused sweeps fold in (same bookkeeping as trmm_gram / combo_gram)
+      for (size_t i = 0; i < cd.launched.size(); ++i) {
+        if (!ran[i]) continue;
+        if (cd.launched[i] == OP_TRMMG) stats.flops[DLA_OP_GRAM] += 2.0 * (double)cd.n * cd.k * cd.k;
+        if (cd.launched[i] == OP_COMBO) { stats.flops[DLA_OP_GRAM] += 2.0 * (double)cd.n * cd.k * cd.k; stats.flops[DLA_OP_GEMM] -= 1.0 * (double)cd.n * cd.k * cd.k; }
+      }
+    }
+    unaccounted.clear();
+  }
+
+  // enqueue run.plan (every launch predicated on the device state machine standing where the plan expects it)
+  int chain_enqueue()
+  {
+    spec_rec = &run.recs;
+    int stc = DLA_OK;
+    for (size_t pi = 0; pi < run.plan.size(); ++pi) {
+      spec_tag = (int)run.launched.size();
+      run.launched.push_back(run.plan[pi]);
+      stc = launch_op(run.plan[pi], run.n, run.m, run.k, run.x, run.bx, run.u, pi + 1 == run.plan.size(), run.fold);
+      if (stc) break;
+    }
+    spec_rec = nullptr;
+    if (stc) { (void)hipStreamSynchronize(st); chain_armed = false; return stc; }
+    return DLA_OK;
+  }
+
+  // `waited`: the caller has waited for the stream since ortho_chain_begin (its own result came through the same wait).
+  // rep->clean = 1 when the planned launches were the whole chain (nothing was enqueued here).
+  int ortho_chain_finish(dla::OrthoReport* rep, bool waited) override
+  {
+    if (!run.active) { err = "ortho_chain_finish: no chain in flight"; return DLA_ERR_RUNTIME; }
+    run.active = false;
+    const int n = run.n, m = run.m, k = run.k, fold = run.fold;
+    const bool vsx = run.vsx;
+    std::vector<int>& plan = run.plan;
+    std::vector<int>& launched = run.launched;
+    std::vector<SpecRec>& recs = run.recs;
+    std::vector<int>& hist = ortho_history[run.key];
+    std::vector<int>& last_k = ortho_history[run.key_last];
+    int stc = DLA_OK;
+    rep->clean = 1;
     OrthoDev sres{};
     for (int round = 0; round < 256; ++round) {
-      spec_rec = &recs;
-      for (size_t pi = 0; pi < plan.size(); ++pi) {
-        spec_tag = (int)launched.size();
-        launched.push_back(plan[pi]);
-        stc = launch_op(plan[pi], n, m, k, x, bx, u, pi + 1 == plan.size(), fold);
-        if (stc) break;
+      if (round > 0) {
+        rep->clean = 0;
+        stc = chain_enqueue();
+        if (stc) return stc;
       }
-      spec_rec = nullptr;
-      if (stc) { (void)hipStreamSynchronize(st); return stc; }
-      stc = wait_stream();
-      if (stc) return stc;
-      stats.host_syncs++;
+      if (round > 0 || !waited) {
+        stc = wait_stream();
+        if (stc) { chain_armed = false; return stc; }
+        stats.host_syncs++;
+      }
       sres = *h_ost;
       if (sres.status < 0) { err = "ortho_chain: the device reported nothing"; return DLA_ERR_RUNTIME; }
       if (sres.status != OST_RUNNING) break;
@@ -3360,24 +3451,15 @@ struct HipEngine : dla::Engine {
         (void)hipMemset(d_dbg, 0, sizeof(unsigned long long) * 48 * 16);
       }
     }
-    // account for the launches the device executed: they are the greedy match of its log inside the launch sequence
+    // the launches the device executed are accounted for later, off the critical path (account_chains): the caller is
+    // waiting for this report with the device idle
     {
       const int nlog = std::min(sres.nops, 48);
-      std::vector<char> ran(launched.size(), 0);
-      int j = 0;
-      for (size_t i = 0; i < launched.size() && j < nlog; ++i)
-        if (launched[i] == sres.log[j]) { ran[i] = 1; ++j; }
-      for (auto& r : recs) {
-        if (!ran[r.tag]) continue;
-        stats.launches[r.cls] += 1; stats.alg_bytes[r.cls] += r.bytes; stats.flops[r.cls] += r.flops;
-        if (!r.kname.empty()) { auto& ks = kstats[r.kname]; ks.launches += 1; ks.alg_bytes += r.bytes; ks.flops += r.flops; }
-      }
-      // reference-schedule flops of what the fused sweeps fold in (same bookkeeping as trmm_gram / combo_gram)
-      for (size_t i = 0; i < launched.size(); ++i) {
-        if (!ran[i]) continue;
-        if (launched[i] == OP_TRMMG) stats.flops[DLA_OP_GRAM] += 2.0 * (double)n * k * k;
-        if (launched[i] == OP_COMBO) { stats.flops[DLA_OP_GRAM] += 2.0 * (double)n * k * k; stats.flops[DLA_OP_GEMM] -= 1.0 * (double)n * k * k; }
-      }
+      ChainDone cd;
+      cd.launched.swap(launched); cd.recs.swap(recs);
+      std::copy(sres.log, sres.log + nlog, cd.log);
+      cd.nlog = nlog; cd.n = n; cd.k = k;
+      unaccounted.push_back(std::move(cd));
       if (sres.status == OST_DONE && sres.nops <= 48) { hist.assign(sres.log, sres.log + nlog); last_k = hist; }
     }
     rep->handled = 1;

@@ -173,6 +173,9 @@ int dla_set_option(dla_ctx* c, int option, int value)
       if (value < 0) return fail(c, DLA_ERR_ARG, "p2p timeout must be >= 0 ms (0 = no limit)");
       c->p2p_timeout_ms = value;
       return engfail(c, c->eng->set_p2p_timeout(value));
+    case DLA_OPT_RUN_AHEAD:
+      c->run_ahead = value ? 1 : 0;
+      break;
     case DLA_OPT_CALLBACK_ORDER:
       if (value < 0 || value > 2) return fail(c, DLA_ERR_ARG, "callback order must be 0, 1 or 2");
       c->callback_order = value;
@@ -197,6 +200,7 @@ int dla_get_option(dla_ctx* c, int option)
     case DLA_OPT_CASLR_ALGORITHM: return c->caslr_algorithm;
     case DLA_OPT_STAGE_CHUNKS: return c->stage_chunks;
     case DLA_OPT_P2P_TIMEOUT_MS: return c->p2p_timeout_ms;
+    case DLA_OPT_RUN_AHEAD: return c->run_ahead;
     default: return -1;
   }
 }
@@ -660,19 +664,30 @@ int dla_ortho_qr(dla_ctx* c, int n, int k, double* u)
   return ortho_qr_impl(c, c->eng, c->row0, global_rows(c, n), n, k, u);
 }
 
+// ortho_vs_x from the device chain's report onwards (`chain` = nullptr: no chain has run, the host-driven loop does it all)
+static int ortho_vs_x_after_chain(dla_ctx* c, dla::BlockOps* ops, long long row0, long long n_rows_global, int n, int m, int k,
+                                  const double* x, const double* bx, double* u, const dla::OrthoReport* chain);
+
 static int ortho_vs_x_impl(dla_ctx* c, dla::BlockOps* ops, long long row0, long long n_rows_global, int n, int m, int k,
                            const double* x, const double* bx, double* u)
 {
   if (k <= 0) return DLA_OK;
+  // device-driven chain first (one host wait per call); shapes / modes it does not take run the host-driven loop
+  dla::OrthoReport rep;
+  int stc = ops->ortho_chain(n, m, k, x, bx, u, &rep);
+  if (stc) return opsfail(c, ops, stc);
+  return ortho_vs_x_after_chain(c, ops, row0, n_rows_global, n, m, k, x, bx, u, rep.handled ? &rep : nullptr);
+}
+
+static int ortho_vs_x_after_chain(dla_ctx* c, dla::BlockOps* ops, long long row0, long long n_rows_global, int n, int m, int k,
+                                  const double* x, const double* bx, double* u, const dla::OrthoReport* chain)
+{
   const int kMaxIt = ops->ortho_maxit;    // maxit, diaglib.f90:3521
   bool resume = false;                    // the device chain stopped in ortho_cd and the Householder fallback has run
   int resume_it = 0;                      // ... after this many outer iterations
-  // device-driven chain first (one host wait per call); shapes / modes it does not take run the host-driven loop below
   {
-    dla::OrthoReport rep;
-    int stc = ops->ortho_chain(n, m, k, x, bx, u, &rep);
-    if (stc) return opsfail(c, ops, stc);
-    if (rep.handled) {
+    if (chain) {
+      const dla::OrthoReport& rep = *chain;
       if (c->verbose_ortho)
         std::printf("  [dla] ortho_vs_x (device chain): %d outer iterations, %d macro iterations, status %d\n", rep.outer_its,
                     rep.macro_its, rep.status);
@@ -977,6 +992,60 @@ int dla_call_matvec(dla_ctx* c, dla_matvec_fn fn, int n, int m, const double* x,
     return engfail(c, c->eng->callback_end(order));
   }
   return staged_callback(c, n, m, x, ax, [&](int mc, const double* hx, double* hy) { fn(&n, &mc, hx, hy); });
+}
+
+// Expansion step of the Davidson / LOBPCG drivers (include/diaglib_amd.h).  The three operations form a dependent chain on
+// the device and the host has nothing to decide between them unless the orthogonalisation takes an unusual turn -- so they
+// are enqueued back to back and the chain's report comes in with the projected block.
+static int expand_apply_project(dla_ctx* c, int mode, int n, int m, int k, double* basis, double* abasis, dla_matvec_fn fn,
+                                double shift, double* h, int ldh)
+{
+  double* u = basis + (size_t)n * m;
+  double* au = abasis + (size_t)n * m;
+  int st = dla_call_matvec(c, fn, n, k, u, au);
+  if (st) return st;
+  if (shift != 0.0) { st = dla_axpy(c, (size_t)n * k, shift, u, au); if (st) return st; }
+  if (mode == 0) return dla_gram(c, n, m + k, basis, k, au, h, ldh);
+  return dla_gram_lower(c, n, m + k, basis, abasis, h, ldh);
+}
+
+int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis, double* abasis, dla_matvec_fn fn,
+                       double shift, double* h, int ldh)
+{
+  DLA_T("dla_expand_project");
+  if (!c || !basis || !abasis || !h || (mode != 0 && mode != 1) || m < 0 || k <= 0) return fail(c, DLA_ERR_ARG, "dla_expand_project: bad argument");
+  double* u = basis + (size_t)n * m;
+  const long long nglob = global_rows(c, n);
+  const bool builtin = (void*)fn == (void*)&dla_synth_matvec || (void*)fn == (void*)&dla_spmm_matvec;
+  const int order = builtin ? 2 : c->callback_order;
+  if (c->run_ahead && c->callbacks_on_device && order != 1 && m > 0) {
+    dla::OrthoReport rep;
+    int st = c->eng->ortho_chain_begin(n, m, k, basis, basis, u, &rep);
+    if (st) return engfail(c, st);
+    if (rep.handled) {
+      // in flight: the operator and the projection follow on the same stream; the projection's wait covers the chain
+      int sta = expand_apply_project(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
+      st = c->eng->ortho_chain_finish(&rep, sta == DLA_OK);
+      if (st) return engfail(c, st);
+      if (sta) return sta;
+      if (rep.status == 1 && rep.clean) {
+        if (c->verbose_ortho)
+          std::printf("  [dla] ortho_vs_x (device chain): %d outer iterations, %d macro iterations, status %d\n", rep.outer_its,
+                      rep.macro_its, rep.status);
+        return DLA_OK;
+      }
+      // the chain took more launches than planned, or stopped: what ran behind it has read an unfinished block
+      st = ortho_vs_x_after_chain(c, c->eng, c->row0, nglob, n, m, k, basis, basis, u, &rep);
+      if (st) return st;
+      return expand_apply_project(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
+    }
+    st = ortho_vs_x_after_chain(c, c->eng, c->row0, nglob, n, m, k, basis, basis, u, nullptr);
+    if (st) return st;
+    return expand_apply_project(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
+  }
+  int st = ortho_vs_x_impl(c, c->eng, c->row0, nglob, n, m, k, basis, basis, u);
+  if (st) return st;
+  return expand_apply_project(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
 }
 
 int dla_call_precnd(dla_ctx* c, dla_precnd_fn fn, int n, int m, double fac, const double* x, double* px)

@@ -240,6 +240,15 @@ module diaglib
       integer(c_int), value :: n, m
       integer(c_int) :: st
     end function
+    function dla_expand_project(ctx,mode,n,m,k,basis,abasis,fn,shift,h,ldh) bind(C,name='dla_expand_project') result(st)
+      import :: c_ptr, c_funptr, c_int, c_double
+      type(c_ptr), value :: ctx, basis, abasis
+      type(c_funptr), value :: fn
+      integer(c_int), value :: mode, n, m, k, ldh
+      real(c_double), value :: shift
+      real(c_double) :: h(*)
+      integer(c_int) :: st
+    end function
     function dla_call_precnd(ctx,fn,n,m,fac,x,px) bind(C,name='dla_call_precnd') result(st)
       import :: c_ptr, c_funptr, c_int, c_double
       type(c_ptr), value :: ctx, x, px
@@ -615,7 +624,7 @@ contains
     real(dp), allocatable :: h(:,:), y(:,:), theta(:)
     real(dp)        :: t_begin(2), t_end(2)
     integer         :: it, sweeps, kept, col, first, j
-    logical         :: patch_kept
+    logical         :: patch_kept, projected
 !
     call env_open(e, n, n_max, evec)
 !
@@ -652,6 +661,7 @@ contains
 !
     kept       = 0            ! locked Ritz vectors carried over a restart
     patch_kept = .false.
+    projected  = .false.      ! the newest block already has its operator image and its columns of h (dla_expand_project)
     sweeps     = max_iter
     if (verbose) then
       if (with_metric) then
@@ -668,14 +678,17 @@ contains
 !     `kept` zero columns past the Ritz block, exactly like the reference's offsets (:1685, SURVEY App. B 4).
 !
       col = s%head + kept
-      call lap_start(w)
-      call chk(e%ctx, dla_call_matvec(e%ctx, op, n, s%act, colp(basis,n,col), colp(abasis,n,col)), 'matvec')
-      call lap_charge(w, w%mv)
+      if (.not.projected) then
+        call lap_start(w)
+        call chk(e%ctx, dla_call_matvec(e%ctx, op, n, s%act, colp(basis,n,col), colp(abasis,n,col)), 'matvec')
+        call lap_charge(w, w%mv)
+!
+!       new columns of the projected matrix (:1691); the kept roots enter through their Ritz values (:1696-1702)
+!
+        call chk(e%ctx, dla_gram(e%ctx, n, s%cols, basis, s%act, colp(abasis,n,col), h(1,col), s%ld), 'projection')
+      end if
+      projected = .false.
       e%op_cols = e%op_cols + s%act
-!
-!     new columns of the projected matrix (:1691); the kept roots enter through their Ritz values (:1696-1702)
-!
-      call chk(e%ctx, dla_gram(e%ctx, n, s%cols, basis, s%act, colp(abasis,n,col), h(1,col), s%ld), 'projection')
       if (patch_kept) then
         do j = 1, kept
           h(j,j) = theta(j)
@@ -724,10 +737,18 @@ contains
           call chk(e%ctx, dla_b_ortho_vs_x(e%ctx, n, s%cols, s%act, basis, bbasis, colp(basis,n,s%head)), 'b_ortho_vs_x')
           call chk(e%ctx, dla_call_matvec(e%ctx, metric, n, s%act, colp(basis,n,s%head), colp(bbasis,n,s%head)), 'bvec')
           call chk(e%ctx, dla_b_ortho(e%ctx, n, s%act, colp(basis,n,s%head), colp(bbasis,n,s%head)), 'b_ortho')
+          call lap_charge(w, w%ortho)
         else
-          call chk(e%ctx, dla_ortho_vs_x(e%ctx, n, s%cols, s%act, basis, colp(basis,n,s%head)), 'ortho_vs_x')
+!
+!         standard problem: the new block is orthogonalised against the basis (:1790), and the operator on it (:1685) and
+!         its columns of the projected matrix (:1691) -- the head of the next sweep -- follow in the same call, so that
+!         the three run back to back on the device (dla_expand_project)
+!
+          call chk(e%ctx, dla_expand_project(e%ctx, 0_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
+                                             h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
+          projected = .true.
+          call lap_charge(w, w%ortho)
         end if
-        call lap_charge(w, w%ortho)
       else
 !
 !       basis full: restart from the current Ritz vectors (:1796-1824)
@@ -819,6 +840,7 @@ contains
     real(dp), allocatable :: h(:,:), theta(:), cx(:,:), cp(:,:), seen(:,:,:)
     real(dp)        :: t_begin(2), t_end(2)
     integer         :: it, sweeps, width, live, c_x, c_p, c_w, wide, bet
+    logical         :: projected           ! the W block already has its operator image and S^T A S is in h (dla_expand_project)
 !
     op     = c_funloc(matvec)
     prec   = c_funloc(precnd)
@@ -840,6 +862,7 @@ contains
     h    = zero
     seen = zero
     ok   = .false.
+    projected = .false.
     call clock_now(t_begin)
 !
 !   guess (:295), for the generalised problem made B-orthonormal (:299-302)
@@ -878,10 +901,15 @@ contains
 !
 !     A on the W block (:394-397), then all of S^T A S for S = [X | P | W] (:401-403); no P block in the first sweep
 !
-      call apply_operator(c_w, live)
       width = n_max + 2*live
       if (it.eq.1) width = 2*n_max
-      call chk(e%ctx, dla_gram_lower(e%ctx, n, width, sp(rd), asp(rd), h, wide), 'projection')
+      if (projected) then
+        e%op_cols = e%op_cols + live          ! (orthogonalise_w has applied the operator and projected already)
+      else
+        call apply_operator(c_w, live)
+        call chk(e%ctx, dla_gram_lower(e%ctx, n, width, sp(rd), asp(rd), h, wide), 'projection')
+      end if
+      projected = .false.
       call lap_start(w)
       call need_eigensolver(dla_syev_lowest('l', width, h, wide, theta, n_max))
       call lap_charge(w, w%diag)
@@ -1035,7 +1063,10 @@ contains
         call chk(e%ctx, dla_call_matvec(e%ctx, metric, n, k, colp(sp(rd),n,m+1), colp(bsp(rd),n,m+1)), 'bvec')
         call chk(e%ctx, dla_b_ortho(e%ctx, n, k, colp(sp(rd),n,m+1), colp(bsp(rd),n,m+1)), 'b_ortho')
       else
-        call chk(e%ctx, dla_ortho_vs_x(e%ctx, n, m, k, sp(rd), colp(sp(rd),n,m+1)), 'ortho_vs_x')
+!       (the operator on the W block and S^T A S -- the head of the next sweep -- in the same call: dla_expand_project)
+        call chk(e%ctx, dla_expand_project(e%ctx, 1_c_int, n, m, k, sp(rd), asp(rd), op, shift, h, wide), &
+                 'ortho_vs_x + matvec + projection')
+        projected = .true.
       end if
       call lap_charge(w, w%ortho)
     end subroutine orthogonalise_w

@@ -82,6 +82,9 @@ enum {
                                       as failed in every rank's mailbox: all ranks return DLA_ERR_COMM at their next host wait and
                                       the transport stays down until dla_p2p_detach + a fresh export.  Callers whose ranks can be
                                       further apart than this (host-mode callbacks of unequal length) raise it or use RCCL  */
+  DLA_OPT_RUN_AHEAD = 10,          /* dla_expand_project: 1 (default) enqueue the operator and the projection sweep behind the
+                                      orthogonalisation chain and read the chain's report at THEIR host wait; 0 = one call after
+                                      the other (A/B and debugging)                                                            */
   DLA_OPT_TUNE0 = 100              /* 100..107: kernel-shape experiment knobs for the interleaved A/B tools
                                       (tools/tune_*.py, tools/kernel_bench.py); 0 = the shipped default          */
 };
@@ -202,6 +205,19 @@ int  dla_ritz_residual_p(dla_ctx* ctx, int n, int l, int m, const double* v_dev,
                          const double* y_host, int ldy, const double* eig, int n_res, const int* skip,
                          double* evec_dev, double* r_dev, double* avy_dev, double* rnorm,
                          int k2, const double* c2_host, int ldc2, double* p_dev, double* ap_dev);
+/* Expansion step of the Davidson and LOBPCG drivers on the contiguous panels basis = [X | U] (n x (m+k)) and
+ * abasis = [AX | AU]:   ortho_vs_x(X, U)  (diaglib.f90:1790, 358-366, 523-529),  AU = A U [+ shift U]  (the caller's matvec,
+ * :1685, 394-397; daxpy :397)  and the projection --
+ *   mode 0 (Davidson, :1691):  h(1:m+k, 1:k) = [X | U]^T AU, the new columns of the projected matrix;
+ *   mode 1 (LOBPCG, :401-403): h = lower triangle of [X | U]^T [AX | AU], (m+k) x (m+k).
+ * Same result as dla_ortho_vs_x + dla_call_matvec (+ dla_axpy) + dla_gram / dla_gram_lower.  With device-mode callbacks
+ * that need no host wait (DLA_OPT_CALLBACK_ORDER 0 or 2) the three are enqueued back to back and the chain's report is
+ * read at the projection's host wait: one wait per expansion instead of two.  When the chain did not end with the planned
+ * launches (first call of a shape, or a block that needs more passes than the previous one of its width) the
+ * orthogonalisation is completed and the operator and the projection are simply repeated on the finished block -- the
+ * operator must therefore be a pure function of its input (it is called a second time for the same block then). */
+int  dla_expand_project(dla_ctx* ctx, int mode, int n, int m, int k, double* basis_dev, double* abasis_dev,
+                        dla_matvec_fn matvec, double shift, double* h_host, int ldh);
 /* y += alpha x over len contiguous doubles.  daxpy at diaglib.f90:312,397 (LOBPCG shift). */
 int  dla_axpy(dla_ctx* ctx, size_t len, double alpha, const double* x_dev, double* y_dev);
 /* sqrt(sum x^2) over len contiguous doubles (all ranks).  dnrm2 at diaglib.f90:3749, 3268. */

@@ -71,7 +71,7 @@ def test_headline_line_finds_its_counters():
     r = d["roofline"]
     assert r["traffic"] is not None, r["kernel"]
     assert 0.9 < r["traffic"] / r["alg_bytes_per_launch"] < 1.1          # no wasted re-reads
-    assert d["config"]["iters"] == 9 and d["host"]["host_syncs"] / (d["steps"] + d["warmup"]) <= 35
+    assert d["config"]["iters"] == 9 and d["host"]["host_syncs"] / (d["steps"] + d["warmup"]) <= 20
     assert r["step"]["sweeps_only"]["frac"] > r["step"]["frac"]
 
 

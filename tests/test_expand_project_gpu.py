@@ -1,0 +1,159 @@
+"""dla_expand_project (the drivers' expansion step: ortho_vs_x + operator + projection in one call, reference
+diaglib.f90:1790 + 1685 + 1691 for Davidson, :523-529 + 394-397 + 401-403 for LOBPCG) against the three separate entry
+points it replaces, on the same inputs.
+
+With device-mode callbacks the call enqueues the operator and the projection sweep BEHIND the orthogonalisation chain and
+reads the chain's report at the projection's host wait.  When the chain needs more launches than planned (first call of a
+shape, rank-deficient block) what ran behind it is repeated on the finished block: the results must be the same either way,
+bit for bit -- the run-ahead changes the order in which the host learns things, not one kernel's arithmetic."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from diaglib_amd import capi
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+def _setup(ctx, n):
+    ctx.set_shard(n, 0)
+    ctx.synth_setup(n, 0, n)
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+
+
+def _blocks(rng, n, m, k, kind):
+    x = np.linalg.qr(rng.standard_normal((n, m)))[0]
+    if kind == "random":
+        u = rng.standard_normal((n, k))
+    elif kind == "near_span":
+        u = x @ rng.standard_normal((m, k)) + 1e-7 * rng.standard_normal((n, k))
+    else:
+        u = rng.standard_normal((n, k)); u[:, -1] = u[:, 0] + u[:, 1]
+    return np.asfortranarray(x), np.asfortranarray(u)
+
+
+def _apply(ctx, x):
+    """A x through the built-in operator (at most 64 columns per call)"""
+    px = ctx.panel(x); pax = ctx.panel(np.zeros_like(x))
+    for c0 in range(0, x.shape[1], 48):
+        w = min(48, x.shape[1] - c0)
+        ctx.synth_matvec(px.col(c0, w), pax.col(c0, w))
+    return pax.download()
+
+
+def _run(ctx, mode, x, u, ax, shift, ahead):
+    n, m = x.shape
+    k = u.shape[1]
+    ctx.set_option(capi.OPT_RUN_AHEAD, 1 if ahead else 0)
+    basis = ctx.panel(np.asfortranarray(np.hstack([x, u])))
+    abasis = ctx.panel(np.asfortranarray(np.hstack([ax, np.zeros((n, k))])))
+    s0 = ctx.stats()["host_syncs"]
+    h = ctx.expand_project(mode, basis, abasis, m, k, capi.fn_address("dla_synth_matvec"), shift)
+    syncs = ctx.stats()["host_syncs"] - s0
+    return basis.download(), abasis.download(), h, syncs
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("n,m,k,kind", [(4000, 26, 13, "random"), (4000, 52, 11, "near_span"), (3000, 26, 13, "rank_deficient"),
+                                        (2500, 74, 37, "random"), (3001, 21, 8, "random")])
+def test_expand_project_equals_the_three_calls(ctx, rng, mode, n, m, k, kind):
+    _setup(ctx, n)
+    try:
+        x, u = _blocks(rng, n, m, k, kind)
+        ax = _apply(ctx, x)
+        shift = 0.25 if mode == 1 else 0.0
+        # reference result: the separate entry points
+        basis = ctx.panel(np.asfortranarray(np.hstack([x, u])))
+        abasis = ctx.panel(np.asfortranarray(np.hstack([ax, np.zeros((n, k))])))
+        bx, bu = basis.col(0, m), basis.col(m, k)
+        ctx.ortho_vs_x(bx, bu)
+        ctx.synth_matvec(bu, abasis.col(m, k))
+        if shift:
+            au = abasis.download(); au[:, m:] += shift * basis.download()[:, m:]
+            abasis = ctx.panel(np.asfortranarray(au))
+        want_b, want_ab = basis.download(), abasis.download()
+        if mode == 0:
+            want_h = ctx.gram(basis, abasis.col(m, k))
+        else:
+            want_h = ctx.gram_lower(basis, abasis)
+        # the fused call: first time for this shape in this order (plan from history or the default), then again with the
+        # history it has just written, then with the run-ahead switched off
+        for ahead in (True, True, False):
+            got_b, got_ab, got_h, syncs = _run(ctx, mode, x, u, ax, shift, ahead)
+            assert np.array_equal(got_b[:, :m], x)
+            assert np.abs(got_b[:, m:] - want_b[:, m:]).max() < 1e-13, kind
+            q = got_b[:, m:]
+            assert np.abs(q.T @ q - np.eye(k)).max() < 50 * EPS and np.abs(x.T @ q).max() < 50 * EPS
+            scale = np.abs(want_ab[:, m:]).max()
+            assert np.abs(got_ab[:, m:] - want_ab[:, m:]).max() < 1e-12 * scale
+            if mode == 0:
+                assert np.abs(got_h - want_h).max() < 1e-11 * np.abs(want_h).max()
+            else:
+                assert np.abs(np.tril(got_h) - np.tril(want_h)).max() < 1e-11 * np.abs(want_h).max()
+        # projection of what is stored: h is consistent with the panels the call left behind
+        gb, gab = got_b, got_ab
+        ref_h = gb.T @ gab[:, m:] if mode == 0 else np.tril(gb.T @ gab)
+        assert np.abs((got_h if mode == 0 else np.tril(got_h)) - ref_h).max() < 1e-10 * np.abs(ref_h).max()
+    finally:
+        ctx.set_option(capi.OPT_RUN_AHEAD, 1)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
+
+
+def test_expand_project_one_wait_when_the_plan_holds(ctx, rng):
+    """Steady state (the plan remembered from the previous block of this width fits): ONE host wait for the whole expansion --
+    the projection's -- against two for the separate calls; and a block that takes another route (rank deficient after
+    well-conditioned ones) costs more waits and a repeated operator call, not a different result."""
+    n, m, k = 6000, 39, 13
+    _setup(ctx, n)
+    try:
+        x, u = _blocks(rng, n, m, k, "random")
+        ax = _apply(ctx, x)
+        _run(ctx, 0, x, u, ax, 0.0, True)                      # writes the history
+        _, _, _, syncs = _run(ctx, 0, x, u, ax, 0.0, True)
+        assert syncs == 1, syncs
+        _, _, _, syncs_off = _run(ctx, 0, x, u, ax, 0.0, False)
+        assert syncs_off == 2, syncs_off
+        x2, u2 = _blocks(rng, n, m, k, "rank_deficient")
+        b_on, ab_on, h_on, syncs_rd = _run(ctx, 0, x2, u2, ax, 0.0, True)
+        assert syncs_rd >= 2
+        b_off, ab_off, h_off, _ = _run(ctx, 0, x2, u2, ax, 0.0, False)
+        assert np.array_equal(b_on, b_off) and np.array_equal(ab_on, ab_off) and np.array_equal(h_on, h_off)
+    finally:
+        ctx.set_option(capi.OPT_RUN_AHEAD, 1)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
+
+
+def test_expand_project_with_a_user_device_callback_is_repeated_not_skipped(ctx, rng):
+    """A caller's own device-mode operator (ordering contract 2: it launches on the engine's stream) is called once when
+    the chain ends as planned and a second time for the same block when it does not."""
+    n, m, k = 3000, 26, 13
+    _setup(ctx, n)
+    calls = []
+
+    def op(pn, pm, px, pax):
+        calls.append(pm[0])
+        ctx.lib.dla_synth_matvec(pn, pm, px, pax)
+
+    cb = capi.MATVEC_T(op)
+    try:
+        ctx.set_option(capi.OPT_CALLBACK_ORDER, 2)
+        x, u = _blocks(rng, n, m, k, "random")
+        ax = _apply(ctx, x)
+        for kind, expect in (("random", None), ("random", 1), ("rank_deficient", 2)):
+            x2, u2 = (x, u) if kind == "random" else _blocks(rng, n, m, k, kind)
+            basis = ctx.panel(np.asfortranarray(np.hstack([x2, u2])))
+            abasis = ctx.panel(np.asfortranarray(np.hstack([ax, np.zeros((n, k))])))
+            calls.clear()
+            ctx.expand_project(0, basis, abasis, m, k, C.cast(cb, C.c_void_p).value, 0.0)
+            if expect is not None:
+                assert len(calls) == expect and all(c == k for c in calls), (kind, calls)
+            q = basis.download()[:, m:]
+            assert np.abs(q.T @ q - np.eye(k)).max() < 50 * EPS
+    finally:
+        ctx.set_option(capi.OPT_CALLBACK_ORDER, 0)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
