@@ -186,9 +186,11 @@ struct ApiTimer {
   static void add(const char* name, double dt);
   static void report();
   static double now();
+  static void enter(const char* name, double t);     // charges the time since the previous entry point returned to "<prev> .. <name>"
+  static void leave(const char* name, double t);
   const char* name; double t0;
-  explicit ApiTimer(const char* n) : name(n), t0(on() ? now() : 0.0) {}
-  ~ApiTimer() { if (on()) add(name, now() - t0); }
+  explicit ApiTimer(const char* n) : name(n), t0(on() ? now() : 0.0) { if (on()) enter(name, t0); }
+  ~ApiTimer() { if (on()) { const double t1 = now(); add(name, t1 - t0); leave(name, t1); } }
 };
 #define DLA_CAT2(a, b) a##b
 #define DLA_CAT(a, b) DLA_CAT2(a, b)

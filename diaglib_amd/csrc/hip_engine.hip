@@ -2786,6 +2786,7 @@ struct HipEngine : dla::Engine {
   bool mirror_fresh = false;         // the last cross-rank sum already wrote h_small (peer-to-peer exchange)
   int small_to_host(size_t count)
   {
+    DLA_T("  wait for a small result");
     if (!local_only && (nranks > 1 || comm || p2p.on) && !mirror_fresh)
       HIPCHK(hipMemcpyAsync(h_small, d_small, sizeof(double) * count, hipMemcpyDeviceToHost, st));
     mirror_fresh = false;

@@ -28,6 +28,14 @@ namespace { std::map<std::string, std::pair<double, long>>& api_tab() { static s
 bool ApiTimer::on() { static const bool v = std::getenv("DIAGLIB_AMD_HOSTTIME") != nullptr; return v; }
 double ApiTimer::now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 void ApiTimer::add(const char* name, double dt) { auto& e = api_tab()[name]; e.first += dt; e.second += 1; }
+namespace { const char* g_prev_api = nullptr; double g_prev_exit = 0.0; int g_api_depth = 0; }
+void ApiTimer::enter(const char* name, double t)
+{
+  // (only outermost entry points, and only gaps below 10 ms: the caller's own work between solves is not ours to report)
+  if (g_api_depth++ == 0 && g_prev_api && name[0] != ' ' && t - g_prev_exit < 0.01)
+    add((std::string("  caller between ") + g_prev_api + " .. " + name).c_str(), t - g_prev_exit);
+}
+void ApiTimer::leave(const char* name, double t) { if (--g_api_depth == 0 && name[0] != ' ') { g_prev_api = name; g_prev_exit = t; } }
 void ApiTimer::report()
 {
   if (!on()) return;
