@@ -157,3 +157,15 @@ def test_expand_project_with_a_user_device_callback_is_repeated_not_skipped(ctx,
         ctx.set_option(capi.OPT_CALLBACK_ORDER, 0)
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
         ctx.set_shard(-1, 0)
+
+
+def test_whole_solves_give_the_same_bits_with_and_without_run_ahead():
+    """tools/fuzz_run_ahead.py: random Davidson / LOBPCG solves (odd and even n, one to three column tiles, shifts, restarts) on the
+    device-resident operator, run-ahead on / off / on: eigenvalues, eigenvectors and iteration counts compare equal bit for
+    bit (30 cases of seed 1 pass as well; 8 here to keep the suite short)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_run_ahead.py"), "8", "5"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "8 cases, 0 failures" in p.stdout
