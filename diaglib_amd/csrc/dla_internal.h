@@ -152,6 +152,11 @@ struct Engine : BlockOps {
   virtual int stage_wait(int /*slot*/) { return 0; }
   virtual int stage_h2d(void* dev, const void* host, size_t bytes) { return h2d(dev, host, bytes); }
   virtual int stage_end() { return 0; }
+  // projection of a block that arrives in column chunks (dla_expand_project with host-mode callbacks): chunk c0 .. c0 + kc - 1
+  // of C = X^T U (l x k_total) behind the uploads issued so far, no host wait; collect waits once and copies C out
+  virtual bool gram_chunks_ok(int, int, int) { return false; }
+  virtual int gram_chunk(int, int, const double*, int, int, int, const double*) { return DLA_ERR_ARG; }
+  virtual int gram_chunks_collect(int, int, double*, int) { return DLA_ERR_ARG; }
 
   // pinned host staging for host-mode callbacks
   virtual int host_alloc(size_t bytes, void** p) = 0;

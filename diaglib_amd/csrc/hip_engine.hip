@@ -3640,12 +3640,44 @@ struct HipEngine : dla::Engine {
         HIPCHK(hipMalloc((void**)&d_lvl2, lvl2_bytes));
       }
       if (passes * slots > 4096) { err = "gram: too many output tiles"; return DLA_ERR_ARG; }
-      GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small, pred_phase ? nullptr : h_small_dev, blocks_per_pass, l, k, tlw, kt, px,
+      GramReduceArgs ra{d_partial, d_lvl2, d_ticket, d_small + small_off, pred_phase ? nullptr : h_small_dev + small_off, blocks_per_pass, l, k, tlw, kt, px,
                         pred_phase, pred_want, 0, passes * slots, d_ticket + 4096, OrthoTailArgs{}};
       launch_reduce(ra, dim3(passes * slots, groups));
     }
     HIPCHK(hipGetLastError());
+    if (in_chunk) return DLA_OK;           // (column chunk of a larger result: one rank only, gram_chunk)
     return allreduce_dev(d_small, l * k, 0, h_small);
+  }
+
+  // ---- projection of a block that arrives in column chunks (host-mode callbacks: SURVEY 8f row 4, reference README.md:34-35).
+  // C(:, c0 : c0 + kc) = X^T U_chunk is enqueued behind the uploads issued so far and lands in its columns of the l x k result;
+  // the sweep runs while the caller's routine works on the next chunk.  gram_chunks_collect waits once for all of them.
+  size_t small_off = 0;              // element offset of the result of the Gram being launched inside d_small / h_small
+  hipEvent_t ev_chunk = nullptr;
+  bool gram_chunks_ok(int n, int l, int k) override
+  {
+    (void)n;
+    return !hook && !comm && !p2p.on && (local_only || nranks <= 1) && l > 0 && k > 0 && pred_phase == nullptr;
+  }
+  int gram_chunk(int n, int l, const double* x, int k_total, int c0, int kc, const double* u_chunk) override
+  {
+    if (c0 == 0) { int stc = ensure_small(sizeof(double) * (size_t)l * k_total); if (stc) return stc; }
+    if (!ev_chunk) HIPCHK(hipEventCreateWithFlags(&ev_chunk, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev_chunk, st_up));
+    HIPCHK(hipStreamWaitEvent(st, ev_chunk, 0));
+    small_off = (size_t)c0 * l;
+    in_chunk = true;
+    int stc = gram_dev(n, l, x, kc, u_chunk);
+    in_chunk = false; small_off = 0;
+    return stc;
+  }
+  bool in_chunk = false;
+  int gram_chunks_collect(int l, int k, double* c_host, int ldc) override
+  {
+    int stc = small_to_host((size_t)l * k);
+    if (stc) return stc;
+    for (int j = 0; j < k; ++j) std::memcpy(c_host + (size_t)j * ldc, h_small + (size_t)j * l, sizeof(double) * l);
+    return DLA_OK;
   }
 
   int gram_lower(int n, int l, const double* x, const double* u, double* c_host, int ldc) override

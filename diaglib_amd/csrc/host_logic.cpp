@@ -950,7 +950,8 @@ static int ensure_stage(dla_ctx* c, size_t bytes)
 // The staging buffers must outlive the uploads still in flight when this returns: they are only reused by the next
 // callback, whose stage_begin() follows those uploads on the engine's stream (ensure_stage reallocations drain first).
 static int staged_callback(dla_ctx* c, int n, int m, const double* x, double* y,
-                           const std::function<void(int, const double*, double*)>& call)
+                           const std::function<void(int, const double*, double*)>& call,
+                           const std::function<int(int, int)>& after_upload = nullptr, int min_chunks = 1)
 {
   const size_t col = sizeof(double) * (size_t)n;
   int st = ensure_stage(c, col * m);
@@ -959,7 +960,7 @@ static int staged_callback(dla_ctx* c, int n, int m, const double* x, double* y,
   // host operator pays its fixed traffic (its own matrix) once per call -- measured on the benchmark with the harness'
   // operator (tools/host_mode_probe.py): 2 chunks are the optimum, 4 and more are slower than no pipeline at all
   int nchunk = (col * m >= ((size_t)64 << 20)) ? 2 : 1;
-  nchunk = std::min(nchunk, m);
+  nchunk = std::min(std::max(nchunk, min_chunks), m);
   if (c->stage_chunks > 0) nchunk = std::min(c->stage_chunks, m);
   const int per = (m + nchunk - 1) / nchunk;
   st = c->eng->stage_begin();
@@ -980,6 +981,7 @@ static int staged_callback(dla_ctx* c, int n, int m, const double* x, double* y,
     DLA_T("  stage h2d (enqueue)");
     st = c->eng->stage_h2d(y + (size_t)c0 * n, c->stage_y + (size_t)c0 * n, col * mc);
     if (st) return engfail(c, st);
+    if (after_upload) { st = after_upload(c0, mc); if (st) return st; }     // (device work on this chunk, behind its upload)
   }
   return engfail(c, c->eng->stage_end());
 }
@@ -1053,6 +1055,15 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
   }
   int st = ortho_vs_x_impl(c, c->eng, c->row0, nglob, n, m, k, basis, basis, u);
   if (st) return st;
+  if (!c->callbacks_on_device && mode == 0 && shift == 0.0 && k >= 2 && c->eng->gram_chunks_ok(n, m + k, k)) {
+    // host-mode callback (the block goes through the caller's routine in column chunks): the projection of a chunk is
+    // enqueued behind its upload and runs while the caller's routine works on the next one
+    double* au = abasis + (size_t)n * m;
+    st = staged_callback(c, n, k, u, au, [&](int mc, const double* hx, double* hy) { fn(&n, &mc, hx, hy); },
+                         [&](int c0, int mc) { return engfail(c, c->eng->gram_chunk(n, m + k, basis, k, c0, mc, au + (size_t)c0 * n)); });
+    if (st) return st;
+    return engfail(c, c->eng->gram_chunks_collect(m + k, k, h, ldh));
+  }
   return expand_apply_project(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
 }
 

@@ -176,6 +176,28 @@ def test_dense_reference_matrix_host_callbacks(ctx, oracle, rng, solver, guess_k
     assert np.allclose(eig[:n_targ], np.linalg.eigvalsh(a)[:n_targ], rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("chunks", [2, 3, 5])
+def test_host_callbacks_in_column_chunks_overlap_the_projection(ctx, oracle, chunks):
+    """Drop-in mode with the block cut into column chunks (DLA_OPT_STAGE_CHUNKS; automatic for blocks of 64 MB and more): every
+    chunk flows download | caller's routine | upload, and the projection sweep of a chunk (its columns of [X | U]^T AU,
+    reference diaglib.f90:1691) runs behind its upload while the caller's routine has the next chunk.
+    Same history as the oracle, eigenvalues to 1e-12, and as many calls of the caller's routine as chunks."""
+    n, n_targ, n_max = 3000, 6, 11
+    oracle.dense_setup(n)
+    mv, pc = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd")
+    g = np.zeros((n, n_max), order="F"); g[np.arange(n_max), np.arange(n_max)] = 1.0
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+    ctx.set_option(capi.OPT_STAGE_CHUNKS, chunks)
+    try:
+        eig, v, ok, info = ctx.davidson_driver(n, n_targ, n_max, 100, 1e-8, 20, 0.0, mv, pc, g)
+    finally:
+        ctx.set_option(capi.OPT_STAGE_CHUNKS, 0)
+    eo, vo, oko, tr = oracle.davidson(n, n_targ, n_max, 100, 1e-8, 20, 0.0, mv, pc, g)
+    assert ok and oko and info["iters"] == tr.iters and info["matvec_cols"] == tr.matvec_cols
+    assert np.allclose(eig[:n_targ], eo[:n_targ], rtol=1e-12, atol=0)
+    _cmp_vecs(v, vo, n_targ, 1e-6)
+
+
 def test_davidson_python_callbacks_and_restarts(ctx, oracle, rng):
     """max_dav=10 forces several restarts; callbacks are Python callables."""
     n, n_targ, n_max = 1000, 10, 15
