@@ -1735,6 +1735,9 @@ __device__ __forceinline__ v4d mfma16(double a, double b, v4d c) { return __buil
 // (pivot), a reciprocal (hardware estimate + two Newton steps), three selects, one multiply, two MFMAs.
 // One step, row j = 4 RR + gj: the register index RR is a template argument (the loop branches to one of four copies of the step;
 // a register picked by a run-time index costs a dozen selects per access).
+#ifndef CHOL_BLOCKED
+#define CHOL_BLOCKED 1
+#endif
 template <int RR>
 __device__ __forceinline__ void ldl_inv_step(int j, double d, v4d& a, v4d& x, v4d& drow, int c, int g)
 {
@@ -1751,6 +1754,71 @@ __device__ __forceinline__ void ldl_inv_step(int j, double d, v4d& a, v4d& x, v4
   x = mfma16(ua, xb, x);      // X[i][c'] -= Lu[i][j] X[j][c'],     i > j
 }
 
+// The same factorisation four rows at a time.  The rows 4B .. 4B+3 of the working matrix are the four 16-lane groups of register
+// B, so the 4 x 4 diagonal block is ten readlanes away from every lane; its LDL^T factors are computed by all lanes alike
+// (uniform values), the four rows are gathered per column with three cross-group shuffles and eliminated against each other in
+// registers, and the trailing matrix gets ONE rank-4 update: v_mfma_f64_16x16x4 with A(i, q) = -u_q[i] / d_q and B(q, c) = u_q[c]
+// is exactly that (operand index q = lane >> 4 = the row's group).  L^-1 follows with the same A operand, as before.  Four block
+// steps of a few hundred cycles each replace sixteen dependent row steps (13 k cycles at k = 13).
+__device__ __forceinline__ double rcp_nr(double d)
+{
+  double inv = __builtin_amdgcn_rcp(d);
+  inv = fma(fma(-d, inv, 1.0), inv, inv);
+  return fma(fma(-d, inv, 1.0), inv, inv);
+}
+template <int B>
+__device__ __forceinline__ int ldl_inv_block(int k, v4d& a, v4d& x, v4d& drow, int c, int g, double& dlo, double& dhi)
+{
+  constexpr int j0 = 4 * B;
+  const double ab = a[B], xb = x[B];
+  // upper triangle of the diagonal block: D[p][q] = A[j0 + p][j0 + q] sits in lane 16 p + j0 + q
+  const double d00 = rlane(ab, j0), d01 = rlane(ab, j0 + 1), d02 = rlane(ab, j0 + 2), d03 = rlane(ab, j0 + 3);
+  const double d11 = rlane(ab, 16 + j0 + 1), d12 = rlane(ab, 16 + j0 + 2), d13 = rlane(ab, 16 + j0 + 3);
+  const double d22 = rlane(ab, 32 + j0 + 2), d23 = rlane(ab, 32 + j0 + 3);
+  const double d33 = rlane(ab, 48 + j0 + 3);
+  // the rows of the block at this lane's column, and the rows of X (independent of the scalar chain below)
+  const double a0 = __shfl(ab, c, 64), a1 = __shfl(ab, 16 + c, 64), a2 = __shfl(ab, 32 + c, 64), a3 = __shfl(ab, 48 + c, 64);
+  const double x0 = __shfl(xb, c, 64), x1 = __shfl(xb, 16 + c, 64), x2 = __shfl(xb, 32 + c, 64), x3 = __shfl(xb, 48 + c, 64);
+  const double p0 = d00;
+  if (!(p0 > 0.0) || !isfinite(p0)) return j0 + 1;
+  const double i0 = rcp_nr(p0);
+  const double l10 = d01 * i0, l20 = d02 * i0, l30 = d03 * i0;
+  const double p1 = fma(-l10, d01, d11), e12 = fma(-l10, d02, d12), e13 = fma(-l10, d03, d13);
+  if (!(p1 > 0.0) || !isfinite(p1)) return j0 + 2;
+  const double i1 = rcp_nr(p1);
+  const double l21 = e12 * i1, l31 = e13 * i1;
+  const double p2 = fma(-l21, e12, fma(-l20, d02, d22)), e23 = fma(-l21, e13, fma(-l20, d03, d23));
+  if (!(p2 > 0.0) || !isfinite(p2)) return j0 + 3;
+  const double i2 = rcp_nr(p2);
+  const double l32 = e23 * i2;
+  const double p3 = fma(-l32, e23, fma(-l31, e13, fma(-l30, d03, d33)));
+  if (!(p3 > 0.0) || !isfinite(p3)) return j0 + 4;
+  const double i3 = rcp_nr(p3);
+  // (pivots of the padding rows beyond k are 1 and do not count)
+  dlo = fmin(dlo, fmin(fmin(p0, j0 + 1 < k ? p1 : p0), fmin(j0 + 2 < k ? p2 : p0, j0 + 3 < k ? p3 : p0)));
+  dhi = fmax(dhi, fmax(fmax(p0, j0 + 1 < k ? p1 : p0), fmax(j0 + 2 < k ? p2 : p0, j0 + 3 < k ? p3 : p0)));
+  // eliminated rows u_q = row q - sum_{s<q} l_qs u_s, the same for X
+  const double u0 = a0;
+  const double u1 = fma(-l10, u0, a1);
+  const double u2 = fma(-l21, u1, fma(-l20, u0, a2));
+  const double u3 = fma(-l32, u2, fma(-l31, u1, fma(-l30, u0, a3)));
+  const double y0 = x0;
+  const double y1 = fma(-l10, y0, x1);
+  const double y2 = fma(-l21, y1, fma(-l20, y0, x2));
+  const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, x3)));
+  const double um = g == 0 ? u0 : (g == 1 ? u1 : (g == 2 ? u2 : u3));
+  const double ym = g == 0 ? y0 : (g == 1 ? y1 : (g == 2 ? y2 : y3));
+  const double im = g == 0 ? i0 : (g == 1 ? i1 : (g == 2 ? i2 : i3));
+  a[B] = um; x[B] = ym;
+  drow[B] = g == 0 ? p0 : (g == 1 ? p1 : (g == 2 ? p2 : p3));
+  const bool trail = c > j0 + 3;
+  const double ua = trail ? -um * im : 0.0;
+  const double ub = trail ? um : 0.0;
+  a = mfma16(ua, ub, a);      // A[i][c'] -= sum_q u_q[i] u_q[c'] / d_q,  i, c' > j0 + 3
+  x = mfma16(ua, ym, x);      // X[i][c'] -= sum_q Lu[i][j0 + q] X[j0 + q][c'],  i > j0 + 3
+  return 0;
+}
+
 __device__ __forceinline__ int chol_inv16(int k, v4d& a, v4d& x, double& dmax, double& xmax, int lane)
 {
   const int c = lane & 15, g = lane >> 4;
@@ -1759,6 +1827,14 @@ __device__ __forceinline__ int chol_inv16(int k, v4d& a, v4d& x, double& dmax, d
   for (int r = 0; r < 4; ++r) { x[r] = (g + 4 * r == c) ? 1.0 : 0.0; drow[r] = 1.0; }
   double dlo = 1.0e300, dhi = 0.0;
   int info = 0;
+  if (CHOL_BLOCKED) {
+    // (the matrix is the identity beyond k: a partly filled last block factors like any other)
+    info = ldl_inv_block<0>(k, a, x, drow, c, g, dlo, dhi);
+    if (!info && k > 4) info = ldl_inv_block<1>(k, a, x, drow, c, g, dlo, dhi);
+    if (!info && k > 8) info = ldl_inv_block<2>(k, a, x, drow, c, g, dlo, dhi);
+    if (!info && k > 12) info = ldl_inv_block<3>(k, a, x, drow, c, g, dlo, dhi);
+    if (info > k) info = 0;                  // (cannot happen: the padding rows are unit vectors)
+  } else
 #pragma unroll 1
   for (int j = 0; j < k; ++j) {
     const int src = 16 * (j & 3) + j;                        // the lane that holds A[j][j], in register j >> 2
