@@ -856,9 +856,23 @@ int dla_check_guess(dla_ctx* c, int n, int m, double* evec)
 // reductions over ranks (the coefficient blocks are replicated on every rank).
 namespace {
 struct CoeffOps final : dla::BlockOps {
+  // (four columns of the right-hand block per pass over a column of the left-hand one: the loops below sit on the critical
+  //  path of every LOBPCG iteration -- the device waits for the P coefficients -- and at n_max = 37 the plain triple loops
+  //  took 190 us per get_coeffs call)
   int gram(int n, int l, const double* x, int k, const double* u, double* ch, int ldc) override
   {
-    for (int j = 0; j < k; ++j)
+    int j = 0;
+    for (; j + 4 <= k; j += 4) {
+      const double* u0 = u + (size_t)j * n; const double* u1 = u0 + n; const double* u2 = u1 + n; const double* u3 = u2 + n;
+      for (int i = 0; i < l; ++i) {
+        const double* xi = x + (size_t)i * n;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int r = 0; r < n; ++r) { const double xv = xi[r]; a0 += xv * u0[r]; a1 += xv * u1[r]; a2 += xv * u2[r]; a3 += xv * u3[r]; }
+        ch[(size_t)i + (size_t)j * ldc] = a0; ch[(size_t)i + (size_t)(j + 1) * ldc] = a1;
+        ch[(size_t)i + (size_t)(j + 2) * ldc] = a2; ch[(size_t)i + (size_t)(j + 3) * ldc] = a3;
+      }
+    }
+    for (; j < k; ++j)
       for (int i = 0; i < l; ++i) {
         const double* xi = x + (size_t)i * n;
         const double* uj = u + (size_t)j * n;
@@ -868,34 +882,44 @@ struct CoeffOps final : dla::BlockOps {
       }
     return DLA_OK;
   }
+  // out(:, j .. j+3) (+)= X C(:, j .. j+3), the columns of X read once per four output columns
+  static void mul4(int n, int l, const double* x, const double* ch, int ldc, int j, int jn, double* o0, double* o1, double* o2, double* o3)
+  {
+    for (int i = 0; i < l; ++i) {
+      const double* xi = x + (size_t)i * n;
+      const double c0 = ch[(size_t)i + (size_t)j * ldc];
+      const double c1 = jn > 1 ? ch[(size_t)i + (size_t)(j + 1) * ldc] : 0.0;
+      const double c2 = jn > 2 ? ch[(size_t)i + (size_t)(j + 2) * ldc] : 0.0;
+      const double c3 = jn > 3 ? ch[(size_t)i + (size_t)(j + 3) * ldc] : 0.0;
+      if (c0 == 0.0 && c1 == 0.0 && c2 == 0.0 && c3 == 0.0) continue;      // (triangular factors)
+      for (int r = 0; r < n; ++r) { const double xv = xi[r]; o0[r] += xv * c0; o1[r] += xv * c1; o2[r] += xv * c2; o3[r] += xv * c3; }
+    }
+  }
   int gemm(int n, int l, const double* x, int k, const double* ch, int ldc, double* z, int mode) override
   {
-    std::vector<double> col(n);
-    for (int j = 0; j < k; ++j) {
+    std::vector<double> col((size_t)4 * n);
+    for (int j = 0; j < k; j += 4) {
+      const int jn = std::min(4, k - j);
       std::fill(col.begin(), col.end(), 0.0);
-      for (int i = 0; i < l; ++i) {
-        const double cij = ch[(size_t)i + (size_t)j * ldc];
-        const double* xi = x + (size_t)i * n;
-        for (int r = 0; r < n; ++r) col[r] += xi[r] * cij;
+      mul4(n, l, x, ch, ldc, j, jn, &col[0], &col[n], &col[(size_t)2 * n], &col[(size_t)3 * n]);
+      for (int q = 0; q < jn; ++q) {
+        double* zj = z + (size_t)(j + q) * n;
+        const double* cq = &col[(size_t)q * n];
+        if (mode == 0) for (int r = 0; r < n; ++r) zj[r] = cq[r];
+        else if (mode == 1) for (int r = 0; r < n; ++r) zj[r] -= cq[r];
+        else for (int r = 0; r < n; ++r) zj[r] += cq[r];
       }
-      double* zj = z + (size_t)j * n;
-      if (mode == 0) for (int r = 0; r < n; ++r) zj[r] = col[r];
-      else if (mode == 1) for (int r = 0; r < n; ++r) zj[r] -= col[r];
-      else for (int r = 0; r < n; ++r) zj[r] += col[r];
     }
     return DLA_OK;
   }
   int trmm(int n, int k, double* u, const double* w, int ld) override
   {
-    std::vector<double> out((size_t)n * k, 0.0);
-    for (int j = 0; j < k; ++j)
-      for (int i = 0; i < k; ++i) {
-        const double wij = w[(size_t)i + (size_t)j * ld];
-        if (wij == 0.0) continue;
-        const double* ui = u + (size_t)i * n;
-        double* oj = out.data() + (size_t)j * n;
-        for (int r = 0; r < n; ++r) oj[r] += ui[r] * wij;
-      }
+    std::vector<double> out((size_t)n * (k + 3), 0.0);
+    for (int j = 0; j < k; j += 4) {
+      const int jn = std::min(4, k - j);
+      double* o = out.data() + (size_t)j * n;
+      mul4(n, k, u, w, ld, j, jn, o, o + n, o + (size_t)2 * n, o + (size_t)3 * n);
+    }
     std::memcpy(u, out.data(), sizeof(double) * (size_t)n * k);
     return DLA_OK;
   }

@@ -708,7 +708,9 @@ int dla_syev_lowest(char uplo, int n, double* a, int lda, double* w, int m)
   if (n <= 0) return 0;
   if (lda < n) return -1;
   if (m > n) m = n;
-  if (n <= 32 || 2 * m >= n) return dla_syev(uplo, n, a, lda, w);   // small or mostly-wanted: full solve
+  // (measured: the partial solver wins from n = 21 on whatever the share of wanted pairs -- 230 us against 568 at n = 74, m = 37,
+  //  24 against 34 at n = 26, m = 13; below 20 the full one is 20-50 % faster)
+  if (n <= 20 || m >= n) return dla_syev(uplo, n, a, lda, w);   // small or all wanted: full solve
   bool up = (uplo == 'u' || uplo == 'U');
   std::vector<double> s((size_t)n * n), wall, zt((size_t)m * n);
   for (int j = 0; j < n; ++j)

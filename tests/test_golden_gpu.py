@@ -172,10 +172,14 @@ def test_full_size_solve_residual(ctx, solver, n, t, m, max_dav, guess):
             ev = ctx.panel(n, m); ctx.fill_guess(ev, 2, support_rows=6000)
         mv, pc = capi.fn_address("dla_synth_matvec"), capi.fn_address("dla_synth_precnd")
         # reference tolerance semantics (rms < tol, max < 10 tol, diaglib.f90:1741).  At n = 1e7 max|r| of a converged pair
-        # stops falling at a rounding floor of 3.9e-13 (2.2e-13 .. 5.0e-13 from iteration to iteration; measured with
-        # tools/floor_probe.py, see tests/test_floor_gpu.py: the reference stalls at such a floor too, and higher): the
-        # tolerance keeps 10 tol six times above it
-        tol = 1e-13 if n < 10_000_000 else 3e-13
+        # stops falling at a rounding floor: 3.4e-13 (2.6e-13 .. 5.0e-13 from iteration to iteration) while no root is locked
+        # (tools/floor_probe.py, tests/test_floor_gpu.py), and up to 3.7e-12 for the last two roots once the other thirty are
+        # locked and the basis is [X | P | W] with two live columns (measured on the LOBPCG run of this test at tol = 3e-13:
+        # max|r| of roots 31 / 32 stays at 3.65e-12 / 3.76e-12 from iteration 19 on while their rms goes on to 1.2e-15 --
+        # whether a history ends above or below 3e-12 depends on the last bits of the Rayleigh-Ritz eigenvectors).  The
+        # reference's floor is higher still (4.1e-11 at n = 1e6).  tol = 1e-12 keeps 10 tol 2.7 times above the highest floor
+        # seen and 30 times above the unlocked one; it is the tolerance of the bench line of this shape.
+        tol = 1e-13 if n < 10_000_000 else 1e-12
         if solver == "davidson":
             eig, _, ok, info = ctx.davidson_driver(n, t, m, 400, tol, max_dav, 0.0, mv, pc, ev)
         else:

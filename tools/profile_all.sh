@@ -1,0 +1,49 @@
+#!/bin/bash
+# Everything profiles/<tag>/ holds, from the build in the tree, in ONE pass on one GPU box (run through gpurun from the repo root):
+#   bash tools/profile_all.sh r03
+# = tools/profile_round.sh (headline: bench line, rocprofv3 kernel statistics + one-solve trace, FETCH_SIZE / WRITE_SIZE / MFMA
+# counter passes), the same counter passes on the cfg 5 shape, tools/profile_extra.sh (cfg 3 / 4 / 5 bench lines, 250 k-row
+# shard), the shard rehearsal, the linear-response / generalised runs, the host-time report, the k x k step's time stamps, the
+# host-mode probe and the HIP legs of the floor probes.  Results are collected in gpurun_out/profiles_<tag>/ (copy to profiles/<tag>/).
+set -e
+TAG=${1:-r03}
+OUT=gpurun_out/profiles_$TAG
+rm -rf $OUT; mkdir -p $OUT
+P=gpurun_out/profile_$TAG
+bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
+cp $P/bench_default.json $P/pmc_traffic.txt $P/mfma_util.json $P/mfma_util.txt $OUT/
+cp $P/kt/run_kernel_stats.csv $OUT/kernel_stats_bench_steps5.csv
+cp $P/kt_gaps.txt $OUT/kernel_trace_one_solve.txt
+cp $P/fetch/run_counter_collection.csv $OUT/pmc_fetch_counter_collection.csv
+cp $P/write/run_counter_collection.csv $OUT/pmc_write_counter_collection.csv
+cp $P/pmc_traffic.json $OUT/pmc_traffic_headline.json
+echo "headline done"
+bash tools/profile_round.sh ${TAG}c5 --solver lobpcg --n 10000000 --roots 32 --tol 1e-12 --no-cpu-baseline --no-random-leg > $OUT/profile_round_c5.log 2>&1
+cp gpurun_out/profile_${TAG}c5/mfma_util.txt $OUT/mfma_util_cfg5shape.txt
+cp gpurun_out/profile_${TAG}c5/mfma_util.json $OUT/mfma_util_cfg5shape.json
+cp gpurun_out/profile_${TAG}c5/pmc_traffic.txt $OUT/pmc_traffic_cfg5shape.txt
+cp gpurun_out/profile_${TAG}c5/pmc_traffic.json $OUT/pmc_traffic_cfg5shape.json
+echo "cfg5 counters done"
+bash tools/profile_extra.sh $TAG > $OUT/profile_extra.log 2>&1
+cp $P/bench_lobpcg_cfg5shape_1gpu.json $P/bench_davidson_cfg4shape_1gpu.json $P/bench_lobpcg_cfg3.json $P/bench_250k_rows.json \
+   $P/kernel_stats_lobpcg_cfg5shape.csv $P/kernel_trace_one_solve_250k_rows.txt $OUT/
+echo "extra done"
+bash tools/shard_rehearsal.sh 1 2 4 > $OUT/shard_rehearsal_2e6.txt 2>&1
+python3 tools/lr_gen_bench.py > $OUT/bench_lr_gen_2e6.jsonl 2> $OUT/lr_gen.err
+DIAGLIB_AMD_HOSTTIME=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --n 250000 --steps 20 --warmup 3 --no-cpu-baseline --no-random-leg > $OUT/hosttime_250k_rows.txt 2>&1
+DIAGLIB_AMD_CHAIN_DEBUG=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-random-leg 2>&1 | grep -A6 "chain k=13 m=52" | tail -7 | cut -c1-260 > $OUT/chain_timing_k13_m52.txt
+python3 tools/host_mode_probe.py 2>&1 | tail -8 > $OUT/host_mode_probe.txt
+echo "rehearsal / lr / host done"
+python3 tools/floor_probe.py --n 10000000 --roots 32 --solver lobpcg --iters 30 --impl hip > $OUT/floor_probe_lobpcg_n1e7_32roots_hip.txt 2>/dev/null
+python3 tools/floor_probe.py --n 2000000 --roots 8 --solver davidson --iters 16 --impl hip > $OUT/floor_probe_davidson_n2e6_8roots_hip.txt 2>/dev/null
+python3 tools/floor_probe.py --n 1000000 --roots 32 --solver lobpcg --iters 40 --impl hip,oracle,reference > $OUT/floor_probe_lobpcg_n1e6_32roots.txt 2>/dev/null
+rm -f $OUT/lr_gen.err
+python3 - <<PY
+import json
+a = json.load(open("$OUT/pmc_traffic_headline.json")); c = json.load(open("$OUT/pmc_traffic_cfg5shape.json"))
+k1 = "davidson n=2000000 roots=8 n_max=13 max_dav=20 guess=unit"; k5 = "lobpcg n=10000000 roots=32 n_max=37 max_dav=20 guess=unit"
+json.dump({k1: a[k1], k5: c[k5]}, open("$OUT/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+PY
+rm -f $OUT/pmc_traffic_headline.json $OUT/pmc_traffic_cfg5shape.json
+rm -rf $P/kt $P/mfma $P/fetch $P/write gpurun_out/profile_${TAG}c5
+ls $OUT
