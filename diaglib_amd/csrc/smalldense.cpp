@@ -356,12 +356,13 @@ inline v8 abs8(v8 x) { return x < bc8(0.0) ? -x : x; }
 inline v8 sel8(v8i m, v8 x, v8 y) { return m ? x : y; }
 
 struct TriLU16 {
-  // U: diagonal, first and second super-diagonal; multipliers; pivot masks -- [index][lane]
+  // U: reciprocal diagonal, first and second super-diagonal; multipliers; pivot masks -- [index][lane]
   std::vector<v8> a, b, c, l;
   std::vector<v8i> piv;
-  explicit TriLU16(int n) : a(2 * n), b(2 * n), c(2 * n), l(2 * n), piv(2 * n) {}
+  void reserve(int n) { if ((int)a.size() < 2 * n) { a.resize(2 * n); b.resize(2 * n); c.resize(2 * n); l.resize(2 * n); piv.resize(2 * n); } }
   void factor(int n, const std::vector<double>& d, const std::vector<double>& e, const double* lam, double tiny)
   {
+    reserve(n);
     for (int h = 0; h < 2; ++h) {
       v8 lm; std::memcpy(&lm, lam + 8 * h, sizeof lm);
       v8 ai = bc8(d[0]) - lm, bi = bc8(n > 1 ? e[0] : 0.0);
@@ -371,9 +372,10 @@ struct TriLU16 {
         const v8 an = bc8(d[i + 1]) - lm, bn = bc8(i + 2 < n ? e[i + 1] : 0.0);
         const v8i swp = abs8(ai) < abs8(sub);              // swap rows i and i+1
         const v8 a0 = sel8(ai == bc8(0.0), vt, ai);        // (only used where no swap happens)
-        const v8 mlt = sel8(swp, ai / sub, sub / a0);
+        const v8 piv_i = sel8(swp, sub, a0);               // the pivot of this step
+        const v8 mlt = sel8(swp, ai, sub) / piv_i;         // (one division per step on the dependent chain)
         // no swap: U_i = (a0, bi, 0), next row (an - mlt bi, bn);  swap: U_i = (sub, an, bn), next row (bi - mlt an, -mlt bn)
-        a[2 * i + h] = sel8(swp, sub, a0);
+        a[2 * i + h] = piv_i;
         b[2 * i + h] = sel8(swp, an, bi);
         c[2 * i + h] = sel8(swp, bn, bc8(0.0));
         l[2 * i + h] = mlt;
@@ -383,9 +385,11 @@ struct TriLU16 {
         ai = na; bi = nb;
       }
       a[2 * (n - 1) + h] = ai; b[2 * (n - 1) + h] = bc8(0.0); c[2 * (n - 1) + h] = bc8(0.0);
+      // tiny pivots are replaced by +-tiny (inverse iteration only needs the direction); the back substitution multiplies by
+      // the reciprocals (off the dependent chain here, on it there)
       for (int i = 0; i < n; ++i) {
         const v8 x = a[2 * i + h];
-        a[2 * i + h] = sel8(abs8(x) < vt, sel8(x < bc8(0.0), -vt, vt), x);
+        a[2 * i + h] = bc8(1.0) / sel8(abs8(x) < vt, sel8(x < bc8(0.0), -vt, vt), x);
       }
     }
   }
@@ -404,7 +408,7 @@ struct TriLU16 {
       x[2 * (n - 1) + h] = xi;
       v8 x1 = bc8(0.0), x2 = bc8(0.0);
       for (int i = n - 1; i >= 0; --i) {
-        const v8 t = (x[2 * i + h] - b[2 * i + h] * x1 - c[2 * i + h] * x2) / a[2 * i + h];
+        const v8 t = (x[2 * i + h] - b[2 * i + h] * x1 - c[2 * i + h] * x2) * a[2 * i + h];
         x[2 * i + h] = t;
         x2 = x1; x1 = t;
       }
@@ -538,71 +542,105 @@ int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_
       lam[j] = lj; cstart[j] = cluster_start;
     }
   }
-  TriLU16 lu(n);
-  std::vector<v8> xl(2 * (size_t)n);                  // iterates, [index][lane]
-  std::vector<double> cols((size_t)LW * n);           // the same, one contiguous column per lane
+  // The iterates stay in the [index][lane] layout of the solver: normalisation and the convergence test are vertical
+  // operations on all sixteen lanes; a lane's column is only gathered for the rare re-orthogonalisation inside a cluster and
+  // once at the end.  Work arrays live as long as the thread (the solver runs once per iteration of every driver).
+  static thread_local TriLU16 lu;
+  static thread_local std::vector<v8> xl_store;
+  static thread_local std::vector<double> col_store;
+  if (xl_store.size() < 2 * (size_t)n) xl_store.resize(2 * (size_t)n);
+  if (col_store.size() < (size_t)n) col_store.resize(n);
+  v8* xl = xl_store.data();
+  double* xs = reinterpret_cast<double*>(xl);          // xs[i * LW + lane]
+  double* col = col_store.data();
   for (int j0 = 0; j0 < m; j0 += LW) {
     const int nb = std::min(LW, m - j0);
-    double lm[LW];
-    for (int q = 0; q < LW; ++q) lm[q] = lam[j0 + std::min(q, nb - 1)];   // (idle lanes shadow the last shift)
-    for (int q = 0; q < nb; ++q)
-      for (int i = 0; i < n; ++i) cols[(size_t)q * n + i] = rnd();
-    for (int q = nb; q < LW; ++q)
-      for (int i = 0; i < n; ++i) cols[(size_t)q * n + i] = cols[(size_t)(nb - 1) * n + i];
+    double lm[LW], wq[LW], slack[LW];
+    bool clustered = false;
+    for (int q = 0; q < LW; ++q) {
+      const int j = j0 + std::min(q, nb - 1);          // (idle lanes shadow the last shift)
+      lm[q] = lam[j]; wq[q] = w_all[j];
+      slack[q] = 64.0 * eps * onenrm + 2.0 * std::fabs(lam[j] - w_all[j]);
+      if (q < nb && cstart[j] < j) clustered = true;
+    }
+    for (int i = 0; i < n; ++i)
+      for (int q = 0; q < LW; ++q) xs[(size_t)i * LW + q] = rnd();
     lu.factor(n, t.d, t.e, lm, tiny);
+    v8 vw[2]; std::memcpy(vw, wq, sizeof vw);
     bool conv[LW];
     for (int q = 0; q < LW; ++q) conv[q] = false;
     for (int it = 0; it < 8; ++it) {
-      double* xs = reinterpret_cast<double*>(xl.data());
-      for (int q = 0; q < LW; ++q)
-        for (int i = 0; i < n; ++i) xs[(size_t)i * LW + q] = cols[(size_t)q * n + i];
-      lu.solve(n, xl.data());
-      for (int q = 0; q < nb; ++q)
-        for (int i = 0; i < n; ++i) cols[(size_t)q * n + i] = xs[(size_t)i * LW + q];
-      bool all = true;
-      for (int q = 0; q < nb; ++q) {
-        const int j = j0 + q;
-        double* x = &cols[(size_t)q * n];
+      lu.solve(n, xl);
+      if (clustered) {
         // re-orthogonalise against the earlier members of the cluster (modified Gram-Schmidt): finished vectors of earlier
-        // batches, then the lower lanes of this one (already orthonormalised in this iteration); zt rows are still in
-        // tridiagonal coordinates here (back-transformation comes last)
-        for (int p = cstart[j]; p < j; ++p) {
-          const double* zq = (p < j0) ? &zt[(size_t)p * n] : &cols[(size_t)(p - j0) * n];
-          double dot = 0.0;
-          for (int i = 0; i < n; ++i) dot += zq[i] * x[i];
-          for (int i = 0; i < n; ++i) x[i] -= dot * zq[i];
-        }
-        double xinf = 0.0;
-        for (int i = 0; i < n; ++i) xinf = std::max(xinf, std::fabs(x[i]));
-        if (!(xinf > 0.0) || !std::isfinite(xinf)) {
-          for (int i = 0; i < n; ++i) x[i] = rnd();
-          double nr = 0.0;
-          for (int i = 0; i < n; ++i) nr += x[i] * x[i];
-          nr = std::sqrt(nr);
-          for (int i = 0; i < n; ++i) x[i] /= nr;
-          conv[q] = false; all = false;
-          continue;
-        }
-        double nrm = 0.0;
-        for (int i = 0; i < n; ++i) { x[i] /= xinf; nrm += x[i] * x[i]; }
-        nrm = std::sqrt(nrm);
-        for (int i = 0; i < n; ++i) x[i] /= nrm;
-        if (it >= 1) {
-          // converged when the eigen-residual is at rounding level (plus the shift perturbation)
-          double res = 0.0;
-          for (int i = 0; i < n; ++i) {
-            double ti = (t.d[i] - w_all[j]) * x[i];
-            if (i > 0) ti += t.e[i - 1] * x[i - 1];
-            if (i + 1 < n) ti += t.e[i] * x[i + 1];
-            res += ti * ti;
+        // batches, then the lower lanes of this one (already orthogonalised in this iteration, not yet normalised: the
+        // projection divides by their squared norm); zt rows are still in tridiagonal coordinates here
+        for (int q = 0; q < nb; ++q) {
+          const int j = j0 + q;
+          if (cstart[j] >= j) continue;
+          for (int i = 0; i < n; ++i) col[i] = xs[(size_t)i * LW + q];
+          for (int p = cstart[j]; p < j; ++p) {
+            double dot = 0.0, nn = 1.0;
+            if (p < j0) {
+              const double* zq = &zt[(size_t)p * n];
+              for (int i = 0; i < n; ++i) dot += zq[i] * col[i];
+              for (int i = 0; i < n; ++i) col[i] -= dot * zq[i];
+            } else {
+              const int qp = p - j0;
+              nn = 0.0;
+              for (int i = 0; i < n; ++i) { const double z = xs[(size_t)i * LW + qp]; dot += z * col[i]; nn += z * z; }
+              if (nn > 0.0) { const double f = dot / nn; for (int i = 0; i < n; ++i) col[i] -= f * xs[(size_t)i * LW + qp]; }
+            }
           }
-          conv[q] = std::sqrt(res) <= 64.0 * eps * onenrm + 2.0 * std::fabs(lam[j] - w_all[j]);
+          for (int i = 0; i < n; ++i) xs[(size_t)i * LW + q] = col[i];
         }
-        all = all && conv[q];
       }
+      // largest entry and 2-norm of every lane
+      v8 amax[2] = {bc8(0.0), bc8(0.0)};
+      for (int i = 0; i < n; ++i)
+        for (int h = 0; h < 2; ++h) { const v8 ax = abs8(xl[2 * i + h]); amax[h] = ax > amax[h] ? ax : amax[h]; }
+      double am[LW]; std::memcpy(am, amax, sizeof am);
+      bool all = true;
+      double sc[LW];
+      for (int q = 0; q < LW; ++q) {
+        if (!(am[q] > 0.0) || !std::isfinite(am[q])) {
+          // a lane that broke down starts again from a fresh vector
+          for (int i = 0; i < n; ++i) xs[(size_t)i * LW + q] = rnd();
+          sc[q] = 1.0; conv[q] = false; if (q < nb) all = false;
+        } else sc[q] = 1.0 / am[q];
+      }
+      v8 vs[2]; std::memcpy(vs, sc, sizeof vs);
+      v8 ss[2] = {bc8(0.0), bc8(0.0)};
+      for (int i = 0; i < n; ++i)
+        for (int h = 0; h < 2; ++h) { const v8 y = xl[2 * i + h] * vs[h]; xl[2 * i + h] = y; ss[h] += y * y; }
+      double s2[LW]; std::memcpy(s2, ss, sizeof s2);
+      for (int q = 0; q < LW; ++q) sc[q] = 1.0 / std::sqrt(s2[q]);
+      std::memcpy(vs, sc, sizeof vs);
+      for (int i = 0; i < n; ++i)
+        for (int h = 0; h < 2; ++h) xl[2 * i + h] *= vs[h];
+      if (it >= 1) {
+        // converged when the eigen-residual is at rounding level (plus the shift perturbation)
+        v8 rs[2] = {bc8(0.0), bc8(0.0)};
+        for (int i = 0; i < n; ++i)
+          for (int h = 0; h < 2; ++h) {
+            v8 ti = (bc8(t.d[i]) - vw[h]) * xl[2 * i + h];
+            if (i > 0) ti += bc8(t.e[i - 1]) * xl[2 * (i - 1) + h];
+            if (i + 1 < n) ti += bc8(t.e[i]) * xl[2 * (i + 1) + h];
+            rs[h] += ti * ti;
+          }
+        double r2[LW]; std::memcpy(r2, rs, sizeof r2);
+        for (int q = 0; q < nb; ++q) {
+          if (!(am[q] > 0.0) || !std::isfinite(am[q])) continue;
+          conv[q] = std::sqrt(r2[q]) <= slack[q];
+          all = all && conv[q];
+        }
+      } else all = false;
       if (it >= 1 && all) break;
     }
-    for (int q = 0; q < nb; ++q) std::memcpy(&zt[(size_t)(j0 + q) * n], &cols[(size_t)q * n], sizeof(double) * n);
+    for (int q = 0; q < nb; ++q) {
+      double* z = &zt[(size_t)(j0 + q) * n];
+      for (int i = 0; i < n; ++i) z[i] = xs[(size_t)i * LW + q];
+    }
   }
   // back-transformation: eigenvector of S = H_0 H_1 ... H_{n-3} z  (apply the last reflector first).
   // All m vectors advance together: zz[r][j] = component r of vector j, so both loops run along j.
