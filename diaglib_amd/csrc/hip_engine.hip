@@ -889,6 +889,10 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
   double th[KR][4];
   int act[KR][4];
   double ssq[KR][4], smx[KR][4];
+  // (four and five tiles: the norm accumulators live in LDS, one slot per lane -- 48 registers less in a kernel whose
+  //  accumulators the compiler otherwise shuffles between VGPRs and AGPRs in every stage)
+  __shared__ double s_nrm[TH_LDS ? 4 * 48 * 16 * 2 : 2];
+  double* my_nrm = s_nrm + (TH_LDS ? (size_t)wave * 48 * 16 * 2 + i * 2 : 0);      // [col j][lane i][2], this wave
 #pragma unroll
   for (int q = 0; q < KR; ++q)
 #pragma unroll
@@ -898,6 +902,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
       act[q][reg] = s_active[j];
       ssq[q][reg] = 0.0;
       smx[q][reg] = 0.0;
+      if constexpr (TH_LDS) { my_nrm[(size_t)j * 32 + 0] = 0.0; my_nrm[(size_t)j * 32 + 1] = 0.0; }
     }
 
   for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
@@ -1024,12 +1029,22 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
           const int actv = TH_LDS ? s_active[j] : act[qr][reg];
           if (actv) {
             r0 = r0 - thv * e0;            // daxpy(-eig), reference diaglib.f90:1729
-            ssq[qr][reg] += r0 * r0;
-            smx[qr][reg] = fmax(smx[qr][reg], fabs(r0));
-            if constexpr (VEC == 2) {
-              r1 = r1 - thv * e1;
-              ssq[qr][reg] += r1 * r1;
-              smx[qr][reg] = fmax(smx[qr][reg], fabs(r1));
+            if constexpr (TH_LDS) {
+              // (same order of additions as the register accumulators of the narrower kernels: same bits)
+              double* slot = my_nrm + (size_t)j * 32;
+              double sq = slot[0], mx = slot[1];
+              sq += r0 * r0; mx = fmax(mx, fabs(r0));
+              if constexpr (VEC == 2) { r1 = r1 - thv * e1; sq += r1 * r1; mx = fmax(mx, fabs(r1)); }
+              slot[0] = sq;
+              slot[1] = mx;
+            } else {
+              ssq[qr][reg] += r0 * r0;
+              smx[qr][reg] = fmax(smx[qr][reg], fabs(r0));
+              if constexpr (VEC == 2) {
+                r1 = r1 - thv * e1;
+                ssq[qr][reg] += r1 * r1;
+                smx[qr][reg] = fmax(smx[qr][reg], fabs(r1));
+              }
             }
           }
           pstore<VEC, NT>(a.evec + (size_t)j * (size_t)n + row, vmake<VEC>(e0, e1));
@@ -1045,6 +1060,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       double s = ssq[q][reg], m = smx[q][reg];
+      if constexpr (TH_LDS) { const int j = 16 * q + g + 4 * reg; s = my_nrm[(size_t)j * 32 + 0]; m = my_nrm[(size_t)j * 32 + 1]; }
 #pragma unroll
       for (int off = 1; off < 16; off <<= 1) {
         s += __shfl_xor(s, off, 64);
@@ -4121,6 +4137,8 @@ struct HipEngine : dla::Engine {
     return with_lds_retry([&]() { return ritz_residual_once(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, out); });
   }
   bool ritz_p_declined = false;
+  // dynamic LDS a Ritz sweep may ask for: the four- and five-tile kernels keep their norm accumulators in 48.6 KiB of static LDS
+  static size_t ritz_lds_cap(int kt) { return (size_t)(kt >= 4 ? 100 : 150) * 1024; }
   // the sweep with k2 extra products (Engine::ritz_residual_p): one pass when [Y | C2] fits five column tiles and the LDS copy,
   // otherwise the Ritz step and two panel products
   int ritz_residual_p(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
@@ -4131,7 +4149,7 @@ struct HipEngine : dla::Engine {
     const uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy | (uintptr_t)p2 | (uintptr_t)ap2;
     const int ktot = (m + k2 + 15) / 16, l4 = ((l + 3) / 4) * 4;
     const bool one_pass = (n % 2 == 0) && (al % 16 == 0) && m <= 48 && ktot <= 5 && tune[0] != 5 &&
-                          sizeof(double) * (size_t)l4 * 16 * ktot <= std::min((size_t)150 * 1024, lds_limit);
+                          sizeof(double) * (size_t)l4 * 16 * ktot <= std::min(ritz_lds_cap(ktot), lds_limit);
     if (!one_pass) return Engine::ritz_residual_p(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, out, k2, c2_host, ldc2, p2, ap2);
     // [Y | C2] as one coefficient block
     std::vector<double> yc((size_t)l * (m + k2));
@@ -4167,7 +4185,7 @@ struct HipEngine : dla::Engine {
     const int qt = (tune[0] == 1 || tune[0] == 4) ? 0 : quarter_tiles(m + k2, vec2);
     // LDS copy of Y (a quarter-tile kernel keeps 8 columns of the last tile)
     const size_t lds_c = sizeof(double) * (size_t)l4 * (qt > 0 ? 16 * (kt - 1) + 8 : 16 * kt);
-    if (lds_c > std::min((size_t)150 * 1024, lds_limit)) {
+    if (lds_c > std::min(ritz_lds_cap(kt), lds_limit)) {
       if (k2 > 0) { ritz_p_declined = true; err = "ritz sweep with extra products: coefficient block beyond the LDS limit"; return DLA_ERR_RUNTIME; }
       // Y does not fit the LDS copy in one piece (wide block times deep subspace, e.g. 37 columns x 20 blocks): form the
       // two products with the chunked panel GEMM, then run the fused sweep on the n x m results with Y = identity
