@@ -142,6 +142,32 @@ def cpu_baseline(n_sample: int, n_targ: int, n_max: int, max_dav: int, tol: floa
     return res
 
 
+def _launch_ranks(n_ranks: int) -> int:
+    """`python bench.py --gpus N` started without a launcher: run the N ranks under torch.distributed.run as a child
+    process of this one (which has initialised neither torch nor the GPU, and is never replaced by exec), pass the child's
+    stdout / stderr through -- rank 0 prints the JSON line -- and return its exit code (non-zero when any rank failed:
+    torch.distributed.run ends all ranks and fails when one does)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                       # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    for a in sys.argv[1:]:                           # "--n" is an abbreviation of the launcher's own "--nnodes": spell it "--rows"
+        cmd.append("--rows" if a == "--n" else "--rows=" + a[4:] if a.startswith("--n=") else a)
+    child = subprocess.Popen(cmd, cwd=os.getcwd())
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        try:
+            return child.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            child.kill()
+            return child.wait()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,9 +196,12 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process has touched neither torch nor the GPU; it starts
+        # the ranks as a CHILD (one process per GPU under torch.distributed.run), relays their output and exit code
+        raise SystemExit(_launch_ranks(args.gpus))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():

@@ -26,6 +26,7 @@ ALLREDUCE_T = C.CFUNCTYPE(None, C.c_void_p, c_dp, C.c_int, C.c_int)
 OPT_CALLBACKS_ON_DEVICE, OPT_EVEC_ON_DEVICE, OPT_PROFILE, OPT_VERBOSE_ORTHO, OPT_CALLBACK_ORDER, OPT_ORTHO_MAXIT, OPT_CASLR_ALGORITHM, OPT_STAGE_CHUNKS = 1, 2, 3, 4, 5, 6, 7, 8
 OPT_P2P_TIMEOUT_MS = 9
 OPT_RUN_AHEAD = 10
+ERR_NO_DEVICE, ERR_ALLOC, ERR_ARG, ERR_RUNTIME, ERR_ORTHO, ERR_LAPACK, ERR_COMM = 1, 2, 3, 4, 5, 6, 7
 OP_NAMES = ["gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd"]
 
 # every symbol include/diaglib_amd.h declares (checked by tests/test_abi.py)

@@ -180,6 +180,10 @@ struct Engine : BlockOps {
   dla_stats stats{};
   bool profile = false;
   virtual void collect_times() {}
+  // dla_expand_project's run-ahead: what is launched between begin and end(discard = true) was speculation whose output
+  // nobody uses -- it is taken out of the launch / byte / flop statistics (and its events out of the time statistics) again
+  virtual void spec_stats_begin() {}
+  virtual void spec_stats_end(bool /*discard*/) {}
   virtual int kernel_stats(dla_kernel_stat*, int) { return 0; }
   virtual void reset_kernel_stats() {}
   virtual void set_tune(int, int) {}

@@ -2488,6 +2488,8 @@ struct HipEngine : dla::Engine {
   static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
   std::vector<TimedLaunch> timed;
   std::vector<hipEvent_t> ev_pool;
+  struct SpecRec { int tag, cls; std::string kname; double bytes, flops; };
+  std::vector<SpecRec> ahead_log;
 
   const char* name() const override { return nm.c_str(); }
   void* stream() override { return (void*)st; }
@@ -2595,6 +2597,7 @@ struct HipEngine : dla::Engine {
         return;
       }
       if (!kname.empty()) { auto& ks = e->kstats[kname]; ks.launches += 1; ks.alg_bytes += bytes; ks.flops += flops; }
+      if (e->ahead_log_on) e->ahead_log.push_back({0, cls_, kname_, bytes, flops});
       if (e->trace) {
         timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
         std::fprintf(stderr, "[dla] %ld.%06ld launch class %d, %.3e alg bytes\n", (long)ts.tv_sec, ts.tv_nsec / 1000, cls_, bytes);
@@ -2623,6 +2626,27 @@ struct HipEngine : dla::Engine {
       }
     }
   };
+  // launches booked while dla_expand_project runs ahead of a chain's report (see dla_internal.h)
+  bool ahead_log_on = false;
+  size_t ahead_timed0 = 0, ahead_timed1 = 0;
+  void spec_stats_begin() override { ahead_log.clear(); ahead_log_on = true; ahead_timed0 = ahead_timed1 = timed.size(); }
+  // first call: stop logging; a call with discard = true (the same or a later one) takes the logged launches out again
+  void spec_stats_end(bool discard) override
+  {
+    if (ahead_log_on) { ahead_log_on = false; ahead_timed1 = timed.size(); }
+    if (!discard) return;
+    for (auto& r : ahead_log) {
+      stats.launches[r.cls] -= 1; stats.alg_bytes[r.cls] -= r.bytes; stats.flops[r.cls] -= r.flops;
+      if (!r.kname.empty()) { auto& ks = kstats[r.kname]; ks.launches -= 1; ks.alg_bytes -= r.bytes; ks.flops -= r.flops; }
+    }
+    ahead_log.clear();
+    // their event pairs (a collection in between has emptied the list: then there is nothing left to drop)
+    if (ahead_timed0 < ahead_timed1 && ahead_timed1 <= timed.size()) {
+      for (size_t i = ahead_timed0; i < ahead_timed1; ++i) { ev_pool.push_back(timed[i].a); ev_pool.push_back(timed[i].b); }
+      timed.erase(timed.begin() + ahead_timed0, timed.begin() + ahead_timed1);
+    }
+    ahead_timed0 = ahead_timed1 = 0;
+  }
   hipEvent_t get_event()
   {
     if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
@@ -2647,6 +2671,7 @@ struct HipEngine : dla::Engine {
       ev_pool.push_back(t.a); ev_pool.push_back(t.b);
     }
     timed.clear();
+    ahead_timed0 = ahead_timed1 = 0;       // (a run-ahead's event pairs went with the rest)
   }
 
   // ---- memory
@@ -3119,7 +3144,6 @@ struct HipEngine : dla::Engine {
   // ---- device-driven orthogonalisation chain (see ortho_tail_kernel)
   const int* pred_phase = nullptr;   // predicate of the launches being enqueued (nullptr = unconditional)
   int pred_want = 0;
-  struct SpecRec { int tag, cls; std::string kname; double bytes, flops; };
   std::vector<SpecRec>* spec_rec = nullptr;
   int spec_tag = 0;
   OrthoDev* d_ost = nullptr;        // state machine (device)

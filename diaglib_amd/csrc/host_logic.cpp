@@ -182,7 +182,8 @@ int dla_set_option(dla_ctx* c, int option, int value)
       c->p2p_timeout_ms = value;
       return engfail(c, c->eng->set_p2p_timeout(value));
     case DLA_OPT_RUN_AHEAD:
-      c->run_ahead = value ? 1 : 0;
+      if (value < 0 || value > 2) return fail(c, DLA_ERR_ARG, "run-ahead must be 0, 1 or 2");
+      c->run_ahead = value;
       break;
     case DLA_OPT_CALLBACK_ORDER:
       if (value < 0 || value > 2) return fail(c, DLA_ERR_ARG, "callback order must be 0, 1 or 2");
@@ -1010,16 +1011,22 @@ static int staged_callback(dla_ctx* c, int n, int m, const double* x, double* y,
   return engfail(c, c->eng->stage_end());
 }
 
+// the library's own device-resident operators: they enqueue on the engine's stream (ordering contract 2 whatever the
+// context says) and are pure functions of their input block (safe to call again on the same block)
+static bool builtin_operator(dla_matvec_fn fn)
+{
+  return (void*)fn == (void*)&dla_synth_matvec || (void*)fn == (void*)&dla_spmm_matvec || (void*)fn == (void*)&dla_synth_apbmul ||
+         (void*)fn == (void*)&dla_synth_ambmul || (void*)fn == (void*)&dla_synth_spdmul || (void*)fn == (void*)&dla_synth_smdmul ||
+         (void*)fn == (void*)&dla_synth_metric;
+}
+
 int dla_call_matvec(dla_ctx* c, dla_matvec_fn fn, int n, int m, const double* x, double* ax)
 {
   DLA_T("dla_call_matvec");
   if (m <= 0) return DLA_OK;
   if (c->callbacks_on_device) {
     // the built-in operators run on the engine's own stream: nothing to order
-    const bool builtin = (void*)fn == (void*)&dla_synth_matvec || (void*)fn == (void*)&dla_spmm_matvec || (void*)fn == (void*)&dla_synth_apbmul ||
-                         (void*)fn == (void*)&dla_synth_ambmul || (void*)fn == (void*)&dla_synth_spdmul || (void*)fn == (void*)&dla_synth_smdmul ||
-                         (void*)fn == (void*)&dla_synth_metric;
-    const int order = builtin ? 2 : c->callback_order;
+    const int order = builtin_operator(fn) ? 2 : c->callback_order;
     int st = c->eng->callback_begin(order);
     if (st) return engfail(c, st);
     fn(&n, &m, x, ax);
@@ -1047,19 +1054,28 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
                        double shift, double* h, int ldh)
 {
   DLA_T("dla_expand_project");
-  if (!c || !basis || !abasis || !h || (mode != 0 && mode != 1) || m < 0 || k <= 0) return fail(c, DLA_ERR_ARG, "dla_expand_project: bad argument");
+  if (!c || !basis || !abasis || !h || !fn || (mode != 0 && mode != 1) || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
+    return fail(c, DLA_ERR_ARG, "dla_expand_project: bad argument (n > 0, m >= 0, k > 0, ldh >= m + k)");
   double* u = basis + (size_t)n * m;
   const long long nglob = global_rows(c, n);
-  const bool builtin = (void*)fn == (void*)&dla_synth_matvec || (void*)fn == (void*)&dla_spmm_matvec;
+  const bool builtin = builtin_operator(fn);
   const int order = builtin ? 2 : c->callback_order;
-  if (c->run_ahead && c->callbacks_on_device && order != 1 && m > 0) {
+  // The run-ahead may call the operator a second time on the same block (and drop the first result) when the chain takes
+  // another route than planned.  The reference calls matvec exactly once per block (diaglib.f90:1685, 394-397), and a
+  // caller's operator may count its calls or keep state between them: by default only the library's own operators -- pure
+  // functions of their input -- run ahead; DLA_OPT_RUN_AHEAD = 2 is the caller's statement that theirs is pure too.
+  const bool ahead = c->run_ahead == 2 || (c->run_ahead == 1 && builtin);
+  if (ahead && c->callbacks_on_device && order != 1 && m > 0) {
     dla::OrthoReport rep;
     int st = c->eng->ortho_chain_begin(n, m, k, basis, basis, u, &rep);
     if (st) return engfail(c, st);
     if (rep.handled) {
       // in flight: the operator and the projection follow on the same stream; the projection's wait covers the chain
+      c->eng->spec_stats_begin();
       int sta = expand_apply_project(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
+      c->eng->spec_stats_end(false);
       st = c->eng->ortho_chain_finish(&rep, sta == DLA_OK);
+      c->eng->spec_stats_end(!(st == DLA_OK && sta == DLA_OK && rep.status == 1 && rep.clean));
       if (st) return engfail(c, st);
       if (sta) return sta;
       if (rep.status == 1 && rep.clean) {

@@ -744,9 +744,14 @@ contains
 !         its columns of the projected matrix (:1691) -- the head of the next sweep -- follow in the same call, so that
 !         the three run back to back on the device (dla_expand_project)
 !
-          call chk(e%ctx, dla_expand_project(e%ctx, 0_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
-                                             h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
-          projected = .true.
+          if (it.lt.max_iter) then
+            call chk(e%ctx, dla_expand_project(e%ctx, 0_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
+                                               h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
+            projected = .true.
+          else
+!           (last sweep allowed: nobody will read the operator's image of this block -- the caller's routine is not called)
+            call chk(e%ctx, dla_ortho_vs_x(e%ctx, n, s%cols, s%act, basis, colp(basis,n,s%head)), 'ortho_vs_x')
+          end if
           call lap_charge(w, w%ortho)
         end if
       else
@@ -891,6 +896,7 @@ contains
     c_x = 1
     c_w = 1 + n_max
     call chk(e%ctx, dla_call_precnd(e%ctx, prec, n, n_max, shift-eig(c_x), colp(resid,n,c_x), colp(sp(rd),n,c_w)), 'precnd')
+    it = 0
     call orthogonalise_w(n_max, n_max)
 !
     live   = n_max
@@ -1064,9 +1070,14 @@ contains
         call chk(e%ctx, dla_b_ortho(e%ctx, n, k, colp(sp(rd),n,m+1), colp(bsp(rd),n,m+1)), 'b_ortho')
       else
 !       (the operator on the W block and S^T A S -- the head of the next sweep -- in the same call: dla_expand_project)
-        call chk(e%ctx, dla_expand_project(e%ctx, 1_c_int, n, m, k, sp(rd), asp(rd), op, shift, h, wide), &
-                 'ortho_vs_x + matvec + projection')
-        projected = .true.
+        if (it.lt.max_iter) then
+          call chk(e%ctx, dla_expand_project(e%ctx, 1_c_int, n, m, k, sp(rd), asp(rd), op, shift, h, wide), &
+                   'ortho_vs_x + matvec + projection')
+          projected = .true.
+        else
+!         (last sweep allowed: the operator's image of this block would never be read)
+          call chk(e%ctx, dla_ortho_vs_x(e%ctx, n, m, k, sp(rd), colp(sp(rd),n,m+1)), 'ortho_vs_x')
+        end if
       end if
       call lap_charge(w, w%ortho)
     end subroutine orthogonalise_w

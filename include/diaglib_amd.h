@@ -82,9 +82,16 @@ enum {
                                       as failed in every rank's mailbox: all ranks return DLA_ERR_COMM at their next host wait and
                                       the transport stays down until dla_p2p_detach + a fresh export.  Callers whose ranks can be
                                       further apart than this (host-mode callbacks of unequal length) raise it or use RCCL  */
-  DLA_OPT_RUN_AHEAD = 10,          /* dla_expand_project: 1 (default) enqueue the operator and the projection sweep behind the
-                                      orthogonalisation chain and read the chain's report at THEIR host wait; 0 = one call after
-                                      the other (A/B and debugging)                                                            */
+  DLA_OPT_RUN_AHEAD = 10,          /* dla_expand_project: enqueue the operator and the projection sweep behind the
+                                      orthogonalisation chain and read the chain's report at THEIR host wait.  When the chain
+                                      takes another route than planned the operator is called a SECOND time on the finished
+                                      block and its first output is dropped -- the reference calls matvec exactly once per
+                                      block (diaglib.f90:1685, 394-397), so:
+                                      1 (default): only for the library's own device operators (dla_synth_*, dla_spmm_matvec),
+                                         which are pure functions of their input; a caller's callback is called once, in order;
+                                      2: also for the caller's device-mode callbacks (ordering contract 0 or 2) -- the caller
+                                         states that the operator keeps no state between calls;
+                                      0: never (one call after the other; A/B and debugging)                                  */
   DLA_OPT_TUNE0 = 100              /* 100..107: kernel-shape experiment knobs for the interleaved A/B tools
                                       (tools/tune_*.py, tools/kernel_bench.py); 0 = the shipped default          */
 };
