@@ -2074,6 +2074,15 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
           if (sweep_xu) t.have_xu = 1;
           const double rcond = l_norm * linv_norm;
           if (lane == 0 && a.dbg != nullptr && dslot < 48) a.dbg[dslot * 16 + 10] = (unsigned long long)__double_as_longlong(rcond);
+          if (a.dbg != nullptr && dslot < 48) {
+            // (debug) how far the Gram matrix of this step is from the identity: max |G - I|
+            double dev = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dev = fmax(dev, fabs(g0[r] - ((g + 4 * r == c) ? 1.0 : 0.0)));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dev = fmax(dev, __shfl_xor(dev, off, 64));
+            if (lane == 0) a.dbg[dslot * 16 + 12] = (unsigned long long)__double_as_longlong(dev);
+          }
           t.growth *= linv_norm;
           // The ortho_cd in front of the loop is not iterated (lead_once): its result feeds the first projection, which is
           // linear in the block and does not care how orthonormal it is, and every later decision is taken on Gram matrices
@@ -3106,9 +3115,10 @@ struct HipEngine : dla::Engine {
   size_t lds_limit = (size_t)160 * 1024;
   bool lds_retry = false;
   int force_lds_refusal = 0;   // $DIAGLIB_AMD_FORCE_LDS_REFUSAL=1 (tests): treat the first > 64 KiB request as refused
-  bool raise_lds(const void* kfn, size_t lds)
+  // static_lds: what the kernel declares itself (__shared__ arrays); the 64 KiB a launch gets without asking cover both
+  bool raise_lds(const void* kfn, size_t lds, size_t static_lds = 0)
   {
-    if (lds <= (size_t)64 * 1024) return true;
+    if (lds + static_lds <= (size_t)64 * 1024) return true;
     bool refused = false;
     if (force_lds_refusal > 0) { force_lds_refusal = 0; refused = true; }
     if (!refused)
@@ -3561,9 +3571,9 @@ struct HipEngine : dla::Engine {
         for (int i = 0; i < std::min(sres.nops, 48); ++i) {
           const unsigned long long* q = &hs[i * 16];
           auto us = [&](int a_, int b_) { return (q[a_] && q[b_]) ? (double)(long long)(q[b_] - q[a_]) * 0.01 : -1.0; };
-          double rc; std::memcpy(&rc, &q[10], 8);
-          std::printf("    op %llu (err est %.2e, chol %llu cycles = %.2f GHz): kernel entry->tail %.2f us | G load %.2f | chol+inv %.2f | norms %.2f | products+stores %.2f | decide %.2f | publish %.2f | assemble %.2f\n",
-                      q[9], 2.2e-16 * rc * rc, q[11], us(1, 2) > 0 ? (double)q[11] / (us(1, 2) * 1e3) : 0.0, us(8, 0), us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7));
+          double rc, gdev; std::memcpy(&rc, &q[10], 8); std::memcpy(&gdev, &q[12], 8);
+          std::printf("    op %llu (err est %.2e, max|G-I| %.2e, chol %llu cycles = %.2f GHz): kernel entry->tail %.2f us | G load %.2f | chol+inv %.2f | norms %.2f | products+stores %.2f | decide %.2f | publish %.2f | assemble %.2f\n",
+                      q[9], 2.2e-16 * rc * rc, gdev, q[11], us(1, 2) > 0 ? (double)q[11] / (us(1, 2) * 1e3) : 0.0, us(8, 0), us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7));
         }
         (void)hipMemset(d_dbg, 0, sizeof(unsigned long long) * 48 * 16);
       }
@@ -4163,6 +4173,10 @@ struct HipEngine : dla::Engine {
   bool ritz_p_declined = false;
   // dynamic LDS a Ritz sweep may ask for: the four- and five-tile kernels keep their norm accumulators in 48.6 KiB of static LDS
   static size_t ritz_lds_cap(int kt) { return (size_t)(kt >= 4 ? 100 : 150) * 1024; }
+  // static LDS of ritz_kernel: theta / active, and for four and five tiles the per-lane norm accumulators (s_nrm, 48 KiB)
+  static size_t ritz_static_lds(int kt) { return (size_t)1024 + (kt >= 4 ? sizeof(double) * 4 * 48 * 16 * 2 : 0); }
+  // dynamic LDS a Ritz sweep of kt column tiles may ask for: its own cap, and the engine's limit minus what the kernel holds statically
+  size_t ritz_dyn_limit(int kt) const { const size_t st_ = ritz_static_lds(kt); return std::min(ritz_lds_cap(kt), lds_limit > st_ ? lds_limit - st_ : (size_t)0); }
   // the sweep with k2 extra products (Engine::ritz_residual_p): one pass when [Y | C2] fits five column tiles and the LDS copy,
   // otherwise the Ritz step and two panel products
   int ritz_residual_p(int n, int l, int m, const double* v, const double* av, const double* y_host, int ldy,
@@ -4173,7 +4187,7 @@ struct HipEngine : dla::Engine {
     const uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy | (uintptr_t)p2 | (uintptr_t)ap2;
     const int ktot = (m + k2 + 15) / 16, l4 = ((l + 3) / 4) * 4;
     const bool one_pass = (n % 2 == 0) && (al % 16 == 0) && m <= 48 && ktot <= 5 && tune[0] != 5 &&
-                          sizeof(double) * (size_t)l4 * 16 * ktot <= std::min(ritz_lds_cap(ktot), lds_limit);
+                          sizeof(double) * (size_t)l4 * 16 * ktot <= ritz_dyn_limit(ktot);
     if (!one_pass) return Engine::ritz_residual_p(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, out, k2, c2_host, ldc2, p2, ap2);
     // [Y | C2] as one coefficient block
     std::vector<double> yc((size_t)l * (m + k2));
@@ -4209,7 +4223,7 @@ struct HipEngine : dla::Engine {
     const int qt = (tune[0] == 1 || tune[0] == 4) ? 0 : quarter_tiles(m + k2, vec2);
     // LDS copy of Y (a quarter-tile kernel keeps 8 columns of the last tile)
     const size_t lds_c = sizeof(double) * (size_t)l4 * (qt > 0 ? 16 * (kt - 1) + 8 : 16 * kt);
-    if (lds_c > std::min(ritz_lds_cap(kt), lds_limit)) {
+    if (lds_c > ritz_dyn_limit(kt)) {
       if (k2 > 0) { ritz_p_declined = true; err = "ritz sweep with extra products: coefficient block beyond the LDS limit"; return DLA_ERR_RUNTIME; }
       // Y does not fit the LDS copy in one piece (wide block times deep subspace, e.g. 37 columns x 20 blocks): form the
       // two products with the chunked panel GEMM, then run the fused sweep on the n x m results with Y = identity
@@ -4256,7 +4270,7 @@ struct HipEngine : dla::Engine {
       // (flops: the two Ritz products and, with extra columns, the two panel products they replace)
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m + 2.0 * k2),
               4.0 * (double)n * l * (m + k2) + 5.0 * (double)n * nact, kn);
-#define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME; DLA_LAUNCH(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
+#define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds, ritz_static_lds(kt))) return DLA_ERR_RUNTIME; DLA_LAUNCH(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
       if (k2 > 0) {
         // [Y | C2]: vec2 guaranteed by the caller (ritz_residual_p)
         if (qt == 1) { if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 1, true>)); else RZ((ritz_kernel<3, 2, 3, 3, 1, true>)); }

@@ -73,3 +73,37 @@ def test_refused_lds_request_inside_a_device_driven_chain():
     env = dict(os.environ, DIAGLIB_AMD_FORCE_LDS_REFUSAL="1")
     p = subprocess.run([sys.executable, "-c", CODE_CHAIN % ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0 and "refusal inside a chain handled" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+CODE_WIDE_RITZ = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from diaglib_amd import capi
+ctx = capi.Context()
+rng = np.random.default_rng(11)
+n, l, m, k2 = 4096, 111, 37, 37                   # [Y | C2] = 74 columns = five tiles: ritz_kernel<5, ...> holds 48 KiB of static LDS
+v = np.asfortranarray(rng.standard_normal((n, l))); av = np.asfortranarray(rng.standard_normal((n, l)))
+pv, pav = ctx.panel(v), ctx.panel(av)
+y = np.asfortranarray(rng.standard_normal((l, m))); c2 = np.asfortranarray(rng.standard_normal((l, k2)))
+theta = np.arange(1.0, m + 1)
+for trial in range(2):
+    # trial 0: the wide sweep's request (48 KiB static + 71 KiB dynamic) is refused -- the engine's limit drops to 64 KiB, under
+    # which that kernel can no longer be launched at all (its static part alone leaves 15 KiB): the call must come back
+    # correct through the separate sweeps, and so must every later one
+    ev, r, p, ap = ctx.panel(n, m), ctx.panel(n, m), ctx.panel(n, k2), ctx.panel(n, k2)
+    rn = ctx.ritz_residual_p(pv, pav, y, theta, m, np.zeros(m, np.int32), ev, r, None, c2, p, ap)
+    want_r = av @ y - (v @ y) * theta
+    assert np.abs(ev.download() - v @ y).max() < 1e-10
+    assert np.abs(r.download() - want_r).max() < 1e-9
+    assert np.abs(p.download() - v @ c2).max() < 1e-10 and np.abs(ap.download() - av @ c2).max() < 1e-10
+    assert np.allclose(rn[1], np.abs(want_r).max(0), rtol=1e-12)
+print("refusal of the wide ritz sweep handled")
+"""
+
+
+def test_refused_lds_request_of_the_five_tile_ritz_sweep():
+    '''ADVICE r03: the four- and five-tile Ritz kernels hold 48 KiB of static LDS; after a refusal (limit 64 KiB) a launch with
+    48 KiB static + up to 64 KiB dynamic must not be attempted -- static and dynamic LDS are counted together.'''
+    env = dict(os.environ, DIAGLIB_AMD_FORCE_LDS_REFUSAL="1")
+    p = subprocess.run([sys.executable, "-c", CODE_WIDE_RITZ % ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and "refusal of the wide ritz sweep handled" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
