@@ -981,10 +981,13 @@ static int staged_callback(dla_ctx* c, int n, int m, const double* x, double* y,
   const size_t col = sizeof(double) * (size_t)n;
   int st = ensure_stage(c, col * m);
   if (st) return st;
-  // Two chunks for blocks of 64 MB and more, one below: every chunk is a call of the user's routine, and a memory-bound
-  // host operator pays its fixed traffic (its own matrix) once per call -- measured on the benchmark with the harness'
-  // operator (tools/host_mode_probe.py): 2 chunks are the optimum, 4 and more are slower than no pipeline at all
-  int nchunk = (col * m >= ((size_t)64 << 20)) ? 2 : 1;
+  // One call of the caller's routine per block, like the reference (diaglib.f90:1685, 1786: matvec / precnd see every block
+  // exactly once, whole).  Column chunks (DLA_OPT_STAGE_CHUNKS >= 2) overlap a chunk's transfers with the routine's work on
+  // its neighbours, but every chunk is another call: an operator pays its own fixed traffic (its matrix) per call and a
+  // caller may count calls.  Measured r04 on the benchmark with the harness' operator (tools/host_mode_timeline.py, time
+  // inside the caller's routine per solve): 74 ms in 17 calls, 113 ms in 34 half-block calls, 184 ms in 66, 284 ms in 113 --
+  // 231 / 216 / 255 / 350 ms per solve: what the overlap gains the extra calls take back.  Hence opt-in.
+  int nchunk = 1;
   nchunk = std::min(std::max(nchunk, min_chunks), m);
   if (c->stage_chunks > 0) nchunk = std::min(c->stage_chunks, m);
   const int per = (m + nchunk - 1) / nchunk;

@@ -76,7 +76,10 @@ enum {
   DLA_OPT_CASLR_ALGORITHM = 7,     /* reduced problem of caslr_driver: 0 (default) the 2 ldu-dimensional pencil (reference
                                       i_alg = 0, dsygv at diaglib.f90:783), 1 the Helmich-Paris route (i_alg = 1, :805-860) */
   DLA_OPT_STAGE_CHUNKS = 8,        /* host-mode callbacks: column chunks a block is cut into for the download | user routine |
-                                      upload pipeline (0 = automatic: ~32 MB chunks, at most 8; 1 = whole block at once) */
+                                      upload pipeline.  0 / 1 (default): the caller's routine sees every block once and whole,
+                                      like the reference (diaglib.f90:1685, 1786); >= 2: that many chunks (at most 16) = that
+                                      many calls per block, whose transfers overlap the routine's work on the neighbouring
+                                      chunks -- pays only for an operator without fixed cost per call                       */
   DLA_OPT_P2P_TIMEOUT_MS = 9,      /* peer-to-peer all-reduce (dla_p2p_attach): how long a rank waits INSIDE a kernel for its peers'
                                       contributions, in ms (default 5000; 0 = no limit).  A rank that gives up marks the exchange
                                       as failed in every rank's mailbox: all ranks return DLA_ERR_COMM at their next host wait and

@@ -113,3 +113,47 @@ def test_fortran_caller_sparse_device_operator(tmp_path, ctx):
     want = np.sort(spl.eigsh(a, k=6, sigma=0.0, which="LM", return_eigenvectors=False))
     assert np.allclose(vals, want, atol=2e-8), (vals, want)
     assert float(re.search(r"SPARSE max residual:\s+([0-9.Ee+-]+)", out).group(1)) < 1e-6
+
+
+def test_fortran_caller_generalised_and_linear_response(tmp_path, ctx, oracle):
+    """examples/fortran_gen_caller: gen_david_driver, lobpcg_driver(gen_eig = .true.) with a host `bvec` callback and
+    caslr_driver, called through the MODULE interface from Fortran (reference callers main.f90:403-526, 528-730), on the
+    matrices the golden fixtures were generated with -- eigenvalues against the unmodified reference's (fixtures
+    gdav_n600_unit, glob_n600_unit, lrt_n300_unit), residuals and the S-norm of the returned vectors from the caller itself."""
+    if not os.path.exists(FLANG):
+        pytest.skip("no Fortran compiler on this box")
+    n, nlr = 600, 300
+    s = oracle.metric_setup(n)
+    mats = oracle.lr_setup(nlr)
+    with open(tmp_path / "gen_caller.in", "wb") as f:
+        f.write(np.int32(n).tobytes()); f.write(np.asfortranarray(s).tobytes(order="F"))
+        f.write(np.int32(nlr).tobytes())
+        for m_ in mats:
+            f.write(np.asfortranarray(m_).tobytes(order="F"))
+    lib = os.path.join(ROOT, "diaglib_amd", "lib")
+    srcs = [os.path.join(ROOT, "diaglib_amd", "fortran", "real_precision.f90"),
+            os.path.join(ROOT, "diaglib_amd", "fortran", "diaglib.f90"),
+            os.path.join(ROOT, "examples", "fortran_gen_caller", "gen_caller.f90")]
+    objs = []
+    for src in srcs:
+        o = str(tmp_path / (os.path.basename(src) + ".o"))
+        subprocess.run([FLANG, "-O2", "-c", src, "-o", o, "-module-dir", str(tmp_path), "-I", str(tmp_path)], check=True)
+        objs.append(o)
+    exe = str(tmp_path / "gen_caller.exe")
+    subprocess.run([FLANG, "-o", exe] + objs + ["-L" + lib, "-ldiaglib_amd", "-Wl,-rpath," + lib], check=True)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = p.stdout
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "reference_fixtures.npz"), allow_pickle=True)
+    lr = np.load(os.path.join(ROOT, "tests", "golden", "reference_lr_fixtures.npz"), allow_pickle=True)
+    for tag, key in (("GEN_DAVIDSON", "gdav_n600_unit"), ("GEN_LOBPCG", "glob_n600_unit")):
+        m1 = re.search(tag + r" ok/matvec/bvec columns:\s+T\s+(\d+)\s+(\d+)", out)
+        assert m1, out
+        vals = [float(v) for v in re.search(tag + r" eig:(.*)", out).group(1).split()]
+        assert np.allclose(vals, fx[key + "_eig"][:4], rtol=1e-9, atol=0), (tag, vals, fx[key + "_eig"][:4])
+        res, orth = [float(v) for v in re.search(tag + r" max residual, max \|x\^T S x - 1\|:(.*)", out).group(1).split()]
+        assert res < 1e-6 and orth < 1e-12, (tag, res, orth)
+        assert int(m1.group(1)) > 0 and int(m1.group(2)) > 0          # the caller's own routines did the work
+    assert re.search(r"CASLR ok:\s+T", out), out
+    w = [float(v) for v in re.search(r"CASLR eig:(.*)", out).group(1).split()]
+    assert np.allclose(w, lr["lrt_n300_unit_eig"][:4], rtol=1e-9, atol=0), (w, lr["lrt_n300_unit_eig"][:4])

@@ -176,9 +176,38 @@ def test_dense_reference_matrix_host_callbacks(ctx, oracle, rng, solver, guess_k
     assert np.allclose(eig[:n_targ], np.linalg.eigvalsh(a)[:n_targ], rtol=0, atol=1e-7)
 
 
+def test_host_callbacks_see_every_block_once_by_default(ctx, oracle):
+    """Drop-in default: the caller's matvec / precnd are called once per block with the whole block, like the reference
+    (diaglib.f90:1685, 1786) -- as many matvec calls as sweeps, every column exactly once; column chunks only on request."""
+    import ctypes as C
+    n, n_targ, n_max = 3000, 6, 11
+    oracle.dense_setup(n)
+    mv_addr, pc = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd")
+    inner = C.cast(mv_addr, capi.MATVEC_T)
+    calls = []
+
+    def counted(pn, pm, px, pax):
+        calls.append(pm[0])
+        inner(pn, pm, px, pax)
+
+    cb = capi.MATVEC_T(counted)
+    g = np.zeros((n, n_max), order="F"); g[np.arange(n_max), np.arange(n_max)] = 1.0
+    ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+    eig, v, ok, info = ctx.davidson_driver(n, n_targ, n_max, 100, 1e-8, 20, 0.0, C.cast(cb, C.c_void_p).value, pc, g)
+    assert ok and len(calls) == info["iters"] and sum(calls) == info["matvec_cols"], (calls, info)
+    ctx.set_option(capi.OPT_STAGE_CHUNKS, 2)
+    try:
+        calls.clear()
+        eig2, v2, ok2, info2 = ctx.davidson_driver(n, n_targ, n_max, 100, 1e-8, 20, 0.0, C.cast(cb, C.c_void_p).value, pc, g)
+    finally:
+        ctx.set_option(capi.OPT_STAGE_CHUNKS, 0)
+    assert ok2 and len(calls) > info2["iters"] and sum(calls) == info2["matvec_cols"] and info2["iters"] == info["iters"]
+    assert np.allclose(eig2[:n_targ], eig[:n_targ], rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("chunks", [2, 3, 5])
 def test_host_callbacks_in_column_chunks_overlap_the_projection(ctx, oracle, chunks):
-    """Drop-in mode with the block cut into column chunks (DLA_OPT_STAGE_CHUNKS; automatic for blocks of 64 MB and more): every
+    """Drop-in mode with the block cut into column chunks (DLA_OPT_STAGE_CHUNKS >= 2, on request): every
     chunk flows download | caller's routine | upload, and the projection sweep of a chunk (its columns of [X | U]^T AU,
     reference diaglib.f90:1691) runs behind its upload while the caller's routine has the next chunk.
     Same history as the oracle, eigenvalues to 1e-12, and as many calls of the caller's routine as chunks."""
