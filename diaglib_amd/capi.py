@@ -35,7 +35,7 @@ EXPORTS = [
     "dla_backend_name", "dla_get_stats", "dla_reset_stats", "dla_get_kernel_stats", "dla_stream",
     "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_p2p_export", "dla_p2p_attach", "dla_p2p_detach", "dla_set_allreduce_hook", "dla_set_shard",
     "dla_alloc", "dla_free", "dla_trim", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
-    "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_trmm_gram", "dla_update_gram", "dla_combo_gram", "dla_ritz_residual", "dla_ritz_residual_p", "dla_axpy",
+    "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_trmm_gram", "dla_update_gram", "dla_combo_gram", "dla_ritz_residual", "dla_ritz_residual_p", "dla_ritz_residual2", "dla_axpy",
     "dla_nrm2", "dla_stream_triad", "dla_random_fill", "dla_fill_guess",
     "dla_ortho_cd", "dla_ortho_qr", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
     "dla_call_matvec", "dla_call_precnd", "dla_expand_project",
@@ -113,6 +113,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_combo_gram": (i, [vp, i, i, vp, i, c_dp, i, vp, c_dp, i]),
         "dla_ritz_residual": (i, [vp, i, i, i, vp, vp, c_dp, i, c_dp, i, c_ip, vp, vp, vp, c_dp]),
         "dla_ritz_residual_p": (i, [vp, i, i, i, vp, vp, c_dp, i, c_dp, i, c_ip, vp, vp, vp, c_dp, i, c_dp, i, vp, vp]),
+        "dla_ritz_residual2": (i, [vp, i, i, i, vp, vp, c_dp, i, c_dp, i, c_dp, i, c_ip, vp, vp, vp, vp, c_dp]),
         "dla_axpy": (i, [vp, sz, d, vp, vp]), "dla_nrm2": (i, [vp, sz, vp, c_dp]),
         "dla_stream_triad": (i, [vp, sz, i, c_dp]),
         "dla_random_fill": (i, [vp, i, i, vp]), "dla_fill_guess": (i, [vp, i, i, vp, C.c_ulonglong, C.c_longlong]),
@@ -367,6 +368,21 @@ class Context:
                                                n_res, skip.ctypes.data_as(c_ip), evec.ptr, r.ptr,
                                                avy.ptr if avy is not None else None, _dp(rn),
                                                c2.shape[1], _dp(c2), c2.shape[0], p.ptr, ap.ptr))
+        return rn
+
+    def ritz_residual2(self, v: DevPanel, av: DevPanel, y1: np.ndarray, y2: np.ndarray, eig: np.ndarray, n_res: int,
+                       skip: np.ndarray, e: DevPanel, r: DevPanel) -> np.ndarray:
+        """e = V y1, r = AV y2 - eig e with the norms of r, one sweep (the residual blocks of the linear-response drivers)"""
+        y1 = np.asfortranarray(y1, dtype=np.float64); y2 = np.asfortranarray(y2, dtype=np.float64)
+        eig = np.ascontiguousarray(eig, dtype=np.float64)
+        skip = np.ascontiguousarray(skip, dtype=np.int32)
+        rn = np.zeros((2, max(1, n_res)), order="F")
+        tw, jk = self.panel(v.n, e.m), self.panel(v.n, e.m)
+        try:
+            self._chk(self.lib.dla_ritz_residual2(self.h, v.n, v.m, e.m, v.ptr, av.ptr, _dp(y1), y1.shape[0], _dp(y2), y2.shape[0],
+                                                  _dp(eig), n_res, skip.ctypes.data_as(c_ip), e.ptr, r.ptr, tw.ptr, jk.ptr, _dp(rn)))
+        finally:
+            tw.free(); jk.free()
         return rn
 
     def axpy(self, alpha: float, x: DevPanel, y: DevPanel) -> None:

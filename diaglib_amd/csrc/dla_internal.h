@@ -112,6 +112,21 @@ struct Engine : BlockOps {
     if (!st && k2 > 0) st = gemm(n, l, av, k2, c2_host, ldc2, ap, 0);
     return st;
   }
+  // e = V Y1, r = AV Y2 - eig e for the first n_res columns (skip as above) with the norms of r: the residual blocks of the
+  // linear-response drivers (two panels, two coefficient sets).  Default: two panel products (e, and t = AV Y2 in t_work) and
+  // the Ritz sweep on the two n x m results with Y = identity (its copy of e goes to `junk`).
+  virtual int ritz_residual2(int n, int l, int m, const double* v, const double* av, const double* y1_host, int ldy1,
+                             const double* y2_host, int ldy2, const double* eig, int n_res, const int* skip,
+                             double* e, double* r, double* t_work, double* junk, double* sumsq_max)
+  {
+    int st = gemm(n, l, v, m, y1_host, ldy1, e, 0);
+    if (!st) st = gemm(n, l, av, m, y2_host, ldy2, t_work, 0);
+    if (st) return st;
+    std::string ident_s((size_t)m * m * sizeof(double), '\0');
+    double* ident = (double*)&ident_s[0];
+    for (int j = 0; j < m; ++j) ident[(size_t)j * m + j] = 1.0;
+    return ritz_residual(n, m, m, e, t_work, ident, m, eig, n_res, skip, junk, r, nullptr, sumsq_max);
+  }
   virtual int axpy(size_t len, double alpha, const double* x, double* y) = 0;
   virtual int sumsq(size_t len, const double* x, double* out) = 0;
   virtual int stream_triad(size_t /*len*/, int /*reps*/, double* gbps) { *gbps = 0.0; return DLA_ERR_ARG; }

@@ -1085,6 +1085,122 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
   }
 }
 
+// The same sweep with TWO coefficient blocks: e = V Y1 (stored when a.evec is given), r = AV Y2 - theta e for the active columns,
+// sum r^2 and max |r| -- the residual blocks of the linear-response drivers (reference diaglib.f90:872-889, 1337-1353:
+// rp = (A+B) vp u+ - w (S-D) vm u-, two panels with two different coefficient sets), which the reference forms with two dgemms and
+// a daxpy / dnrm2 loop.  Packed coefficients: [2 KT][l4][16], Y1 in the leading KT tiles, Y2 behind.  Blocks of up to 48 columns,
+// no register pipeline (these blocks are n_max <= 16 wide in practice: one tile, like the plain one-tile Ritz step).
+template <int KT, int VEC>
+__global__ __launch_bounds__(256) void ritz2_kernel(RitzArgs a)
+{
+  constexpr int RG = 16 * VEC;
+  extern __shared__ __attribute__((aligned(16))) double cs[];  // [2 KT][l4][16], later reduction scratch
+  typedef typename VecOf<VEC>::type vec_t;
+  const long long n = a.n;
+  const int l = a.l, l4 = a.l4;
+  for (int idx = threadIdx.x; idx < 2 * KT * l4 * 16; idx += 256) cs[idx] = a.cpk[idx];
+  __shared__ double s_theta[48];
+  __shared__ int s_active[48];
+  if (threadIdx.x < 48) { s_theta[threadIdx.x] = a.theta[threadIdx.x]; s_active[threadIdx.x] = a.active[threadIdx.x]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const long long ntiles = (n + RG - 1) / RG;
+  const int nsteps = l4 / 4;
+  double th[KT][4], ssq[KT][4], smx[KT][4];
+  int act[KT][4];
+#pragma unroll
+  for (int q = 0; q < KT; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = 16 * q + g + 4 * reg;
+      th[q][reg] = s_theta[j]; act[q][reg] = s_active[j]; ssq[q][reg] = 0.0; smx[q][reg] = 0.0;
+    }
+  const double* cs2 = cs + (size_t)KT * l4 * 16;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    long long row = tile * RG + VEC * i;
+    const bool rok = row < n;
+    if (!rok) row = 0;
+    v4d av[VEC][KT], aav[VEC][KT];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+      for (int q = 0; q < KT; ++q) { av[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; aav[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll 2
+    for (int cs4 = 0; cs4 < nsteps; ++cs4) {
+      int col = 4 * cs4 + g;
+      const bool cok = col < l;
+      col = cok ? col : l - 1;
+      vec_t xv = pload<VEC, 3>(a.v + (size_t)col * (size_t)n + row);
+      vec_t yv = pload<VEC, 3>(a.av + (size_t)col * (size_t)n + row);
+      xv = cok ? xv : vzero<VEC>();
+      yv = cok ? yv : vzero<VEC>();
+#pragma unroll
+      for (int q = 0; q < KT; ++q) {
+        const double c1 = cs[(size_t)q * l4 * 16 + (size_t)(4 * cs4 + g) * 16 + i];
+        const double c2 = cs2[(size_t)q * l4 * 16 + (size_t)(4 * cs4 + g) * 16 + i];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          av[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, vget<VEC>(xv, e), av[e][q], 0, 0, 0);
+          aav[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(c2, vget<VEC>(yv, e), aav[e][q], 0, 0, 0);
+        }
+      }
+    }
+    if (rok) {
+#pragma unroll
+      for (int q = 0; q < KT; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int j = 16 * q + g + 4 * reg;
+          if (j >= a.k) continue;
+          const double e0 = av[0][q][reg], e1 = av[VEC - 1][q][reg];
+          double r0 = aav[0][q][reg], r1 = aav[VEC - 1][q][reg];
+          if (act[q][reg]) {
+            r0 = r0 - th[q][reg] * e0;
+            ssq[q][reg] += r0 * r0;
+            smx[q][reg] = fmax(smx[q][reg], fabs(r0));
+            if constexpr (VEC == 2) {
+              r1 = r1 - th[q][reg] * e1;
+              ssq[q][reg] += r1 * r1;
+              smx[q][reg] = fmax(smx[q][reg], fabs(r1));
+            }
+          }
+          if (a.evec) pstore<VEC, 3>(a.evec + (size_t)j * (size_t)n + row, vmake<VEC>(e0, e1));
+          pstore<VEC, 3>(a.r + (size_t)j * (size_t)n + row, vmake<VEC>(r0, r1));
+        }
+    }
+  }
+  __syncthreads();
+  double* sred = cs; // [4 waves][16*KT][2]
+#pragma unroll
+  for (int q = 0; q < KT; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      double sv = ssq[q][reg], m = smx[q][reg];
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        sv += __shfl_xor(sv, off, 64);
+        m = fmax(m, __shfl_xor(m, off, 64));
+      }
+      if (i == 0) {
+        const int j = 16 * q + g + 4 * reg;
+        sred[(wave * 16 * KT + j) * 2 + 0] = sv;
+        sred[(wave * 16 * KT + j) * 2 + 1] = m;
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x < 16 * KT) {
+    const int j = threadIdx.x;
+    double sv = 0.0, m = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      sv += sred[(w * 16 * KT + j) * 2 + 0];
+      m = fmax(m, sred[(w * 16 * KT + j) * 2 + 1]);
+    }
+    a.red[((size_t)blockIdx.x * 16 * KT + j) * 2 + 0] = sv;
+    a.red[((size_t)blockIdx.x * 16 * KT + j) * 2 + 1] = m;
+  }
+}
+
 // fixed-shape block reduction (shuffle tree inside each wave, then the 4 waves in order)
 __device__ __forceinline__ void block_sum_max(double& s, double& m, double* sh /* >= 8 doubles */)
 {
@@ -1126,6 +1242,14 @@ __global__ __launch_bounds__(256) void ritz_reduce_kernel(const double* red, int
 // ======================================================================================
 // Elementwise
 // ======================================================================================
+// small host matrix (pinned, device-mapped) -> device, 16 bytes per lane (HipEngine::stage_commit)
+__global__ __launch_bounds__(256) void small_copy_kernel(double* __restrict__ dst, const double* __restrict__ src, int n)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (2 * i + 1 < n) ((v2d*)dst)[i] = ((const v2d*)src)[i];
+  else if (2 * i < n) dst[2 * i] = src[2 * i];
+}
+
 __global__ void axpy_kernel(size_t len, double alpha, const double* __restrict__ x, double* __restrict__ y)
 {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2922,15 +3046,22 @@ struct HipEngine : dla::Engine {
     return DLA_OK;
   }
 
-  // stage a small host matrix to the device through a ring of pinned buffers (no host sync)
-  int stage_to_device(const double* host_packed, size_t bytes, double* dev)
+  // Stage a small host matrix to the device through a ring of pinned, device-mapped buffers (no host sync): the caller packs
+  // straight into the slot (stage_slot), stage_commit enqueues the copy.
+  // (The runtime's copy shows up as __amd_rocclr_copyBuffer, 16 us of stream time per 30 KB in a solve's trace, and in isolation
+  // a copy kernel of the engine's own is faster -- tools/upload_probe.hip: 26 us host-to-consumer against 20 us -- but inside a
+  // solve it buys nothing: interleaved A/B, knob 7 = 9, 16.88 / 16.90 ms against 16.90 / 16.88 at n = 2e6 and 3.90 / 3.90 against
+  // 3.86 / 3.87 at 250 k rows.  The runtime's copy stays.)
+  double* h_ring_dev[RING] = {nullptr};
+  int stage_slot(size_t bytes, double** host, int* slot_out)
   {
     bind();
     if (bytes > ring_bytes) {
       HIPCHK(hipStreamSynchronize(st));
       for (int i = 0; i < RING; ++i) {
         if (h_ring[i]) { HIPCHK(hipHostFree(h_ring[i])); } else { HIPCHK(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming)); }
-        HIPCHK(hipHostMalloc((void**)&h_ring[i], std::max(bytes, (size_t)1 << 16), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&h_ring[i], std::max(bytes, (size_t)1 << 16), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void**)&h_ring_dev[i], h_ring[i], 0));
       }
       ring_bytes = std::max(bytes, (size_t)1 << 16);
     }
@@ -2939,10 +3070,31 @@ struct HipEngine : dla::Engine {
     const double t0 = now();
     HIPCHK(hipEventSynchronize(ring_ev[slot]));
     t_evsync += now() - t0;
-    std::memcpy(h_ring[slot], host_packed, bytes);
-    HIPCHK(hipMemcpyAsync(dev, h_ring[slot], bytes, hipMemcpyHostToDevice, st));
+    *host = h_ring[slot];
+    *slot_out = slot;
+    return DLA_OK;
+  }
+  int stage_commit(int slot, size_t bytes, double* dev)
+  {
+    if (tune[7] != 9) {
+      HIPCHK(hipMemcpyAsync(dev, h_ring[slot], bytes, hipMemcpyHostToDevice, st));
+    } else {                                 // A/B: a copy kernel of the engine's own reading the mapped slot
+      const int cnt = (int)(bytes / sizeof(double));
+      hipLaunchKernelGGL(small_copy_kernel, dim3((cnt / 2 + 255) / 256 > 0 ? (cnt / 2 + 255) / 256 : 1), dim3(256), 0, st, dev,
+                         (const double*)h_ring_dev[slot], cnt);
+      HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(ring_ev[slot], st));
     return DLA_OK;
+  }
+  int stage_to_device(const double* host_packed, size_t bytes, double* dev)
+  {
+    double* h = nullptr;
+    int slot = 0;
+    const int stc = stage_slot(bytes, &h, &slot);
+    if (stc) return stc;
+    std::memcpy(h, host_packed, bytes);
+    return stage_commit(slot, bytes, dev);
   }
 
   // ---- collectives on small device buffers
@@ -3965,12 +4117,18 @@ struct HipEngine : dla::Engine {
       cpk_bytes = std::max(sizeof(double) * cnt, (size_t)1 << 16);
       HIPCHK(hipMalloc((void**)&d_cpk, cpk_bytes));
     }
-    std::vector<double> pk(cnt, 0.0);
+    double* pk = nullptr;                    // packed straight into the pinned slot
+    int slot = 0;
+    const int stc = stage_slot(sizeof(double) * cnt, &pk, &slot);
+    if (stc) return stc;
+    std::memset(pk, 0, sizeof(double) * cnt);
     for (int j = 0; j < k; ++j) {
       const int q = j / 16, jj = j % 16;
-      for (int p = 0; p < l; ++p) pk[(size_t)q * l4 * 16 + (size_t)p * 16 + jj] = c_host[(size_t)(l0 + p) + (size_t)j * ldc];
+      double* dst = pk + (size_t)q * l4 * 16 + jj;
+      const double* src = c_host + (size_t)l0 + (size_t)j * ldc;
+      for (int p = 0; p < l; ++p) dst[(size_t)p * 16] = src[p];
     }
-    return stage_to_device(pk.data(), sizeof(double) * cnt, d_cpk);
+    return stage_commit(slot, sizeof(double) * cnt, d_cpk);
   }
 
   // quarter tiles of the last 16-column tile (0: none): blocks of 17..24 and 33..40 columns on the 16-byte path
@@ -4318,6 +4476,73 @@ struct HipEngine : dla::Engine {
     for (int j = 0; j < n_res; ++j) {
       double mx = 0.0;
       for (int r = 0; r < nslots; ++r) mx = std::max(mx, h_small[ncol + r * ncol + j]);
+      out[2 * j] = h_small[j]; out[2 * j + 1] = mx;
+    }
+    return DLA_OK;
+  }
+
+  // the Ritz sweep with two coefficient blocks (ritz2_kernel); shapes it does not take go through the three-sweep default
+  int ritz_residual2(int n, int l, int m, const double* v, const double* av, const double* y1_host, int ldy1,
+                     const double* y2_host, int ldy2, const double* eig, int n_res, const int* skip,
+                     double* e, double* r, double* t_work, double* junk, double* out) override
+  {
+    const int kt = (m + 15) / 16, l4 = ((l + 3) / 4) * 4;
+    const size_t lds_c = sizeof(double) * (size_t)l4 * 16 * 2 * kt;
+    if (m > 48 || m <= 0 || l <= 0 || lds_c > std::min((size_t)150 * 1024, lds_limit > 2048 ? lds_limit - 2048 : 0) || tune[0] == 6)
+      return Engine::ritz_residual2(n, l, m, v, av, y1_host, ldy1, y2_host, ldy2, eig, n_res, skip, e, r, t_work, junk, out);
+    // [Y1 | Y2] packed as 2 kt tiles: Y2 starts at tile kt
+    std::vector<double> yy((size_t)l * (16 * kt + m), 0.0);
+    for (int j = 0; j < m; ++j) {
+      std::memcpy(&yy[(size_t)j * l], y1_host + (size_t)j * ldy1, sizeof(double) * l);
+      std::memcpy(&yy[(size_t)(16 * kt + j) * l], y2_host + (size_t)j * ldy2, sizeof(double) * l);
+    }
+    int stc = upload_packed(yy.data(), l, 0, l, 16 * kt + m, 2 * kt, l4);
+    if (stc) return stc;
+    RitzArgs a{};
+    int nact = 0;
+    for (int j = 0; j < n_res && j < 48; ++j) {
+      if (skip && skip[j]) continue;
+      a.theta[j] = eig[j]; a.active[j] = 1; ++nact;
+    }
+    const uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)e | (uintptr_t)r;
+    const bool vec2 = (n % 2 == 0) && (al % 16 == 0);
+    const int rg = vec2 ? 32 : 16;
+    const long long ntiles = ((long long)n + rg - 1) / rg;
+    const size_t lds = std::max(lds_c, sizeof(double) * 4 * 16 * kt * 2);
+    const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
+    const int blocks = (int)std::max(1LL, std::min((long long)ncu * per_cu, (ntiles + 7) / 8));
+    stc = ensure_partial(sizeof(double) * (size_t)blocks * 16 * kt * 2);
+    if (stc) return stc;
+    const int nslots = (local_only || nranks < 1) ? 1 : nranks;
+    stc = ensure_small(sizeof(double) * (size_t)16 * kt * (1 + nslots));
+    if (stc) return stc;
+    a.v = v; a.av = av; a.cpk = d_cpk; a.evec = e; a.r = r; a.avy = nullptr; a.red = d_partial;
+    a.n = n; a.l = l; a.l4 = l4; a.k = m;
+    const int ncol = 16 * kt;
+    {
+      char kn[64];
+      std::snprintf(kn, sizeof kn, "ritz2_kernel<%d, %d>", kt, vec2 ? 2 : 1);
+      // (flops: the two products and the residual correction, as the reference's dgemm pair + daxpy / dnrm2 loop)
+      Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + 2.0 * m), 4.0 * (double)n * l * m + 5.0 * (double)n * nact, kn);
+#define RZ2(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds, 1024)) return DLA_ERR_RUNTIME; DLA_LAUNCH(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
+      if (vec2) { if (kt == 1) RZ2((ritz2_kernel<1, 2>)); else if (kt == 2) RZ2((ritz2_kernel<2, 2>)); else RZ2((ritz2_kernel<3, 2>)); }
+      else { if (kt == 1) RZ2((ritz2_kernel<1, 1>)); else if (kt == 2) RZ2((ritz2_kernel<2, 1>)); else RZ2((ritz2_kernel<3, 1>)); }
+#undef RZ2
+    }
+    {
+      Scope s2(this, DLA_OP_RITZ, 0.0, 0.0, "ritz_reduce_kernel");
+      DLA_LAUNCH(ritz_reduce_kernel, dim3(ncol), dim3(256), 0, st, (const double*)d_partial, blocks, ncol, d_small,
+                         h_small_dev, nslots, local_only ? 0 : rank);
+    }
+    HIPCHK(hipGetLastError());
+    exchange_fused = false;
+    stc = allreduce_dev(d_small, ncol * (1 + nslots), 0, h_small);
+    if (stc) return stc;
+    stc = small_to_host((size_t)ncol * (1 + nslots));
+    if (stc) return stc;
+    for (int j = 0; j < n_res; ++j) {
+      double mx = 0.0;
+      for (int rr = 0; rr < nslots; ++rr) mx = std::max(mx, h_small[ncol + rr * ncol + j]);
       out[2 * j] = h_small[j]; out[2 * j + 1] = mx;
     }
     return DLA_OK;

@@ -409,6 +409,26 @@ int dla_ritz_residual_p(dla_ctx* c, int n, int l, int m, const double* v, const 
   return DLA_OK;
 }
 
+int dla_ritz_residual2(dla_ctx* c, int n, int l, int m, const double* v, const double* av, const double* y1, int ldy1,
+                       const double* y2, int ldy2, const double* eig, int n_res, const int* skip, double* e, double* r,
+                       double* t_work, double* junk, double* rnorm)
+{
+  DLA_T("dla_ritz_residual2");
+  if (!c || !v || !av || !y1 || !y2 || !eig || !e || !r || !t_work || !junk || !rnorm || n <= 0 || l <= 0 || m <= 0 || ldy1 < l || ldy2 < l ||
+      n_res < 0 || n_res > m)
+    return fail(c, DLA_ERR_ARG, "dla_ritz_residual2: bad argument");
+  std::vector<double> sm((size_t)2 * (n_res > 0 ? n_res : 1), 0.0);
+  int st = c->eng->ritz_residual2(n, l, m, v, av, y1, ldy1, y2, ldy2, eig, n_res, skip, e, r, t_work, junk, sm.data());
+  if (st) return engfail(c, st);
+  const double sqrtn = std::sqrt((double)global_rows(c, n));
+  for (int i = 0; i < n_res; ++i) {
+    if (skip && skip[i]) continue;
+    rnorm[2 * i] = std::sqrt(sm[2 * i]) / sqrtn;
+    rnorm[2 * i + 1] = sm[2 * i + 1];
+  }
+  return DLA_OK;
+}
+
 int dla_axpy(dla_ctx* c, size_t len, double alpha, const double* x, double* y)
 {
   DLA_T("dla_axpy");

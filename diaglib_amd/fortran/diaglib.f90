@@ -181,6 +181,15 @@ module diaglib
       integer(c_int) :: skip(*)
       integer(c_int) :: st
     end function
+    function dla_ritz_residual2(ctx,n,l,m,v,av,y1,ldy1,y2,ldy2,eig,n_res,skip,e,r,twork,junk,rnorm) &
+             bind(C,name='dla_ritz_residual2') result(st)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr),    value :: ctx, v, av, e, r, twork, junk
+      integer(c_int), value :: n, l, m, ldy1, ldy2, n_res
+      real(c_double)        :: y1(*), y2(*), eig(*), rnorm(*)
+      integer(c_int)        :: skip(*)
+      integer(c_int)        :: st
+    end function
     function dla_axpy(ctx,len,alpha,x,y) bind(C,name='dla_axpy') result(st)
       import :: c_ptr, c_int, c_double, c_size_t
       type(c_ptr), value :: ctx, x, y
@@ -623,10 +632,11 @@ contains
     type(c_ptr)     :: basis, abasis, bbasis, resid, britz
     real(dp), allocatable :: h(:,:), y(:,:), theta(:)
     real(dp)        :: t_begin(2), t_end(2)
-    integer         :: it, sweeps, kept, col, first, j
+    integer         :: it, sweeps, kept, col, first, j, ritz_cols
     logical         :: patch_kept, projected
 !
     call env_open(e, n, n_max, evec)
+    ritz_cols = 0
 !
 !   the basis holds at least min_dav blocks whatever the caller asks for (reference :1595-1596)
 !
@@ -709,9 +719,14 @@ contains
 !
       call sub_refresh_mask(s)
       if (with_metric) then
+!
+!       with a metric the sweep reads B*basis and A*basis (residual A x - theta B x, :2108-2123); the Ritz vectors
+!       themselves, basis*y (:2103), are a third panel nobody reads before the solve ends or restarts: they are formed there
+!       (ritz_cols remembers the width y belongs to)
+!
         call chk(e%ctx, dla_ritz_residual(e%ctx, n, s%cols, n_max, bbasis, abasis, y, s%ld, eig, n_targ, s%mask, &
                                           britz, resid, c_null_ptr, s%rnorm), 'ritz/residual')
-        call chk(e%ctx, dla_panel_gemm(e%ctx, n, s%cols, basis, n_max, y, s%ld, e%ritz), 'ritz vectors')
+        ritz_cols = s%cols
       else
         call chk(e%ctx, dla_ritz_residual(e%ctx, n, s%cols, n_max, basis, abasis, y, s%ld, eig, n_targ, s%mask, &
                                           e%ritz, resid, c_null_ptr, s%rnorm), 'ritz/residual')
@@ -760,6 +775,10 @@ contains
 !
         if (verbose) write(6,'(t7,a)') 'Restarting davidson.'
         e%restarts = e%restarts + 1
+        if (ritz_cols.gt.0) then
+          call chk(e%ctx, dla_panel_gemm(e%ctx, n, ritz_cols, basis, n_max, y, s%ld, e%ritz), 'ritz vectors')
+          ritz_cols = 0
+        end if
         call chk(e%ctx, dla_copy(e%ctx, basis, e%ritz, nbytes(n,n_max)), 'copy')
         if (with_metric) then
           call chk(e%ctx, dla_copy(e%ctx, bbasis, britz, nbytes(n,n_max)), 'copy')
@@ -780,6 +799,9 @@ contains
       end if
       if (verbose) call print_block_report(s)
     end do
+!
+!   (generalised problem: the Ritz vectors of the last sweep, converged or not)
+    if (ritz_cols.gt.0) call chk(e%ctx, dla_panel_gemm(e%ctx, n, ritz_cols, basis, n_max, y, s%ld, e%ritz), 'ritz vectors')
 !
     call clock_now(t_end)
     w%total = t_end - t_begin
@@ -842,7 +864,7 @@ contains
     type(c_funptr)  :: op, prec, metric
     type(c_ptr)     :: sp(2), asp(2), bsp(2), resid, latest
     integer         :: rd, wr              ! the copy the basis is read from / the copy that receives the new X and P
-    real(dp), allocatable :: h(:,:), theta(:), cx(:,:), cp(:,:), seen(:,:,:)
+    real(dp), allocatable :: h(:,:), theta(:), cx(:,:), cp(:,:), ycp(:,:), seen(:,:,:)
     real(dp)        :: t_begin(2), t_end(2)
     integer         :: it, sweeps, width, live, c_x, c_p, c_w, wide, bet
     logical         :: projected           ! the W block already has its operator image and S^T A S is in h (dla_expand_project)
@@ -927,19 +949,30 @@ contains
 !     sweep the bet is lost and the block is formed again below, as before.
 !
       call sub_refresh_mask(s)
-      bet = 0
+      bet = open_roots_expected()
+      allocate (cx(width,n_max), cp(width,bet))
+      call chk(e%ctx, dla_get_coeffs(e%ctx, wide, width, n_max, bet, h, cx, cp), 'get_coeffs')
       if (.not.gen_eig) then
-        bet = open_roots_expected()
-        allocate (cx(width,n_max), cp(width,bet))
-        call chk(e%ctx, dla_get_coeffs(e%ctx, wide, width, n_max, bet, h, cx, cp), 'get_coeffs')
         call chk(e%ctx, dla_ritz_residual_p(e%ctx, n, width, n_max, sp(rd), asp(rd), h, wide, eig, n_max, s%mask, &
                                             sp(wr), resid, asp(wr), s%rnorm, bet, cp, width, &
                                             colp(sp(wr),n,n_max+1), colp(asp(wr),n,n_max+1)), 'ritz/residual + p block')
-        latest = sp(wr)
-        deallocate (cx, cp)
       else
-        call ritz_step(width)
+!
+!       with a metric: the sweep over B S and A S gives B X, A X, the residual A X - eig B X and the B P, A P blocks; X and P
+!       themselves come from ONE product S [y | cp] -- every basis panel is read once per iteration (the separate products of
+!       :420-424 and :495-503 read each of them twice)
+!
+        call chk(e%ctx, dla_ritz_residual_p(e%ctx, n, width, n_max, bsp(rd), asp(rd), h, wide, eig, n_max, s%mask, &
+                                            bsp(wr), resid, asp(wr), s%rnorm, bet, cp, width, &
+                                            colp(bsp(wr),n,n_max+1), colp(asp(wr),n,n_max+1)), 'ritz/residual + p block')
+        allocate (ycp(width,n_max+bet))
+        ycp(:,1:n_max)  = h(1:width,1:n_max)
+        ycp(:,n_max+1:) = cp
+        call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, sp(rd), n_max+bet, ycp, width, sp(wr)), 'ritz vectors + p block')
+        deallocate (ycp)
       end if
+      latest = sp(wr)
+      deallocate (cx, cp)
       seen(:,:,1) = seen(:,:,2)
       seen(:,:,2) = s%rnorm(1:2,1:n_max)
 !
@@ -1442,10 +1475,9 @@ contains
       type(c_ptr), intent(in)    :: bpanel, tpanel, res
       real(dp),    intent(in)    :: cb(s%ld,n_max), ct(s%ld,n_max)
       real(dp),    intent(inout) :: norms(2,n_max)
-      call chk(e%ctx, dla_panel_gemm(e%ctx, n, s%cols, bpanel, n_max, cb, s%ld, bp), 'residual')
-      call chk(e%ctx, dla_panel_gemm(e%ctx, n, s%cols, tpanel, n_max, ct, s%ld, tp), 'residual')
-      call chk(e%ctx, dla_ritz_residual(e%ctx, n, n_max, n_max, bp, tp, eye, n_max, eig, n_targ, s%mask, &
-                                        tm, res, c_null_ptr, norms), 'residual')
+!     (one sweep over the two panels with the two coefficient blocks; the reference: two dgemms, then daxpy / dnrm2 per root)
+      call chk(e%ctx, dla_ritz_residual2(e%ctx, n, s%cols, n_max, bpanel, tpanel, cb, s%ld, ct, s%ld, eig, n_targ, s%mask, &
+                                         bp, res, tp, tm, norms), 'residual')
     end subroutine residual_pair
 !
 !   Ritz vectors vp u+ and vm u- (in the scratch blocks bp, bm), then Y = sum, Z = difference (:862-868, 1324-1333)

@@ -215,6 +215,13 @@ int  dla_ritz_residual_p(dla_ctx* ctx, int n, int l, int m, const double* v_dev,
                          const double* y_host, int ldy, const double* eig, int n_res, const int* skip,
                          double* evec_dev, double* r_dev, double* avy_dev, double* rnorm,
                          int k2, const double* c2_host, int ldc2, double* p_dev, double* ap_dev);
+/* The sweep with TWO coefficient sets: e_dev = V Y1, r_dev = AV Y2, then for i < n_res with skip[i]==0: r_i -= eig_i e_i and the
+ * norms as above.  The residual blocks of the linear-response drivers are of this shape -- rp = (A+B) vp u+ - w (S-D) vm u-
+ * (diaglib.f90:872-889, 1337-1353: two dgemms on two panels with two coefficient blocks, then the daxpy / dnrm2 loop).
+ * t_work_dev, junk_dev: n x m scratch blocks (used only for shapes the one-sweep kernel does not take: m > 48). */
+int  dla_ritz_residual2(dla_ctx* ctx, int n, int l, int m, const double* v_dev, const double* av_dev,
+                        const double* y1_host, int ldy1, const double* y2_host, int ldy2, const double* eig, int n_res,
+                        const int* skip, double* e_dev, double* r_dev, double* t_work_dev, double* junk_dev, double* rnorm);
 /* Expansion step of the Davidson and LOBPCG drivers on the contiguous panels basis = [X | U] (n x (m+k)) and
  * abasis = [AX | AU]:   ortho_vs_x(X, U)  (diaglib.f90:1790, 358-366, 523-529),  AU = A U [+ shift U]  (the caller's matvec,
  * :1685, 394-397; daxpy :397)  and the projection --

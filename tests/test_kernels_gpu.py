@@ -282,3 +282,30 @@ def test_ritz_sweep_with_extra_products(ctx, rng, n, l, m, k2):
         assert np.array_equal(gap[:, 1:k2 + 1], zap.download())
         bound = 64 * EPS * (np.abs(v) @ np.abs(c2[:l])) + 1e-300
         assert np.all(np.abs(gp[:, 1:k2 + 1] - v @ c2[:l]) <= bound)
+
+
+@pytest.mark.parametrize("n,l,m", [(4096, 40, 8), (3001, 77, 13), (2048, 160, 8), (2500, 64, 21), (1024, 30, 52)])
+def test_ritz_sweep_with_two_coefficient_blocks(ctx, rng, n, l, m):
+    """dla_ritz_residual2: e = V y1, r = AV y2 - theta e and the norms of r in one sweep (the residual blocks of the linear-response
+    drivers, reference diaglib.f90:872-889, 1337-1353: two dgemms + daxpy / dnrm2), against numpy; skipped roots stay uncorrected;
+    m = 52 goes through the three-sweep default."""
+    v = np.asfortranarray(rng.standard_normal((n, l))); av = np.asfortranarray(rng.standard_normal((n, l)))
+    y1 = np.asfortranarray(rng.standard_normal((l, m))); y2 = np.asfortranarray(rng.standard_normal((l, m)))
+    theta = rng.standard_normal(m)
+    n_res = max(1, m - 2)
+    skip = np.zeros(n_res, np.int32); skip[0] = 1
+    pv, pav, pe, pr = ctx.panel(v), ctx.panel(av), ctx.panel(n, m), ctx.panel(n, m)
+    rn = ctx.ritz_residual2(pv, pav, y1, y2, theta, n_res, skip, pe, pr)
+    e_want = v @ y1
+    r_want = av @ y2
+    for j in range(n_res):
+        if not skip[j]:
+            r_want[:, j] -= theta[j] * e_want[:, j]
+    bound = 64 * EPS * (np.abs(v) @ np.abs(y1) + np.abs(av) @ np.abs(y2) * (1 + np.abs(theta).max()))
+    assert np.all(np.abs(pe.download() - e_want) <= bound)
+    assert np.all(np.abs(pr.download() - r_want) <= bound)
+    for j in range(n_res):
+        if skip[j]:
+            continue
+        assert np.isclose(rn[0, j], np.linalg.norm(r_want[:, j]) / np.sqrt(n), rtol=1e-12)
+        assert np.isclose(rn[1, j], np.abs(r_want[:, j]).max(), rtol=1e-12)
