@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
               }
             }
           }
-          pstore<VEC, NT>(a.evec + (size_t)j * (size_t)n + row, vmake<VEC>(e0, e1));
+          if (a.evec) pstore<VEC, NT>(a.evec + (size_t)j * (size_t)n + row, vmake<VEC>(e0, e1));     // (optional: Ritz vectors nobody reads are not written)
           pstore<VEC, NT>(a.r + (size_t)j * (size_t)n + row, vmake<VEC>(r0, r1));
         }
     }
@@ -4368,7 +4368,7 @@ struct HipEngine : dla::Engine {
         const int nr = std::max(0, std::min(n_res - j0, mc));
         std::vector<double> o2((size_t)2 * std::max(nr, 1), 0.0);
         int stq = ritz_residual(n, l, mc, v, av, y_host + (size_t)j0 * ldy, ldy, eig + j0, nr, skip ? skip + j0 : nullptr,
-                                evec + (size_t)j0 * n, r + (size_t)j0 * n, avy ? avy + (size_t)j0 * n : nullptr, o2.data());
+                                evec ? evec + (size_t)j0 * n : nullptr, r + (size_t)j0 * n, avy ? avy + (size_t)j0 * n : nullptr, o2.data());
         if (stq) return stq;
         for (int j = 0; j < nr; ++j) { out[2 * (j0 + j)] = o2[2 * j]; out[2 * (j0 + j) + 1] = o2[2 * j + 1]; }
       }
@@ -4376,7 +4376,7 @@ struct HipEngine : dla::Engine {
     }
     const int kt = (m + k2 + 15) / 16;      // column tiles of [Y | C2]
     const int l4 = ((l + 3) / 4) * 4;
-    uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy | (uintptr_t)p2 | (uintptr_t)ap2;
+    uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy | (uintptr_t)p2 | (uintptr_t)ap2;   // (null pointers are aligned)
     const bool vec2 = (n % 2 == 0) && (al % 16 == 0);
     const int qt = (tune[0] == 1 || tune[0] == 4) ? 0 : quarter_tiles(m + k2, vec2);
     // LDS copy of Y (a quarter-tile kernel keeps 8 columns of the last tile)
@@ -4387,8 +4387,14 @@ struct HipEngine : dla::Engine {
       // two products with the chunked panel GEMM, then run the fused sweep on the n x m results with Y = identity
       // for the residual correction and the norms (same arithmetic for r; evec and AV Y are plain products)
       void* tmp = nullptr;
+      void* ev_tmp = nullptr;
       int stf = alloc(sizeof(double) * (size_t)n * m, &tmp);
       if (stf) return stf;
+      if (!evec) {                         // (the caller does not want the vectors, this path needs them as an operand)
+        stf = alloc(sizeof(double) * (size_t)n * m, &ev_tmp);
+        if (stf) { (void)free_(tmp); return stf; }
+        evec = (double*)ev_tmp;
+      }
       stf = gemm(n, l, av, m, y_host, ldy, (double*)tmp, 0);
       if (!stf) stf = gemm(n, l, v, m, y_host, ldy, evec, 0);
       if (!stf && avy) stf = d2d(avy, tmp, sizeof(double) * (size_t)n * m);
@@ -4398,6 +4404,7 @@ struct HipEngine : dla::Engine {
         stf = ritz_residual(n, m, m, evec, (const double*)tmp, ident.data(), m, eig, n_res, skip, evec, r, nullptr, out);
       }
       int stq = free_(tmp);
+      if (ev_tmp) { const int stq2 = free_(ev_tmp); if (!stq) stq = stq2; }
       return stf ? stf : stq;
     }
     int stc = upload_packed(y_host, ldy, 0, l, m + k2, kt, l4);
@@ -4426,7 +4433,7 @@ struct HipEngine : dla::Engine {
       char kn[64];
       std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d, %s>", kt, vec2 ? 2 : 1, kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt, k2 > 0 ? "true" : "false");
       // (flops: the two Ritz products and, with extra columns, the two panel products they replace)
-      Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + (avy ? 3.0 : 2.0) * m + 2.0 * k2),
+      Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + ((avy ? 2.0 : 1.0) + (evec ? 1.0 : 0.0)) * m + 2.0 * k2),
               4.0 * (double)n * l * (m + k2) + 5.0 * (double)n * nact, kn);
 #define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds, ritz_static_lds(kt))) return DLA_ERR_RUNTIME; DLA_LAUNCH(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
       if (k2 > 0) {

@@ -545,6 +545,27 @@ contains
     yes = all(s%locked(1:s%want))
   end function sub_finished
 !
+!
+! Can the sweep of this iteration end the solve?  Every wanted root that is still open must come under both thresholds in
+! ONE sweep.  A Davidson-Liu sweep shrinks a residual by one to two orders of magnitude; a root whose last residual stood
+! more than four orders above its threshold is taken not to make it (when it does, the driver forms the Ritz vectors after
+! the sweep instead of inside it).  The first sweep cannot lock anything (:1741).
+!
+  function sub_may_finish(s, iteration) result(yes)
+    type(subspace), intent(in) :: s
+    integer,        intent(in) :: iteration
+    logical :: yes
+    integer :: r
+    real(dp), parameter :: reach = 1.0e4_dp
+    yes = .false.
+    if (iteration.le.1) return
+    do r = 1, s%want
+      if (s%locked(r)) cycle
+      if (s%rnorm(1,r).gt.reach*s%tol_rms .or. s%rnorm(2,r).gt.reach*s%tol_max) return
+    end do
+    yes = .true.
+  end function sub_may_finish
+!
   function sub_has_room(s) result(yes)
     type(subspace), intent(in) :: s
     logical :: yes
@@ -728,8 +749,20 @@ contains
                                           britz, resid, c_null_ptr, s%rnorm), 'ritz/residual')
         ritz_cols = s%cols
       else
-        call chk(e%ctx, dla_ritz_residual(e%ctx, n, s%cols, n_max, basis, abasis, y, s%ld, eig, n_targ, s%mask, &
-                                          e%ritz, resid, c_null_ptr, s%rnorm), 'ritz/residual')
+!
+!       The Ritz vectors basis*y (:1717) are read by nobody before the solve ends or restarts: the sweep writes them only
+!       when that can happen after it -- the last sweep allowed, a full basis, or convergence in sight (sub_may_finish) --
+!       and the rare sweep that converges unannounced forms them afterwards.
+!
+        if (it.eq.max_iter .or. .not.sub_has_room(s) .or. sub_may_finish(s, it)) then
+          call chk(e%ctx, dla_ritz_residual(e%ctx, n, s%cols, n_max, basis, abasis, y, s%ld, eig, n_targ, s%mask, &
+                                            e%ritz, resid, c_null_ptr, s%rnorm), 'ritz/residual')
+          ritz_cols = 0
+        else
+          call chk(e%ctx, dla_ritz_residual(e%ctx, n, s%cols, n_max, basis, abasis, y, s%ld, eig, n_targ, s%mask, &
+                                            c_null_ptr, resid, c_null_ptr, s%rnorm), 'ritz/residual')
+          ritz_cols = s%cols
+        end if
       end if
 !
       call sub_lock(s, it, n_targ)

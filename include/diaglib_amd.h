@@ -203,7 +203,9 @@ int  dla_panel_update(dla_ctx* ctx, int n, int l, const double* x_dev, int k, co
 int  dla_trmm_linvt(dla_ctx* ctx, int n, int k, double* u_dev, const double* linv_host, int ld);
 /* Fused Ritz step.  evec = V Y(:,1:m), r = AV Y(:,1:m); then for i < n_res with skip[i]==0:
  * r_i -= eig_i evec_i, rnorm[2i] = ||r_i||_2/sqrt(n_global), rnorm[2i+1] = max|r_i|.
- * avy_dev (may be NULL) also receives the uncorrected AV Y (LOBPCG's ax_new).
+ * avy_dev (may be NULL) also receives the uncorrected AV Y (LOBPCG's ax_new).  evec_dev may be NULL: the Ritz vectors are
+ * then not written (8 n m bytes less) -- the Davidson driver asks for them only in sweeps after which somebody reads them
+ * (convergence in sight, restart, last sweep).
  * diaglib.f90:1717-1732 (Davidson, n_res = n_targ) and 420-442 (LOBPCG, n_res = n_max). */
 int  dla_ritz_residual(dla_ctx* ctx, int n, int l, int m, const double* v_dev, const double* av_dev,
                        const double* y_host, int ldy, const double* eig, int n_res, const int* skip,

@@ -81,6 +81,8 @@ struct HostSimEngine : dla::Engine {
   int ritz_residual(int n, int l, int m, const double* v, const double* av, const double* y, int ldy, const double* eig,
                     int n_res, const int* skip, double* evec, double* r, double* avy, double* out) override
   {
+    std::vector<double> ev_tmp;
+    if (!evec) { ev_tmp.resize((size_t)n * m); evec = ev_tmp.data(); }       // (evec is optional: the caller does not want the vectors)
     orc_gemm_nn(n, l, m, 1.0, v, n, y, ldy, 0.0, evec, n);
     orc_gemm_nn(n, l, m, 1.0, av, n, y, ldy, 0.0, r, n);
     if (avy) std::memcpy(avy, r, sizeof(double) * (size_t)n * m);
