@@ -2430,6 +2430,11 @@ struct GramReduceArgs {
   int extra;           // 1: one more output tile, slot tlw * kt of pass 0 (gram_lds_kernel WP: the Gram matrix of the U block);
                        // it lands in rows l .. l + k - 1 of c
   int ldc;             // leading dimension of c: l, or l + k with the extra tile
+  int fenced;          // 1: hand the level-2 rows and C over behind agent-scope release / acquire fences (the portable form: what
+                       // the HIP memory model guarantees) instead of write-through stores + drained store counter + sc1 loads
+                       // (what gfx942 / gfx950 make of relaxed agent-scope atomics: 3.4 us per launch less).  Tune knob 5 = 3;
+                       // tests/test_ortho_chain_gpu.py runs both and requires identical bits, tests/test_abi.py checks the
+                       // sc1 bits in the code object.
 };
 
 // Second stage of every reduction: sum the block partials in a fixed order and scatter into column-major C.
@@ -2487,9 +2492,11 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+      if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       const unsigned t = __hip_atomic_fetch_add(&a.ticket[ps], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = (t == (unsigned)(G - 1));
       if (last) __hip_atomic_store(&a.ticket[ps], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (last && a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       s_last = last;
     }
     __syncthreads();
@@ -2511,7 +2518,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
   const bool exchange = TAIL && a.p2p.nranks > 1;
   // the chain's tail reads C in this same launch: for ortho_tail16 (sc1 loads) write-through stores, drained, and a ticket
   // are the whole hand-over; the LDS-loop tail and the peer-to-peer exchange read with plain loads behind an acquire
-  const bool wt = TAIL && a.tail.fold && !exchange;
+  const bool wt = TAIL && a.tail.fold && !exchange && !a.fenced;
   if (live) {
     double* dst = a.c + (size_t)xcol + (size_t)ucol * a.ldc;
     if (wt) __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3354,6 +3361,7 @@ struct HipEngine : dla::Engine {
   {
     exchange_fused = false;
     if (ra.ldc == 0) ra.ldc = ra.l;
+    ra.fenced = tune[5] == 3 ? 1 : 0;
     if (fuse_tail && p2p.on && ra.ldc * ra.k > P2P_MAX_DOUBLES) fuse_tail = false;   // beyond a mailbox slot: separate launches
     if (fuse_tail) {
       ra.do_tail = 1; ra.tail = pending_tail; tail_fused = true;

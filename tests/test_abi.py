@@ -65,3 +65,36 @@ def test_fails_loudly_without_gpu():
     env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert "status 1" in p.stdout or "status 4" in p.stdout, (p.stdout, p.stderr)
+
+
+def test_reduction_hand_over_carries_sc1_in_the_code_object(tmp_path):
+    """gram_reduce_kernel hands its level-2 rows to the last-arriving block with relaxed agent-scope atomic stores /
+    loads and a relaxed ticket.  That is only a hand-over because gfx950 lowers them to write-through (sc1) stores and sc1 loads
+    (MI355X_MICROARCH.md, "Valid forms"); a toolchain that lowered them differently would break it silently.  Look at the ISA
+    the build produced: the kernel must carry sc1 on those stores and loads."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "diaglib_amd", "_obj", "hip_engine.hip.o")
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
+        pytest.skip("no object file / llvm tools here")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.run([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+    subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    "--input=" + fat, "--output=" + co, "--unbundle"], check=True)
+    dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+    for variant in ("ILb1E", "ILb0E"):
+        body, on = [], False
+        for ln in dis.splitlines():
+            if ln.endswith(">:"):
+                on = ("gram_reduce_kernel" + variant) in ln
+                continue
+            if on:
+                body.append(ln)
+        assert body, variant
+        stores = [ln for ln in body if "global_store_dwordx2" in ln]
+        loads = [ln for ln in body if "global_load_dwordx2" in ln and "sc1" in ln]
+        atomics = [ln for ln in body if "global_atomic_add" in ln]
+        assert any("sc1" in ln for ln in stores), variant               # the level-2 rows go out write-through
+        assert len(loads) >= 32, (variant, len(loads))                   # ... and come back through sc1 loads (up to 32 groups)
+        assert atomics, variant                                          # the tickets (agent-scope RMWs, executed at the L2 / fabric)

@@ -127,3 +127,28 @@ def test_chain_speculation_recovers_from_a_wrong_plan(ctx, rng):
         assert np.abs(got - u).max() < 1e-13
         if attempt == 1:
             assert used == 1, used
+
+
+@pytest.mark.parametrize("n,m,k", [(300000, 104, 13), (262144, 39, 13), (200000, 74, 37)])
+def test_hand_over_forms_give_identical_bits(ctx, rng, n, m, k):
+    """the reduction hands its level-2 rows and the reduced matrix to the k x k step with write-through stores, a
+    drained store counter and sc1 loads (what gfx942 / gfx950 make of relaxed agent-scope atomics) instead of release / acquire
+    fences.  Both forms are in the build (tune knob 5 = 3 selects the fenced one): on reductions with many blocks and several
+    output tiles (256 partial blocks -> 8 groups, m / 16 + 1 tiles) a whole ortho_vs_x chain must give the same bits either way,
+    repeatedly."""
+    x = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, m)))[0])
+    u = np.asfortranarray(rng.standard_normal((n, k)) + x[:, :k] * 3.0)
+    outs = []
+    for fenced in (0, 3, 0, 3):
+        ctx.set_option(100 + 5, fenced)
+        try:
+            big = ctx.panel(np.asfortranarray(np.hstack([x, u])))
+            ctx.ortho_vs_x(big.col(0, m), big.col(m, k))
+            outs.append(big.col(m, k).download())
+            big.free()
+        finally:
+            ctx.set_option(100 + 5, 0)
+    q = outs[0]
+    assert np.abs(q.T @ q - np.eye(k)).max() < 50 * np.finfo(float).eps and np.abs(x.T @ q).max() < 50 * np.finfo(float).eps
+    for o in outs[1:]:
+        assert np.array_equal(o, q)
