@@ -281,8 +281,8 @@ template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0, int QT = 0, int
 __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
 {
   DLA_PREDICATED(a);
-  static_assert(!WP || (KT == 1 && QT == 0 && LOW == 0), "pending factor: one U tile");
-  constexpr int UU = (WP && !SELF) ? 1 : 0;   // extra output slot (U W)^T (U W)
+  static_assert(!WP || (QT == 0 && LOW == 0 && KT <= 3 && (KT == 1 || (!SELF && R == 16))), "pending factor: up to three U tiles");
+  constexpr int UU = (WP && !SELF) ? KT * (KT + 1) / 2 : 0;   // extra output slots: the tiles (qi >= qj) of (U W)^T (U W)
   constexpr int NSLOT = TLW * KT + UU;
   // R rows per wave tile (16 or 32): R/2 lanes cover one column segment, 128/R columns per load instruction
   constexpr int RS = R + 2;                // doubles per staged column (+2 keeps 16-byte alignment)
@@ -352,11 +352,25 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   for (int t = 0; t < (SELF ? KT : TLW); ++t)
 #pragma unroll
     for (int qq = 0; qq < (QT > 0 ? QT : 1); ++qq) accq[t][qq] = 0.0;
-  v4d accuu = (v4d){0.0, 0.0, 0.0, 0.0};
-  double wa[WP ? 4 : 1];                     // A operands of the tile transform: W(4 s + g, c)
-  if constexpr (WP) {
+  v4d accuu[UU > 0 ? UU : 1];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wa[s] = a.wp ? a.wp[(4 * s + g) * 16 + c] : ((4 * s + g) == c ? 1.0 : 0.0);
+  for (int e = 0; e < (UU > 0 ? UU : 1); ++e) accuu[e] = (v4d){0.0, 0.0, 0.0, 0.0};
+  // A operands of the tile transform: W(16 p + 4 s + g, 16 q + c) for the tile pairs p <= q (W is upper triangular).
+  // One tile: wp is the 16 x 16 image ortho_tail16 writes; more: the packed [KT][k4][16] image of ortho_tail (rows >= k4 are not there)
+  double wa[WP ? KT * (KT + 1) / 2 : 1][WP ? 4 : 1];
+  if constexpr (WP) {
+    const int k4w = ((a.k + 3) / 4) * 4;
+#pragma unroll
+    for (int q = 0; q < KT; ++q)
+#pragma unroll
+      for (int p = 0; p <= q; ++p)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int pp = 16 * p + 4 * s + g;
+          double v = (pp == 16 * q + c) ? 1.0 : 0.0;
+          if (a.wp) v = (KT == 1) ? a.wp[pp * 16 + c] : (pp < k4w ? a.wp[((size_t)q * k4w + pp) * 16 + c] : 0.0);
+          wa[q * (q + 1) / 2 + p][s] = v;
+        }
   }
   typedef VecOf<2>::type vec_t;
   vec_t stg[NI];
@@ -392,22 +406,46 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
       if (a.wp == nullptr && a.uw == nullptr) return;      // nothing pending: the staged tile is the block itself
       // (all fragment reads first, then the MFMA chains of the R / 16 row groups side by side, then the stores)
       double* ut = my + (size_t)UOFF * RS + c;
-      double uin[R / 16][4];
+      if constexpr (KT == 1) {
+        double uin[R / 16][4];
 #pragma unroll
-      for (int h = 0; h < R / 16; ++h)
+        for (int h = 0; h < R / 16; ++h)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) uin[h][s] = lds_load1(ut + (size_t)(4 * s + g) * RS + 16 * h);
-      v4d d[R / 16];
+          for (int s = 0; s < 4; ++s) uin[h][s] = lds_load1(ut + (size_t)(4 * s + g) * RS + 16 * h);
+        v4d d[R / 16];
 #pragma unroll
-      for (int h = 0; h < R / 16; ++h) d[h] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int h = 0; h < R / 16; ++h) d[h] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int h = 0; h < R / 16; ++h) d[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], uin[h][s], d[h], 0, 0, 0);
+          for (int h = 0; h < R / 16; ++h) d[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[0][s], uin[h][s], d[h], 0, 0, 0);
 #pragma unroll
-      for (int h = 0; h < R / 16; ++h)
+        for (int h = 0; h < R / 16; ++h)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lds_store1(ut + (size_t)(g + 4 * r) * RS + 16 * h, d[h][r]);
+          for (int r = 0; r < 4; ++r) lds_store1(ut + (size_t)(g + 4 * r) * RS + 16 * h, d[h][r]);
+      } else {
+        // several tiles (R == 16): output tile q = sum over the input tiles p <= q; every fragment is read before anything is
+        // stored (an output tile overwrites an input tile other output tiles have read)
+        double uin[KT][4];
+#pragma unroll
+        for (int p = 0; p < KT; ++p)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) uin[p][s] = lds_load1(ut + (size_t)(16 * p + 4 * s + g) * RS);
+        v4d d[KT];
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+          d[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int p = 0; p <= q; ++p)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) d[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q * (q + 1) / 2 + p][s], uin[p][s], d[q], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < KT; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds_store1(ut + (size_t)(16 * q + g + 4 * r) * RS, d[q][r]);
+      }
       __builtin_amdgcn_wave_barrier();
       if (a.uw != nullptr && rows_ok) {
         // the wave's own rows of the block: 128-byte segments of CPI columns per instruction
@@ -425,7 +463,13 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
       double uf[KT];
 #pragma unroll
       for (int q = 0; q < (SELF ? KT : KF); ++q) uf[q] = lds_load1(my + (size_t)(UOFF + 16 * q + c) * RS + 4 * s4 + g);
-      if constexpr (UU) accuu = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[0], uf[0], accuu, 0, 0, 0);
+      if constexpr (UU > 0) {
+#pragma unroll
+        for (int qi = 0; qi < KT; ++qi)
+#pragma unroll
+          for (int qj = 0; qj <= qi; ++qj)
+            accuu[qi * (qi + 1) / 2 + qj] = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[qi], uf[qj], accuu[qi * (qi + 1) / 2 + qj], 0, 0, 0);
+      }
       double uq[QT > 0 ? QT : 1];
       if constexpr (QT > 0 && !SELF) {
 #pragma unroll
@@ -491,12 +535,15 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   __syncthreads();
   double* red = glds;   // [4][256]
   double* pout = a.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)NSLOT * 256;
-  if constexpr (UU) {
+  if constexpr (UU > 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = accuu[r];
-    __syncthreads();
-    pout[(size_t)(TLW * KT) * 256 + threadIdx.x] = ((red[threadIdx.x] + red[256 + threadIdx.x]) + red[512 + threadIdx.x]) + red[768 + threadIdx.x];
-    __syncthreads();
+    for (int e = 0; e < UU; ++e) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = accuu[e][r];
+      __syncthreads();
+      pout[(size_t)(TLW * KT + e) * 256 + threadIdx.x] = ((red[threadIdx.x] + red[256 + threadIdx.x]) + red[512 + threadIdx.x]) + red[768 + threadIdx.x];
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int t = 0; t < TLW; ++t)
@@ -1563,6 +1610,8 @@ struct OrthoTailArgs {
   const double* xug;   // X^T U and U^T U of the last OP_GRAMX / OP_XW sweep: (m + k) x k, ld m + k
   double* wst;         // pending factors between launches, accumulator layout: [0,256) Wp^T, [256,512) Wd^T, [512,768) Wp
   unsigned long long* dbg;   // $DIAGLIB_AMD_CHAIN_DEBUG: time stamps of the step (100 MHz ticks), 16 per executed sweep
+  int xw_ok;           // blocks of 17..48 columns (ortho_tail): the storing sweep OP_XW exists for this shape -- a triangular update
+                       // inside the loop is written together with X^T U and U^T U of what it stores (one sweep instead of two)
 };
 #define TSTAMP(a, nops, i) do { if ((a).dbg != nullptr && (nops) < 48) (a).dbg[(nops) * 16 + (i)] = wall_clock64(); } while (0)
 
@@ -1729,8 +1778,9 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
     } else {
       ++t.macro_total;
       if (!g_in_lds) {
-        // (OP_GRAMX: [X | U]^T U in one sweep, (m + k) x k: the Gram matrix of U sits under X^T U)
-        const int roff = a.after == OP_GRAMX ? m : 0, ldg = a.after == OP_GRAMX ? m + k : k;
+        // (OP_GRAMX / OP_XW: [X | U]^T U in one sweep, (m + k) x k: the Gram matrix of U sits under X^T U)
+        const bool xu_above = a.after == OP_GRAMX || a.after == OP_XW;
+        const int roff = xu_above ? m : 0, ldg = xu_above ? m + k : k;
         for (int idx = lane; idx < k * k; idx += 64) {
           const int i = idx % k, j = idx / k;
           if (i >= j) { const double v = a.gsrc[(size_t)(roff + i) + (size_t)j * ldg]; lds_store1(A + i * TLD + j, v); lds_store1(S + i * TLD + j, v); }
@@ -1783,7 +1833,11 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
         //  reference's order is kept: ortho_cd in front of the loop runs to convergence before the first projection)
         const bool lead = force_defer && a.lead_once && it_micro == 0 && (a.after == OP_GRAM_UU || a.after == OP_GRAMX);
         const bool macro_done = (eps * rcond * rcond < tol) || lead;      // :3331-3332
-        if (a.after == OP_GRAMX && lead) {
+        // OP_XW measured X^T U and U^T U on the block it stored.  When this factor ends the ortho_cd pass and ortho_vs_x goes on
+        // (growth eps >= tol, :3562-3564), the next projection has its coefficients already: C' = [-(xu W) ; W] with the
+        // factor of this step pending -- exactly what the separate X^T U sweep (OP_XU) would have produced
+        const bool xw_project = a.after == OP_XW && macro_done && can_defer && (t.sloppy || t.growth * eps >= tol) && t.it_outer <= maxit;
+        if ((a.after == OP_GRAMX && lead) || xw_project) {
           // X^T U came with the Gram matrix: the first projection follows at once, C' = [-(xu W) ; W] (one factorisation step
           // in front of the loop, closing pass mandatory after a factor that is not near the identity: see lead_once above)
           TSYNC();
@@ -1795,12 +1849,13 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
           for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx / k) * TLD + idx % k, lds_load1(S + (idx / k) * TLD + idx % k));
           TSYNC();
           assemble(a.gsrc, m + k);
-          t.sloppy = (t.growth * eps >= tol) ? 1 : 0;
+          t.sloppy = (!xw_project && t.growth * eps >= tol) ? 1 : 0;      // (a measured X^T U of the stored block is not sloppy)
           ++t.it_outer;
           t.it_macro = 0; t.growth = 1.0;
           t.phase = OP_COMBO;
         } else if (!macro_done) {
-          t.phase = OP_TRMMG;
+          // inside the loop, without a level shift: the update is stored together with X^T U and U^T U of what it stores
+          t.phase = (a.xw_ok && can_defer && !force_defer && it_micro == 0) ? OP_XW : OP_TRMMG;
         } else if (can_defer && (force_defer || t.sloppy || t.growth * eps >= tol)) {
           // the pass ends with W pending; ortho_vs_x goes on with a projection pass (xu_norm = growth eps >= tol)
           if (!force_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;     // :3568
@@ -2427,8 +2482,8 @@ struct GramReduceArgs {
   // ... and with several ranks on the peer-to-peer transport the same block first exchanges the reduced matrix with
   // its peers (p2p.nranks > 1), so that sweep -> [reduce, cross-rank sum, k x k step] is still one launch
   P2PArgs p2p;
-  int extra;           // 1: one more output tile, slot tlw * kt of pass 0 (gram_lds_kernel WP: the Gram matrix of the U block);
-                       // it lands in rows l .. l + k - 1 of c
+  int extra;           // more output tiles behind the tlw * kt slots of pass 0 (gram_lds_kernel WP: the tiles qi >= qj of the Gram
+                       // matrix of the U block, 1 / 3 / 6 for one / two / three column tiles); they land in rows l .. l + k - 1 of c
   int ldc;             // leading dimension of c: l, or l + k with the extra tile
   int fenced;          // 1: hand the level-2 rows and C over behind agent-scope release / acquire fences (the portable form: what
                        // the HIP memory model guarantees) instead of write-through stores + drained store counter + sc1 loads
@@ -2454,7 +2509,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
   const int slots = nsl + a.extra;           // partial slots per (pass, block)
   const int ps = blockIdx.x, grp = blockIdx.y, G = gridDim.y;
   const bool is_extra = ps >= a.n_ps - a.extra;
-  const int pass = is_extra ? 0 : ps / nsl, slot = is_extra ? nsl : ps % nsl;
+  const int pass = is_extra ? 0 : ps / nsl, slot = is_extra ? nsl + (ps - (a.n_ps - a.extra)) : ps % nsl;
   const int e = threadIdx.x;
   const double* p = a.partial + ((size_t)pass * a.nblk) * (size_t)slots * 256 + (size_t)slot * 256 + e;
   const int per = (a.nblk + G - 1) / G;
@@ -2512,8 +2567,15 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
   const int xg = pass % a.passes_x, ug = pass / a.passes_x;
   const int t = slot / a.kt, q = slot % a.kt;
   const int reg = e >> 6, lane = e & 63;
-  const int xcol = is_extra ? a.l + (lane >> 4) + 4 * reg : (xg * a.tlw + t) * 16 + (lane >> 4) + 4 * reg;
-  const int ucol = is_extra ? (lane & 15) : (ug * a.kt + q) * 16 + (lane & 15);
+  // extra tile e = ps - (n_ps - extra): the tile (qi >= qj) of the Gram matrix of the U block, e = qi (qi + 1) / 2 + qj
+  int eqi = 0, eqj = 0;
+  if (is_extra) {
+    const int ei = ps - (a.n_ps - a.extra);
+    while ((eqi + 1) * (eqi + 2) / 2 <= ei) ++eqi;
+    eqj = ei - eqi * (eqi + 1) / 2;
+  }
+  const int xcol = is_extra ? a.l + 16 * eqi + (lane >> 4) + 4 * reg : (xg * a.tlw + t) * 16 + (lane >> 4) + 4 * reg;
+  const int ucol = is_extra ? 16 * eqj + (lane & 15) : (ug * a.kt + q) * 16 + (lane & 15);
   const bool live = (is_extra ? xcol < a.l + a.k : xcol < a.l) && ucol < a.k;
   const bool exchange = TAIL && a.p2p.nranks > 1;
   // the chain's tail reads C in this same launch: for ortho_tail16 (sc1 loads) write-through stores, drained, and a ticket
@@ -3126,6 +3188,7 @@ struct HipEngine : dla::Engine {
       double* dst = dev;
       if (pred_phase && d_red_small && count <= RED_DOUBLES && (dev == d_small || dev == d_xug)) dst = (dev == d_xug) ? d_red_xug : d_red_small;
       chain_reduced = (dst != dev);
+      chain_red_dst = dst;
       ncclResult_t r = ncclAllReduce(dev, dst, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax, comm, st);
       if (r != ncclSuccess) { err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return DLA_ERR_COMM; }
       return DLA_OK;
@@ -3153,6 +3216,8 @@ struct HipEngine : dla::Engine {
   }
   bool exchange_fused = false;       // the reduction just enqueued carries the cross-rank sum (gram_reduce_kernel<true>)
   bool chain_reduced = false;        // the last RCCL all-reduce of a chain went out of place (d_red_small / d_red_xug)
+  double* chain_red_dst = nullptr;   // ... to this buffer
+  bool chain_xw = false;             // the chain being enqueued may use the storing sweep OP_XW for its wide block (ortho_tail)
   // ---- one-shot peer-to-peer all-reduce (p2p_allreduce_kernel)
   struct P2P {
     bool on = false;
@@ -3384,8 +3449,8 @@ struct HipEngine : dla::Engine {
   int launch_op(int op, int n, int m, int k, const double* x, const double* bx, double* u, bool publish, int fold)
   {
     pending_tail = OrthoTailArgs{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, op, m, k, m > 0 ? 1 : 0, ortho_maxit, publish ? 1 : 0,
-                                 fold, tune[6] == 7 ? 0 : 1, d_xug, d_wst, d_dbg};
-    if (fold == 1 && (op == OP_GRAMX || op == OP_XW)) pending_tail.gsrc = d_xug;
+                                 fold, tune[6] == 7 ? 0 : 1, d_xug, d_wst, d_dbg, chain_xw ? 1 : 0};
+    if ((fold == 1 && op == OP_GRAMX) || op == OP_XW) pending_tail.gsrc = d_xug;
     fuse_tail = p2p.on ? tune[6] != 4 : (nranks <= 1 && !comm);     // (knob 6 = 4: the exchange as a launch of its own)
     tail_fused = false;
     pred_phase = &d_ost->phase; pred_want = (op == OP_GRAMX) ? (int)OP_GRAM_UU : op;   // the first sweep answers the start phase
@@ -3415,7 +3480,7 @@ struct HipEngine : dla::Engine {
     if (stc || tail_fused) return stc;
     if (comm && !p2p.on && d_red_small) {
       // RCCL: the reduced matrices live in the out-of-place destinations of the all-reduce
-      if (chain_reduced) pending_tail.gsrc = (op == OP_GRAMX || op == OP_XW) ? d_red_xug : d_red_small;
+      if (chain_reduced) pending_tail.gsrc = chain_red_dst;
       pending_tail.xug = d_red_xug;
     }
     chain_reduced = false;
@@ -3428,39 +3493,47 @@ struct HipEngine : dla::Engine {
   // Sweeps of the pending-factor schedule (gram_lds_kernel WP; k <= 16, even n):
   //   m > 0:  X^T (U W) and (U W)^T (U W) in one pass over [X | U] -> d_xug ((m + k) x k, the Gram matrix in rows m..);
   //   m == 0: (U W)^T (U W) -> d_small (k x k).   wp == nullptr: W = identity.
-  template <int TLW, int R>
+  template <int TLW, int KT, int R>
   int launch_gram_wp(const GramArgs& a, dim3 grid, bool self)
   {
     if (self) {
-      if constexpr (TLW == 1) {
+      if constexpr (TLW == 1 && KT == 1) {
         auto kfn = gram_lds_kernel<1, 1, 1, 32, 1, 0, 0, 1>;
         const size_t lds = sizeof(double) * 4 * 16 * 34;
         DLA_LAUNCH(kfn, grid, dim3(256), lds, st, a);
       }
       return DLA_OK;
     }
-    auto kfn = gram_lds_kernel<TLW, 1, 1, R, 0, 0, 0, 1>;
-    const size_t lds = sizeof(double) * 4 * 16 * (TLW + 1) * (R + 2);
+    auto kfn = gram_lds_kernel<TLW, KT, 1, R, 0, 0, 0, 1>;
+    const size_t lds = sizeof(double) * 4 * 16 * (TLW + KT) * (R + 2);
     if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;
     DLA_LAUNCH(kfn, grid, dim3(256), lds, st, a);
     return DLA_OK;
   }
+  // widest X pass of the pending-factor sweeps: 12 X tiles beside one U tile, 8 beside two (16 + 3 accumulator tiles), 5 beside
+  // three (15 + 6)
+  static int wp_max_tlw(int kt) { return kt <= 1 ? 12 : kt == 2 ? 8 : 5; }
   int gram_wp_once(int n, int m, const double* x, int k, const double* u, const double* wp, double* uw)
   {
     const bool self = (m == 0);
+    const int kt = (k + 15) / 16;
+    if (kt > 3 || (self && kt > 1)) { err = "gram_wp: block too wide"; return DLA_ERR_ARG; }
     const int tx = self ? 1 : (m + 15) / 16;
-    const int passes = self ? 1 : (tx + 11) / 12;
+    const int passes = self ? 1 : (tx + wp_max_tlw(kt) - 1) / wp_max_tlw(kt);
     int tlw = (tx + passes - 1) / passes;
-    static const int avail[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
-    for (int v : avail) if (v >= tlw) { tlw = v; break; }
+    if (kt == 1) {
+      static const int avail[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
+      for (int v : avail) if (v >= tlw) { tlw = v; break; }
+    }
     // the staged image of the widest pass: 13 tiles of 16 rows (4 waves x 13 x 16 x 18 doubles = 117 KiB); under a refused
     // LDS raise the chain is not taken at all (ortho_chain)
-    const int R = tlw <= 2 ? 32 : 16;
+    const int R = (kt == 1 && tlw <= 2) ? 32 : 16;
     const long long nchunks = ((long long)n + 31) / 32;
     const long long want = (nchunks + 15) / 16;
     int blocks = (int)std::max(1LL, std::min((long long)ncu * (self ? 2 : 1), want));
     if (tune[4] > 0) blocks = (int)std::max(1LL, std::min((long long)tune[4], want));
-    const int slots = self ? 1 : tlw + 1;
+    const int extra = self ? 0 : kt * (kt + 1) / 2;          // tiles (qi >= qj) of the Gram matrix of the U block
+    const int slots = self ? 1 : tlw * kt + extra;
     int stc = ensure_partial(sizeof(double) * (size_t)passes * blocks * slots * 256);
     if (stc) return stc;
     stc = ensure_small(sizeof(double) * (size_t)k * k);
@@ -3472,26 +3545,19 @@ struct HipEngine : dla::Engine {
     dim3 grid(blocks, passes);
     {
       char kn[64];
-      std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, 1, 1, %d, %d, 0, 0, 1>", tlw, self ? 32 : R, self ? 1 : 0);
+      std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d, %d, 0, 0, 1>", tlw, kt, self ? 32 : R, self ? 1 : 0);
       // reference-schedule flops: the Gram matrix (2 n k^2), X^T U (2 n m k), and the triangular update the sweep applies on the fly (n k^2)
       Scope s(this, DLA_OP_GRAM, 8.0 * (double)n * (double)(m + k + (uw ? k : 0)), 2.0 * (double)n * (m + k) * k + (wp ? 1.0 * (double)n * k * k : 0.0), kn);
       int r_ = DLA_ERR_RUNTIME;
-      switch (tlw) {
-        case 1: r_ = launch_gram_wp<1, 32>(a, grid, self); break;
-        case 2: r_ = launch_gram_wp<2, 32>(a, grid, self); break;
-        case 3: r_ = launch_gram_wp<3, 16>(a, grid, self); break;
-        case 4: r_ = launch_gram_wp<4, 16>(a, grid, self); break;
-        case 5: r_ = launch_gram_wp<5, 16>(a, grid, self); break;
-        case 6: r_ = launch_gram_wp<6, 16>(a, grid, self); break;
-        case 7: r_ = launch_gram_wp<7, 16>(a, grid, self); break;
-        case 8: r_ = launch_gram_wp<8, 16>(a, grid, self); break;
-        case 10: r_ = launch_gram_wp<10, 16>(a, grid, self); break;
-        case 12: r_ = launch_gram_wp<12, 16>(a, grid, self); break;
-        default: err = "gram_wp: no kernel instance";
-      }
+#define GWP(T, K, RR) if (tlw == T && kt == K) r_ = launch_gram_wp<T, K, RR>(a, grid, self); else
+      GWP(1, 1, 32) GWP(2, 1, 32) GWP(3, 1, 16) GWP(4, 1, 16) GWP(5, 1, 16) GWP(6, 1, 16) GWP(7, 1, 16) GWP(8, 1, 16) GWP(10, 1, 16) GWP(12, 1, 16)
+      GWP(1, 2, 16) GWP(2, 2, 16) GWP(3, 2, 16) GWP(4, 2, 16) GWP(5, 2, 16) GWP(6, 2, 16) GWP(7, 2, 16) GWP(8, 2, 16)
+      GWP(1, 3, 16) GWP(2, 3, 16) GWP(3, 3, 16) GWP(4, 3, 16) GWP(5, 3, 16)
+      { err = "gram_wp: no kernel instance"; }
+#undef GWP
       if (r_) return r_;
     }
-    const int n_out = self ? 1 : passes * tlw + 1;
+    const int n_out = self ? 1 : passes * tlw * kt + extra;
     double* cdst = self ? d_small : d_xug;
     {
       Scope s2(this, DLA_OP_GRAM, 0.0, 0.0, "gram_reduce_kernel");
@@ -3503,8 +3569,8 @@ struct HipEngine : dla::Engine {
         lvl2_bytes = std::max(need2, (size_t)1 << 20);
         HIPCHK(hipMalloc((void**)&d_lvl2, lvl2_bytes));
       }
-      GramReduceArgs ra{d_partial, d_lvl2, d_ticket, cdst, nullptr, blocks, self ? k : m, k, tlw, 1, passes,
-                        pred_phase, pred_want, 0, n_out, d_ticket + 4096, OrthoTailArgs{}, P2PArgs{}, self ? 0 : 1, self ? k : m + k};
+      GramReduceArgs ra{d_partial, d_lvl2, d_ticket, cdst, nullptr, blocks, self ? k : m, k, tlw, kt, passes,
+                        pred_phase, pred_want, 0, n_out, d_ticket + 4096, OrthoTailArgs{}, P2PArgs{}, extra, self ? k : m + k};
       launch_reduce(ra, dim3(n_out, groups));
     }
     HIPCHK(hipGetLastError());
@@ -3523,6 +3589,7 @@ struct HipEngine : dla::Engine {
     const double *x = nullptr, *bx = nullptr;
     double* u = nullptr;
     long long key = 0, key_last = 0;
+    bool xw = false;                 // wide block with the storing sweep OP_XW (see ortho_chain_begin)
     std::vector<int> plan, launched;
     std::vector<SpecRec> recs;
   } run;
@@ -3553,21 +3620,27 @@ struct HipEngine : dla::Engine {
     const int ktw = (k + 15) / 16;
     const bool wide_gramx = fold == 0 && vsx && vec2 && bx == x && tune[6] != 7 && tune[6] != 8 && ktw >= 2 && ktw <= 3 &&
                             (m + k + 15) / 16 <= (ktw == 2 ? 8 : 7) && lds_limit > (size_t)128 * 1024;
+    // ... and inside the loop the triangular update is stored together with X^T U and U^T U of what it stores (OP_XW, the sweep the
+    // one-tile schedule closes with) while X^T U fits one pass beside the block's tiles: 5 sweeps per call instead of 6
+    // (two-tile blocks: measured r04 at n = 1e7, m = 64, k = 32: 1777 us against 937 + 1010 for the two sweeps it replaces; the
+    //  three-tile sweep does 108 MFMAs per 16 rows with one wave per SIMD and runs at 3.9 TB/s -- 2960 us against 1212 + 1682: it
+    //  stays off unless tune knob 6 = 10 asks for it)
+    const bool wide_xw = wide_gramx && (ktw == 2 || tune[6] == 10) && (m + 15) / 16 <= wp_max_tlw(ktw) && (m + k) * k <= XUG_DOUBLES && tune[6] != 9;
     int stc = ensure_chain_buffers();
     if (stc) return stc;
     // First chain of a shape: walk every launch path it may take WITHOUT launching (workspaces grow now, not half way; a
     // refused request for more than 64 KiB of LDS shows up before anything has touched U).  After a refusal the engine's LDS
     // limit is down and the host-driven loop, which redoes single operations under it, takes the call.
     {
-      const long long vkey = (long long)k * 1000000 + m + fold * 500000000000LL + (vsx ? 0 : 250000000000LL);
+      const long long vkey = (long long)k * 1000000 + m + fold * 500000000000LL + (vsx ? 0 : 250000000000LL) + (wide_xw ? 125000000000LL : 0LL);
       if (!chain_verified.count(vkey)) {
         static const int every_op[] = {OP_GRAM_UU, OP_GRAMX, OP_GRAMW, OP_XW, OP_XU, OP_TRMMG, OP_COMBO, OP_FINAL};
         std::vector<SpecRec> dummy;
-        dry_launch = true; spec_rec = &dummy; lds_retry = false;
+        dry_launch = true; spec_rec = &dummy; lds_retry = false; chain_xw = wide_xw;
         int std_ = DLA_OK;
         for (int op : every_op) {
           if (!vsx && (op == OP_GRAMX || op == OP_XW || op == OP_XU || op == OP_COMBO || op == OP_GRAMW)) continue;
-          if (fold != 1 && (op == OP_GRAMW || op == OP_XW)) continue;
+          if (fold != 1 && (op == OP_GRAMW || (op == OP_XW && !wide_xw))) continue;
           if (fold != 1 && op == OP_GRAMX && !wide_gramx) continue;
           std_ = launch_op(op, n, m, k, x, bx, u, false, fold);
           if (std_) break;
@@ -3597,21 +3670,25 @@ struct HipEngine : dla::Engine {
     h_ost->nops = 0;
 
     // the schedule depends on how much of the new block already lies in span(X): remembered per basis width
-    const long long key = (long long)k * 1000000 + m + fold * 500000000000LL + (wide_gramx ? 250000000000LL : 0LL);
+    const long long key = (long long)k * 1000000 + m + fold * 500000000000LL + (wide_gramx ? 250000000000LL : 0LL) + (wide_xw ? 125000000000LL : 0LL);
     std::vector<int>& hist = ortho_history[key];
     std::vector<int> plan = hist;
-    std::vector<int>& last_k = ortho_history[-(long long)(16 * k + (vsx ? 1 : 0) + 2 * fold + (wide_gramx ? 8 : 0)) - 1];   // most recent call of this kind and width
+    const long long kind_key = -(long long)(64 * k + (vsx ? 1 : 0) + 2 * fold + (wide_gramx ? 8 : 0) + (wide_xw ? 16 : 0)) - 1;
+    std::vector<int>& last_k = ortho_history[kind_key];   // most recent call of this kind and width
     if (plan.empty()) plan = last_k;
     if (plan.empty()) {
       // the schedule measured on the reference: cd x2, [projection, cd x2], [projection, cd x1]
       if (fold == 1) plan = {OP_GRAMX, OP_COMBO, OP_TRMMG, OP_XW, OP_COMBO, OP_FINAL};
+      else if (wide_xw) plan = {OP_GRAMX, OP_COMBO, OP_XW, OP_COMBO, OP_FINAL};
       else if (wide_gramx) plan = {OP_GRAMX, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
       else if (vsx) plan = {OP_GRAM_UU, OP_TRMMG, OP_XU, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
       else plan = {OP_GRAM_UU, OP_TRMMG, OP_FINAL};
     }
     run.n = n; run.m = m; run.k = k; run.fold = fold; run.vsx = vsx; run.x = x; run.bx = bx; run.u = u;
     run.key = key;
-    run.key_last = -(long long)(16 * k + (vsx ? 1 : 0) + 2 * fold + (wide_gramx ? 8 : 0)) - 1;
+    run.key_last = kind_key;
+    run.xw = wide_xw;
+    chain_xw = wide_xw;
     run.plan = plan; run.launched.clear(); run.recs.clear();
     stc = chain_enqueue();
     if (stc) return stc;
@@ -3652,6 +3729,7 @@ struct HipEngine : dla::Engine {
   int chain_enqueue()
   {
     spec_rec = &run.recs;
+    chain_xw = run.xw;
     int stc = DLA_OK;
     for (size_t pi = 0; pi < run.plan.size(); ++pi) {
       spec_tag = (int)run.launched.size();
@@ -3711,6 +3789,7 @@ struct HipEngine : dla::Engine {
       } else {
         switch (sres.phase) {
           case OP_TRMMG: plan = vsx ? std::vector<int>{OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL} : std::vector<int>{OP_TRMMG, OP_FINAL}; break;
+          case OP_XW:    plan = {OP_XW, OP_COMBO, OP_FINAL}; break;
           case OP_XU:    plan = {OP_XU, OP_COMBO, OP_FINAL}; break;
           case OP_COMBO: plan = {OP_COMBO, OP_FINAL}; break;
           case OP_FINAL: plan = {OP_FINAL}; break;
