@@ -129,7 +129,8 @@ def cpu_baseline(n_sample: int, n_targ: int, n_max: int, max_dav: int, tol: floa
            "seconds_whole_call": round(dt, 3),
            "sample": f"same Davidson-Liu solve (synthetic operator, {n_targ} roots, n_max={n_max}, tol={tol:g}) at "
                      f"n={n_sample} rows, whole call incl. the reference's allocation + zero-fill of its panels, "
-                     f"{dt:.2f} s on {CPU_THREADS} threads (MKL + OpenMP callbacks), converged={bool(ok)}; "
+                     f"{dt:.2f} s on {CPU_THREADS} threads (MKL + OpenMP callbacks; {CPU_THREADS} = the cores this process may use: "
+                     f"affinity mask / cgroup CPU quota of the box, which has {HOST_CPUS}), converged={bool(ok)}; "
                      "flops = GPU run's reference-schedule flops per row x n_sample"}
     if buckets and buckets.get("total"):
         # the reference's own timers (diaglib.f90:1835-1841): in-loop wall time and its three buckets; the rest of the

@@ -256,7 +256,10 @@ int  dla_random_fill(dla_ctx* ctx, int n, int m, double* evec_dev);
 int  dla_fill_guess(dla_ctx* ctx, int n, int m, double* evec_dev, unsigned long long seed, long long support_rows);
 
 /* ---------------------------------------------------------------- orthogonalisation */
-int  dla_ortho_cd(dla_ctx* ctx, int n, int k, double* u_dev, double* growth, int* ok);      /* Fused sweeps of the orthogonalisation loops (one pass over the panel instead of two), as the engine runs them inside
+/* ortho_cd(n,m,u,growth,ok), diaglib.f90:3185-3341: Cholesky-QR with refinement and the level-shift ladder; growth = product of
+ * the norm estimates of the inverse factors, ok = 0 when the iteration cap was reached (the reference prints and returns) */
+int  dla_ortho_cd(dla_ctx* ctx, int n, int k, double* u_dev, double* growth, int* ok);
+/* Fused sweeps of the orthogonalisation loops (one pass over the panel instead of two), as the engine runs them inside
  * ortho_cd / ortho_vs_x; entry points of their own so that each can be checked against the BLAS pair it replaces:
  *   dla_trmm_gram    U <- U W (k x k, general W; dtrmm at diaglib.f90:3327)          and G = U^T U of the result (:3256)
  *   dla_update_gram  U <- U - X C (dgemm at :3544)                                   and G = U^T U of the result
@@ -272,7 +275,6 @@ int  dla_combo_gram(dla_ctx* ctx, int n, int m, const double* x_dev, int k, cons
  * with LAPACK's sign convention for diag(R).  The reference calls it when ortho_cd gives up (:3534, :3549).  Device path:
  * column-wise Gram-Schmidt for the factor, the Householder recurrence on an isometric 2k x k host matrix for the signs. */
 int  dla_ortho_qr(dla_ctx* ctx, int n, int k, double* u_dev);
-/* diaglib.f90:3185-3341 */
 int  dla_ortho_vs_x(dla_ctx* ctx, int n, int m, int k, const double* x_dev, double* u_dev); /* diaglib.f90:3481-3574 */
 int  dla_b_ortho(dla_ctx* ctx, int n, int m, double* u_dev, double* bu_dev);                /* diaglib.f90:3094-3183 */
 int  dla_b_ortho_vs_x(dla_ctx* ctx, int n, int m, int k, const double* x_dev, const double* bx_dev,

@@ -100,9 +100,11 @@ def test_shard_rehearsal_exchange_cost_is_bounded():
     holds n / 4 rows, every small product crosses ranks through the peer-to-peer mailboxes (the transport of the real run).
     The ranks share one HBM, so the sweeps take what they take on one rank; what the 4-rank solve costs on top is the
     exchanges (66 per solve, each inside a reduction kernel) and the skew of four processes that time-share one device.
-    Bound: 2 ms per solve (measured r03, events off: 9.50 ms on one rank, 10.62 ms on four at n = 1e6 on one box, 11.05 / 12.61 on
-    a slower one -- four processes time-sharing one device are at the mercy of its scheduler; 16.87 / 17.22 / 18.01 ms on 1 / 2 / 4
-    ranks at n = 2e6; tools/shard_rehearsal.sh prints the same figures)."""
+    Bound, derived from the exchange count: (exchanges per solve) x 20 us + 0.5 ms.  Per exchange: 17 us measured with four
+    processes time-sharing one device (r03, events off: 9.50 -> 10.62 ms at n = 1e6 and 17.06 -> 18.20 ms at n = 2e6, 66 exchanges
+    per solve either way; 23.6 us on the slowest box seen, 11.05 -> 12.61 ms) -- the exchange itself is one block writing four
+    mailboxes and polling four flags, the rest is the device switching between the four processes' queues.  The 0.5 ms cover
+    the skew of the ranks' host threads over a solve's 19 host waits.  tools/shard_rehearsal.sh prints the same figures."""
     n = 1_000_000
     env = dict(os.environ, DIAGLIB_BENCH_NOPROFILE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     common = ["--rows", str(n), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-random-leg"]
@@ -120,4 +122,5 @@ def test_shard_rehearsal_exchange_cost_is_bounded():
     assert sum(four["rows_per_rank"]) == n and four["iters"] == one["iters"]
     per_solve_exchanges = four["allreduces"] / four["steps"]
     assert per_solve_exchanges > 20
-    assert four["ms_per_step"] - one["ms_per_step"] <= 2.0, (four["ms_per_step"], one["ms_per_step"], per_solve_exchanges)
+    allowed_ms = per_solve_exchanges * 0.020 + 0.5
+    assert four["ms_per_step"] - one["ms_per_step"] <= allowed_ms, (four["ms_per_step"], one["ms_per_step"], per_solve_exchanges, allowed_ms)

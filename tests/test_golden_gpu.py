@@ -179,6 +179,11 @@ def test_full_size_solve_residual(ctx, solver, n, t, m, max_dav, guess):
         # whether a history ends above or below 3e-12 depends on the last bits of the Rayleigh-Ritz eigenvectors).  The
         # reference's floor is higher still (4.1e-11 at n = 1e6).  tol = 1e-12 keeps 10 tol 2.7 times above the highest floor
         # seen and 30 times above the unlocked one; it is the tolerance of the bench line of this shape.
+        # NB the north star's ||A x - lambda x||_2 / |lambda| <= 1e-10 is ASSERTED below, not implied by this tolerance: rms < tol
+        # only guarantees rms sqrt(n) / |lambda_min| = 1e-12 * 3162 / 2.9 = 1.1e-9 at n = 1e7.  The rule that ends the solve is
+        # max|r| < 10 tol, which trips long after the rms has passed tol: the LOBPCG run of this shape ends at a relative
+        # residual of 1.2e-11 (bench line of r04, gpurun_out/r04_cfg5_1.json: max_rel_residual), a margin of 8 under the bound
+        # checked here.
         tol = 1e-13 if n < 10_000_000 else 1e-12
         if solver == "davidson":
             eig, _, ok, info = ctx.davidson_driver(n, t, m, 400, tol, max_dav, 0.0, mv, pc, ev)
