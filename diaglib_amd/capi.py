@@ -38,7 +38,7 @@ EXPORTS = [
     "dla_gram", "dla_gram_lower", "dla_panel_gemm", "dla_panel_update", "dla_trmm_linvt", "dla_trmm_gram", "dla_update_gram", "dla_combo_gram", "dla_ritz_residual", "dla_ritz_residual_p", "dla_ritz_residual2", "dla_axpy",
     "dla_nrm2", "dla_stream_triad", "dla_random_fill", "dla_fill_guess",
     "dla_ortho_cd", "dla_ortho_qr", "dla_ortho_vs_x", "dla_b_ortho", "dla_b_ortho_vs_x", "dla_check_guess", "dla_get_coeffs",
-    "dla_call_matvec", "dla_call_precnd", "dla_expand_project",
+    "dla_call_matvec", "dla_call_precnd", "dla_expand_project", "dla_expand_project_metric",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
     "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd", "dla_synth_apbmul", "dla_synth_ambmul", "dla_synth_spdmul", "dla_synth_smdmul",
     "dla_synth_metric", "dla_synth_lrprec1", "dla_synth_lrprec2", "dla_spmm_setup_csr", "dla_spmm_matvec", "dla_spmm_precnd",
@@ -122,6 +122,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_check_guess": (i, [vp, i, i, vp]),
         "dla_get_coeffs": (i, [vp, i, i, i, i, c_dp, c_dp, c_dp]),
         "dla_expand_project": (i, [vp, i, i, i, i, vp, vp, vp, d, c_dp, i]),
+        "dla_expand_project_metric": (i, [vp, i, i, i, i, vp, vp, vp, vp, vp, d, c_dp, i]),
         "dla_call_matvec": (i, [vp, vp, i, i, vp, vp]), "dla_call_precnd": (i, [vp, vp, i, i, d, vp, vp]),
         "dla_syev": (i, [C.c_char, i, c_dp, i, c_dp]), "dla_syev_lowest": (i, [C.c_char, i, c_dp, i, c_dp, i]),
         "dla_potrf_lower": (i, [i, c_dp, i]),
@@ -425,6 +426,14 @@ class Context:
         projection -- mode 0: [X | U]^T AU ((m+k) x k), mode 1: lower triangle of [X | U]^T [AX | AU]"""
         h = np.zeros((m + k, k if mode == 0 else m + k), order="F")
         self._chk(self.lib.dla_expand_project(self.h, mode, basis.n, m, k, basis.ptr, abasis.ptr, matvec, shift, _dp(h), m + k))
+        return h
+
+    def expand_project_metric(self, mode: int, basis: DevPanel, bbasis: DevPanel, abasis: DevPanel, m: int, k: int, matvec: int,
+                              bvec: int, shift: float = 0.0) -> np.ndarray:
+        """dla_expand_project_metric on the leading m + k columns of the three panels"""
+        h = np.zeros((m + k, k if mode == 0 else m + k), order="F")
+        self._chk(self.lib.dla_expand_project_metric(self.h, mode, basis.n, m, k, basis.ptr, bbasis.ptr, abasis.ptr, matvec, bvec, shift,
+                                                     _dp(h), m + k))
         return h
 
     def b_ortho(self, u: DevPanel, bu: DevPanel) -> None:

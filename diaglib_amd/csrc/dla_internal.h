@@ -56,6 +56,11 @@ struct BlockOps {
   // enqueued in between has read an unfinished block).  Nothing but launches on the engine's stream may come in between.
   virtual int ortho_chain_begin(int, int, int, const double*, const double*, double*, OrthoReport* rep) { rep->handled = 0; return 0; }
   virtual int ortho_chain_finish(OrthoReport*, bool /*waited*/) { return DLA_ERR_ARG; }
+  // b_ortho (M = U^T BU, L = chol(M), U <- U L^-T, BU <- BU L^-T) enqueued without a host wait, optionally only behind a chain
+  // that ended well; *handled = 0: not taken (the caller runs the host-driven b_ortho).  b_ortho_ahead_status() after the
+  // caller's next host wait: 1 done, 0 did not run, -1 the metric is not positive definite.
+  virtual int b_ortho_ahead(int /*n*/, int /*k*/, double* /*u*/, double* /*bu*/, bool /*behind_chain*/, int* handled) { *handled = 0; return 0; }
+  virtual int b_ortho_ahead_status() { return 0; }
   // the top k GLOBAL rows of the n x k block u (row0 = global index of local row 0), k x k to the host
   virtual int top_rows(int n, int k, const double* u, long long row0, double* qt_host) = 0;
   int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests

@@ -1588,7 +1588,8 @@ struct OrthoDev {
   int have_xu;        // pending-factor schedule: X^T U of the block in memory is known (xug) up to the factors in wst
   double growth;      // prod ||L^-1||_est of the current ortho_cd pass
   int sloppy;         // pending-factor schedule: the last projection used an X^T U carried through ill-conditioned factors
-  int pad2_;
+  int last_status;    // how the last chain ended (OST_*), kept when the machine re-arms: what runs behind a chain on the device
+                      // without the host in between (bortho_tail_kernel) continues only after OST_DONE
   int log[48];        // the sweeps executed, in order
 };
 
@@ -1707,6 +1708,7 @@ __device__ __forceinline__ void tail_publish(const OrthoTailArgs& a, const TailS
   if (t.status != OST_RUNNING) {
     // finished (or failed): re-arm the machine for the next chain, so that no initial state has to be copied in
     st->it_macro = 0; st->it_outer = 0; st->nops = 0; st->macro_total = 0; st->shifts = 0; st->growth = 1.0; st->have_xu = 0; st->sloppy = 0;
+    st->last_status = t.status;
     st->status = OST_RUNNING;
     __hip_atomic_store(&st->phase, (int)OP_GRAM_UU, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
@@ -2353,6 +2355,48 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
   }
 }
 
+// b_ortho (reference diaglib.f90:3094-3183) behind a device-driven chain, without the host in between: M = U^T B U has been reduced
+// into g (k x k, ld k); this one-wave kernel factors it (dpotrf 'l', :3173 -- no level shift, no refinement: the reference has
+// none here), inverts the factor and leaves W = L^-T packed for the two triangular updates U <- U W, BU <- BU W (:3177-3178) that
+// follow on the stream, predicated on *go == seq.  It only goes on when the chain in front of it has ENDED WELL (the state machine
+// is re-armed and its last status is OST_DONE): after a chain that stopped half way the block is not orthogonal to X yet and
+// must not be touched.  status (pinned host word): seq = done, -seq = the metric is not positive definite, 0 = did not run.
+struct BOrthoTailArgs {
+  const OrthoDev* st;
+  const double* g;     // k x k, ld k (lower triangle used)
+  double* wpk;         // [kt][k4][16]
+  int k;
+  int need_chain;      // 1: only behind a chain that ended with OST_DONE
+  int seq;
+  int* go;             // device word the updates are predicated on
+  int* status_host;
+};
+__global__ __launch_bounds__(64) void bortho_tail_kernel(BOrthoTailArgs a)
+{
+  __shared__ __attribute__((aligned(16))) double lds[48 * TLD];
+  const int lane = threadIdx.x, k = a.k;
+  if (a.need_chain) {
+    const bool ended_well = __hip_atomic_load(&a.st->phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)OP_GRAM_UU && a.st->nops == 0 &&
+                            a.st->last_status == (int)OST_DONE;
+    if (!ended_well) { if (lane == 0) { *a.go = 0; *a.status_host = 0; } return; }
+  }
+  double* A = lds;
+  for (int idx = lane; idx < k * k; idx += 64) {
+    const int i = idx % k, j = idx / k;
+    if (i >= j) lds_store1(A + i * TLD + j, a.g[(size_t)i + (size_t)j * k]);
+  }
+  const int info = lds_potrf(k, A, lane);
+  if (info != 0) { if (lane == 0) { *a.go = 0; *a.status_host = -a.seq; } return; }
+  lds_trtri(k, A, lane);
+  const int kt = (k + 15) / 16, k4 = ((k + 3) / 4) * 4;
+  for (int idx = lane; idx < kt * k4 * 16; idx += 64) {
+    const int q = idx / (k4 * 16), pp = (idx / 16) % k4, j = 16 * q + (idx % 16);
+    a.wpk[idx] = (j < k && pp <= j) ? lds_load1(A + j * TLD + pp) : 0.0;
+  }
+  __threadfence();
+  if (lane == 0) { *a.go = a.seq; *a.status_host = a.seq; }
+}
+
 __global__ __launch_bounds__(64) void ortho_tail_kernel(OrthoTailArgs a)
 {
   __shared__ __attribute__((aligned(16))) double lds[TAIL_LDS_DOUBLES];
@@ -2727,6 +2771,9 @@ struct HipEngine : dla::Engine {
     if (d_xug) (void)hipFree(d_xug);
     if (d_red_small) (void)hipFree(d_red_small);
     if (d_red_xug) (void)hipFree(d_red_xug);
+    if (d_bgo) (void)hipFree(d_bgo);
+    if (h_bstat) (void)hipHostFree(h_bstat);
+    if (d_wpk_b) (void)hipFree(d_wpk_b);
     for (int i = 0; i < RING; ++i) if (h_ring[i]) { (void)hipHostFree(h_ring[i]); (void)hipEventDestroy(ring_ev[i]); }
     if (d_cpk) (void)hipFree(d_cpk);
     if (d_w) (void)hipFree(d_w);
@@ -3835,6 +3882,50 @@ struct HipEngine : dla::Engine {
     rep->macro_its = sres.macro_total;
     rep->shifts = sres.shifts;
     return DLA_OK;
+  }
+
+  // ---- b_ortho behind a chain (dla_expand_project_metric): Gram sweep U^T BU, k x k step on the device, the two updates
+  // predicated on its outcome; nothing waits.  b_ortho_ahead_status() after the caller's next host wait: 1 done, 0 did not run
+  // (the chain in front of it had not ended well: the caller repeats everything behind the chain), -1 metric not positive definite.
+  int* d_bgo = nullptr; int* h_bstat = nullptr; int* h_bstat_dev = nullptr; double* d_wpk_b = nullptr;
+  int b_seq = 0;
+  int b_ortho_ahead(int n, int k, double* u, double* bu, bool behind_chain, int* handled) override
+  {
+    *handled = 0;
+    if (k <= 0 || k > 48 || hook || local_only || tune[6] == 11) return DLA_OK;
+    bind();
+    if (!d_bgo) {
+      HIPCHK(hipMalloc((void**)&d_bgo, sizeof(int)));
+      HIPCHK(hipMemset(d_bgo, 0, sizeof(int)));
+      HIPCHK(hipHostMalloc((void**)&h_bstat, sizeof(int), hipHostMallocMapped));
+      HIPCHK(hipHostGetDevicePointer((void**)&h_bstat_dev, h_bstat, 0));
+      HIPCHK(hipMalloc((void**)&d_wpk_b, sizeof(double) * 3 * 48 * 16));
+    }
+    int stc = ensure_chain_buffers();
+    if (stc) return stc;
+    // M = U^T (B U): every rank's share summed like any other small product
+    stc = gram_dev(n, k, u, k, bu);
+    if (stc) return stc;
+    b_seq = b_seq >= 1000000 ? 1 : b_seq + 1;
+    *h_bstat = 0;
+    {
+      Scope s(this, DLA_OP_GRAM, 0.0, 0.0, "bortho_tail_kernel");
+      BOrthoTailArgs ta{d_ost, d_small, d_wpk_b, k, behind_chain ? 1 : 0, b_seq, d_bgo, h_bstat_dev};
+      DLA_LAUNCH(bortho_tail_kernel, dim3(1), dim3(64), 0, st, ta);
+      HIPCHK(hipGetLastError());
+    }
+    pred_phase = d_bgo; pred_want = b_seq;
+    stc = gemm_chunk(n, 0, k, u, k, nullptr, 0, u, 2, DLA_OP_TRMM, false, d_wpk_b);
+    if (!stc) stc = gemm_chunk(n, 0, k, bu, k, nullptr, 0, bu, 2, DLA_OP_TRMM, false, d_wpk_b);
+    pred_phase = nullptr; pred_want = 0;
+    if (stc) return stc;
+    *handled = 1;
+    return DLA_OK;
+  }
+  int b_ortho_ahead_status() override
+  {
+    const int v = *(volatile int*)h_bstat;
+    return v == b_seq ? 1 : (v == -b_seq ? -1 : 0);
   }
 
   // ---- Gram

@@ -1130,6 +1130,77 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
   return expand_apply_project(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
 }
 
+// The same expansion step with a metric B (gen_david_driver, reference diaglib.f90:2170-2190; LOBPCG gen_eig, :523-529 + 394-403):
+//   b_ortho_vs_x(X, BX, U) -> BU = B U -> b_ortho(U, BU) -> AU = A U [+ shift U] -> projection.
+// With device-mode callbacks that may run ahead (see dla_expand_project) everything is enqueued behind the orthogonalisation
+// chain: the k x k factorisation of b_ortho runs on the device and goes on only when the chain in front of it has ended well
+// (bortho_tail_kernel), the chain's report and b_ortho's outcome are read at the projection's host wait -- one wait per
+// expansion instead of three.  When the chain took another route, everything behind it is repeated on the finished block.
+static int metric_tail_steps(dla_ctx* c, int mode, int n, int m, int k, double* basis, double* bbasis, double* abasis, dla_matvec_fn op,
+                             dla_matvec_fn metric, double shift, double* h, int ldh, bool ahead, bool behind_chain, int* b_handled)
+{
+  double* u = basis + (size_t)n * m;
+  double* bu = bbasis + (size_t)n * m;
+  int st = dla_call_matvec(c, metric, n, k, u, bu);
+  if (st) return st;
+  *b_handled = 0;
+  if (ahead) { st = c->eng->b_ortho_ahead(n, k, u, bu, behind_chain, b_handled); if (st) return engfail(c, st); }
+  if (!*b_handled) { st = dla_b_ortho(c, n, k, u, bu); if (st) return st; }
+  return expand_apply_project(c, mode, n, m, k, basis, abasis, op, shift, h, ldh);
+}
+
+int dla_expand_project_metric(dla_ctx* c, int mode, int n, int m, int k, double* basis, double* bbasis, double* abasis, dla_matvec_fn op,
+                              dla_matvec_fn metric, double shift, double* h, int ldh)
+{
+  DLA_T("dla_expand_project_metric");
+  if (!c || !basis || !bbasis || !abasis || !h || !op || !metric || (mode != 0 && mode != 1) || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
+    return fail(c, DLA_ERR_ARG, "dla_expand_project_metric: bad argument (n > 0, m >= 0, k > 0, ldh >= m + k)");
+  double* u = basis + (size_t)n * m;
+  const long long nglob = global_rows(c, n);
+  const bool builtin = builtin_operator(op) && builtin_operator(metric);
+  const int order = builtin ? 2 : c->callback_order;
+  const bool ahead = (c->run_ahead == 2 || (c->run_ahead == 1 && builtin)) && c->callbacks_on_device && order != 1;
+  int b_handled = 0;
+  if (ahead && m > 0) {
+    dla::OrthoReport rep;
+    int st = c->eng->ortho_chain_begin(n, m, k, basis, bbasis, u, &rep);
+    if (st) return engfail(c, st);
+    if (rep.handled) {
+      c->eng->spec_stats_begin();
+      int sta = metric_tail_steps(c, mode, n, m, k, basis, bbasis, abasis, op, metric, shift, h, ldh, true, true, &b_handled);
+      c->eng->spec_stats_end(false);
+      st = c->eng->ortho_chain_finish(&rep, sta == DLA_OK);
+      const int bst = b_handled ? c->eng->b_ortho_ahead_status() : 1;
+      const bool good = st == DLA_OK && sta == DLA_OK && rep.status == 1 && rep.clean && bst == 1;
+      c->eng->spec_stats_end(!good);
+      if (st) return engfail(c, st);
+      if (sta) return sta;
+      if (rep.status == 1 && rep.clean && bst < 0) return fail(c, DLA_ERR_LAPACK, "b_ortho: metric not positive definite");
+      if (good) return DLA_OK;
+      // the chain took another route (or stopped): nothing behind it has touched U (the factorisation did not go on);
+      // finish the orthogonalisation and repeat the rest on the finished block
+      st = ortho_vs_x_after_chain(c, c->eng, c->row0, nglob, n, m, k, basis, bbasis, u, &rep);
+      if (st) return st;
+      return metric_tail_steps(c, mode, n, m, k, basis, bbasis, abasis, op, metric, shift, h, ldh, false, false, &b_handled);
+    }
+    st = ortho_vs_x_after_chain(c, c->eng, c->row0, nglob, n, m, k, basis, bbasis, u, nullptr);
+    if (st) return st;
+  } else {
+    int st = ortho_vs_x_impl(c, c->eng, c->row0, nglob, n, m, k, basis, bbasis, u);
+    if (st) return st;
+  }
+  // one call after the other; the factorisation of b_ortho still runs on the device when the callbacks allow it (its outcome is
+  // read at the projection's wait)
+  int st = metric_tail_steps(c, mode, n, m, k, basis, bbasis, abasis, op, metric, shift, h, ldh, ahead, false, &b_handled);
+  if (st) return st;
+  if (b_handled) {
+    const int bst = c->eng->b_ortho_ahead_status();
+    if (bst < 0) return fail(c, DLA_ERR_LAPACK, "b_ortho: metric not positive definite");
+    if (bst == 0) return fail(c, DLA_ERR_RUNTIME, "b_ortho: the device step did not run");
+  }
+  return DLA_OK;
+}
+
 int dla_call_precnd(dla_ctx* c, dla_precnd_fn fn, int n, int m, double fac, const double* x, double* px)
 {
   DLA_T("dla_call_precnd");

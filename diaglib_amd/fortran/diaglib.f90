@@ -258,6 +258,16 @@ module diaglib
       real(c_double) :: h(*)
       integer(c_int) :: st
     end function
+    function dla_expand_project_metric(ctx,mode,n,m,k,basis,bbasis,abasis,fn,bfn,shift,h,ldh) &
+             bind(C,name='dla_expand_project_metric') result(st)
+      import :: c_ptr, c_funptr, c_int, c_double
+      type(c_ptr),    value :: ctx, basis, bbasis, abasis
+      type(c_funptr), value :: fn, bfn
+      integer(c_int), value :: mode, n, m, k, ldh
+      real(c_double), value :: shift
+      real(c_double)        :: h(*)
+      integer(c_int)        :: st
+    end function
     function dla_call_precnd(ctx,fn,n,m,fac,x,px) bind(C,name='dla_call_precnd') result(st)
       import :: c_ptr, c_funptr, c_int, c_double
       type(c_ptr), value :: ctx, x, px
@@ -782,9 +792,19 @@ contains
                                         colp(basis,n,s%head)), 'precnd')
         call lap_start(w)
         if (with_metric) then
-          call chk(e%ctx, dla_b_ortho_vs_x(e%ctx, n, s%cols, s%act, basis, bbasis, colp(basis,n,s%head)), 'b_ortho_vs_x')
-          call chk(e%ctx, dla_call_matvec(e%ctx, metric, n, s%act, colp(basis,n,s%head), colp(bbasis,n,s%head)), 'bvec')
-          call chk(e%ctx, dla_b_ortho(e%ctx, n, s%act, colp(basis,n,s%head), colp(bbasis,n,s%head)), 'b_ortho')
+!
+!         with a metric: B-orthogonalisation against the basis (:2170), B on the new block (:2184), b_ortho (:2185) -- and, as for
+!         the standard problem, the operator on the finished block and its columns of the projected matrix in the same call
+!
+          if (it.lt.max_iter) then
+            call chk(e%ctx, dla_expand_project_metric(e%ctx, 0_c_int, n, s%cols, s%act, basis, bbasis, abasis, op, metric, zero, &
+                                                      h(1,s%head), s%ld), 'b_ortho_vs_x + bvec + b_ortho + matvec + projection')
+            projected = .true.
+          else
+            call chk(e%ctx, dla_b_ortho_vs_x(e%ctx, n, s%cols, s%act, basis, bbasis, colp(basis,n,s%head)), 'b_ortho_vs_x')
+            call chk(e%ctx, dla_call_matvec(e%ctx, metric, n, s%act, colp(basis,n,s%head), colp(bbasis,n,s%head)), 'bvec')
+            call chk(e%ctx, dla_b_ortho(e%ctx, n, s%act, colp(basis,n,s%head), colp(bbasis,n,s%head)), 'b_ortho')
+          end if
           call lap_charge(w, w%ortho)
         else
 !
@@ -1131,9 +1151,15 @@ contains
       integer, intent(in) :: m, k
       call lap_start(w)
       if (gen_eig) then
-        call chk(e%ctx, dla_b_ortho_vs_x(e%ctx, n, m, k, sp(rd), bsp(rd), colp(sp(rd),n,m+1)), 'b_ortho_vs_x')
-        call chk(e%ctx, dla_call_matvec(e%ctx, metric, n, k, colp(sp(rd),n,m+1), colp(bsp(rd),n,m+1)), 'bvec')
-        call chk(e%ctx, dla_b_ortho(e%ctx, n, k, colp(sp(rd),n,m+1), colp(bsp(rd),n,m+1)), 'b_ortho')
+        if (it.lt.max_iter) then
+          call chk(e%ctx, dla_expand_project_metric(e%ctx, 1_c_int, n, m, k, sp(rd), bsp(rd), asp(rd), op, metric, shift, h, wide), &
+                   'b_ortho_vs_x + bvec + b_ortho + matvec + projection')
+          projected = .true.
+        else
+          call chk(e%ctx, dla_b_ortho_vs_x(e%ctx, n, m, k, sp(rd), bsp(rd), colp(sp(rd),n,m+1)), 'b_ortho_vs_x')
+          call chk(e%ctx, dla_call_matvec(e%ctx, metric, n, k, colp(sp(rd),n,m+1), colp(bsp(rd),n,m+1)), 'bvec')
+          call chk(e%ctx, dla_b_ortho(e%ctx, n, k, colp(sp(rd),n,m+1), colp(bsp(rd),n,m+1)), 'b_ortho')
+        end if
       else
 !       (the operator on the W block and S^T A S -- the head of the next sweep -- in the same call: dla_expand_project)
         if (it.lt.max_iter) then

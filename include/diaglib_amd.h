@@ -237,6 +237,14 @@ int  dla_ritz_residual2(dla_ctx* ctx, int n, int l, int m, const double* v_dev, 
  * operator must therefore be a pure function of its input (it is called a second time for the same block then). */
 int  dla_expand_project(dla_ctx* ctx, int mode, int n, int m, int k, double* basis_dev, double* abasis_dev,
                         dla_matvec_fn matvec, double shift, double* h_host, int ldh);
+/* The expansion step with a metric B (gen_david_driver diaglib.f90:2170-2190, lobpcg_driver with gen_eig :523-529): on
+ * basis = [X | U], bbasis = [BX | BU], abasis = [AX | AU]:  b_ortho_vs_x(X, BX, U) (:3576-3663),  BU = B U (the caller's bvec),
+ * b_ortho(U, BU) (:3094-3183),  AU = A U [+ shift U],  and the projection as in dla_expand_project (mode 0 / 1).  Same result as
+ * the separate entry points.  With device-mode callbacks that may run ahead (DLA_OPT_RUN_AHEAD) all of it is enqueued behind
+ * the orthogonalisation chain -- the k x k factorisation of b_ortho runs on the device and only behind a chain that ended
+ * well -- and one host wait serves the whole step (three with the separate calls). */
+int  dla_expand_project_metric(dla_ctx* ctx, int mode, int n, int m, int k, double* basis_dev, double* bbasis_dev, double* abasis_dev,
+                               dla_matvec_fn matvec, dla_matvec_fn bvec, double shift, double* h_host, int ldh);
 /* y += alpha x over len contiguous doubles.  daxpy at diaglib.f90:312,397 (LOBPCG shift). */
 int  dla_axpy(dla_ctx* ctx, size_t len, double alpha, const double* x_dev, double* y_dev);
 /* sqrt(sum x^2) over len contiguous doubles (all ranks).  dnrm2 at diaglib.f90:3749, 3268. */

@@ -185,3 +185,68 @@ def test_expand_project_rejects_bad_sizes(ctx, rng):
     finally:
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
         ctx.set_shard(-1, 0)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("n,m,k,kind", [(4000, 26, 13, "random"), (4000, 52, 11, "near_span"), (3000, 42, 21, "random"), (3001, 21, 8, "random")])
+def test_expand_project_metric_equals_the_separate_calls(ctx, rng, mode, n, m, k, kind):
+    """dla_expand_project_metric (b_ortho_vs_x + bvec + b_ortho + matvec + projection, reference diaglib.f90:2170-2190 and
+    :523-529) against the separate entry points on the same inputs, with the library's device operators (A = dla_synth_matvec,
+    B = dla_synth_metric): run ahead of the chain's report (first call of a shape, then with its history) and one call after the
+    other -- U is B-orthonormal and B-orthogonal to X every time, and the results agree to rounding."""
+    _setup(ctx, n)
+    mv, bv = capi.fn_address("dla_synth_matvec"), capi.fn_address("dla_synth_metric")
+
+    def apply(fn_name, x):
+        px = ctx.panel(x); py = ctx.panel(np.zeros_like(x))
+        fn = getattr(ctx.lib, fn_name)
+        nn, mm = C.c_int(x.shape[0]), C.c_int(0)
+        for c0 in range(0, x.shape[1], 48):
+            mm.value = min(48, x.shape[1] - c0)
+            fn(C.byref(nn), C.byref(mm), C.c_void_p(px.col(c0, mm.value).ptr), C.c_void_p(py.col(c0, mm.value).ptr))
+        return py.download()
+
+    try:
+        x0, u = _blocks(rng, n, m, k, kind)
+        # a B-orthonormal X: X <- X L^-T with L = chol(X^T B X)
+        bx0 = apply("dla_synth_metric", x0)
+        lx = np.linalg.cholesky(x0.T @ bx0)
+        x = np.asfortranarray(x0 @ np.linalg.inv(lx).T)
+        bx = apply("dla_synth_metric", x); ax = apply("dla_synth_matvec", x)
+        shift = 0.25 if mode == 1 else 0.0
+        # the separate entry points
+        basis = ctx.panel(np.asfortranarray(np.hstack([x, u])))
+        bbasis = ctx.panel(np.asfortranarray(np.hstack([bx, np.zeros((n, k))])))
+        abasis = ctx.panel(np.asfortranarray(np.hstack([ax, np.zeros((n, k))])))
+        bu_, u_ = bbasis.col(m, k), basis.col(m, k)
+        ctx.b_ortho_vs_x(basis.col(0, m), bbasis.col(0, m), u_)
+        ctx._chk(ctx.lib.dla_call_matvec(ctx.h, bv, n, k, u_.ptr, bu_.ptr))
+        ctx.b_ortho(u_, bu_)
+        ctx._chk(ctx.lib.dla_call_matvec(ctx.h, mv, n, k, u_.ptr, abasis.col(m, k).ptr))
+        want_b, want_bb, want_ab = basis.download(), bbasis.download(), abasis.download()
+        want_ab[:, m:] += shift * want_b[:, m:]
+        want_h = want_b.T @ want_ab[:, m:] if mode == 0 else np.tril(want_b.T @ want_ab)
+        steady = None
+        for ahead in (1, 1, 0):
+            ctx.set_option(capi.OPT_RUN_AHEAD, ahead)
+            basis = ctx.panel(np.asfortranarray(np.hstack([x, u])))
+            bbasis = ctx.panel(np.asfortranarray(np.hstack([bx, np.zeros((n, k))])))
+            abasis = ctx.panel(np.asfortranarray(np.hstack([ax, np.zeros((n, k))])))
+            s0 = ctx.stats()["host_syncs"]
+            h = ctx.expand_project_metric(mode, basis, bbasis, abasis, m, k, mv, bv, shift)
+            syncs = ctx.stats()["host_syncs"] - s0
+            gb, gbb, gab = basis.download(), bbasis.download(), abasis.download()
+            q, bq = gb[:, m:], gbb[:, m:]
+            assert np.array_equal(gb[:, :m], x)
+            assert np.abs(q.T @ bq - np.eye(k)).max() < 1e-12 and np.abs(bx.T @ q).max() < 1e-12, (kind, ahead)
+            assert np.abs(q - want_b[:, m:]).max() < 1e-10 * max(1.0, np.abs(want_b[:, m:]).max())
+            assert np.abs(gab[:, m:] - want_ab[:, m:]).max() < 1e-10 * np.abs(want_ab[:, m:]).max()
+            got = h if mode == 0 else np.tril(h)
+            assert np.abs(got - want_h).max() < 1e-10 * np.abs(want_h).max()
+            if ahead and kind == "random":
+                steady = syncs          # (second pass: the plan of the first is remembered)
+        assert steady in (None, 1), steady       # one host wait for the whole step once the plan holds
+    finally:
+        ctx.set_option(capi.OPT_RUN_AHEAD, 1)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)

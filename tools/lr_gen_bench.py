@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=2_000_000)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--ab-run-ahead", action="store_true", help="every driver with DLA_OPT_RUN_AHEAD 1 / 0 alternately, three times each")
     args = ap.parse_args()
     n = args.n
     ctx = capi.Context()
@@ -47,6 +48,18 @@ def main():
         def run():
             ctx.lib.dla_copy(ctx.h, ev.ptr, guess.ptr, 8 * rows * m)
             return solve(ev, t, m, tol)
+        if args.ab_run_ahead:
+            for rep in range(6):
+                ctx.set_option(capi.OPT_RUN_AHEAD, 1 - rep % 2)
+                run()
+                ctx.sync(); ctx.reset_stats()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    eig, _, ok, info = run()
+                ctx.sync()
+                print(f"{name}: run-ahead {1 - rep % 2}: {(time.perf_counter() - t0) / args.steps * 1e3:.3f} ms per solve, "
+                      f"{ctx.stats()['host_syncs'] / args.steps:.0f} host waits, {info['iters']} iterations", flush=True)
+            ctx.set_option(capi.OPT_RUN_AHEAD, 1)
         run()
         ctx.sync(); ctx.reset_stats()
         t0 = time.perf_counter()
