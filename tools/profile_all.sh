@@ -6,7 +6,7 @@
 # shard), the shard rehearsal, the linear-response / generalised runs, the host-time report, the k x k step's time stamps, the
 # host-mode probe and the HIP legs of the floor probes.  Results are collected in gpurun_out/profiles_<tag>/ (copy to profiles/<tag>/).
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
 P=gpurun_out/profile_$TAG
@@ -33,7 +33,20 @@ python3 tools/lr_gen_bench.py > $OUT/bench_lr_gen_2e6.jsonl 2> $OUT/lr_gen.err
 DIAGLIB_AMD_HOSTTIME=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --n 250000 --steps 20 --warmup 3 --no-cpu-baseline --no-random-leg > $OUT/hosttime_250k_rows.txt 2>&1
 DIAGLIB_AMD_CHAIN_DEBUG=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-random-leg 2>&1 | grep -A6 "chain k=13 m=52" | tail -7 | cut -c1-260 > $OUT/chain_timing_k13_m52.txt
 python3 tools/host_mode_probe.py 2>&1 | tail -8 > $OUT/host_mode_probe.txt
+# drop-in mode: time inside the caller's routine / waiting for downloads / waiting for small results against the chunk count
+for c in 1 2 4 8; do
+  echo "== DLA_OPT_STAGE_CHUNKS = $c (two solves; api lines = totals over both)" >> $OUT/host_mode_chunks.txt
+  DIAGLIB_AMD_HOSTTIME=1 python3 tools/host_mode_timeline.py 2000000 $c 2>&1 | grep -E "solve 1|user callback|stage d2h \(wait\)|small result|alone" >> $OUT/host_mode_chunks.txt
+done
+python3 tools/lr_gen_bench.py --ab-run-ahead 2>/dev/null | grep "run-ahead" > $OUT/lr_gen_run_ahead_ab.txt
+python3 tools/fuzz_run_ahead.py 16 7 > $OUT/fuzz_run_ahead.txt 2>&1 || true
+mkdir -p tools/bin && hipcc --offload-arch=gfx950 -O2 -o tools/bin/upload_probe tools/upload_probe.hip && timeout -k 5 60 tools/bin/upload_probe > $OUT/upload_probe.txt 2>&1 || true
+python3 tools/ritz_skew_probe.py > $OUT/ritz_skew_probe.txt 2>&1 || true
 echo "rehearsal / lr / host done"
+bash tools/profile_stalls.sh headline > /dev/null 2>&1 && cp gpurun_out/stall_counters_headline.txt $OUT/stall_counters_headline.txt
+bash tools/profile_stalls.sh cfg5 --solver lobpcg --n 10000000 --roots 32 --tol 1e-12 > /dev/null 2>&1 && cp gpurun_out/stall_counters_cfg5.txt $OUT/stall_counters_cfg5shape.txt
+rm -rf gpurun_out/stalls_headline gpurun_out/stalls_cfg5
+echo "stall counters done"
 python3 tools/floor_probe.py --n 10000000 --roots 32 --solver lobpcg --iters 30 --impl hip > $OUT/floor_probe_lobpcg_n1e7_32roots_hip.txt 2>/dev/null
 python3 tools/floor_probe.py --n 2000000 --roots 8 --solver davidson --iters 16 --impl hip > $OUT/floor_probe_davidson_n2e6_8roots_hip.txt 2>/dev/null
 python3 tools/floor_probe.py --n 1000000 --roots 32 --solver lobpcg --iters 40 --impl hip,oracle,reference > $OUT/floor_probe_lobpcg_n1e6_32roots.txt 2>/dev/null
