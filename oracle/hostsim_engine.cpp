@@ -150,6 +150,45 @@ struct HostSimEngine : dla::Engine {
     orc_synth_precnd(&n, &m, &fac, x, px);
     return 0;
   }
+  // the sample operators of the generalised / linear-response drivers, y = d(i) x + W C W^T x (definitions: SynthKind in
+  // hip_engine.hip -- restated here so that the host-memory engine can run those drivers on row shards)
+  int synth_apply(int kind, int n, int m, const double* x, double* y) override
+  {
+    if (kind < 0 || kind > 5) return DLA_ERR_ARG;
+    const double* w = orc_synth_w();
+    const int rw = syn_rw;
+    std::vector<double> t((size_t)rw * m), ct((size_t)rw * m, 0.0);
+    orc_gemm_tn(n, rw, m, w, n, x, n, t.data(), rw);
+    int st = reduce(t.data(), rw * m, 0);
+    if (st) return st;
+    double cpl[16] = {0.0};
+    const double tau = 0.05;
+    for (int q = 0; q < 4; ++q) {
+      if (kind == 0 || kind == 1) cpl[q + 4 * q] = syn_sigma;
+      else if (kind == 2) cpl[q + 4 * q] = 0.2 * syn_sigma;
+      else if (kind == 5) cpl[q + 4 * q] = 0.1;
+    }
+    if (kind == 3 || kind == 4) {
+      const double tj = kind == 3 ? tau : -tau;
+      cpl[0 + 4 * 1] = tj; cpl[1 + 4 * 0] = -tj; cpl[2 + 4 * 3] = tj; cpl[3 + 4 * 2] = -tj;
+    }
+    for (int c = 0; c < m; ++c)
+      for (int q = 0; q < rw; ++q) {
+        double v = 0.0;
+        for (int p = 0; p < rw; ++p) v += cpl[q + 4 * p] * t[p + (size_t)c * rw];
+        ct[q + (size_t)c * rw] = v;
+      }
+    for (int c = 0; c < m; ++c)
+      for (int i = 0; i < n; ++i) {
+        const unsigned long long gi = (unsigned long long)(syn_row0 + i + 1);
+        const double si = 1.0 + 0.5 / (1.0 + (double)(gi % 7ULL));
+        const double d = kind == 0 ? (double)gi + 1.0 : kind == 1 ? (double)gi + 5.0 : kind == 2 ? (double)gi + 2.0 : si;
+        double s = 0.0;
+        for (int q = 0; q < rw; ++q) s += w[(size_t)q * n + i] * ct[q + (size_t)c * rw];
+        y[(size_t)c * n + i] = d * x[(size_t)c * n + i] + s;
+      }
+    return 0;
+  }
 };
 
 }  // namespace

@@ -48,8 +48,13 @@ else:
     g = np.asfortranarray(full[row0:row0 + n_loc])
 ev = ctx.panel(g)
 mv, pc = capi.fn_address("dla_synth_matvec"), capi.fn_address("dla_synth_precnd")
+bv = capi.fn_address("dla_synth_metric")
 if spec["solver"] == "davidson":
     eig, _, ok, info = ctx.davidson_driver(n_loc, t, m, 200, spec["tol"], spec["max_dav"], 0.0, mv, pc, ev)
+elif spec["solver"] == "gen_david":
+    eig, _, ok, info = ctx.gen_david_driver(n_loc, t, m, 200, spec["tol"], spec["max_dav"], 0.0, mv, pc, bv, ev)
+elif spec["solver"] == "gen_lobpcg":
+    eig, _, ok, info = ctx.lobpcg_driver(n_loc, t, m, 200, spec["tol"], 0.0, mv, pc, ev, bvec=bv)
 else:
     eig, _, ok, info = ctx.lobpcg_driver(n_loc, t, m, 200, spec["tol"], 0.0, mv, pc, ev)
 np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), eig=eig, ok=ok, iters=info["iters"], cols=info["matvec_cols"],
@@ -107,7 +112,8 @@ def test_hostsim_single_rank_matches_oracle(sim, oracle, tmp_path):
         assert np.abs(v * sgn - vo)[:, :t].max() < 1e-6
 
 
-@pytest.mark.parametrize("solver,guess", [("davidson", "unit"), ("davidson", "rand"), ("lobpcg", "unit"), ("davidson", "zero")])
+@pytest.mark.parametrize("solver,guess", [("davidson", "unit"), ("davidson", "rand"), ("lobpcg", "unit"), ("davidson", "zero"),
+                                          ("gen_david", "unit"), ("gen_lobpcg", "unit")])
 def test_two_ranks_gloo_equals_one_rank(sim, tmp_path, solver, guess):
     spec = dict(n=5000, n_targ=4, n_max=8, max_dav=10, tol=1e-9, solver=solver, guess=guess, seed=11)
     d1 = tmp_path / "w1"; d1.mkdir()
@@ -131,7 +137,8 @@ def test_two_ranks_gloo_equals_one_rank(sim, tmp_path, solver, guess):
     v1 = one["vec"]
     sgn = np.sign((v1 * v2).sum(0))
     assert np.abs(v2 * sgn - v1)[:, :t].max() < 1e-6
-    assert np.abs(v2[:, :t].T @ v2[:, :t] - np.eye(t)).max() < 1e-12
+    if not solver.startswith("gen_"):          # (with a metric the vectors are B-orthonormal)
+        assert np.abs(v2[:, :t].T @ v2[:, :t] - np.eye(t)).max() < 1e-12
 
 
 def test_shard_rows_partition():
