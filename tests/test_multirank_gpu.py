@@ -64,6 +64,10 @@ if spec["solver"] == "check_guess":
     eig, ok, info = np.zeros(m), True, dict(iters=0, matvec_cols=0)
 elif spec["solver"] == "davidson":
     eig, _, ok, info = ctx.davidson_driver(n_loc, t, m, 200, spec["tol"], 20, 0.0, mv, pc, ev)
+elif spec["solver"] == "gen_david":
+    eig, _, ok, info = ctx.gen_david_driver(n_loc, t, m, 200, spec["tol"], 20, 0.0, mv, pc, capi.fn_address("dla_synth_metric"), ev)
+elif spec["solver"] == "gen_lobpcg":
+    eig, _, ok, info = ctx.lobpcg_driver(n_loc, t, m, 200, spec["tol"], 0.0, mv, pc, ev, bvec=capi.fn_address("dla_synth_metric"))
 else:
     eig, _, ok, info = ctx.lobpcg_driver(n_loc, t, m, 200, spec["tol"], 0.0, mv, pc, ev)
 st = ctx.stats()
@@ -93,7 +97,8 @@ def _run_world(tmp_path, spec, world, one_gpu_each=False):
 
 
 @pytest.mark.parametrize("transport", ["hook", "p2p"])
-@pytest.mark.parametrize("solver,guess", [("davidson", "unit"), ("lobpcg", "unit"), ("check_guess", "zero")])
+@pytest.mark.parametrize("solver,guess", [("davidson", "unit"), ("lobpcg", "unit"), ("check_guess", "zero"),
+                                          ("gen_david", "unit"), ("gen_lobpcg", "unit")])
 def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, solver, guess, transport):
     spec = dict(n=200_000, n_targ=8, n_max=13, tol=1e-10, solver=solver, guess=guess, transport=transport)
     d1 = tmp_path / "w1"; d1.mkdir()
@@ -121,7 +126,8 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, solver, guess, transport)
     v1 = one["vec"]
     sgn = np.sign((v1 * v2).sum(0))
     assert np.abs(v2 * sgn - v1)[:, :t].max() < 1e-6
-    assert np.abs(v2[:, :t].T @ v2[:, :t] - np.eye(t)).max() < 1e-12
+    if not solver.startswith("gen_"):          # (with a metric the vectors are B-orthonormal)
+        assert np.abs(v2[:, :t].T @ v2[:, :t] - np.eye(t)).max() < 1e-12
 
 
 def test_two_gpus_rccl_equal_one_rank(tmp_path):
