@@ -130,6 +130,27 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, solver, guess, transport)
         assert np.abs(v2[:, :t].T @ v2[:, :t] - np.eye(t)).max() < 1e-12
 
 
+@pytest.mark.parametrize("solver", ["davidson", "lobpcg"])
+def test_two_ranks_wide_blocks_peer_to_peer(tmp_path, solver):
+    """Blocks of 21 columns (two column tiles: the LDS-loop k x k step, the one-sweep X^T U + U^T U and the storing sweep OP_XW)
+    with the cross-rank sum inside the reduction kernels: two ranks on one GPU over the peer-to-peer mailboxes against one rank."""
+    spec = dict(n=120_000, n_targ=16, n_max=21, tol=1e-10, solver=solver, guess="unit", transport="p2p")
+    d1 = tmp_path / "w1"; d1.mkdir()
+    d2 = tmp_path / "w2"; d2.mkdir()
+    one = _run_world(d1, spec, 1)[0]
+    two = _run_world(d2, spec, 2)
+    t = spec["n_targ"]
+    assert bool(one["ok"]) and all(bool(r["ok"]) for r in two)
+    assert int(two[0]["iters"]) == int(two[1]["iters"]) and np.array_equal(two[0]["eig"], two[1]["eig"])
+    assert np.allclose(two[0]["eig"][:t], one["eig"][:t], rtol=1e-11, atol=0)
+    assert abs(int(two[0]["iters"]) - int(one["iters"])) <= max(1, int(one["iters"]) // 5)
+    assert int(two[0]["host_syncs"]) <= int(one["host_syncs"]) + 10, (int(two[0]["host_syncs"]), int(one["host_syncs"]))
+    v2 = np.vstack([two[0]["vec"], two[1]["vec"]]); v1 = one["vec"]
+    sgn = np.sign((v1 * v2).sum(0))
+    assert np.abs(v2 * sgn - v1)[:, :t].max() < 1e-6
+    assert np.abs(v2[:, :t].T @ v2[:, :t] - np.eye(t)).max() < 1e-12
+
+
 def test_two_gpus_rccl_equal_one_rank(tmp_path):
     """the RCCL data path with more than one rank -- one rank per GPU, ncclAllReduce on the engines' streams,
     device-driven chains with the collective between reduction and tail.  Needs two visible GPUs (skipped on the
