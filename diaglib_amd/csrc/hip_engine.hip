@@ -907,7 +907,9 @@ struct RitzArgs {
 // (+6 % measured, tools/tune_ab.py)
 // XP: the coefficient block carries extra product columns behind the k Ritz columns (RitzArgs::k2); a template argument so
 // that the plain Ritz step keeps its code (the same tests as run-time branches cost the one-tile kernel 37 %)
-template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int QT = 0, bool XP = false>
+// SCHED (A/B, tune knob 0 = 7 / 8, wide blocks only): 1 = __builtin_amdgcn_iglp_opt(0) in the pipelined loop, 2 = an explicit
+// sched_group_barrier pipeline (four MFMAs, then one coefficient read of a later column step / one panel load of the next stage)
+template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int QT = 0, bool XP = false, int SCHED = 0>
 __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 {
   constexpr int RG = 16 * VEC;             // rows per wave tile (one row group)
@@ -1013,12 +1015,54 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
       if (PIPE <= nfull4) {
         vec_t xa[PIPE], ya[PIPE];
         load_stage(0, xa, ya);
+        if constexpr (SCHED == 5) {
+          // two stages per trip with the register sets changing roles: no copies, and a stage's loads are first read a whole
+          // stage of MFMAs after their issue
+          vec_t xc[PIPE], yc[PIPE];
+          for (; cs4 + 3 * PIPE <= nfull4; cs4 += 2 * PIPE) {
+            load_stage(cs4 + PIPE, xc, yc);
+            mfma_stage(cs4, xa, ya);
+            load_stage(cs4 + 2 * PIPE, xa, ya);
+            mfma_stage(cs4 + PIPE, xc, yc);
+          }
+        }
         for (; cs4 + 2 * PIPE <= nfull4; cs4 += PIPE) {
           vec_t xb[PIPE], yb[PIPE];
           load_stage(cs4 + PIPE, xb, yb);
           mfma_stage(cs4, xa, ya);
 #pragma unroll
           for (int u4 = 0; u4 < PIPE; ++u4) { xa[u4] = xb[u4]; ya[u4] = yb[u4]; }
+          if constexpr (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
+          if constexpr (SCHED == 3) __builtin_amdgcn_iglp_opt(1);
+          if constexpr (SCHED == 4) {
+            // per column step: the coefficient reads of the NEXT step behind the first MFMAs, the panel loads of the next stage
+            // spread over the second half
+            __builtin_amdgcn_sched_group_barrier(0x100, KT, 0);
+#pragma unroll
+            for (int u4 = 0; u4 < PIPE; ++u4) {
+#pragma unroll
+              for (int q = 0; q < KT; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (u4 + 1 < PIPE) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+#pragma unroll
+              for (int q = 0; q < KT; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * VEC - 2, 0);
+                if (q < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+              }
+            }
+          }
+          if constexpr (SCHED == 2) {
+            constexpr int NG = PIPE * VEC * KT / 2;        // groups of four MFMAs
+            constexpr int ND = PIPE * KT, NV = 2 * PIPE;   // coefficient reads, panel loads of the next stage
+            __builtin_amdgcn_sched_group_barrier(0x100, KT, 0);
+#pragma unroll
+            for (int sg = 0; sg < NG; ++sg) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+              if (sg < ND - KT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              if ((sg & 1) == 0 && sg / 2 < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+          }
         }
         mfma_stage(cs4, xa, ya);
         cs4 += PIPE;
@@ -4621,6 +4665,14 @@ struct HipEngine : dla::Engine {
         else if (kt == 1) RZ((ritz_kernel<1, 2, 3, 0, 0, true>));
         else if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 0, true>));
         else if (kt == 3) RZ((ritz_kernel<3, 2, 3, 3, 0, true>));
+        else if (kt == 4 && tune[0] == 7) RZ((ritz_kernel<4, 2, 3, 3, 0, true, 1>));
+        else if (kt == 4 && tune[0] == 8) RZ((ritz_kernel<4, 2, 3, 3, 0, true, 2>));
+        else if (kt == 5 && tune[0] == 7) RZ((ritz_kernel<5, 2, 3, 3, 0, true, 1>));
+        else if (kt == 5 && tune[0] == 8) RZ((ritz_kernel<5, 2, 3, 3, 0, true, 2>));
+        else if (kt == 4 && tune[0] == 11) RZ((ritz_kernel<4, 2, 3, 3, 0, true, 5>));
+        else if (kt == 5 && tune[0] == 11) RZ((ritz_kernel<5, 2, 3, 3, 0, true, 5>));
+        else if (kt == 5 && tune[0] == 9) RZ((ritz_kernel<5, 2, 3, 3, 0, true, 3>));
+        else if (kt == 5 && tune[0] == 10) RZ((ritz_kernel<5, 2, 3, 3, 0, true, 4>));
         else if (kt == 4) RZ((ritz_kernel<4, 2, 3, 3, 0, true>));
         else RZ((ritz_kernel<5, 2, 3, 3, 0, true>));        // (pipeline depth 2 / 4 measured: 8.9 / 7.9 ms against 7.5 at 37 + 37 columns)
       } else if (vec2 && kt >= 2 && tune[0] == 1) {
