@@ -2591,7 +2591,9 @@ struct GramReduceArgs {
 template <bool TAIL>
 __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
 {
-  DLA_PREDICATED(a);
+  // (the predicate of a device-driven chain is looked at AFTER the first level's loads and sums: the word and the partials are
+  //  independent latencies, and nothing before the test has a side effect)
+  const int turn = (a.phase != nullptr) ? *a.phase : a.want;
   const unsigned long long t_entry = (TAIL && a.tail.dbg != nullptr) ? wall_clock64() : 0ULL;
   const int nsl = a.tlw * a.kt;              // output tiles of one pass
   const int slots = nsl + a.extra;           // partial slots per (pass, block)
@@ -2628,6 +2630,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
     for (int q = 0; q < 8; ++q) s += v[q];
   }
   for (; b < b1; ++b) s += p[(size_t)b * slots * 256];
+  if (turn != a.want) return;
   __shared__ int s_last;
   double tot = s;
   if (G > 1) {
