@@ -4656,7 +4656,10 @@ struct HipEngine : dla::Engine {
     const int ncol = 16 * kt;
     {
       char kn[64];
-      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d, %s>", kt, vec2 ? 2 : 1, kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt, k2 > 0 ? "true" : "false");
+      // (the name rocprofv3 prints: the last argument is the scheduling variant of the wide sweeps, tune knob 0 = 7 ... 11)
+      const int t0 = tune[0];
+      const int sched = (k2 > 0 && qt == 0 && kt >= 4) ? (t0 == 7 ? 1 : t0 == 8 ? 2 : t0 == 11 ? 5 : (kt == 5 && t0 == 9) ? 3 : (kt == 5 && t0 == 10) ? 4 : 0) : 0;
+      std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d, %s, %d>", kt, vec2 ? 2 : 1, kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt, k2 > 0 ? "true" : "false", sched);
       // (flops: the two Ritz products and, with extra columns, the two panel products they replace)
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + ((avy ? 2.0 : 1.0) + (evec ? 1.0 : 0.0)) * m + 2.0 * k2),
               4.0 * (double)n * l * (m + k2) + 5.0 * (double)n * nact, kn);

@@ -3,7 +3,7 @@
 JSON line per driver (profiles/r03/bench_lr_gen_2e6.jsonl).  Operators = the library's sample operators (dla_synth_apbmul ...
 dla_synth_metric, include/diaglib_amd.h), device callbacks, device-resident eigenvector block.
 
-    python tools/lr_gen_bench.py [--n 2000000] [--steps 5]"""
+    python tools/lr_gen_bench.py [--n 2000000] [--steps 9]"""
 import argparse
 import json
 import os
@@ -19,7 +19,7 @@ from diaglib_amd import capi  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=2_000_000)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--ab-run-ahead", action="store_true", help="every driver with DLA_OPT_RUN_AHEAD 1 / 0 alternately, three times each")
     args = ap.parse_args()
     n = args.n
@@ -62,14 +62,16 @@ def main():
             ctx.set_option(capi.OPT_RUN_AHEAD, 1)
         run()
         ctx.sync(); ctx.reset_stats()
-        t0 = time.perf_counter()
+        per = []
         for _ in range(args.steps):
+            t0 = time.perf_counter()
             eig, _, ok, info = run()
-        ctx.sync()
-        dt = (time.perf_counter() - t0) / args.steps
+            ctx.sync()
+            per.append(time.perf_counter() - t0)
+        dt = float(np.median(per))          # (a solve is 15-25 ms with 20-50 host waits: one descheduled wait moves a mean of five)
         st = ctx.stats()
         gb = sum(st[c]["alg_bytes"] for c in ("gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd")) / args.steps / 1e9
-        print(json.dumps({"driver": name, "n": n, "roots": t, "n_max": m, "tol": tol, "ms_per_solve": round(dt * 1e3, 3), "converged": bool(ok),
+        print(json.dumps({"driver": name, "n": n, "roots": t, "n_max": m, "tol": tol, "ms_per_solve": round(dt * 1e3, 3), "ms_min_max": [round(min(per) * 1e3, 3), round(max(per) * 1e3, 3)], "converged": bool(ok),
                           "iters": info["iters"], "restarts": info["restarts"], "eig": [round(float(e), 9) for e in eig[:t]],
                           "alg_GB_per_solve": round(gb, 2), "alg_TBps_over_wall": round(gb / dt / 1e3, 3),
                           "host_syncs_per_solve": st["host_syncs"] / args.steps, "callbacks": "device (sample operators)"}), flush=True)
