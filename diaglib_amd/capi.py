@@ -41,7 +41,7 @@ EXPORTS = [
     "dla_call_matvec", "dla_call_precnd", "dla_expand_project", "dla_expand_project_metric",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
     "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd", "dla_synth_apbmul", "dla_synth_ambmul", "dla_synth_spdmul", "dla_synth_smdmul",
-    "dla_synth_metric", "dla_synth_lrprec1", "dla_synth_lrprec2", "dla_spmm_setup_csr", "dla_spmm_matvec", "dla_spmm_precnd",
+    "dla_synth_metric", "dla_synth_lrprec1", "dla_synth_lrprec2", "dla_spmm_setup_csr", "dla_spmm_setup_csr_sharded", "dla_spmm_matvec", "dla_spmm_precnd",
     "dla_davidson_driver", "dla_gen_david_driver", "dla_lobpcg_driver", "dla_caslr_eff_driver", "dla_caslr_driver", "dla_call_lrprec",
     "dla_last_solve_info", "dla_set_solve_info",
 ]
@@ -129,6 +129,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_trtri_lower": (i, [i, c_dp, i]), "dla_norm_est": (d, [i, c_dp, i]),
         "dla_synth_setup": (i, [vp, C.c_longlong, C.c_longlong, i, i, d]),
         "dla_spmm_setup_csr": (i, [vp, i, vp, vp, vp]),
+        "dla_spmm_setup_csr_sharded": (i, [vp, i, C.c_longlong, C.c_longlong, vp, vp, vp]),
         "dla_davidson_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, c_ip]),
         "dla_lobpcg_driver": (None, [i, i, i, i, i, i, d, d, vp, vp, vp, vp, vp, c_ip]),
         "dla_caslr_eff_driver": (None, [i, i, i, i, i, d, i, vp, vp, vp, vp, vp, vp, vp, c_ip]),
@@ -462,6 +463,15 @@ class Context:
         ci = np.ascontiguousarray(a.indices, dtype=np.int32)
         va = np.ascontiguousarray(a.data, dtype=np.float64)
         self._chk(self.lib.dla_spmm_setup_csr(self.h, a.shape[0], rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
+
+    def spmm_setup_sharded(self, a_rows, row0: int, n_global: int) -> None:
+        """hand THIS rank's rows (a scipy.sparse matrix of shape n_local x n_global, global column indices) of a banded
+        symmetric matrix to the sample operator; collective over the ranks of the context's transport"""
+        a = a_rows.tocsr()
+        rp = np.ascontiguousarray(a.indptr, dtype=np.int64)
+        ci = np.ascontiguousarray(a.indices, dtype=np.int64)
+        va = np.ascontiguousarray(a.data, dtype=np.float64)
+        self._chk(self.lib.dla_spmm_setup_csr_sharded(self.h, a.shape[0], row0, n_global, rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
 
     def synth_matvec(self, x: DevPanel, ax: DevPanel) -> None:
         self._chk(self.lib.dla_call_matvec(self.h, fn_address("dla_synth_matvec"), x.n, x.m, x.ptr, ax.ptr))

@@ -5,6 +5,7 @@
 #pragma once
 #include <cstddef>
 #include <string>
+#include <vector>
 #include "../../include/diaglib_amd.h"
 
 namespace dla {
@@ -157,6 +158,12 @@ struct Engine : BlockOps {
 
   // sample sparse operator (ELLPACK SpMM + its diagonal preconditioner)
   virtual int spmm_setup_csr(int /*n*/, const long long* /*rowptr*/, const int* /*colind*/, const double* /*values*/) { return DLA_ERR_ARG; }
+  // the same operator on a row shard: rows row0 .. row0 + n_local - 1 of A with GLOBAL column indices.  Columns outside the
+  // shard must lie within `halo` rows of it (a banded matrix); every rank publishes its first and last `halo` rows of x through
+  // the all-reduce of the small-product transport (disjoint slots: a sum that gathers), see sharded_ell_* below.  Collective:
+  // every rank calls it (the halo width is agreed by a max-reduction).
+  virtual int spmm_setup_csr_sharded(int /*n_local*/, long long /*row0*/, long long /*n_global*/, const long long* /*rowptr*/,
+                                     const long long* /*colind*/, const double* /*values*/) { return DLA_ERR_ARG; }
   virtual int spmm_matvec(int /*n*/, int /*m*/, const double* /*x*/, double* /*ax*/) { return DLA_ERR_ARG; }
   virtual int spmm_precnd(int /*n*/, int /*m*/, double /*fac*/, const double* /*x*/, double* /*px*/) { return DLA_ERR_ARG; }
 
@@ -226,6 +233,54 @@ struct ApiTimer {
 #define DLA_T(name) dla::ApiTimer DLA_CAT(dla_api_timer_, __LINE__)(name)
 
 // provided by the engine translation unit linked into the library
+// ---- a row shard of a sparse matrix as ELLPACK with a halo (spmm_setup_csr_sharded of both engines)
+// Column indices are kept relative to an EXTENDED local vector [halo rows of the previous rank | the shard's n rows | halo rows of
+// the next rank]: index = global column - row0 + halo.
+struct ShardedEll {
+  int n = 0, w = 0, halo = 0;
+  long long row0 = 0;
+  std::vector<int> col;          // [w][n]
+  std::vector<double> val, diag; // [w][n], [n]
+};
+// widest row and the number of rows of the neighbours this shard's columns reach into; checks the indices
+inline int sharded_ell_need(int n, long long row0, long long n_global, const long long* rowptr, const long long* colind, int* w,
+                            long long* need, std::string& err)
+{
+  *w = 0; *need = 0;
+  if (n <= 0 || row0 < 0 || row0 + n > n_global || !rowptr || !colind) { err = "spmm_setup_csr_sharded: bad arguments"; return DLA_ERR_ARG; }
+  for (int i = 0; i < n; ++i) {
+    const long long p0 = rowptr[i], p1 = rowptr[i + 1];
+    if (p1 < p0) { err = "spmm_setup_csr_sharded: row pointers not ascending"; return DLA_ERR_ARG; }
+    if (p1 - p0 > *w) *w = (int)(p1 - p0);
+    for (long long p = p0; p < p1; ++p) {
+      const long long c = colind[p];
+      if (c < 0 || c >= n_global) { err = "spmm_setup_csr_sharded: column index out of range"; return DLA_ERR_ARG; }
+      if (c < row0 && row0 - c > *need) *need = row0 - c;
+      if (c >= row0 + n && c - (row0 + n - 1) > *need) *need = c - (row0 + n - 1);
+    }
+  }
+  if (*w <= 0) { err = "spmm_setup_csr_sharded: empty shard"; return DLA_ERR_ARG; }
+  return DLA_OK;
+}
+inline void sharded_ell_build(int n, long long row0, const long long* rowptr, const long long* colind, const double* values,
+                              int halo, ShardedEll& e)
+{
+  int w = 0;
+  for (int i = 0; i < n; ++i) if ((int)(rowptr[i + 1] - rowptr[i]) > w) w = (int)(rowptr[i + 1] - rowptr[i]);
+  e.n = n; e.w = w; e.halo = halo; e.row0 = row0;
+  e.col.assign((size_t)w * n, 0); e.val.assign((size_t)w * n, 0.0); e.diag.assign((size_t)n, 0.0);
+  for (int i = 0; i < n; ++i) {
+    const long long p0 = rowptr[i], p1 = rowptr[i + 1];
+    for (int q = 0; q < w; ++q) {
+      const bool in = p0 + q < p1;
+      const long long c = in ? colind[p0 + q] : row0 + i;      // (padding: a zero that points at the row itself)
+      e.col[(size_t)q * n + i] = (int)(c - row0 + halo);
+      e.val[(size_t)q * n + i] = in ? values[p0 + q] : 0.0;
+      if (in && c == row0 + i) e.diag[i] += values[p0 + q];
+    }
+  }
+}
+
 Engine* make_engine(int device, std::string& err);
 int engine_unique_id(char id[128]);
 

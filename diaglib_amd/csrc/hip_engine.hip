@@ -1604,6 +1604,55 @@ __global__ void diag_precnd_kernel(int n, int m, double fac, const double* __res
   }
 }
 
+// The same product on a ROW SHARD of A (dla_spmm_setup_csr_sharded): col[] indexes the extended local vector
+// [last `halo` rows of the previous rank | the shard's n rows | first `halo` rows of the next rank]; the two halo pieces have
+// arrived through the small-product all-reduce (halo_pack_kernel: every rank fills its own two slots of a zeroed buffer, the sum
+// gathers).  Only the wavefronts at the two ends of the shard ever take the halo branches.
+template <int W>
+__global__ __launch_bounds__(256) void ell_spmm_halo_kernel(int n, int m, int w, int halo, const int* __restrict__ col,
+                                                            const double* __restrict__ val, const double* __restrict__ x,
+                                                            const double* __restrict__ prev, const double* __restrict__ next,
+                                                            double* __restrict__ ax)
+{
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    constexpr int WW = W > 0 ? W : 1;
+    int cj[WW]; double vj[WW];
+    if constexpr (W > 0) {
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        const bool in = q < w;
+        cj[q] = in ? col[(size_t)q * n + i] : i + halo;
+        vj[q] = in ? val[(size_t)q * n + i] : 0.0;
+      }
+    }
+    for (int c = 0; c < m; ++c) {
+      const double* xc = x + (size_t)c * n;
+      const double* pc = prev + (size_t)c * halo;
+      const double* nc = next + (size_t)c * halo;
+      double s = 0.0;
+      auto fetch = [&](int idx) -> double { return idx < halo ? pc[idx] : (idx < halo + n ? xc[idx - halo] : nc[idx - halo - n]); };
+      if constexpr (W > 0) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) s += vj[q] * fetch(cj[q]);
+      } else {
+        for (int q = 0; q < w; ++q) s += val[(size_t)q * n + i] * fetch(col[(size_t)q * n + i]);
+      }
+      __builtin_nontemporal_store(s, ax + (size_t)c * n + i);
+    }
+  }
+}
+
+// buf[((r * 2 + side) * m + c) * halo + h]: side 0 = the first, side 1 = the last `halo` rows of rank r's x; this rank's slots
+// are filled, everybody else's are zero (the all-reduce that follows is a gather)
+__global__ void halo_pack_kernel(int n, int m, int halo, int nranks, int rank, const double* __restrict__ x, double* __restrict__ buf)
+{
+  const int total = nranks * 2 * m * halo;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int h = idx % halo, c = (idx / halo) % m, side = (idx / (halo * m)) % 2, r = idx / (2 * halo * m);
+    buf[idx] = (r == rank) ? x[(size_t)c * n + (side == 0 ? h : n - halo + h)] : 0.0;
+  }
+}
+
 // ======================================================================================
 // Device-resident control of the orthogonalisation loops
 // ======================================================================================
@@ -2830,6 +2879,7 @@ struct HipEngine : dla::Engine {
     if (d_ell_col) (void)hipFree(d_ell_col);
     if (d_ell_val) (void)hipFree(d_ell_val);
     if (d_ell_diag) (void)hipFree(d_ell_diag);
+    if (d_halo) (void)hipFree(d_halo);
     if (st_down) {
       (void)hipStreamSynchronize(st_down); (void)hipStreamSynchronize(st_up);
       (void)hipStreamDestroy(st_down); (void)hipStreamDestroy(st_up);
@@ -4897,13 +4947,113 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipMemcpy(d_ell_col, col.data(), sizeof(int) * col.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_ell_val, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_ell_diag, diag.data(), sizeof(double) * diag.size(), hipMemcpyHostToDevice));
-    ell_n = n; ell_w = w;
+    ell_n = n; ell_w = w; ell_sharded = false; ell_halo = 0;
+    return DLA_OK;
+  }
+  // ---- ... on a row shard (banded matrices: the columns of a shard reach at most `halo` rows into its neighbours)
+  int ell_halo = 0;                  // rows exchanged with each neighbour; 0 = the operator is not sharded
+  bool ell_sharded = false;
+  double* d_halo = nullptr; size_t halo_doubles = 0;
+  std::vector<double> h_halo;        // host mirror for the hook transport
+  // all-reduce of a few host values through the engine's small-product transport (setup-time agreement between the ranks)
+  int host_allreduce(std::vector<double>& v, int op)
+  {
+    if (local_only || (nranks <= 1 && !comm && !p2p.on)) return DLA_OK;
+    bind();
+    int stc = ensure_small(sizeof(double) * v.size());
+    if (stc) return stc;
+    HIPCHK(hipMemcpyAsync(d_small, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, st));
+    stc = allreduce_dev(d_small, (int)v.size(), op, h_small);
+    if (stc) return stc;
+    stc = small_to_host(v.size());
+    if (stc) return stc;
+    std::memcpy(v.data(), h_small, sizeof(double) * v.size());
+    return DLA_OK;
+  }
+  int spmm_setup_csr_sharded(int n, long long row0, long long n_global, const long long* rowptr, const long long* colind,
+                             const double* values) override
+  {
+    int w = 0; long long need = 0;
+    std::string lerr;
+    const int bad = (values == nullptr) ? DLA_ERR_ARG : dla::sharded_ell_need(n, row0, n_global, rowptr, colind, &w, &need, lerr);
+    const int nr = std::max(1, nranks);
+    // agree on the halo width and check the layout, collectively: [max need | any failure | row0 and n of every rank (slots)]
+    std::vector<double> mx{(double)need, bad ? 1.0 : 0.0};
+    int stc = host_allreduce(mx, 1);
+    if (stc) return stc;
+    if (mx[1] != 0.0) { err = bad ? (lerr.empty() ? std::string("spmm_setup_csr_sharded: bad arguments") : lerr) : std::string("spmm_setup_csr_sharded: another rank rejected its shard"); return DLA_ERR_ARG; }
+    std::vector<double> lay((size_t)2 * nr, 0.0);
+    lay[2 * rank] = (double)row0; lay[2 * rank + 1] = (double)n;
+    stc = host_allreduce(lay, 0);
+    if (stc) return stc;
+    const long long halo = (long long)mx[0];
+    long long expect = 0;
+    for (int r = 0; r < nr; ++r) {
+      if ((long long)lay[2 * r] != expect) { err = "spmm_setup_csr_sharded: the shards are not contiguous in rank order"; return DLA_ERR_ARG; }
+      if (halo > (long long)lay[2 * r + 1]) { err = "spmm_setup_csr_sharded: a shard reaches beyond its neighbour (halo wider than a shard)"; return DLA_ERR_ARG; }
+      expect += (long long)lay[2 * r + 1];
+    }
+    if (expect != n_global) { err = "spmm_setup_csr_sharded: the shards do not cover n_global rows"; return DLA_ERR_ARG; }
+    if (halo > 4096) { err = "spmm_setup_csr_sharded: halo wider than 4096 rows (not a banded matrix)"; return DLA_ERR_ARG; }
+    dla::ShardedEll e;
+    dla::sharded_ell_build(n, row0, rowptr, colind, values, (int)halo, e);
+    bind();
+    HIPCHK(hipStreamSynchronize(st));
+    if (d_ell_col) HIPCHK(hipFree(d_ell_col));
+    if (d_ell_val) HIPCHK(hipFree(d_ell_val));
+    if (d_ell_diag) HIPCHK(hipFree(d_ell_diag));
+    d_ell_col = nullptr; d_ell_val = nullptr; d_ell_diag = nullptr;
+    HIPCHK(hipMalloc((void**)&d_ell_col, sizeof(int) * e.col.size()));
+    HIPCHK(hipMalloc((void**)&d_ell_val, sizeof(double) * e.val.size()));
+    HIPCHK(hipMalloc((void**)&d_ell_diag, sizeof(double) * e.diag.size()));
+    HIPCHK(hipMemcpy(d_ell_col, e.col.data(), sizeof(int) * e.col.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_ell_val, e.val.data(), sizeof(double) * e.val.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_ell_diag, e.diag.data(), sizeof(double) * e.diag.size(), hipMemcpyHostToDevice));
+    ell_n = n; ell_w = e.w; ell_halo = (int)halo; ell_sharded = true;
+    return DLA_OK;
+  }
+  int spmm_matvec_sharded(int n, int m, const double* x, double* ax)
+  {
+    const int nr = std::max(1, nranks), H = ell_halo;
+    const int blocks = std::max(1, std::min(ncu * 8, (n + 255) / 256));
+    // columns per exchange: a mailbox slot of the peer-to-peer transport holds P2P_MAX_DOUBLES
+    int mc = m;
+    if (H > 0 && nr > 1) mc = std::max(1, std::min(m, P2P_MAX_DOUBLES / (nr * 2 * H)));
+    const size_t need = (size_t)std::max(1, nr * 2 * mc * std::max(1, H));
+    if (need > halo_doubles) {
+      HIPCHK(hipStreamSynchronize(st));
+      if (d_halo) HIPCHK(hipFree(d_halo));
+      d_halo = nullptr;
+      HIPCHK(hipMalloc((void**)&d_halo, sizeof(double) * need));
+      HIPCHK(hipMemset(d_halo, 0, sizeof(double) * need));
+      halo_doubles = need;
+      h_halo.assign(need, 0.0);
+    }
+    for (int c0 = 0; c0 < m; c0 += mc) {
+      const int mcur = std::min(mc, m - c0);
+      const double* xc = x + (size_t)c0 * n;
+      if (H > 0 && nr > 1) {
+        const int total = nr * 2 * mcur * H;
+        DLA_LAUNCH(halo_pack_kernel, dim3(std::max(1, std::min(64, (total + 255) / 256))), dim3(256), 0, st, n, mcur, H, nr, rank, xc, d_halo);
+        HIPCHK(hipGetLastError());
+        const int stc = allreduce_dev(d_halo, total, 0, h_halo.data());
+        if (stc) return stc;
+      }
+      // (the first / last rank never index their missing neighbour: any valid address serves)
+      const double* prev = d_halo + (size_t)((rank > 0 ? (rank - 1) * 2 + 1 : 0) * mcur) * H;
+      const double* next = d_halo + (size_t)((rank + 1 < nr ? (rank + 1) * 2 : 0) * mcur) * H;
+#define ELLH(W) DLA_LAUNCH((ell_spmm_halo_kernel<W>), dim3(blocks), dim3(256), 0, st, n, mcur, ell_w, H, (const int*)d_ell_col, (const double*)d_ell_val, xc, prev, next, ax + (size_t)c0 * n)
+      if (ell_w <= 4) ELLH(4); else if (ell_w <= 8) ELLH(8); else if (ell_w <= 16) ELLH(16); else if (ell_w <= 32) ELLH(32); else ELLH(0);
+#undef ELLH
+      HIPCHK(hipGetLastError());
+    }
     return DLA_OK;
   }
   int spmm_matvec(int n, int m, const double* x, double* ax) override
   {
     if (n != ell_n || !d_ell_col) { err = "spmm_matvec: n differs from setup"; return DLA_ERR_ARG; }
     Scope s(this, DLA_OP_MATVEC, 12.0 * (double)ell_w * n + 16.0 * (double)n * m, 2.0 * (double)ell_w * n * m);
+    if (ell_sharded) return spmm_matvec_sharded(n, m, x, ax);
     const int blocks = std::max(1, std::min(ncu * 8, (n + 255) / 256));
 #define ELL(W) DLA_LAUNCH((ell_spmm_kernel<W>), dim3(blocks), dim3(256), 0, st, n, m, ell_w, (const int*)d_ell_col, (const double*)d_ell_val, x, ax)
     if (ell_w <= 4) ELL(4); else if (ell_w <= 8) ELL(8); else if (ell_w <= 16) ELL(16); else if (ell_w <= 32) ELL(32); else ELL(0);

@@ -588,22 +588,40 @@ static int gram_schmidt2(dla_ctx* c, dla::BlockOps* ops, int n, int k, double* u
   // enough": the second projection removes what the first one left behind for an ill-conditioned block)
   for (int j = 0; j < k; ++j) {
     double* uj = u + (size_t)n * j;
-    for (int rep = 0; rep < 2 && j > 0; ++rep) {
-      std::vector<double> h(j);
-      int st = ops->gram(n, j, u, 1, uj, h.data(), j);
+    double g0 = 0.0;
+    int st = ops->gram(n, 1, uj, 1, uj, &g0, 1);
+    if (st) return opsfail(c, ops, st);
+    // A column that lies in the span of the finished ones (to rounding) has no direction of its own: what two projections
+    // leave of it is noise that normalisation would blow up into a vector that is NOT orthogonal to the others.  LAPACK's
+    // dgeqrf / dorgqr (the reference's `ortho`, diaglib.f90:3052-3092) return an arbitrary unit vector orthogonal to the
+    // finished columns there (H_1 ... H_j-1 e_j, R(j, j) = 0); so does this: the column is replaced by a generated one
+    // (counter-based generator on global row indices, the same on every rank layout) and orthogonalised like any other.
+    for (int attempt = 0;; ++attempt) {
+      for (int rep = 0; rep < 2 && j > 0; ++rep) {
+        std::vector<double> h(j);
+        st = ops->gram(n, j, u, 1, uj, h.data(), j);
+        if (st) return opsfail(c, ops, st);
+        st = ops->gemm(n, j, u, 1, h.data(), j, uj, 1);
+        if (st) return opsfail(c, ops, st);
+        if (attempt == 0) for (int p = 0; p < j; ++p) r[(size_t)p + (size_t)j * k] += h[p];
+      }
+      double g = 0.0;
+      st = ops->gram(n, 1, uj, 1, uj, &g, 1);
       if (st) return opsfail(c, ops, st);
-      st = ops->gemm(n, j, u, 1, h.data(), j, uj, 1);
+      const double floor2 = 4096.0 * kEps * kEps * (double)(j + 1) * g0;      // (64 eps)^2 (j + 1) ||u_j||^2
+      if (g > floor2 && g > 0.0) {
+        if (attempt == 0) r[(size_t)j + (size_t)j * k] = std::sqrt(g);      // (a replaced column has R(j, j) = 0)
+        double w = 1.0 / std::sqrt(g);
+        st = ops->trmm(n, 1, uj, &w, 1);
+        if (st) return opsfail(c, ops, st);
+        break;
+      }
+      if (attempt >= 3 || ops != static_cast<dla::BlockOps*>(c->eng)) return fail(c, DLA_ERR_ORTHO, "ortho: a column without a direction of its own");
+      st = c->eng->random_fill(n, 1, uj, c->row0, 0x51EDULL + 131ULL * (unsigned long long)j + (unsigned long long)attempt, -0.5, 0);
+      if (st) return engfail(c, st);
+      st = ops->gram(n, 1, uj, 1, uj, &g0, 1);
       if (st) return opsfail(c, ops, st);
-      for (int p = 0; p < j; ++p) r[(size_t)p + (size_t)j * k] += h[p];
     }
-    double g = 0.0;
-    int st = ops->gram(n, 1, uj, 1, uj, &g, 1);
-    if (st) return opsfail(c, ops, st);
-    if (!(g > 0.0)) return fail(c, DLA_ERR_ORTHO, "ortho: zero column");
-    r[(size_t)j + (size_t)j * k] = std::sqrt(g);
-    double w = 1.0 / std::sqrt(g);
-    st = ops->trmm(n, 1, uj, &w, 1);
-    if (st) return opsfail(c, ops, st);
   }
   return DLA_OK;
 }
@@ -1302,6 +1320,15 @@ int dla_spmm_setup_csr(dla_ctx* c, int n, const long long* rowptr, const int* co
   if (!c) return DLA_ERR_ARG;
   g_spmm_ctx = c;
   return engfail(c, c->eng->spmm_setup_csr(n, rowptr, colind, values));
+}
+
+int dla_spmm_setup_csr_sharded(dla_ctx* c, int n_local, long long row0, long long n_global, const long long* rowptr,
+                               const long long* colind, const double* values)
+{
+  DLA_T("dla_spmm_setup_csr_sharded");
+  if (!c) return DLA_ERR_ARG;
+  g_spmm_ctx = c;
+  return engfail(c, c->eng->spmm_setup_csr_sharded(n_local, row0, n_global, rowptr, colind, values));
 }
 
 void dla_spmm_matvec(const int* n, const int* m, const double* x, double* ax)

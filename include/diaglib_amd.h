@@ -359,9 +359,17 @@ void dla_set_solve_info(int iters, int matvec_cols, int restarts);   /* used by 
  * 0-based, 64-bit row pointers); it is kept on the device as column-major ELLPACK.  dla_spmm_matvec / dla_spmm_precnd have the
  * reference's callback shapes matvec(n,m,x,ax) / precnd(n,m,fac,x,px) (README.md:34-35, main.f90:72-90, 146-171) and expect
  * DEVICE addresses (DLA_OPT_CALLBACKS_ON_DEVICE = 1); the preconditioner is the harness' x / (a_ii + fac).  They act on the
- * operator the calling thread set up last and enqueue on that context's stream.  Not sharded: with several ranks every rank
- * would have to hold the x rows its columns reference (outside the all-reduce-only contract). */
+ * operator the calling thread set up last and enqueue on that context's stream.
+ * Row shards (dla_spmm_setup_csr_sharded): every rank hands over ITS rows row0 .. row0 + n_local - 1 with GLOBAL 64-bit column
+ * indices.  The columns of a shard may reach at most `halo` rows into the two neighbouring shards (a banded matrix; halo is the
+ * largest reach of any rank, agreed at setup, at most 4096 and at most a shard's height); each product then exchanges the first
+ * and last `halo` rows of every rank's x block through the SAME transport as the small products -- every rank fills its own two
+ * slots of a zeroed nranks x 2 x halo x m buffer and the all-reduce sum gathers them (all-reduce only; 2 halo m
+ * doubles per rank and call) -- and a matrix with longer-range couplings is refused.  Collective: every rank calls the setup,
+ * with shards contiguous in rank order; with one rank it equals dla_spmm_setup_csr. */
 int  dla_spmm_setup_csr(dla_ctx* ctx, int n, const long long* rowptr, const int* colind, const double* values);
+int  dla_spmm_setup_csr_sharded(dla_ctx* ctx, int n_local, long long row0, long long n_global, const long long* rowptr,
+                                const long long* colind_global, const double* values);
 void dla_spmm_matvec(const int* n, const int* m, const double* x_dev, double* ax_dev);
 void dla_spmm_precnd(const int* n, const int* m, const double* fac, const double* x_dev, double* px_dev);
 

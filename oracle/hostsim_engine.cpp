@@ -150,6 +150,73 @@ struct HostSimEngine : dla::Engine {
     orc_synth_precnd(&n, &m, &fac, x, px);
     return 0;
   }
+  // the sample sparse operator on a row shard (dla_spmm_setup_csr_sharded): the halo rows of x travel through the reduction
+  // hook exactly as in the HIP engine -- every rank fills its own two slots of a zeroed buffer, the sum gathers
+  dla::ShardedEll ell;
+  int spmm_setup_csr_sharded(int n, long long row0, long long n_global, const long long* rowptr, const long long* colind,
+                             const double* values) override
+  {
+    int w = 0; long long need = 0;
+    std::string lerr;
+    const int bad = (values == nullptr) ? DLA_ERR_ARG : dla::sharded_ell_need(n, row0, n_global, rowptr, colind, &w, &need, lerr);
+    const int nr = nranks > 1 ? nranks : 1;
+    double mx[2] = {(double)need, bad ? 1.0 : 0.0};
+    int st = reduce(mx, 2, 1);
+    if (st) return st;
+    if (mx[1] != 0.0) { err = bad ? lerr : std::string("spmm_setup_csr_sharded: another rank rejected its shard"); return DLA_ERR_ARG; }
+    std::vector<double> lay((size_t)2 * nr, 0.0);
+    lay[2 * rank] = (double)row0; lay[2 * rank + 1] = (double)n;
+    st = reduce(lay.data(), 2 * nr, 0);
+    if (st) return st;
+    const long long halo = (long long)mx[0];
+    long long expect = 0;
+    for (int r = 0; r < nr; ++r) {
+      if ((long long)lay[2 * r] != expect) { err = "spmm_setup_csr_sharded: the shards are not contiguous in rank order"; return DLA_ERR_ARG; }
+      if (halo > (long long)lay[2 * r + 1]) { err = "spmm_setup_csr_sharded: a shard reaches beyond its neighbour (halo wider than a shard)"; return DLA_ERR_ARG; }
+      expect += (long long)lay[2 * r + 1];
+    }
+    if (expect != n_global) { err = "spmm_setup_csr_sharded: the shards do not cover n_global rows"; return DLA_ERR_ARG; }
+    if (halo > 4096) { err = "spmm_setup_csr_sharded: halo wider than 4096 rows (not a banded matrix)"; return DLA_ERR_ARG; }
+    dla::sharded_ell_build(n, row0, rowptr, colind, values, (int)halo, ell);
+    return 0;
+  }
+  int spmm_matvec(int n, int m, const double* x, double* ax) override
+  {
+    if (n != ell.n || ell.col.empty()) { err = "spmm_matvec: n differs from setup"; return DLA_ERR_ARG; }
+    const int nr = nranks > 1 ? nranks : 1, H = ell.halo;
+    std::vector<double> buf((size_t)nr * 2 * m * (H > 0 ? H : 1), 0.0);
+    if (H > 0 && nr > 1) {
+      for (int side = 0; side < 2; ++side)
+        for (int c = 0; c < m; ++c)
+          for (int h = 0; h < H; ++h)
+            buf[(((size_t)rank * 2 + side) * m + c) * H + h] = x[(size_t)c * n + (side == 0 ? h : n - H + h)];
+      int st = reduce(buf.data(), nr * 2 * m * H, 0);
+      if (st) return st;
+    }
+    const double* prev = buf.data() + (size_t)((rank > 0 ? (rank - 1) * 2 + 1 : 0) * m) * H;
+    const double* next = buf.data() + (size_t)((rank + 1 < nr ? (rank + 1) * 2 : 0) * m) * H;
+    for (int c = 0; c < m; ++c)
+      for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int q = 0; q < ell.w; ++q) {
+          const int idx = ell.col[(size_t)q * n + i];
+          const double v = idx < H ? prev[(size_t)c * H + idx] : (idx < H + n ? x[(size_t)c * n + idx - H] : next[(size_t)c * H + idx - H - n]);
+          s += ell.val[(size_t)q * n + i] * v;
+        }
+        ax[(size_t)c * n + i] = s;
+      }
+    return 0;
+  }
+  int spmm_precnd(int n, int m, double fac, const double* x, double* px) override
+  {
+    if (n != ell.n || ell.diag.empty()) { err = "spmm_precnd: n differs from setup"; return DLA_ERR_ARG; }
+    for (int c = 0; c < m; ++c)
+      for (int i = 0; i < n; ++i) {
+        const double den = ell.diag[i] + fac;
+        px[(size_t)c * n + i] = std::fabs(den) > 1.0e-5 ? x[(size_t)c * n + i] / den : x[(size_t)c * n + i];
+      }
+    return 0;
+  }
   // the sample operators of the generalised / linear-response drivers, y = d(i) x + W C W^T x (definitions: SynthKind in
   // hip_engine.hip -- restated here so that the host-memory engine can run those drivers on row shards)
   int synth_apply(int kind, int n, int m, const double* x, double* y) override

@@ -126,3 +126,64 @@ def test_ortho_vs_x_takes_the_qr_fallback_when_ortho_cd_gives_up(ctx, oracle, rn
     # (the device chain takes ONE factorisation step in front of the loop -- DESIGN.md, "pending factors" -- so ortho_cd gives up
     #  one projection later than in the reference and `ortho` sees another block: same span, column signs of its own)
     assert np.abs(got * sgn - want).max() < 2e3 * 1e10 * EPS    # Q of a block of condition 1e10
+
+
+def _rank_deficient_case(rng, n=3000):
+    """X = e_1 .. e_8; U = 8 columns of which only 6 have a direction outside span(X) -- and everything lives in 14 rows, so
+    the rounding noise of the dependent columns has nowhere to go either (the second block of a Davidson run with unit guesses
+    on a matrix of half-bandwidth 6 looks like this)."""
+    x = np.zeros((n, 8), order="F"); x[np.arange(8), np.arange(8)] = 1.0
+    b = np.zeros((n, 6)); b[8:14, :] = rng.standard_normal((6, 6))
+    u = np.asfortranarray(b @ rng.standard_normal((6, 8)) + x @ rng.standard_normal((8, 8)))
+    return x, u, b
+
+
+def _check_completed(v, b):
+    assert np.abs(v.T @ v - np.eye(16)).max() < 50 * EPS                      # a full orthonormal set, X included
+    q = v[:, 8:]
+    assert np.abs(b - q @ (q.T @ b)).max() < 1e-12 * np.abs(b).max()          # the six real directions are in it
+
+
+def test_ortho_vs_x_completes_a_rank_deficient_block_on_host_engine():
+    """The fallback must not normalise noise: a column without a direction of its own is replaced (as dorgqr does) and the
+    result is orthonormal.  Before r04 the call returned a block with duplicate directions and reported success."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hostsim
+    from diaglib_amd import capi
+    lib = hostsim.build()
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import hostsim
+from diaglib_amd import capi
+capi.load(hostsim.build())
+from test_ortho_qr import _rank_deficient_case, _check_completed
+ctx = capi.Context()
+x, u, b = _rank_deficient_case(np.random.default_rng(0))
+big = ctx.panel(np.asfortranarray(np.hstack([x, u])))
+ctx.ortho_vs_x(big.col(0, 8), big.col(8, 8))
+_check_completed(big.download(), b)
+p = ctx.panel(u.copy(order="F"))
+ctx.ortho_qr(p)
+q = p.download()
+assert np.abs(q.T @ q - np.eye(8)).max() < 50 * np.finfo(float).eps
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("contiguous", [True, False])
+def test_ortho_vs_x_completes_a_rank_deficient_block_gpu(ctx, rng, contiguous):
+    x, u, b = _rank_deficient_case(rng, n=40000)
+    if contiguous:
+        big = ctx.panel(np.asfortranarray(np.hstack([x, u])))
+        px, pu = big.col(0, 8), big.col(8, 8)
+        ctx.ortho_vs_x(px, pu)
+        v = big.download()
+    else:
+        px, pu = ctx.panel(x), ctx.panel(u)
+        ctx.ortho_vs_x(px, pu)
+        v = np.hstack([px.download(), pu.download()])
+    _check_completed(v, b)
