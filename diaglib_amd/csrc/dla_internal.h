@@ -64,6 +64,17 @@ struct BlockOps {
   virtual int b_ortho_ahead_status() { return 0; }
   // the top k GLOBAL rows of the n x k block u (row0 = global index of local row 0), k x k to the host
   virtual int top_rows(int n, int k, const double* u, long long row0, double* qt_host) = 0;
+  // replace column uj (n local rows, global index of row 0 = row0) by a generated one -- the Householder fallback's answer to
+  // a column that lies in the span of its predecessors (gram_schmidt2 in host_logic.cpp).  Default: host memory.
+  virtual int fresh_column(int n, double* uj, long long row0, unsigned long long seed)
+  {
+    for (int i = 0; i < n; ++i) {
+      unsigned long long s = (seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(row0 + i + 1));
+      s ^= s >> 30; s *= 0xBF58476D1CE4E5B9ULL; s ^= s >> 27; s *= 0x94D049BB133111EBULL; s ^= s >> 31;
+      uj[i] = (double)(s >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+    return 0;
+  }
   int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests
   std::string err;
 };
@@ -140,6 +151,7 @@ struct Engine : BlockOps {
   // index exceeds support_rows (when > 0) are set to zero
   virtual int random_fill(int n, int m, double* evec, long long row0, unsigned long long seed, double offset,
                           long long support_rows) = 0;
+  int fresh_column(int n, double* uj, long long row0, unsigned long long seed) override { return random_fill(n, 1, uj, row0, seed, -0.5, 0); }
 
   virtual int synth_setup(long long n_global, long long row0, int n_local, int rank_w, double sigma) = 0;
   virtual int synth_matvec(int n, int m, const double* x, double* ax) = 0;

@@ -581,7 +581,7 @@ int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
 //      M holds the columns of U in an orthonormal basis [e_1..e_k, Z] of span(U) + span(e_1..e_k); every Householder
 //      vector of U lies in that span, so the reflections of M are those of U and diag(R) has the same signs.
 // r (k x k, column-major): the triangular factor, U_in = Q r, accumulated from the projection coefficients
-static int gram_schmidt2(dla_ctx* c, dla::BlockOps* ops, int n, int k, double* u, double* r)
+static int gram_schmidt2(dla_ctx* c, dla::BlockOps* ops, long long row0, int n, int k, double* u, double* r)
 {
   std::fill(r, r + (size_t)k * k, 0.0);
   // column by column, each column projected against the finished ones TWICE before it is normalised ("twice is
@@ -616,9 +616,9 @@ static int gram_schmidt2(dla_ctx* c, dla::BlockOps* ops, int n, int k, double* u
         if (st) return opsfail(c, ops, st);
         break;
       }
-      if (attempt >= 3 || ops != static_cast<dla::BlockOps*>(c->eng)) return fail(c, DLA_ERR_ORTHO, "ortho: a column without a direction of its own");
-      st = c->eng->random_fill(n, 1, uj, c->row0, 0x51EDULL + 131ULL * (unsigned long long)j + (unsigned long long)attempt, -0.5, 0);
-      if (st) return engfail(c, st);
+      if (attempt >= 3) return fail(c, DLA_ERR_ORTHO, "ortho: a column without a direction of its own");
+      st = ops->fresh_column(n, uj, row0, 0x51EDULL + 131ULL * (unsigned long long)j + (unsigned long long)attempt);
+      if (st) return opsfail(c, ops, st);
       st = ops->gram(n, 1, uj, 1, uj, &g0, 1);
       if (st) return opsfail(c, ops, st);
     }
@@ -663,7 +663,7 @@ static int ortho_qr_impl(dla_ctx* c, dla::BlockOps* ops, long long row0, long lo
   if (n_rows_global < k) return fail(c, DLA_ERR_ARG, "ortho: more columns than rows");
   // 1. U = Q+ R+ on the device (Q+ replaces U)
   std::vector<double> rp((size_t)k * k);
-  int st = gram_schmidt2(c, ops, n, k, u, rp.data());
+  int st = gram_schmidt2(c, ops, row0, n, k, u, rp.data());
   if (st) return st;
   // 2. top k (global) rows of Q+ (the device engine gets them as E^T Q+ through the Gram door, so a row-sharded panel
   //    needs nothing new; host-size blocks are read directly)
@@ -886,7 +886,15 @@ int dla_check_guess(dla_ctx* c, int n, int m, double* evec)
     for (int j = 0; j < i; ++j) on += ov[(size_t)j + (size_t)i * m] * ov[(size_t)j + (size_t)i * m];
   }
   dn /= (double)m;
-  if (dn != 1.0 || on != 0.0) return dla_ortho_cd(c, n, m, evec, &growth, &ok);   // :3774-3779
+  if (dn != 1.0 || on != 0.0) {
+    st = dla_ortho_cd(c, n, m, evec, &growth, &ok);   // :3774-3779
+    if (st) return st;
+    // The reference ignores ortho_cd's `ok` here (:3779) and goes on with what a failed factorisation left behind: a guess with
+    // a repeated or a zero column then ends in duplicate eigenvectors and ok = .true. (tools/fuzz_degenerate_drivers.py).
+    // Deliberate difference: such a guess is completed with the Householder fallback, as ortho_vs_x does when ortho_cd gives
+    // up (:3534) -- the dependent columns are replaced by generated ones; a full-rank guess never gets here.
+    if (!ok) return dla_ortho_qr(c, n, m, evec);
+  }
   return DLA_OK;
 }
 

@@ -167,6 +167,14 @@ p = ctx.panel(u.copy(order="F"))
 ctx.ortho_qr(p)
 q = p.download()
 assert np.abs(q.T @ q - np.eye(8)).max() < 50 * np.finfo(float).eps
+# check_guess (reference diaglib.f90:3734-3786 ignores ortho_cd's `ok`): a guess with a repeated and a zero column is completed
+g = np.zeros((3000, 8), order="F"); g[np.arange(8), np.arange(8)] = 1.0
+g[:, 6] = g[:, 0]; g[:, 7] = 0.0
+p = ctx.panel(g)
+ctx.check_guess(p)
+q = p.download()
+assert np.abs(q.T @ q - np.eye(8)).max() < 50 * np.finfo(float).eps
+assert np.abs(np.abs(q[:6, :6]) - np.eye(6)).max() < 1e-12
 print("ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
