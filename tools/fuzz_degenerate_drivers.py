@@ -20,7 +20,7 @@ if first < 0:
     # parent: the Fortran drivers end the process on a catastrophic orthogonalisation failure (`error stop`, as the reference
     # does): run the cases in children and go on behind a case that stopped
     import subprocess
-    nxt, bad, notok, stopped = 0, 0, 0, 0
+    nxt, bad, notok, stopped, ref_ok = 0, 0, 0, 0, 0
     while nxt < cases:
         p = subprocess.run([sys.executable, os.path.abspath(__file__), str(cases), str(seed), str(nxt)], capture_output=True, text=True)
         done = nxt
@@ -33,16 +33,33 @@ if first < 0:
                 notok += 1
         if p.returncode != 0 and done < cases:
             stopped += 1
-            print(f"case {done} stopped the process:", (p.stdout.splitlines() + p.stderr.splitlines())[-3:], flush=True)
+            # does the unmodified reference (oracle/_ref, when it has been built) get through this case?
+            verdict = "reference not available"
+            if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdiaglib_ref.so")) or os.environ.get("FUZZ_REF"):
+                env = dict(os.environ, FUZZ_IMPL="reference", FUZZ_ONLY="1")
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), str(cases), str(seed), str(done)], capture_output=True, text=True, env=env)
+                line = [ln for ln in pr.stdout.splitlines() if ln.startswith("reference:")]      # (its `stop` ends with exit code 0)
+                verdict = "THE REFERENCE GETS THROUGH: " + line[0] if line else "the reference stops too: " + " ".join(pr.stderr.split()[:8])
+                if line:
+                    ref_ok += 1
+            print(f"case {done} stopped the process ({verdict}):", (p.stdout.splitlines() + p.stderr.splitlines())[-3:-2], flush=True)
             done += 1
         nxt = done
-    print(f"{cases} cases x 2 solvers, {bad} failures, {notok} not converged / refused, {stopped} stopped with an error", flush=True)
+    print(f"{cases} cases x 2 solvers, {bad} failures, {notok} not converged / refused, {stopped} stopped with an error "
+          f"({ref_ok} of them where the reference gets through)", flush=True)
     sys.exit(1 if bad else 0)
-if os.environ.get("FUZZ_HOSTSIM"):           # the product's host logic on the host-memory test engine (no GPU needed)
+REF = None
+if os.environ.get("FUZZ_IMPL") == "reference":
+    import ctypes as C
+    from oracle.pyoracle import Reference
+    REF = Reference()
+    MV_T = C.CFUNCTYPE(None, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double))
+    PC_T = C.CFUNCTYPE(None, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+elif os.environ.get("FUZZ_HOSTSIM"):         # the product's host logic on the host-memory test engine (no GPU needed)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import hostsim
     capi.load(hostsim.build())
-ctx = capi.Context()
+ctx = capi.Context() if REF is None else None
 bad = 0
 notok = 0
 kinds = ["identity", "zero", "pairs", "band_unit", "dup_guess", "zero_guess_col", "rank_one_plus_shift"]
@@ -62,7 +79,8 @@ for it in range(cases):
         a = np.zeros((n, n))
     elif kind == "pairs":
         a = np.diag(np.repeat(np.arange(1, n // 2 + 2, dtype=np.float64), 2)[:n])
-    elif kind == "band_unit":
+    elif kind in ("band_unit", "dup_guess", "zero_guess_col"):
+        # (a purely diagonal operator with its exact diagonal preconditioner gives Davidson no new direction at all)
         hb = int(rng.integers(1, 5))
         for q in range(1, hb + 1):
             v = 0.3 / q * np.cos(np.arange(n - q) + q)
@@ -78,10 +96,23 @@ for it in range(cases):
         g = np.asfortranarray(rng.standard_normal((n, m)))
     dg = np.diag(a).copy()
     mv = lambda x: a @ x
-    def pc(x, fac):
+    def pc(fac, x):
         den = dg[:, None] + fac
         return np.where(np.abs(den) > 1e-5, x / np.where(den == 0.0, 1.0, den), x)
     want = np.linalg.eigvalsh(a)
+    if REF is not None:
+        def mvf(pn, pm, px, pax):
+            nn, mm = pn[0], pm[0]
+            np.ctypeslib.as_array(pax, (mm, nn)).T[:, :] = mv(np.ctypeslib.as_array(px, (mm, nn)).T)
+        def pcf(pn, pm, pf, px, ppx):
+            nn, mm = pn[0], pm[0]
+            np.ctypeslib.as_array(ppx, (mm, nn)).T[:, :] = pc(pf[0], np.ctypeslib.as_array(px, (mm, nn)).T)
+        cmv, cpc = MV_T(mvf), PC_T(pcf)
+        pmv, ppc = C.cast(cmv, C.c_void_p).value, C.cast(cpc, C.c_void_p).value
+        e1, _, ok1 = REF.davidson(n, t, m, 300, 1e-9, 10, 0.0, pmv, ppc, g.copy(order="F"))
+        e2, _, ok2 = REF.lobpcg(n, t, m, 300, 1e-9, 0.0, pmv, ppc, g.copy(order="F"))
+        print("reference: davidson ok", ok1, "err", float(np.abs(np.sort(e1[:t]) - want[:t]).max()), "lobpcg ok", ok2, "err", float(np.abs(np.sort(e2[:t]) - want[:t]).max()), flush=True)
+        sys.exit(0)
     for solver in ("davidson", "lobpcg"):
         try:
             if solver == "davidson":
