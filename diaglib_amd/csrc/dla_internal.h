@@ -211,6 +211,14 @@ struct Engine : BlockOps {
   virtual int p2p_detach() { return DLA_OK; }
   virtual int set_p2p_timeout(int /*ms*/) { return DLA_OK; }      // DLA_OPT_P2P_TIMEOUT_MS
   int nranks = 1, rank = 0;
+  // Every rank's shard has an even number of rows (agreed when the shards are announced, dla_set_shard).  Whatever decides which
+  // SWEEPS and REDUCTIONS a call consists of must not look at the local row count alone: a rank with an odd shard would take
+  // another schedule than its peers, and the exchanges would no longer pair up (found by tools/fuzz_multirank.py: odd n on three
+  // and four ranks).  even_rows(n) is the test to use.
+  bool peers_even = true;
+  bool even_rows(long long n) const { return n % 2 == 0 && peers_even; }
+  // all-reduce of a few HOST values over the small-product transport (setup-time agreement between the ranks); collective
+  virtual int allreduce_host(double* /*v*/, int /*count*/, int /*op: 0 sum, 1 max*/) { return nranks > 1 ? DLA_ERR_COMM : DLA_OK; }
   bool local_only = false;   // true while working on data that is replicated on every rank (no reductions)
   dla_allreduce_fn hook = nullptr;
   void* hook_user = nullptr;

@@ -3756,7 +3756,7 @@ struct HipEngine : dla::Engine {
     if (!vsx && fused_lds(k, k) > lds_limit) return DLA_OK;
     // k x k steps on the matrix cores (ortho_tail16) for one-tile blocks; with them, on the 16-byte path and while X^T U fits one
     // pass of the storing sweep (12 tiles), the pending-factor schedule (fold = 1); otherwise the sweep-per-update one (fold = 2)
-    const bool vec2 = (n % 2 == 0) && (((uintptr_t)u | (uintptr_t)x | (uintptr_t)bx) % 16 == 0);
+    const bool vec2 = even_rows(n) && (((uintptr_t)u | (uintptr_t)x | (uintptr_t)bx) % 16 == 0);
     int fold = (k <= 16 && tune[6] != 5) ? 2 : 0;
     if (fold && vsx && vec2 && m <= 192 && tune[6] != 6 && lds_limit > (size_t)128 * 1024) fold = 1;
     // wider blocks (LDS-loop tail): X^T U and U^T U in ONE sweep when [X | U] fits one pass of the Gram kernel (the plain
@@ -4101,7 +4101,7 @@ struct HipEngine : dla::Engine {
   {
     const int tx = (l + 15) / 16, tu = (k + 15) / 16;
     // tile shape of one pass: KT U-tiles x TLW X-tiles, at most 12 accumulators
-    const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)u) % 16 == 0);
+    const bool vec2 = even_rows(n) && (((uintptr_t)x | (uintptr_t)u) % 16 == 0);
     // (even n: at most 3 U tiles per pass, so that the LDS-staged kernel serves every pass -- the direct-load kernel a
     // fourth tile would need measured 2.6 TB/s on the 111-column S^T A S of LOBPCG at n_max = 37)
     int kt = std::min(tu, (vec2 && l > 8 && tune[5] != 2) ? 3 : 4);
@@ -4473,7 +4473,7 @@ struct HipEngine : dla::Engine {
       int stc = upload_packed(c_host, ldc, l0, l, k, kt, l4);
       if (stc) return stc;
     }
-    const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)z) % 16 == 0);
+    const bool vec2 = even_rows(n) && (((uintptr_t)x | (uintptr_t)z) % 16 == 0);
     int qt = (tune[2] == 1 || tune[2] == 4) && !fuse ? 0 : quarter_tiles(k, vec2);
     // (the plain two-tile update is the one sweep that measured slower with quarter tiles, -9 % at L = 63, k = 21:
     // tools/quarter_tile_ab.py)
@@ -4619,7 +4619,7 @@ struct HipEngine : dla::Engine {
     if (k2 <= 0) return ritz_residual(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, out);
     const uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy | (uintptr_t)p2 | (uintptr_t)ap2;
     const int ktot = (m + k2 + 15) / 16, l4 = ((l + 3) / 4) * 4;
-    const bool one_pass = (n % 2 == 0) && (al % 16 == 0) && m <= 48 && ktot <= 5 && tune[0] != 5 &&
+    const bool one_pass = even_rows(n) && (al % 16 == 0) && m <= 48 && ktot <= 5 && tune[0] != 5 &&
                           sizeof(double) * (size_t)l4 * 16 * ktot <= ritz_dyn_limit(ktot);
     if (!one_pass) return Engine::ritz_residual_p(n, l, m, v, av, y_host, ldy, eig, n_res, skip, evec, r, avy, out, k2, c2_host, ldc2, p2, ap2);
     // [Y | C2] as one coefficient block
@@ -4652,7 +4652,7 @@ struct HipEngine : dla::Engine {
     const int kt = (m + k2 + 15) / 16;      // column tiles of [Y | C2]
     const int l4 = ((l + 3) / 4) * 4;
     uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)evec | (uintptr_t)r | (uintptr_t)avy | (uintptr_t)p2 | (uintptr_t)ap2;   // (null pointers are aligned)
-    const bool vec2 = (n % 2 == 0) && (al % 16 == 0);
+    const bool vec2 = even_rows(n) && (al % 16 == 0);
     const int qt = (tune[0] == 1 || tune[0] == 4) ? 0 : quarter_tiles(m + k2, vec2);
     // LDS copy of Y (a quarter-tile kernel keeps 8 columns of the last tile)
     const size_t lds_c = sizeof(double) * (size_t)l4 * (qt > 0 ? 16 * (kt - 1) + 8 : 16 * kt);
@@ -4798,7 +4798,7 @@ struct HipEngine : dla::Engine {
       a.theta[j] = eig[j]; a.active[j] = 1; ++nact;
     }
     const uintptr_t al = (uintptr_t)v | (uintptr_t)av | (uintptr_t)e | (uintptr_t)r;
-    const bool vec2 = (n % 2 == 0) && (al % 16 == 0);
+    const bool vec2 = even_rows(n) && (al % 16 == 0);
     const int rg = vec2 ? 32 : 16;
     const long long ntiles = ((long long)n + rg - 1) / rg;
     const size_t lds = std::max(lds_c, sizeof(double) * 4 * 16 * kt * 2);
@@ -4956,6 +4956,14 @@ struct HipEngine : dla::Engine {
   double* d_halo = nullptr; size_t halo_doubles = 0;
   std::vector<double> h_halo;        // host mirror for the hook transport
   // all-reduce of a few host values through the engine's small-product transport (setup-time agreement between the ranks)
+  int allreduce_host(double* v, int count, int op) override
+  {
+    std::vector<double> t(v, v + count);
+    const int stc = host_allreduce(t, op);
+    if (stc) return stc;
+    std::memcpy(v, t.data(), sizeof(double) * (size_t)count);
+    return DLA_OK;
+  }
   int host_allreduce(std::vector<double>& v, int op)
   {
     if (local_only || (nranks <= 1 && !comm && !p2p.on)) return DLA_OK;
@@ -5134,7 +5142,7 @@ struct HipEngine : dla::Engine {
   {
     if (n != syn_n) { err = "synth_precnd: n differs from setup"; return DLA_ERR_ARG; }
     Scope s(this, DLA_OP_PRECND, 8.0 * n * (2.0 * m + 1.0), (double)n * m);
-    const bool vec2 = (n % 2 == 0) && (((uintptr_t)x | (uintptr_t)px) % 16 == 0);
+    const bool vec2 = even_rows(n) && (((uintptr_t)x | (uintptr_t)px) % 16 == 0);
     const size_t nv = (size_t)n / (vec2 ? 2 : 1);
     const int blocks = (int)std::max((size_t)1, std::min((size_t)ncu * 8, (nv + 255) / 256));
     if (vec2) DLA_LAUNCH(synth_precnd_kernel<2>, dim3(blocks), dim3(256), 0, st, n, m, fac, d_diag, x, px);

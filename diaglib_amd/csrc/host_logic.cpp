@@ -244,15 +244,19 @@ int dla_get_kernel_stats(dla_ctx* c, dla_kernel_stat* out, int cap)
 // ------------------------------------------------------------------ multi-GPU
 int dla_comm_unique_id(char id[128]) { return dla::engine_unique_id(id); }
 
+static int agree_on_shards(dla_ctx* c);
+
 int dla_comm_init(dla_ctx* c, int nranks, int rank, const char id[128])
 {
   if (!c) return DLA_ERR_ARG;
-  return engfail(c, c->eng->comm_init(nranks, rank, id));
+  const int st = engfail(c, c->eng->comm_init(nranks, rank, id));
+  return st ? st : agree_on_shards(c);
 }
 
 int dla_comm_finalize(dla_ctx* c)
 {
   if (!c) return DLA_ERR_ARG;
+  c->eng->peers_even = true;
   return engfail(c, c->eng->comm_finalize());
 }
 
@@ -266,12 +270,14 @@ int dla_p2p_export(dla_ctx* c, int nranks, char handles[128])
 int dla_p2p_attach(dla_ctx* c, int nranks, int rank, const char* all_handles)
 {
   if (!c || !all_handles) return DLA_ERR_ARG;
-  return engfail(c, c->eng->p2p_attach(nranks, rank, all_handles));
+  const int st = engfail(c, c->eng->p2p_attach(nranks, rank, all_handles));
+  return st ? st : agree_on_shards(c);
 }
 
 int dla_p2p_detach(dla_ctx* c)
 {
   if (!c) return DLA_ERR_ARG;
+  c->eng->peers_even = true;
   return engfail(c, c->eng->p2p_detach());
 }
 
@@ -290,6 +296,27 @@ int dla_set_allreduce_hook(dla_ctx* c, dla_allreduce_fn fn, void* user, int nran
   c->eng->hook_user = user;
   c->eng->nranks = nranks;
   c->eng->rank = rank;
+  return fn ? agree_on_shards(c) : DLA_OK;
+}
+
+// The ranks agree on what every schedule decision may depend on (dla_internal.h: Engine::peers_even): the shard heights, gathered
+// through the small-product transport.  Runs when both the shard and the transport are known, whichever comes last; collective.
+static int agree_on_shards(dla_ctx* c)
+{
+  dla::Engine* e = c->eng;
+  e->peers_even = true;
+  if (e->nranks <= 1 || c->n_global <= 0) return DLA_OK;
+  std::vector<double> r0((size_t)e->nranks, 0.0);
+  r0[e->rank] = (double)c->row0;
+  const int st = e->allreduce_host(r0.data(), e->nranks, 0);
+  if (st) return engfail(c, st);
+  bool even = true;
+  for (int r = 0; r < e->nranks; ++r) {
+    const long long lo = (long long)r0[r], hi = r + 1 < e->nranks ? (long long)r0[r + 1] : c->n_global;
+    if (hi < lo) return fail(c, DLA_ERR_ARG, "dla_set_shard: the shards are not contiguous in rank order");
+    if ((hi - lo) % 2 != 0) even = false;
+  }
+  e->peers_even = even;
   return DLA_OK;
 }
 
@@ -298,7 +325,7 @@ int dla_set_shard(dla_ctx* c, long long n_global, long long row0)
   if (!c) return DLA_ERR_ARG;
   c->n_global = n_global;
   c->row0 = row0;
-  return DLA_OK;
+  return agree_on_shards(c);
 }
 
 // ------------------------------------------------------------------ memory

@@ -167,7 +167,11 @@ int  dla_p2p_detach(dla_ctx* ctx);
  * (e.g. MPI or torch.distributed/gloo).  Used when no RCCL communicator is attached. */
 typedef void (*dla_allreduce_fn)(void* user, double* buf, int count, int op);
 int  dla_set_allreduce_hook(dla_ctx* ctx, dla_allreduce_fn fn, void* user, int nranks, int rank);
-int  dla_set_shard(dla_ctx* ctx, long long n_global, long long row0);        /* global rows of this rank */
+/* global rows of this rank: the shards are contiguous in rank order, rank r holds rows row0(r) .. row0(r + 1) - 1.  COLLECTIVE
+ * once a transport is attached (and attaching a transport after the shard has been announced is collective in the same way):
+ * the ranks exchange their row0 through the transport and agree on what schedule decisions may depend on -- a rank whose shard
+ * has an odd number of rows would otherwise pick other sweeps than its peers and the exchanges would not pair up. */
+int  dla_set_shard(dla_ctx* ctx, long long n_global, long long row0);
 
 /* ---------------------------------------------------------------- device memory
  * replaces allocate/zero/dcopy of the panels: diaglib.f90:1607-1638,1648,1798-1805, 258-287 */

@@ -45,6 +45,8 @@ struct HostSimEngine : dla::Engine {
     return 0;
   }
 
+  int allreduce_host(double* v, int count, int op) override { return reduce(v, count, op); }
+
   int gram(int n, int l, const double* x, int k, const double* u, double* c, int ldc) override
   {
     std::vector<double> t((size_t)l * k);

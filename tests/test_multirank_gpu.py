@@ -151,6 +151,28 @@ def test_two_ranks_wide_blocks_peer_to_peer(tmp_path, solver):
     assert np.abs(v2[:, :t].T @ v2[:, :t] - np.eye(t)).max() < 1e-12
 
 
+@pytest.mark.parametrize("world,solver", [(3, "davidson"), (4, "lobpcg"), (4, "gen_david")])
+def test_odd_row_count_on_three_and_four_ranks(tmp_path, world, solver):
+    """An odd n leaves ONE rank with an odd shard: that rank cannot use the 16-byte sweeps, and before r04 it also chose another
+    orthogonalisation schedule than its peers -- the exchanges no longer paired up (three ranks waited for a peer, the fourth
+    factorised garbage; found by tools/fuzz_multirank.py).  The ranks now agree on the schedule when the shards are announced
+    (dla_set_shard): every rank takes the same sweeps, identical bits, the single-rank result."""
+    spec = dict(n=95_775, n_targ=4, n_max=9, tol=1e-9, solver=solver, guess="unit", transport="p2p")
+    d1 = tmp_path / "w1"; d1.mkdir()
+    dn = tmp_path / "wn"; dn.mkdir()
+    one = _run_world(d1, spec, 1)[0]
+    many = _run_world(dn, spec, world)
+    t = spec["n_targ"]
+    assert bool(one["ok"]) and all(bool(r["ok"]) for r in many)
+    assert all(np.array_equal(many[0]["eig"], r["eig"]) and int(r["iters"]) == int(many[0]["iters"]) for r in many)
+    assert np.allclose(many[0]["eig"][:t], one["eig"][:t], rtol=1e-11, atol=0)
+    assert abs(int(many[0]["iters"]) - int(one["iters"])) <= max(1, int(one["iters"]) // 5)
+    v = np.vstack([r["vec"] for r in many]); v1 = one["vec"]
+    assert v.shape == v1.shape and many[-1]["vec"].shape[0] % 2 == 1          # (the last shard is the odd one)
+    sgn = np.sign((v1 * v).sum(0))
+    assert np.abs(v * sgn - v1)[:, :t].max() < 1e-6
+
+
 def test_two_gpus_rccl_equal_one_rank(tmp_path):
     """the RCCL data path with more than one rank -- one rank per GPU, ncclAllReduce on the engines' streams,
     device-driven chains with the collective between reduction and tail.  Needs two visible GPUs (skipped on the
