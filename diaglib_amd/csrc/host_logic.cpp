@@ -314,6 +314,8 @@ static int agree_on_shards(dla_ctx* c)
   for (int r = 0; r < e->nranks; ++r) {
     const long long lo = (long long)r0[r], hi = r + 1 < e->nranks ? (long long)r0[r + 1] : c->n_global;
     if (hi < lo) return fail(c, DLA_ERR_ARG, "dla_set_shard: the shards are not contiguous in rank order");
+    // (every rank sees the same layout and refuses it alike: no rank is left waiting for a peer that has given up)
+    if (hi == lo) return fail(c, DLA_ERR_ARG, "dla_set_shard: a rank holds no rows (fewer rows than the layout needs for this many ranks)");
     if ((hi - lo) % 2 != 0) even = false;
   }
   e->peers_even = even;

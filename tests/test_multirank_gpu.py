@@ -173,6 +173,24 @@ def test_odd_row_count_on_three_and_four_ranks(tmp_path, world, solver):
     assert np.abs(v * sgn - v1)[:, :t].max() < 1e-6
 
 
+def test_empty_shard_is_refused_on_every_rank(tmp_path):
+    """300 rows over four ranks in 64-row multiples leave the last rank without rows: every rank learns the layout when the
+    shards are announced and refuses it at once (before r04 the empty rank failed in its first launch and the others waited
+    for the peer-to-peer timeout)."""
+    import socket
+    spec = dict(n=300, n_targ=2, n_max=4, tol=1e-8, solver="davidson", guess="unit", transport="p2p")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, spec=json.dumps(spec), out=str(tmp_path)))
+    procs = []
+    for r in range(4):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode != 0 and "a rank holds no rows" in e, e[-1500:]
+
+
 def test_two_gpus_rccl_equal_one_rank(tmp_path):
     """the RCCL data path with more than one rank -- one rank per GPU, ncclAllReduce on the engines' streams,
     device-driven chains with the collective between reduction and tail.  Needs two visible GPUs (skipped on the
