@@ -173,6 +173,14 @@ def test_odd_row_count_on_three_and_four_ranks(tmp_path, world, solver):
     assert np.abs(v * sgn - v1)[:, :t].max() < 1e-6
 
 
+def test_linear_response_drivers_on_row_shards():
+    """caslr_eff_driver / caslr_driver on 2, 3 (odd n) and 4 ranks sharing the GPU, peer-to-peer mailboxes, built-in LR operators:
+    identical bits on every rank, the single-rank eigenvalues and iteration count (tools/multirank_lr_probe.py)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "multirank_lr_probe.py")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0 and "linear-response drivers on row shards: ok" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
+
+
 def test_empty_shard_is_refused_on_every_rank(tmp_path):
     """300 rows over four ranks in 64-row multiples leave the last rank without rows: every rank learns the layout when the
     shards are announced and refuses it at once (before r04 the empty rank failed in its first launch and the others waited
