@@ -32,7 +32,13 @@ for it in range(cases):
     rng = np.random.default_rng([seed, it])
     t = int(rng.choice([rng.integers(1, 9), rng.integers(9, 25)]))
     m = int(min(t + rng.integers(0, 16), 2 * t + 3, 40))
-    n = int(rng.integers(max(300, 30 * m), 1800)); n += int(rng.integers(0, 2))
+    if os.environ.get("FUZZ_WIDE"):              # blocks beyond the 48 columns the fused sweeps and the device chains take
+        t = int(rng.integers(30, 70)); m = int(min(t + rng.integers(0, 20), 90))
+    n = int(rng.integers(max(300, 30 * m), max(1800, 32 * m))); n += int(rng.integers(0, 2))
+    if rng.random() < 0.3:
+        ctx.set_option(capi.OPT_STAGE_CHUNKS, int(rng.integers(2, 5)))      # host-mode callbacks in column chunks
+    else:
+        ctx.set_option(capi.OPT_STAGE_CHUNKS, 0)
     solver = str(rng.choice(["davidson", "davidson", "lobpcg", "gen_david", "lobpcg_gen"]))
     max_dav = int(rng.choice([2, 3, 5, 10, 20]))
     tol = float(rng.choice([1e-6, 1e-9, 1e-11]))
@@ -95,6 +101,8 @@ for it in range(cases):
     # unit guesses: the history is robust to rounding; random guesses and tolerances near the rounding floor of max|r| (1e-11 on
     # these spectra: DESIGN 11.7) end a few sweeps earlier or later with the last bits of the small eigensolver
     slack = 1 if (guess == "unit" and tol >= 1e-10) else max(3, tr.iters // 8)
+    if "lobpcg" in solver and m > 24:            # (wide LOBPCG blocks: the locking order of 40 .. 60 roots moves the count by 10 %)
+        slack = max(3, tr.iters // 6)
     lim = max(1e-9, 50.0 * tol * tol)          # eigenvalue error ~ residual^2; both sides stop anywhere below tol
     good = ok == oko == okr and (not ok or (res["d_oracle"] < lim and res["d_ref"] < lim)) and abs(info["iters"] - tr.iters) <= slack
     if not good:
