@@ -2918,7 +2918,7 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipHostMalloc((void**)&h_small, small_bytes, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&h_small_dev, h_small, 0));
     HIPCHK(hipMalloc((void**)&d_ticket, sizeof(unsigned) * 4100));     // [4096] per output tile + 1 global
-    HIPCHK(hipMemset(d_ticket, 0, sizeof(unsigned) * 4100));
+    HIPCHK(hipMemsetAsync(d_ticket, 0, sizeof(unsigned) * 4100, st));       // (on the engine's stream: see d_halo)
     return DLA_OK;
   }
 
@@ -3559,7 +3559,7 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipMalloc((void**)&d_wfull, sizeof(double) * 48 * 48));
     HIPCHK(hipMalloc((void**)&d_cpk2, (size_t)80 * 1024));
     HIPCHK(hipMalloc((void**)&d_wst, sizeof(double) * 768));
-    if (chain_debug) { HIPCHK(hipMalloc((void**)&d_dbg, sizeof(unsigned long long) * 48 * 16)); HIPCHK(hipMemset(d_dbg, 0, sizeof(unsigned long long) * 48 * 16)); }
+    if (chain_debug) { HIPCHK(hipMalloc((void**)&d_dbg, sizeof(unsigned long long) * 48 * 16)); HIPCHK(hipMemsetAsync(d_dbg, 0, sizeof(unsigned long long) * 48 * 16, st)); }
     HIPCHK(hipMalloc((void**)&d_xug, sizeof(double) * XUG_DOUBLES));
     HIPCHK(hipMalloc((void**)&d_red_small, sizeof(double) * RED_DOUBLES));
     HIPCHK(hipMalloc((void**)&d_red_xug, sizeof(double) * RED_DOUBLES));
@@ -3993,7 +3993,7 @@ struct HipEngine : dla::Engine {
     bind();
     if (!d_bgo) {
       HIPCHK(hipMalloc((void**)&d_bgo, sizeof(int)));
-      HIPCHK(hipMemset(d_bgo, 0, sizeof(int)));
+      HIPCHK(hipMemsetAsync(d_bgo, 0, sizeof(int), st));
       HIPCHK(hipHostMalloc((void**)&h_bstat, sizeof(int), hipHostMallocMapped));
       HIPCHK(hipHostGetDevicePointer((void**)&h_bstat_dev, h_bstat, 0));
       HIPCHK(hipMalloc((void**)&d_wpk_b, sizeof(double) * 3 * 48 * 16));
@@ -5033,7 +5033,9 @@ struct HipEngine : dla::Engine {
       if (d_halo) HIPCHK(hipFree(d_halo));
       d_halo = nullptr;
       HIPCHK(hipMalloc((void**)&d_halo, sizeof(double) * need));
-      HIPCHK(hipMemset(d_halo, 0, sizeof(double) * need));
+      // (on the engine's stream: hipMemset runs on the null stream, which this non-blocking stream does not wait for -- the
+      //  zeros would land in the middle of the first exchange)
+      HIPCHK(hipMemsetAsync(d_halo, 0, sizeof(double) * need, st));
       halo_doubles = need;
       h_halo.assign(need, 0.0);
     }
