@@ -75,6 +75,9 @@ struct BlockOps {
     }
     return 0;
   }
+  // set by a caller that B-orthonormalises the block by Cholesky-QR right behind ortho_vs_x (dla_expand_project_metric): a device
+  // chain may then end without applying its last pending triangular factor (OrthoTailArgs::drop_final in hip_engine.hip)
+  bool drop_final = false;
   int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests
   std::string err;
 };

@@ -1706,6 +1706,10 @@ struct OrthoTailArgs {
   unsigned long long* dbg;   // $DIAGLIB_AMD_CHAIN_DEBUG: time stamps of the step (100 MHz ticks), 16 per executed sweep
   int xw_ok;           // blocks of 17..48 columns (ortho_tail): the storing sweep OP_XW exists for this shape -- a triangular update
                        // inside the loop is written together with X^T U and U^T U of what it stores (one sweep instead of two)
+  int drop_final;      // 1: the chain ends where it would ask for OP_FINAL -- the pending upper-triangular factor is NOT applied.
+                       // For callers that B-orthonormalise the block by Cholesky-QR right behind the chain (dla_expand_project_metric:
+                       // b_ortho, reference diaglib.f90:3094-3183): the Q factor of U W and of U is the same for any upper-triangular W
+                       // with a positive diagonal, so the sweep U <- U W (16 n k bytes) buys nothing there
 };
 #define TSTAMP(a, nops, i) do { if ((a).dbg != nullptr && (nops) < 48) (a).dbg[(nops) * 16 + (i)] = wall_clock64(); } while (0)
 
@@ -1962,6 +1966,7 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
           }
         } else {
           if (can_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;
+          else if (a.drop_final) t.status = OST_DONE;
           else t.phase = OP_FINAL;
         }
       }
@@ -2391,6 +2396,7 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
             }
           } else {
             if (can_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;
+            else if (a.drop_final) t.status = OST_DONE;
             else t.phase = OP_FINAL;
           }
         }
@@ -3595,6 +3601,7 @@ struct HipEngine : dla::Engine {
     pending_tail = OrthoTailArgs{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, op, m, k, m > 0 ? 1 : 0, ortho_maxit, publish ? 1 : 0,
                                  fold, tune[6] == 7 ? 0 : 1, d_xug, d_wst, d_dbg, chain_xw ? 1 : 0};
     if ((fold == 1 && op == OP_GRAMX) || op == OP_XW) pending_tail.gsrc = d_xug;
+    pending_tail.drop_final = (drop_final && m > 0) ? 1 : 0;
     fuse_tail = p2p.on ? tune[6] != 4 : (nranks <= 1 && !comm);     // (knob 6 = 4: the exchange as a launch of its own)
     tail_fused = false;
     pred_phase = &d_ost->phase; pred_want = (op == OP_GRAMX) ? (int)OP_GRAM_UU : op;   // the first sweep answers the start phase
@@ -3814,10 +3821,12 @@ struct HipEngine : dla::Engine {
     h_ost->nops = 0;
 
     // the schedule depends on how much of the new block already lies in span(X): remembered per basis width
-    const long long key = (long long)k * 1000000 + m + fold * 500000000000LL + (wide_gramx ? 250000000000LL : 0LL) + (wide_xw ? 125000000000LL : 0LL);
+    const bool dropf = drop_final && vsx;
+    const long long key = (long long)k * 1000000 + m + fold * 500000000000LL + (wide_gramx ? 250000000000LL : 0LL) + (wide_xw ? 125000000000LL : 0LL) +
+                          (dropf ? 62500000000LL : 0LL);
     std::vector<int>& hist = ortho_history[key];
     std::vector<int> plan = hist;
-    const long long kind_key = -(long long)(64 * k + (vsx ? 1 : 0) + 2 * fold + (wide_gramx ? 8 : 0) + (wide_xw ? 16 : 0)) - 1;
+    const long long kind_key = -(long long)(64 * k + (vsx ? 1 : 0) + 2 * fold + (wide_gramx ? 8 : 0) + (wide_xw ? 16 : 0) + (dropf ? 32 : 0)) - 1;
     std::vector<int>& last_k = ortho_history[kind_key];   // most recent call of this kind and width
     if (plan.empty()) plan = last_k;
     if (plan.empty()) {
@@ -3828,6 +3837,10 @@ struct HipEngine : dla::Engine {
       else if (vsx) plan = {OP_GRAM_UU, OP_TRMMG, OP_XU, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
       else plan = {OP_GRAM_UU, OP_TRMMG, OP_FINAL};
     }
+    // every plan ends with OP_FINAL: its tail is a launch of its own that always runs and reports where the machine stands (a
+    // fused tail is skipped together with a sweep whose turn it is not).  With drop_final the machine never asks for the sweep
+    // itself, and the executed list a plan is remembered from does not contain it
+    if (plan.empty() || plan.back() != OP_FINAL) plan.push_back(OP_FINAL);
     run.n = n; run.m = m; run.k = k; run.fold = fold; run.vsx = vsx; run.x = x; run.bx = bx; run.u = u;
     run.key = key;
     run.key_last = kind_key;

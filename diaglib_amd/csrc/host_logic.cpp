@@ -1216,6 +1216,10 @@ int dla_expand_project_metric(dla_ctx* c, int mode, int n, int m, int k, double*
   const int order = builtin ? 2 : c->callback_order;
   const bool ahead = (c->run_ahead == 2 || (c->run_ahead == 1 && builtin)) && c->callbacks_on_device && order != 1;
   int b_handled = 0;
+  // b_ortho follows b_ortho_vs_x at once (reference :2170 / :2185, :523-529): its Cholesky-QR gives the same block whether the
+  // chain's last pending factor -- upper triangular, positive diagonal -- has been applied or not, so the chain may end without
+  // the sweep U <- U W (the host-driven loop has nothing pending and is not affected)
+  struct DropFinal { dla::Engine* e; explicit DropFinal(dla::Engine* e_) : e(e_) { e->drop_final = true; } ~DropFinal() { e->drop_final = false; } } drop_guard(c->eng);
   if (ahead && m > 0) {
     dla::OrthoReport rep;
     int st = c->eng->ortho_chain_begin(n, m, k, basis, bbasis, u, &rep);
