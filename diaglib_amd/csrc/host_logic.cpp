@@ -1201,6 +1201,7 @@ static int metric_tail_steps(dla_ctx* c, int mode, int n, int m, int k, double* 
   *b_handled = 0;
   if (ahead) { st = c->eng->b_ortho_ahead(n, k, u, bu, behind_chain, b_handled); if (st) return engfail(c, st); }
   if (!*b_handled) { st = dla_b_ortho(c, n, k, u, bu); if (st) return st; }
+  if (mode == 2) return DLA_OK;            // (no operator, no projection: the linear-response expansion, see below)
   return expand_apply_project(c, mode, n, m, k, basis, abasis, op, shift, h, ldh);
 }
 
@@ -1208,11 +1209,15 @@ int dla_expand_project_metric(dla_ctx* c, int mode, int n, int m, int k, double*
                               dla_matvec_fn metric, double shift, double* h, int ldh)
 {
   DLA_T("dla_expand_project_metric");
-  if (!c || !basis || !bbasis || !abasis || !h || !op || !metric || (mode != 0 && mode != 1) || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
+  // mode 2: b_ortho_vs_x -> metric -> b_ortho only (abasis, op, h unused) -- the expansion of caslr_eff_driver, whose blocks are
+  // made orthonormal in the metric (A+B) resp. (A-B) right after they have been orthogonalised against the basis (reference
+  // diaglib.f90:1417-1424)
+  if (!c || !basis || !bbasis || !metric || mode < 0 || mode > 2 || n <= 0 || m < 0 || k <= 0 ||
+      (mode != 2 && (!abasis || !h || !op || ldh < m + k)))
     return fail(c, DLA_ERR_ARG, "dla_expand_project_metric: bad argument (n > 0, m >= 0, k > 0, ldh >= m + k)");
   double* u = basis + (size_t)n * m;
   const long long nglob = global_rows(c, n);
-  const bool builtin = builtin_operator(op) && builtin_operator(metric);
+  const bool builtin = (mode == 2 || builtin_operator(op)) && builtin_operator(metric);
   const int order = builtin ? 2 : c->callback_order;
   const bool ahead = (c->run_ahead == 2 || (c->run_ahead == 1 && builtin)) && c->callbacks_on_device && order != 1;
   int b_handled = 0;
@@ -1228,7 +1233,8 @@ int dla_expand_project_metric(dla_ctx* c, int mode, int n, int m, int k, double*
       c->eng->spec_stats_begin();
       int sta = metric_tail_steps(c, mode, n, m, k, basis, bbasis, abasis, op, metric, shift, h, ldh, true, true, &b_handled);
       c->eng->spec_stats_end(false);
-      st = c->eng->ortho_chain_finish(&rep, sta == DLA_OK);
+      // (modes 0 / 1: the projection's host wait has covered the chain; mode 2 has none of its own: the report's wait is the one)
+      st = c->eng->ortho_chain_finish(&rep, sta == DLA_OK && mode != 2);
       const int bst = b_handled ? c->eng->b_ortho_ahead_status() : 1;
       const bool good = st == DLA_OK && sta == DLA_OK && rep.status == 1 && rep.clean && bst == 1;
       c->eng->spec_stats_end(!good);
@@ -1253,6 +1259,7 @@ int dla_expand_project_metric(dla_ctx* c, int mode, int n, int m, int k, double*
   int st = metric_tail_steps(c, mode, n, m, k, basis, bbasis, abasis, op, metric, shift, h, ldh, ahead, false, &b_handled);
   if (st) return st;
   if (b_handled) {
+    if (mode == 2) { st = c->eng->sync(); if (st) return engfail(c, st); }      // (no projection whose wait would cover the device step)
     const int bst = c->eng->b_ortho_ahead_status();
     if (bst < 0) return fail(c, DLA_ERR_LAPACK, "b_ortho: metric not positive definite");
     if (bst == 0) return fail(c, DLA_ERR_RUNTIME, "b_ortho: the device step did not run");

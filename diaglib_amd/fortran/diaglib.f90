@@ -1304,7 +1304,7 @@ contains
     type(c_ptr)     :: vp, vm, lvp, lvm, bvp, bvm, rp, rm, bp, bm, tp, tm
     real(dp), allocatable :: smat(:,:), epmat(:,:), emmat(:,:), sts(:,:), lam(:), up(:,:), um(:,:), eye(:,:)
     real(dp), allocatable :: np(:,:), nm(:,:)
-    real(dp)        :: t_begin(2), t_end(2), sqrt2, growth
+    real(dp)        :: t_begin(2), t_end(2), sqrt2, growth, nohmat(1)
     integer         :: it, sweeps, first, r, c, lo
     integer(c_int)  :: flag
     logical         :: vectors_current
@@ -1456,9 +1456,16 @@ contains
           call chk(e%ctx, dla_ortho_vs_x(e%ctx, n, s%cols, s%act, vp, colp(vp,n,s%head)), 'ortho_vs_x')
           call chk(e%ctx, dla_ortho_vs_x(e%ctx, n, s%cols, s%act, vm, colp(vm,n,s%head)), 'ortho_vs_x')
         else
-          call chk(e%ctx, dla_b_ortho_vs_x(e%ctx, n, s%cols, s%act, vp, lvp, colp(vp,n,s%head)), 'b_ortho_vs_x')
-          call chk(e%ctx, dla_b_ortho_vs_x(e%ctx, n, s%cols, s%act, vm, lvm, colp(vm,n,s%head)), 'b_ortho_vs_x')
-          call metric_blocks(s%head, s%act)
+!
+!         efficient variant: each new block is orthogonalised against its basis in the metric (:1397-1416), gets its metric
+!         image (:1417-1423) and is made orthonormal in that metric (:1420-1424) -- one call per block (mode 2 of
+!         dla_expand_project_metric: device chain, operator and the Cholesky step of b_ortho back to back, one host wait)
+!
+          call chk(e%ctx, dla_expand_project_metric(e%ctx, 2_c_int, n, s%cols, s%act, vp, lvp, c_null_ptr, c_null_funptr, apb, zero, &
+                                                    nohmat, 1_c_int), 'b_ortho_vs_x + apbmul + b_ortho')
+          call chk(e%ctx, dla_expand_project_metric(e%ctx, 2_c_int, n, s%cols, s%act, vm, lvm, c_null_ptr, c_null_funptr, amb, zero, &
+                                                    nohmat, 1_c_int), 'b_ortho_vs_x + ambmul + b_ortho')
+          e%op_cols = e%op_cols + 2*s%act
         end if
         call lap_charge(w, w%ortho)
       else

@@ -246,7 +246,13 @@ int  dla_expand_project(dla_ctx* ctx, int mode, int n, int m, int k, double* bas
  * b_ortho(U, BU) (:3094-3183),  AU = A U [+ shift U],  and the projection as in dla_expand_project (mode 0 / 1).  Same result as
  * the separate entry points.  With device-mode callbacks that may run ahead (DLA_OPT_RUN_AHEAD) all of it is enqueued behind
  * the orthogonalisation chain -- the k x k factorisation of b_ortho runs on the device and only behind a chain that ended
- * well -- and one host wait serves the whole step (three with the separate calls). */
+ * well -- and one host wait serves the whole step (three with the separate calls).
+ * "Same result": the same block as the separate calls up to rounding -- b_ortho's Cholesky-QR gives the same Q for U and for U W
+ * (W upper triangular, positive diagonal), so inside this entry the device chain does not apply its last pending factor
+ * (16 n k bytes less); dla_b_ortho_vs_x called on its own does.
+ * mode 2: b_ortho_vs_x, bvec, b_ortho and nothing else (abasis, matvec, h_host unused, may be NULL): the expansion of
+ * caslr_eff_driver, whose new blocks are orthogonalised against the basis in the metric (A+B) resp. (A-B), get their metric
+ * image and are made orthonormal in it (diaglib.f90:1397-1424) -- bvec is apbmul resp. ambmul there. */
 int  dla_expand_project_metric(dla_ctx* ctx, int mode, int n, int m, int k, double* basis_dev, double* bbasis_dev, double* abasis_dev,
                                dla_matvec_fn matvec, dla_matvec_fn bvec, double shift, double* h_host, int ldh);
 /* y += alpha x over len contiguous doubles.  daxpy at diaglib.f90:312,397 (LOBPCG shift). */
