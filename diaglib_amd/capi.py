@@ -41,7 +41,7 @@ EXPORTS = [
     "dla_call_matvec", "dla_call_precnd", "dla_expand_project", "dla_expand_project_metric",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
     "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd", "dla_synth_apbmul", "dla_synth_ambmul", "dla_synth_spdmul", "dla_synth_smdmul",
-    "dla_synth_metric", "dla_synth_lrprec1", "dla_synth_lrprec2", "dla_spmm_setup_csr", "dla_spmm_setup_csr_sharded", "dla_spmm_matvec", "dla_spmm_precnd",
+    "dla_synth_metric", "dla_synth_lrprec1", "dla_synth_lrprec2", "dla_pending_factor", "dla_spmm_setup_csr", "dla_spmm_setup_csr_sharded", "dla_spmm_matvec", "dla_spmm_precnd",
     "dla_davidson_driver", "dla_gen_david_driver", "dla_lobpcg_driver", "dla_caslr_eff_driver", "dla_caslr_driver", "dla_call_lrprec",
     "dla_last_solve_info", "dla_set_solve_info",
 ]
@@ -128,6 +128,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_potrf_lower": (i, [i, c_dp, i]),
         "dla_trtri_lower": (i, [i, c_dp, i]), "dla_norm_est": (d, [i, c_dp, i]),
         "dla_synth_setup": (i, [vp, C.c_longlong, C.c_longlong, i, i, d]),
+        "dla_pending_factor": (i, [vp, i, vp, i]),
         "dla_spmm_setup_csr": (i, [vp, i, vp, vp, vp]),
         "dla_spmm_setup_csr_sharded": (i, [vp, i, C.c_longlong, C.c_longlong, vp, vp, vp]),
         "dla_davidson_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, c_ip]),
@@ -421,6 +422,12 @@ class Context:
 
     def ortho_vs_x(self, x: DevPanel, u: DevPanel, m: Optional[int] = None) -> None:
         self._chk(self.lib.dla_ortho_vs_x(self.h, x.n, x.m if m is None else m, u.m, x.ptr, u.ptr))
+
+    def pending_factor(self, k: int) -> np.ndarray:
+        """the triangular factor the last expand_project(mode 3) left pending (identity when none)"""
+        t = np.zeros((k, k), order="F")
+        self._chk(self.lib.dla_pending_factor(self.h, k, _dp(t), k))
+        return t
 
     def expand_project(self, mode: int, basis: DevPanel, abasis: DevPanel, m: int, k: int, matvec: int, shift: float = 0.0) -> np.ndarray:
         """dla_expand_project on the leading m + k columns of the two panels: ortho_vs_x(X, U), AU = A U + shift U, then the

@@ -78,6 +78,16 @@ struct BlockOps {
   // set by a caller that B-orthonormalises the block by Cholesky-QR right behind ortho_vs_x (dla_expand_project_metric): a device
   // chain may then end without applying its last pending triangular factor (OrthoTailArgs::drop_final in hip_engine.hip)
   bool drop_final = false;
+  // ... and with publish_pending the chain hands that factor to the host instead (pending_factor): for a caller that folds it into
+  // its small matrices and coefficient blocks -- LOBPCG's W block is used once and rebuilt, so it never has to be written
+  // (dla_expand_project mode 3).  Default: the identity (nothing is ever pending in the host-driven loops).
+  bool publish_pending = false;
+  virtual int pending_factor(int k, double* t, int ldt)
+  {
+    for (int j = 0; j < k; ++j)
+      for (int i = 0; i < k; ++i) t[(size_t)i + (size_t)j * ldt] = (i == j) ? 1.0 : 0.0;
+    return 0;
+  }
   int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests
   std::string err;
 };
@@ -321,6 +331,8 @@ struct dla_ctx {
   int run_ahead = 1;         // DLA_OPT_RUN_AHEAD
   long long n_global = -1;   // -1: single shard, n_global == n
   long long row0 = 0;
+  std::vector<double> pending_t;   // dla_expand_project mode 3: the factor the last call left pending (k x k, ld k)
+  int pending_k = 0;
   std::string err;
   // pinned staging buffers for host-mode callbacks
   double* stage_x = nullptr;

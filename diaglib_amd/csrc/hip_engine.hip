@@ -1706,6 +1706,10 @@ struct OrthoTailArgs {
   unsigned long long* dbg;   // $DIAGLIB_AMD_CHAIN_DEBUG: time stamps of the step (100 MHz ticks), 16 per executed sweep
   int xw_ok;           // blocks of 17..48 columns (ortho_tail): the storing sweep OP_XW exists for this shape -- a triangular update
                        // inside the loop is written together with X^T U and U^T U of what it stores (one sweep instead of two)
+  double* t_host;      // drop_final: pinned copy of the factor that stays pending, k x k column-major with ld 48, and behind it
+                       // (index 48 * 48) the chain's sequence number -- for callers that fold the factor into their small matrices
+                       // instead (LOBPCG's W block, dla_expand_project mode 3)
+  int t_seq;
   int drop_final;      // 1: the chain ends where it would ask for OP_FINAL -- the pending upper-triangular factor is NOT applied.
                        // For callers that B-orthonormalise the block by Cholesky-QR right behind the chain (dla_expand_project_metric:
                        // b_ortho, reference diaglib.f90:3094-3183): the Q factor of U W and of U is the same for any upper-triangular W
@@ -1966,7 +1970,18 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
           }
         } else {
           if (can_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;
-          else if (a.drop_final) t.status = OST_DONE;
+          else if (a.drop_final) {
+            t.status = OST_DONE;
+            if (a.t_host != nullptr) {
+              // the factor that stays pending: W of this step (everything before it has been written by the sweeps)
+              for (int idx = lane; idx < k * k; idx += 64) {
+                const int pp = idx % k, j = idx / k;
+                a.t_host[(size_t)pp + (size_t)j * 48] = (pp <= j) ? lds_load1(A + j * TLD + pp) : 0.0;
+              }
+              __threadfence_system();
+              if (lane == 0) a.t_host[48 * 48] = (double)a.t_seq;
+            }
+          }
           else t.phase = OP_FINAL;
         }
       }
@@ -2396,7 +2411,19 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
             }
           } else {
             if (can_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;
-            else if (a.drop_final) t.status = OST_DONE;
+            else if (a.drop_final) {
+              t.status = OST_DONE;
+              if (a.t_host != nullptr) {
+                // the factor that stays pending: Wp (accumulator layout: lane (c, g) holds Wp(g + 4 r, c))
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int pp = g + 4 * r;
+                  if (pp < k && c < k) a.t_host[(size_t)pp + (size_t)c * 48] = pnew[r];
+                }
+                __threadfence_system();
+                if (lane == 0) a.t_host[48 * 48] = (double)a.t_seq;
+              }
+            }
             else t.phase = OP_FINAL;
           }
         }
@@ -2866,6 +2893,7 @@ struct HipEngine : dla::Engine {
     if (d_ost) (void)hipFree(d_ost);
     if (h_ost) (void)hipHostFree(h_ost);
     if (h_ost_init) (void)hipHostFree(h_ost_init);
+    if (h_tpend) (void)hipHostFree(h_tpend);
     if (d_wpk) (void)hipFree(d_wpk);
     if (d_wfull) (void)hipFree(d_wfull);
     if (d_cpk2) (void)hipFree(d_cpk2);
@@ -3544,6 +3572,9 @@ struct HipEngine : dla::Engine {
   // the source is never scaled, and the tail that would read the result is predicated off like its sweep.
   double* d_red_small = nullptr; double* d_red_xug = nullptr;
   static const int RED_DOUBLES = 640 * 48;
+  double* h_tpend = nullptr; double* h_tpend_dev = nullptr;   // the factor a drop_final chain left pending (OrthoTailArgs::t_host)
+  int t_seq = 0;                     // sequence number of the chain being enqueued
+  int t_pending_k = 0;               // > 0: the last chain ended with a k x k factor pending and nobody has fetched it yet
   std::map<long long, std::vector<int>> ortho_history;   // (k, m) -> the sweeps the last call of that shape executed
   std::set<long long> chain_verified;                    // shapes whose launch paths have been walked (see ortho_chain)
 
@@ -3567,6 +3598,9 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipMalloc((void**)&d_wst, sizeof(double) * 768));
     if (chain_debug) { HIPCHK(hipMalloc((void**)&d_dbg, sizeof(unsigned long long) * 48 * 16)); HIPCHK(hipMemsetAsync(d_dbg, 0, sizeof(unsigned long long) * 48 * 16, st)); }
     HIPCHK(hipMalloc((void**)&d_xug, sizeof(double) * XUG_DOUBLES));
+    HIPCHK(hipHostMalloc((void**)&h_tpend, sizeof(double) * (48 * 48 + 8), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&h_tpend_dev, h_tpend, 0));
+    h_tpend[48 * 48] = 0.0;
     HIPCHK(hipMalloc((void**)&d_red_small, sizeof(double) * RED_DOUBLES));
     HIPCHK(hipMalloc((void**)&d_red_xug, sizeof(double) * RED_DOUBLES));
     return DLA_OK;
@@ -3602,6 +3636,8 @@ struct HipEngine : dla::Engine {
                                  fold, tune[6] == 7 ? 0 : 1, d_xug, d_wst, d_dbg, chain_xw ? 1 : 0};
     if ((fold == 1 && op == OP_GRAMX) || op == OP_XW) pending_tail.gsrc = d_xug;
     pending_tail.drop_final = (drop_final && m > 0) ? 1 : 0;
+    pending_tail.t_host = (pending_tail.drop_final && publish_pending) ? h_tpend_dev : nullptr;
+    pending_tail.t_seq = t_seq;
     fuse_tail = p2p.on ? tune[6] != 4 : (nranks <= 1 && !comm);     // (knob 6 = 4: the exchange as a launch of its own)
     tail_fused = false;
     pred_phase = &d_ost->phase; pred_want = (op == OP_GRAMX) ? (int)OP_GRAM_UU : op;   // the first sweep answers the start phase
@@ -3745,6 +3781,18 @@ struct HipEngine : dla::Engine {
     std::vector<SpecRec> recs;
   } run;
 
+  // the factor the last chain left pending (drop_final + publish_pending), or the identity; fetching it clears it
+  int pending_factor(int k, double* t, int ldt) override
+  {
+    for (int j = 0; j < k; ++j)
+      for (int i = 0; i < k; ++i) t[(size_t)i + (size_t)j * ldt] = (i == j) ? 1.0 : 0.0;
+    if (t_pending_k == k && h_tpend) {
+      for (int j = 0; j < k; ++j)
+        for (int i = 0; i <= j; ++i) t[(size_t)i + (size_t)j * ldt] = h_tpend[(size_t)i + (size_t)j * 48];
+    }
+    t_pending_k = 0;
+    return DLA_OK;
+  }
   int ortho_chain(int n, int m, int k, const double* x, const double* bx, double* u, dla::OrthoReport* rep) override
   {
     int stc = ortho_chain_begin(n, m, k, x, bx, u, rep);
@@ -3822,6 +3870,8 @@ struct HipEngine : dla::Engine {
 
     // the schedule depends on how much of the new block already lies in span(X): remembered per basis width
     const bool dropf = drop_final && vsx;
+    t_pending_k = 0;
+    t_seq = t_seq >= 1000000 ? 1 : t_seq + 1;
     const long long key = (long long)k * 1000000 + m + fold * 500000000000LL + (wide_gramx ? 250000000000LL : 0LL) + (wide_xw ? 125000000000LL : 0LL) +
                           (dropf ? 62500000000LL : 0LL);
     std::vector<int>& hist = ortho_history[key];
@@ -3985,6 +4035,8 @@ struct HipEngine : dla::Engine {
       unaccounted.push_back(std::move(cd));
       if (sres.status == OST_DONE && sres.nops <= 48) { hist.assign(sres.log, sres.log + nlog); last_k = hist; }
     }
+    // a chain that ended with its last factor pending has left it in the pinned buffer (the tail wrote the sequence number last)
+    if (sres.status == OST_DONE && drop_final && publish_pending && vsx && h_tpend[48 * 48] == (double)t_seq) t_pending_k = k;
     rep->handled = 1;
     rep->status = sres.status;
     rep->growth = sres.growth;

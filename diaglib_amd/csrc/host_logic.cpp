@@ -1128,12 +1128,77 @@ static int expand_apply_project(dla_ctx* c, int mode, int n, int m, int k, doubl
   return dla_gram_lower(c, n, m + k, basis, abasis, h, ldh);
 }
 
+static int expand_project_impl(dla_ctx* c, int mode, int n, int m, int k, double* basis, double* abasis, dla_matvec_fn fn,
+                               double shift, double* h, int ldh);
+
 int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis, double* abasis, dla_matvec_fn fn,
                        double shift, double* h, int ldh)
 {
   DLA_T("dla_expand_project");
-  if (!c || !basis || !abasis || !h || !fn || (mode != 0 && mode != 1) || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
+  if (!c || !basis || !abasis || !h || !fn || mode < 0 || mode == 2 || mode > 3 || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
     return fail(c, DLA_ERR_ARG, "dla_expand_project: bad argument (n > 0, m >= 0, k > 0, ldh >= m + k)");
+  c->pending_k = 0;
+  // (A/B switch: $DIAGLIB_AMD_NO_PENDING makes mode 3 behave like mode 1 -- the factor is applied by the chain's last sweep)
+  static const bool no_pending = std::getenv("DIAGLIB_AMD_NO_PENDING") != nullptr;
+  if (mode == 3 && no_pending) mode = 1;
+  if (mode != 3) return expand_project_impl(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
+  // mode 3 = mode 1 for a block that is used once and rebuilt (LOBPCG's W, reference diaglib.f90:518-529, 394-403): the chain's last
+  // factor T (upper triangular, near the identity) is not applied to the block; the projection of the stored block is
+  // corrected here, H <- D^T H D with D = diag(I, T), and the caller folds T into the W rows of every coefficient block it
+  // multiplies the panel with (dla_pending_factor) -- the sweep U <- U T (16 n k bytes) is never run
+  {
+    struct Flags { dla::Engine* e; explicit Flags(dla::Engine* e_) : e(e_) { e->drop_final = true; e->publish_pending = true; }
+                   ~Flags() { e->drop_final = false; e->publish_pending = false; } } flags(c->eng);
+    const int st = expand_project_impl(c, 1, n, m, k, basis, abasis, fn, shift, h, ldh);
+    if (st) return st;
+  }
+  c->pending_t.assign((size_t)k * k, 0.0);
+  int st = c->eng->pending_factor(k, c->pending_t.data(), k);
+  if (st) return engfail(c, st);
+  c->pending_k = k;
+  const double* t = c->pending_t.data();
+  bool ident = true;
+  for (int j = 0; j < k && ident; ++j)
+    for (int i = 0; i <= j; ++i) if (t[(size_t)i + (size_t)j * k] != (i == j ? 1.0 : 0.0)) { ident = false; break; }
+  if (ident) return DLA_OK;
+  const int l = m + k;
+  // rows m .. l-1 of the lower triangle: [H_wx | H_ww] <- T^T [H_wx | H_ww T]
+  std::vector<double> ww((size_t)k * k), tmp((size_t)k * l);
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < k; ++i) ww[(size_t)i + (size_t)j * k] = (i >= j) ? h[(size_t)(m + i) + (size_t)(m + j) * ldh] : h[(size_t)(m + j) + (size_t)(m + i) * ldh];
+  // tmp = [H_wx | H_ww T]   (k x l)
+  for (int b = 0; b < m; ++b)
+    for (int i = 0; i < k; ++i) tmp[(size_t)i + (size_t)b * k] = h[(size_t)(m + i) + (size_t)b * ldh];
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < k; ++i) {
+      double acc = 0.0;
+      for (int p = 0; p <= j; ++p) acc += ww[(size_t)i + (size_t)p * k] * t[(size_t)p + (size_t)j * k];
+      tmp[(size_t)i + (size_t)(m + j) * k] = acc;
+    }
+  for (int b = 0; b < l; ++b)
+    for (int i = 0; i < k; ++i) {
+      if (b >= m && b - m > i) continue;                       // (lower triangle only)
+      double acc = 0.0;
+      for (int p = 0; p <= i; ++p) acc += t[(size_t)p + (size_t)i * k] * tmp[(size_t)p + (size_t)b * k];
+      h[(size_t)(m + i) + (size_t)b * ldh] = acc;
+    }
+  return DLA_OK;
+}
+
+int dla_pending_factor(dla_ctx* c, int k, double* t, int ldt)
+{
+  if (!c || !t || k <= 0 || ldt < k) return fail(c, DLA_ERR_ARG, "dla_pending_factor: bad argument");
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < k; ++i) t[(size_t)i + (size_t)j * ldt] = (i == j) ? 1.0 : 0.0;
+  if (c->pending_k == k)
+    for (int j = 0; j < k; ++j)
+      for (int i = 0; i <= j; ++i) t[(size_t)i + (size_t)j * ldt] = c->pending_t[(size_t)i + (size_t)j * k];
+  return DLA_OK;
+}
+
+static int expand_project_impl(dla_ctx* c, int mode, int n, int m, int k, double* basis, double* abasis, dla_matvec_fn fn,
+                               double shift, double* h, int ldh)
+{
   double* u = basis + (size_t)n * m;
   const long long nglob = global_rows(c, n);
   const bool builtin = builtin_operator(fn);

@@ -258,6 +258,13 @@ module diaglib
       real(c_double) :: h(*)
       integer(c_int) :: st
     end function
+    function dla_pending_factor(ctx,k,t,ldt) bind(C,name='dla_pending_factor') result(st)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: k, ldt
+      real(c_double) :: t(*)
+      integer(c_int) :: st
+    end function
     function dla_expand_project_metric(ctx,mode,n,m,k,basis,bbasis,abasis,fn,bfn,shift,h,ldh) &
              bind(C,name='dla_expand_project_metric') result(st)
       import :: c_ptr, c_funptr, c_int, c_double
@@ -917,7 +924,8 @@ contains
     type(c_funptr)  :: op, prec, metric
     type(c_ptr)     :: sp(2), asp(2), bsp(2), resid, latest
     integer         :: rd, wr              ! the copy the basis is read from / the copy that receives the new X and P
-    real(dp), allocatable :: h(:,:), theta(:), cx(:,:), cp(:,:), ycp(:,:), seen(:,:,:)
+    real(dp), allocatable :: h(:,:), theta(:), cx(:,:), cp(:,:), ycp(:,:), seen(:,:,:), tfac(:,:), yf(:,:)
+    integer :: tw                  ! > 0: the W block in memory still lacks the triangular factor tfac(1:tw,1:tw) (see orthogonalise_w)
     real(dp)        :: t_begin(2), t_end(2)
     integer         :: it, sweeps, width, live, c_x, c_p, c_w, wide, bet
     logical         :: projected           ! the W block already has its operator image and S^T A S is in h (dla_expand_project)
@@ -938,7 +946,8 @@ contains
     resid = dev_panel(e%ctx, n, n_max, 'r')
     rd = 1
     wr = 2
-    allocate (h(wide,wide), theta(wide), seen(2,n_max,2))
+    allocate (h(wide,wide), theta(wide), seen(2,n_max,2), tfac(n_max,n_max))
+    tw = 0
     h    = zero
     seen = zero
     ok   = .false.
@@ -1006,9 +1015,23 @@ contains
       allocate (cx(width,n_max), cp(width,bet))
       call chk(e%ctx, dla_get_coeffs(e%ctx, wide, width, n_max, bet, h, cx, cp), 'get_coeffs')
       if (.not.gen_eig) then
-        call chk(e%ctx, dla_ritz_residual_p(e%ctx, n, width, n_max, sp(rd), asp(rd), h, wide, eig, n_max, s%mask, &
-                                            sp(wr), resid, asp(wr), s%rnorm, bet, cp, width, &
-                                            colp(sp(wr),n,n_max+1), colp(asp(wr),n,n_max+1)), 'ritz/residual + p block')
+        if (tw.gt.0) then
+!
+!         the W block in memory is W T^-1 (orthogonalise_w): products with the panel take T on the W rows of their coefficients
+!
+          allocate (yf(width,n_max))
+          yf = h(1:width,1:n_max)
+          call fold_pending(yf, n_max)
+          call fold_pending(cp, bet)
+          call chk(e%ctx, dla_ritz_residual_p(e%ctx, n, width, n_max, sp(rd), asp(rd), yf, width, eig, n_max, s%mask, &
+                                              sp(wr), resid, asp(wr), s%rnorm, bet, cp, width, &
+                                              colp(sp(wr),n,n_max+1), colp(asp(wr),n,n_max+1)), 'ritz/residual + p block')
+          deallocate (yf)
+        else
+          call chk(e%ctx, dla_ritz_residual_p(e%ctx, n, width, n_max, sp(rd), asp(rd), h, wide, eig, n_max, s%mask, &
+                                              sp(wr), resid, asp(wr), s%rnorm, bet, cp, width, &
+                                              colp(sp(wr),n,n_max+1), colp(asp(wr),n,n_max+1)), 'ritz/residual + p block')
+        end if
       else
 !
 !       with a metric: the sweep over B S and A S gives B X, A X, the residual A X - eig B X and the B P, A P blocks; X and P
@@ -1048,6 +1071,7 @@ contains
       if (bet.ne.live) then
         allocate (cx(width,n_max), cp(width,max(live,1)))
         call chk(e%ctx, dla_get_coeffs(e%ctx, wide, width, n_max, live, h, cx, cp), 'get_coeffs')
+        if (tw.gt.0) call fold_pending(cp, live)
         call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, sp(rd),  live, cp, width, colp(sp(wr),n,c_p)), 'p block')
         call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, asp(rd), live, cp, width, colp(asp(wr),n,c_p)), 'ap block')
         if (gen_eig) call chk(e%ctx, dla_panel_gemm(e%ctx, n, width, bsp(rd), live, cp, width, colp(bsp(wr),n,c_p)), 'bp block')
@@ -1138,6 +1162,15 @@ contains
       open = max(1, n_max - front)
     end function open_roots_expected
 !
+!   rows of the W block (the last tw of the current width) of a coefficient block times the pending factor
+!
+    subroutine fold_pending(cf, ncol)
+      integer,  intent(in)    :: ncol
+      real(dp), intent(inout) :: cf(width,ncol)
+      if (tw.le.0 .or. ncol.le.0) return
+      cf(width-tw+1:width,1:ncol) = matmul(tfac(1:tw,1:tw), cf(width-tw+1:width,1:ncol))
+    end subroutine fold_pending
+!
     subroutine turn_over()
       integer :: keep
       keep = rd
@@ -1149,6 +1182,7 @@ contains
 !
     subroutine orthogonalise_w(m, k)
       integer, intent(in) :: m, k
+      tw = 0
       call lap_start(w)
       if (gen_eig) then
         if (it.lt.max_iter) then
@@ -1163,8 +1197,14 @@ contains
       else
 !       (the operator on the W block and S^T A S -- the head of the next sweep -- in the same call: dla_expand_project)
         if (it.lt.max_iter) then
-          call chk(e%ctx, dla_expand_project(e%ctx, 1_c_int, n, m, k, sp(rd), asp(rd), op, shift, h, wide), &
+!
+!         mode 3: W is used by one sweep and then rebuilt, so the last triangular factor of its orthogonalisation is not
+!         applied to it -- the projection comes back corrected, and the sweep's coefficients take the factor (fold_pending)
+!
+          call chk(e%ctx, dla_expand_project(e%ctx, 3_c_int, n, m, k, sp(rd), asp(rd), op, shift, h, wide), &
                    'ortho_vs_x + matvec + projection')
+          call chk(e%ctx, dla_pending_factor(e%ctx, k, tfac, n_max), 'pending factor')
+          tw = k
           projected = .true.
         else
 !         (last sweep allowed: the operator's image of this block would never be read)

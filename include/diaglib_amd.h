@@ -241,6 +241,13 @@ int  dla_ritz_residual2(dla_ctx* ctx, int n, int l, int m, const double* v_dev, 
  * operator must therefore be a pure function of its input (it is called a second time for the same block then). */
 int  dla_expand_project(dla_ctx* ctx, int mode, int n, int m, int k, double* basis_dev, double* abasis_dev,
                         dla_matvec_fn matvec, double shift, double* h_host, int ldh);
+/* mode 3 = mode 1 for a block that is used once and then rebuilt -- LOBPCG's W block (diaglib.f90:518-529, 394-403): the last
+ * triangular factor T of the orthogonalisation (upper triangular, near the identity) is NOT applied to the stored block.  h_host
+ * is the projection for the orthonormal block U T (corrected on the host, D^T H D with D = diag(I, T)); the caller multiplies
+ * the rows of every coefficient block that belong to the new block by T before it forms products with the panel
+ * (S [y | cp] = S_stored D [y | cp]).  dla_pending_factor returns T of the last mode-3 call (k x k, upper triangular; the
+ * identity when nothing stayed pending: host-driven loops, a chain that took the long way).  16 n k bytes less per iteration. */
+int  dla_pending_factor(dla_ctx* ctx, int k, double* t_host, int ldt);
 /* The expansion step with a metric B (gen_david_driver diaglib.f90:2170-2190, lobpcg_driver with gen_eig :523-529): on
  * basis = [X | U], bbasis = [BX | BU], abasis = [AX | AU]:  b_ortho_vs_x(X, BX, U) (:3576-3663),  BU = B U (the caller's bvec),
  * b_ortho(U, BU) (:3094-3183),  AU = A U [+ shift U],  and the projection as in dla_expand_project (mode 0 / 1).  Same result as
