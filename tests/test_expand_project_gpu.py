@@ -259,22 +259,27 @@ def test_expand_project_with_the_last_factor_pending(ctx, rng, n, m, k, kind, ah
     """mode 3 (LOBPCG's W block): the chain's last triangular factor T is handed to the host instead of being applied.  The stored
     block times T is the orthonormal block mode 1 delivers; the operator's image of the stored block times T is mode 1's; the
     projection comes back already corrected; T is upper triangular and near the identity."""
-    _setup(ctx, n)
-    x, u = _blocks(rng, n, m, k, kind)
-    ax = _apply(ctx, x)
-    b1, a1, h1, _ = _run(ctx, 1, x, u, ax, 0.25, ahead)
-    b3, a3, h3, _ = _run(ctx, 3, x, u, ax, 0.25, ahead)
-    t = ctx.pending_factor(k)
-    assert np.array_equal(np.tril(t, -1), np.zeros_like(t)) and np.all(np.diag(t) > 0)
-    if n % 2 == 0:                                    # (an odd row count takes the host-driven schedule: nothing stays pending)
-        assert not np.array_equal(t, np.eye(k))       # the device chain did leave a factor pending
-        assert np.abs(t - np.eye(k)).max() < 0.2, np.abs(t - np.eye(k)).max()   # (the factor of the pass that found U^T U = I + small)
-    w1, w3 = b1[:, m:], b3[:, m:] @ t
-    assert np.abs(w3.T @ w3 - np.eye(k)).max() < 50 * EPS and np.abs(x.T @ w3).max() < 50 * EPS
-    assert np.abs(w3 - w1).max() < 1e-12                                       # the same block (rounding apart)
-    assert np.abs(a3[:, m:] @ t - a1[:, m:]).max() < 1e-11 * max(1.0, np.abs(a1).max())
-    l1, l3 = np.tril(h1), np.tril(h3)
-    assert np.abs(l3 - l1).max() < 1e-11 * max(1.0, np.abs(l1).max())
-    assert np.array_equal(b3[:, :m], x)
-    # a second fetch returns the identity: the factor belongs to the call that left it
-    assert np.array_equal(ctx.pending_factor(k), t)
+    try:
+        _setup(ctx, n)
+        x, u = _blocks(rng, n, m, k, kind)
+        ax = _apply(ctx, x)
+        b1, a1, h1, _ = _run(ctx, 1, x, u, ax, 0.25, ahead)
+        b3, a3, h3, _ = _run(ctx, 3, x, u, ax, 0.25, ahead)
+        t = ctx.pending_factor(k)
+        assert np.array_equal(np.tril(t, -1), np.zeros_like(t)) and np.all(np.diag(t) > 0)
+        if n % 2 == 0:                                    # (an odd row count takes the host-driven schedule: nothing stays pending)
+            assert not np.array_equal(t, np.eye(k))       # the device chain did leave a factor pending
+            assert np.abs(t - np.eye(k)).max() < 0.2, np.abs(t - np.eye(k)).max()   # (the factor of the pass that found U^T U = I + small)
+        w1, w3 = b1[:, m:], b3[:, m:] @ t
+        assert np.abs(w3.T @ w3 - np.eye(k)).max() < 50 * EPS and np.abs(x.T @ w3).max() < 50 * EPS
+        assert np.abs(w3 - w1).max() < 1e-12                                       # the same block (rounding apart)
+        assert np.abs(a3[:, m:] @ t - a1[:, m:]).max() < 1e-11 * max(1.0, np.abs(a1).max())
+        l1, l3 = np.tril(h1), np.tril(h3)
+        assert np.abs(l3 - l1).max() < 1e-11 * max(1.0, np.abs(l1).max())
+        assert np.array_equal(b3[:, :m], x)
+        # a second fetch returns the identity: the factor belongs to the call that left it
+        assert np.array_equal(ctx.pending_factor(k), t)
+    finally:
+        ctx.set_option(capi.OPT_RUN_AHEAD, 1)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
