@@ -82,6 +82,7 @@ struct BlockOps {
   // its small matrices and coefficient blocks -- LOBPCG's W block is used once and rebuilt, so it never has to be written
   // (dla_expand_project mode 3).  Default: the identity (nothing is ever pending in the host-driven loops).
   bool publish_pending = false;
+  double drop_final_tol = 0.0;     // > 0: the factor stays pending only when the closing pass found max |U^T U - I| below it
   virtual int pending_factor(int k, double* t, int ldt)
   {
     for (int j = 0; j < k; ++j)

@@ -1710,6 +1710,9 @@ struct OrthoTailArgs {
                        // (index 48 * 48) the chain's sequence number -- for callers that fold the factor into their small matrices
                        // instead (LOBPCG's W block, dla_expand_project mode 3)
   int t_seq;
+  double drop_tol;     // > 0: drop_final only when max |G - I| of the closing pass is below it (a block that STAYS in the basis may
+                       // keep a pending factor only if later blocks can still be projected against it as if it were orthonormal:
+                       // two passes leave (2 drop_tol)^2 of the component they remove)
   int drop_final;      // 1: the chain ends where it would ask for OP_FINAL -- the pending upper-triangular factor is NOT applied.
                        // For callers that B-orthonormalise the block by Cholesky-QR right behind the chain (dla_expand_project_metric:
                        // b_ortho, reference diaglib.f90:3094-3183): the Q factor of U W and of U is the same for any upper-triangular W
@@ -1970,7 +1973,15 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
           }
         } else {
           if (can_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;
-          else if (a.drop_final) {
+          else if (a.drop_final && (a.drop_tol <= 0.0 || [&]() {
+                     // max |G - I| of this pass (the S image keeps the Gram matrix the factorisation started from)
+                     double dev = 0.0;
+                     for (int idx = lane; idx < k * k; idx += 64) {
+                       const int i = idx % k, j = idx / k;
+                       if (i >= j) dev = fmax(dev, fabs(lds_load1(S + i * TLD + j) - (i == j ? 1.0 : 0.0)));
+                     }
+                     for (int off = 32; off > 0; off >>= 1) dev = fmax(dev, __shfl_xor(dev, off, 64));
+                     return dev < a.drop_tol; }())) {
             t.status = OST_DONE;
             if (a.t_host != nullptr) {
               // the factor that stays pending: W of this step (everything before it has been written by the sweeps)
@@ -2411,7 +2422,12 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
             }
           } else {
             if (can_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;
-            else if (a.drop_final) {
+            else if (a.drop_final && (a.drop_tol <= 0.0 || [&]() {
+                       double dev = 0.0;              // max |G - I| of this pass (g0: the Gram matrix, identity beyond k)
+#pragma unroll
+                       for (int r = 0; r < 4; ++r) dev = fmax(dev, fabs(g0[r] - ((g + 4 * r == c) ? 1.0 : 0.0)));
+                       for (int off = 32; off > 0; off >>= 1) dev = fmax(dev, __shfl_xor(dev, off, 64));
+                       return dev < a.drop_tol; }())) {
               t.status = OST_DONE;
               if (a.t_host != nullptr) {
                 // the factor that stays pending: Wp (accumulator layout: lane (c, g) holds Wp(g + 4 r, c))
@@ -3638,6 +3654,7 @@ struct HipEngine : dla::Engine {
     pending_tail.drop_final = (drop_final && m > 0) ? 1 : 0;
     pending_tail.t_host = (pending_tail.drop_final && publish_pending) ? h_tpend_dev : nullptr;
     pending_tail.t_seq = t_seq;
+    pending_tail.drop_tol = drop_final_tol;
     fuse_tail = p2p.on ? tune[6] != 4 : (nranks <= 1 && !comm);     // (knob 6 = 4: the exchange as a launch of its own)
     tail_fused = false;
     pred_phase = &d_ost->phase; pred_want = (op == OP_GRAMX) ? (int)OP_GRAM_UU : op;   // the first sweep answers the start phase

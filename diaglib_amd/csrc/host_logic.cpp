@@ -1135,12 +1135,29 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
                        double shift, double* h, int ldh)
 {
   DLA_T("dla_expand_project");
-  if (!c || !basis || !abasis || !h || !fn || mode < 0 || mode == 2 || mode > 3 || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
+  if (!c || !basis || !abasis || !h || !fn || mode < 0 || mode == 2 || mode > 4 || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
     return fail(c, DLA_ERR_ARG, "dla_expand_project: bad argument (n > 0, m >= 0, k > 0, ldh >= m + k)");
   c->pending_k = 0;
-  // (A/B switch: $DIAGLIB_AMD_NO_PENDING makes mode 3 behave like mode 1 -- the factor is applied by the chain's last sweep)
+  // (A/B switch: $DIAGLIB_AMD_NO_PENDING makes modes 3 / 4 behave like 1 / 0 -- the factor is applied by the chain's last sweep)
   static const bool no_pending = std::getenv("DIAGLIB_AMD_NO_PENDING") != nullptr;
   if (mode == 3 && no_pending) mode = 1;
+  if (mode == 4 && no_pending) mode = 0;
+  if (mode == 4) {
+    // mode 4 = mode 0 for a block that STAYS in the basis (Davidson, reference diaglib.f90:1790 + 1685 + 1691): the last factor T
+    // stays pending only when the closing pass found the block orthonormal to 1e-8 -- later blocks are projected against the
+    // stored block as if it were orthonormal, and two passes leave (2e-8)^2 of what they remove.  h_host comes back RAW, for the
+    // stored block: the caller keeps the factors of all its blocks (D = diag(T_1, T_2, ...)) and forms D^T h T itself, as it
+    // multiplies the rows of its coefficient blocks by D before any product with the panel (dla_pending_factor)
+    struct Flags { dla::Engine* e; explicit Flags(dla::Engine* e_) : e(e_) { e->drop_final = true; e->publish_pending = true; e->drop_final_tol = 1.0e-8; }
+                   ~Flags() { e->drop_final = false; e->publish_pending = false; e->drop_final_tol = 0.0; } } flags(c->eng);
+    const int st = expand_project_impl(c, 0, n, m, k, basis, abasis, fn, shift, h, ldh);
+    if (st) return st;
+    c->pending_t.assign((size_t)k * k, 0.0);
+    const int stp = c->eng->pending_factor(k, c->pending_t.data(), k);
+    if (stp) return engfail(c, stp);
+    c->pending_k = k;
+    return DLA_OK;
+  }
   if (mode != 3) return expand_project_impl(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
   // mode 3 = mode 1 for a block that is used once and rebuilt (LOBPCG's W, reference diaglib.f90:518-529, 394-403): the chain's last
   // factor T (upper triangular, near the identity) is not applied to the block; the projection of the stored block is

@@ -668,7 +668,9 @@ contains
     type(stopwatch) :: w
     type(solve_env) :: e
     type(c_ptr)     :: basis, abasis, bbasis, resid, britz
-    real(dp), allocatable :: h(:,:), y(:,:), theta(:)
+    real(dp), allocatable :: h(:,:), y(:,:), theta(:), dmat(:,:), tblk(:,:)
+    integer,  allocatable :: bfirst(:)      ! first column of the block a basis column belongs to (dmat is block diagonal)
+    logical :: any_pending                  ! some block of the basis lacks its last triangular factor (see fold_* below)
     real(dp)        :: t_begin(2), t_end(2)
     integer         :: it, sweeps, kept, col, first, j, ritz_cols
     logical         :: patch_kept, projected
@@ -688,7 +690,8 @@ contains
       bbasis = dev_panel(e%ctx, n, s%ld, 'bspace')
       britz  = dev_panel(e%ctx, n, n_max, 'b_evec')
     end if
-    allocate (h(s%ld,s%ld), y(s%ld,s%ld), theta(s%ld))
+    allocate (h(s%ld,s%ld), y(s%ld,s%ld), theta(s%ld), dmat(s%ld,s%ld), tblk(n_max,n_max), bfirst(s%ld))
+    call reset_pending()
 !
 !   The reference zero-fills both n x lda panels (:1632-1633).  On the device no column is read before it has been
 !   written (guess copy, operator output, orthogonalisation output), so those two 8*n*lda-byte memsets do not exist;
@@ -752,6 +755,7 @@ contains
       call need_eigensolver(dla_syev_lowest('u', s%cols, y, s%ld, theta, n_max))
       call lap_charge(w, w%diag)
       eig = theta(1:n_max)
+      if (any_pending) call fold_rows(y, s%cols, n_max)      ! coefficients for the STORED blocks: every product with the panel
 !
 !     Ritz vectors, residuals of the wanted roots that are still open, and their norms: one sweep (:1717-1732)
 !
@@ -820,8 +824,15 @@ contains
 !         the three run back to back on the device (dla_expand_project)
 !
           if (it.lt.max_iter) then
-            call chk(e%ctx, dla_expand_project(e%ctx, 0_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
+!
+!           mode 4: a block that the closing pass found orthonormal to 1e-8 keeps its last triangular factor pending (the sweep
+!           U <- U T is not run); its columns of the projected matrix come back for the stored block and are corrected here,
+!           D^T h T with D = diag(T_1, T_2, ...) over the blocks of the basis
+!
+            call chk(e%ctx, dla_expand_project(e%ctx, 4_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
                                                h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
+            call chk(e%ctx, dla_pending_factor(e%ctx, s%act, tblk, n_max), 'pending factor')
+            call admit_factor(s%head, s%act)
             projected = .true.
           else
 !           (last sweep allowed: nobody will read the operator's image of this block -- the caller's routine is not called)
@@ -845,6 +856,7 @@ contains
           call chk(e%ctx, dla_b_ortho(e%ctx, n, n_max, basis, bbasis), 'b_ortho')               ! :2195-2197
         end if
         h = zero
+        call reset_pending()
         call sub_collapse(s)
         kept = sub_leading(s)
 !
@@ -874,6 +886,84 @@ contains
     call drop_panel(e%ctx, bbasis)
     call drop_panel(e%ctx, britz)
     deallocate (h, y, theta)
+!
+  contains
+!
+!   Blocks whose last triangular factor was left pending (dla_expand_project mode 4): the panel holds U_i T_i^-1 for block i, the
+!   orthonormal basis is basis * D with D = diag(T_1, T_2, ...) -- block diagonal, upper triangular, identity where nothing is
+!   pending.  The projected matrix and the coefficients of every product with the panel take D in k x k pieces.
+!
+    subroutine reset_pending()
+      integer :: j
+      dmat = zero
+      do j = 1, s%ld
+        dmat(j,j) = one
+        bfirst(j) = j
+      end do
+      any_pending = .false.
+    end subroutine reset_pending
+!
+!   the block that starts at column c0 (k columns) has come back with the factor tblk pending: record it and turn the raw columns
+!   of the projected matrix, h(1:c0+k-1, c0:c0+k-1) = [X_c | U_c]^T A U_c, into D^T h T
+!
+    subroutine admit_factor(c0, k)
+      integer, intent(in) :: c0, k
+      integer :: i, j, p, rows
+      logical :: ident
+      ident = .true.
+      do j = 1, k
+        do i = 1, j
+          if (tblk(i,j).ne.merge(one, zero, i.eq.j)) ident = .false.
+        end do
+      end do
+      bfirst(c0:c0+k-1) = c0
+      dmat(c0:c0+k-1,c0:c0+k-1) = zero
+      do j = 1, k
+        dmat(c0:c0+j-1,c0+j-1) = tblk(1:j,j)
+      end do
+      if (.not.ident) any_pending = .true.
+      if (.not.any_pending) return
+      rows = c0 + k - 1
+      if (.not.ident) then
+        do j = k, 1, -1
+          h(1:rows,c0+j-1) = h(1:rows,c0+j-1)*tblk(j,j)
+          do p = 1, j - 1
+            h(1:rows,c0+j-1) = h(1:rows,c0+j-1) + h(1:rows,c0+p-1)*tblk(p,j)
+          end do
+        end do
+      end if
+      call fold_rows_t(h(:,c0:c0+k-1), rows, k)
+    end subroutine admit_factor
+!
+!   g(1:nrow,:) <- D^T g
+!
+    subroutine fold_rows_t(g, nrow, ncol)
+      integer,  intent(in)    :: nrow, ncol
+      real(dp), intent(inout) :: g(s%ld,ncol)
+      integer :: r, p
+      do r = nrow, 1, -1
+        if (bfirst(r).eq.r .and. dmat(r,r).eq.one) cycle          ! (first column of a block: only its diagonal entry)
+        g(r,1:ncol) = g(r,1:ncol)*dmat(r,r)
+        do p = bfirst(r), r - 1
+          g(r,1:ncol) = g(r,1:ncol) + dmat(p,r)*g(p,1:ncol)
+        end do
+      end do
+    end subroutine fold_rows_t
+!
+!   c(1:nrow,:) <- D c
+!
+    subroutine fold_rows(c, nrow, ncol)
+      integer,  intent(in)    :: nrow, ncol
+      real(dp), intent(inout) :: c(s%ld,ncol)
+      integer :: r, p
+      do p = 1, nrow
+        c(p,1:ncol) = c(p,1:ncol)*dmat(p,p)
+        do r = p + 1, nrow
+          if (bfirst(r).ne.bfirst(p)) exit
+          c(p,1:ncol) = c(p,1:ncol) + dmat(p,r)*c(r,1:ncol)
+        end do
+      end do
+    end subroutine fold_rows
   end subroutine davidson_core
 !
   subroutine davidson_driver(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift,matvec,precnd,eig,evec,ok)

@@ -246,7 +246,11 @@ int  dla_expand_project(dla_ctx* ctx, int mode, int n, int m, int k, double* bas
  * is the projection for the orthonormal block U T (corrected on the host, D^T H D with D = diag(I, T)); the caller multiplies
  * the rows of every coefficient block that belong to the new block by T before it forms products with the panel
  * (S [y | cp] = S_stored D [y | cp]).  dla_pending_factor returns T of the last mode-3 call (k x k, upper triangular; the
- * identity when nothing stayed pending: host-driven loops, a chain that took the long way).  16 n k bytes less per iteration. */
+ * identity when nothing stayed pending: host-driven loops, a chain that took the long way).  16 n k bytes less per iteration.
+ * mode 4 = mode 0 for a block that STAYS in the basis (Davidson): T stays pending only when the closing pass of the
+ * orthogonalisation found max |U^T U - I| < 1e-8 (later blocks are projected against the stored block as if it were orthonormal;
+ * two passes leave (2e-8)^2 of what they remove), and h_host comes back RAW, for the stored block -- the caller keeps the factors
+ * of all its blocks, D = diag(T_1, T_2, ...), forms D^T h T itself and multiplies the rows of its coefficient blocks by D. */
 int  dla_pending_factor(dla_ctx* ctx, int k, double* t_host, int ldt);
 /* The expansion step with a metric B (gen_david_driver diaglib.f90:2170-2190, lobpcg_driver with gen_eig :523-529): on
  * basis = [X | U], bbasis = [BX | BU], abasis = [AX | AU]:  b_ortho_vs_x(X, BX, U) (:3576-3663),  BU = B U (the caller's bvec),
