@@ -78,7 +78,15 @@ for it in range(cases):
     elif kind == "zero":
         a = np.zeros((n, n))
     elif kind == "pairs":
+        # every eigenvalue twice, but not a diagonal matrix (with the exact inverse of a diagonal operator as preconditioner the
+        # first correction is the iterate itself and what the solvers find is decided by rounding noise -- in the reference too):
+        # plane rotations between neighbouring pairs keep the spectrum
         a = np.diag(np.repeat(np.arange(1, n // 2 + 2, dtype=np.float64), 2)[:n])
+        cs, sn = np.cos(0.7), np.sin(0.7)
+        for i0 in range(1, n - 1, 2):
+            g2 = np.eye(n); g2[i0, i0] = cs; g2[i0 + 1, i0 + 1] = cs; g2[i0, i0 + 1] = -sn; g2[i0 + 1, i0] = sn
+            a = g2 @ a @ g2.T
+        a = 0.5 * (a + a.T)
     elif kind in ("band_unit", "dup_guess", "zero_guess_col"):
         # (a purely diagonal operator with its exact diagonal preconditioner gives Davidson no new direction at all)
         hb = int(rng.integers(1, 5))
