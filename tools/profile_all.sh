@@ -42,6 +42,10 @@ python3 tools/lr_gen_bench.py --ab-run-ahead 2>/dev/null | grep "run-ahead" > $O
 python3 tools/fuzz_run_ahead.py 16 7 > $OUT/fuzz_run_ahead.txt 2>&1 || true
 mkdir -p tools/bin && hipcc --offload-arch=gfx950 -O2 -o tools/bin/upload_probe tools/upload_probe.hip && timeout -k 5 60 tools/bin/upload_probe > $OUT/upload_probe.txt 2>&1 || true
 python3 tools/ritz_skew_probe.py > $OUT/ritz_skew_probe.txt 2>&1 || true
+for r in 1 2 3; do
+  DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('davidson n=2e6 8 roots, pending factors on :', d['ms_per_step'], 'ms,', d['iters'], 'iterations')"
+  DIAGLIB_AMD_NO_PENDING=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('davidson n=2e6 8 roots, pending factors off:', d['ms_per_step'], 'ms,', d['iters'], 'iterations')"
+done > $OUT/davidson_pending_ab.txt 2>&1 || true
 (python3 tools/lobpcg_pending_ab.py 2000000 8 2e-13; python3 tools/lobpcg_pending_ab.py 10000000 32 1e-11; python3 tools/lobpcg_pending_ab.py 10000000 32 1e-12) 2>/dev/null | grep "pending factor" > $OUT/lobpcg_pending_ab.txt || true
 python3 tools/ritz_sched_ab.py 2000000 5 2>/dev/null | grep -v amdgpu.ids > $OUT/ritz_sched_ab.txt || true
 hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/rr_probe.hip -Ldiaglib_amd/lib -ldiaglib_amd -Wl,-rpath,$PWD/diaglib_amd/lib -o tools/bin/rr_probe && timeout -k 5 120 tools/bin/rr_probe 20 > $OUT/rr_device_probe.txt 2>&1 || true
