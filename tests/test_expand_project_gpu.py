@@ -283,3 +283,35 @@ def test_expand_project_with_the_last_factor_pending(ctx, rng, n, m, k, kind, ah
         ctx.set_option(capi.OPT_RUN_AHEAD, 1)
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
         ctx.set_shard(-1, 0)
+
+
+@pytest.mark.parametrize("n,m,k", [(4000, 26, 13), (6000, 42, 21), (4000, 52, 8)])
+def test_expand_project_keeps_the_factor_of_a_block_that_stays(ctx, rng, n, m, k):
+    """mode 4 (a Davidson block): the factor stays pending only when the closing pass found the block orthonormal to 1e-8.  A block
+    that is orthonormal to 1e-10 on entry keeps it: the stored block times T is orthonormal to rounding, the projection comes back
+    raw (for the stored block), and T^T-corrected it equals mode 0's.  A random block (closing deviation far above 1e-8 or the
+    usual two passes) gets its sweep and returns the identity -- both ways the pair (stored block, T) describes the same basis."""
+    try:
+        _setup(ctx, n)
+        x = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, m)))[0])
+        q = rng.standard_normal((n, k)); q -= x @ (x.T @ q); q = np.linalg.qr(q)[0]
+        for u in (np.asfortranarray(q @ (np.eye(k) + 1e-10 * rng.standard_normal((k, k)))), np.asfortranarray(rng.standard_normal((n, k)))):
+            ax = _apply(ctx, x)
+            b0, a0, h0, _ = _run(ctx, 0, x, u, ax, 0.0, True)
+            b4, a4, h4, _ = _run(ctx, 4, x, u, ax, 0.0, True)
+            t = ctx.pending_factor(k)
+            assert np.array_equal(np.tril(t, -1), np.zeros_like(t)) and np.all(np.diag(t) > 0)
+            w4 = b4[:, m:] @ t
+            assert np.abs(w4.T @ w4 - np.eye(k)).max() < 50 * EPS and np.abs(x.T @ w4).max() < 50 * EPS
+            assert np.abs(w4 - b0[:, m:]).max() < 1e-12
+            # raw projection for the stored block; with D = diag(I, T): D^T h4 T = h0
+            d = np.eye(m + k); d[m:, m:] = t
+            assert np.abs(d.T @ h4 @ t - h0).max() < 1e-11 * max(1.0, np.abs(h0).max())
+            assert np.abs(a4[:, m:] @ t - a0[:, m:]).max() < 1e-11 * max(1.0, np.abs(a0).max())
+            pending = not np.array_equal(t, np.eye(k))
+            if u is not None and np.abs(u.T @ u - np.eye(k)).max() < 1e-8:
+                assert pending and np.abs(t - np.eye(k)).max() < 1e-8        # the nearly orthonormal block keeps its factor
+    finally:
+        ctx.set_option(capi.OPT_RUN_AHEAD, 1)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
