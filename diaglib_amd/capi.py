@@ -26,6 +26,7 @@ ALLREDUCE_T = C.CFUNCTYPE(None, C.c_void_p, c_dp, C.c_int, C.c_int)
 OPT_CALLBACKS_ON_DEVICE, OPT_EVEC_ON_DEVICE, OPT_PROFILE, OPT_VERBOSE_ORTHO, OPT_CALLBACK_ORDER, OPT_ORTHO_MAXIT, OPT_CASLR_ALGORITHM, OPT_STAGE_CHUNKS = 1, 2, 3, 4, 5, 6, 7, 8
 OPT_P2P_TIMEOUT_MS = 9
 OPT_RUN_AHEAD = 10
+OPT_PENDING_BLOCKS = 11
 ERR_NO_DEVICE, ERR_ALLOC, ERR_ARG, ERR_RUNTIME, ERR_ORTHO, ERR_LAPACK, ERR_COMM = 1, 2, 3, 4, 5, 6, 7
 OP_NAMES = ["gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd"]
 
@@ -41,7 +42,7 @@ EXPORTS = [
     "dla_call_matvec", "dla_call_precnd", "dla_expand_project", "dla_expand_project_metric",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
     "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd", "dla_synth_apbmul", "dla_synth_ambmul", "dla_synth_spdmul", "dla_synth_smdmul",
-    "dla_synth_metric", "dla_synth_lrprec1", "dla_synth_lrprec2", "dla_pending_factor", "dla_spmm_setup_csr", "dla_spmm_setup_csr_sharded", "dla_spmm_matvec", "dla_spmm_precnd",
+    "dla_synth_metric", "dla_synth_lrprec1", "dla_synth_lrprec2", "dla_pending_factor", "dla_pending_block", "dla_basis_admit", "dla_basis_fold", "dla_spmm_setup_csr", "dla_spmm_setup_csr_sharded", "dla_spmm_matvec", "dla_spmm_precnd",
     "dla_davidson_driver", "dla_gen_david_driver", "dla_lobpcg_driver", "dla_caslr_eff_driver", "dla_caslr_driver", "dla_call_lrprec",
     "dla_last_solve_info", "dla_set_solve_info",
 ]
@@ -129,6 +130,9 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_trtri_lower": (i, [i, c_dp, i]), "dla_norm_est": (d, [i, c_dp, i]),
         "dla_synth_setup": (i, [vp, C.c_longlong, C.c_longlong, i, i, d]),
         "dla_pending_factor": (i, [vp, i, vp, i]),
+        "dla_pending_block": (i, [vp, i, i, vp, i, vp]),
+        "dla_basis_admit": (i, [i, i, vp, i, i, vp, vp, vp, i]),
+        "dla_basis_fold": (i, [i, i, vp, i, vp, i]),
         "dla_spmm_setup_csr": (i, [vp, i, vp, vp, vp]),
         "dla_spmm_setup_csr_sharded": (i, [vp, i, C.c_longlong, C.c_longlong, vp, vp, vp]),
         "dla_davidson_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, c_ip]),
@@ -428,6 +432,26 @@ class Context:
         t = np.zeros((k, k), order="F")
         self._chk(self.lib.dla_pending_factor(self.h, k, _dp(t), k))
         return t
+
+    def pending_block(self, m: int, k: int) -> np.ndarray:
+        """[E ; T] ((m + k) x k): what the last expand_project(mode 3 / 4) left pending -- the finished block is
+        [X | U_stored] p ([0 ; I] when nothing stayed pending)"""
+        p = np.zeros((m + k, k), order="F")
+        applied = C.c_int(0)
+        self._chk(self.lib.dla_pending_block(self.h, m, k, _dp(p), m + k, C.byref(applied)))
+        self.pending_applied = bool(applied.value)       # the chain's closing sweep has applied p in memory (see the header)
+        return p
+
+    def basis_admit(self, m: int, k: int, p: np.ndarray, hraw: np.ndarray, dmat: np.ndarray, h: np.ndarray, applied: bool = False) -> None:
+        """dla_basis_admit on square Fortran-ordered arrays of one leading dimension (in place; p is completed in place)"""
+        ld = h.shape[0]
+        assert hraw.shape == dmat.shape == h.shape and all(a.flags.f_contiguous for a in (p, hraw, dmat, h))
+        self._chk(self.lib.dla_basis_admit(m, k, _dp(p), p.shape[0], 1 if applied else 0, _dp(hraw), _dp(dmat), _dp(h), ld))
+
+    def basis_fold(self, rows: int, dmat: np.ndarray, c: np.ndarray) -> None:
+        """c[:rows] <- dmat[:rows, :rows] c[:rows] (in place)"""
+        assert dmat.flags.f_contiguous and c.flags.f_contiguous
+        self._chk(self.lib.dla_basis_fold(rows, c.shape[1], _dp(dmat), dmat.shape[0], _dp(c), c.shape[0]))
 
     def expand_project(self, mode: int, basis: DevPanel, abasis: DevPanel, m: int, k: int, matvec: int, shift: float = 0.0) -> np.ndarray:
         """dla_expand_project on the leading m + k columns of the two panels: ortho_vs_x(X, U), AU = A U + shift U, then the

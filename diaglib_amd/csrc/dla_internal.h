@@ -78,15 +78,20 @@ struct BlockOps {
   // set by a caller that B-orthonormalises the block by Cholesky-QR right behind ortho_vs_x (dla_expand_project_metric): a device
   // chain may then end without applying its last pending triangular factor (OrthoTailArgs::drop_final in hip_engine.hip)
   bool drop_final = false;
-  // ... and with publish_pending the chain hands that factor to the host instead (pending_factor): for a caller that folds it into
-  // its small matrices and coefficient blocks -- LOBPCG's W block is used once and rebuilt, so it never has to be written
-  // (dla_expand_project mode 3).  Default: the identity (nothing is ever pending in the host-driven loops).
+  // ... and with publish_pending the chain hands what it left undone to the host instead (pending_block): for a caller that folds it
+  // into its small matrices and coefficient blocks (dla_expand_project modes 3 and 4).  p = [E ; T] is (m + k) x k: the finished
+  // block is [X | U_stored] p -- T the upper-triangular factor that was not applied, E the closing projection that was not run
+  // (only the three-pass schedule of the device chain leaves one).  Default: [0 ; I] (nothing is ever pending in the host-driven loops).
   bool publish_pending = false;
-  double drop_final_tol = 0.0;     // > 0: the factor stays pending only when the closing pass found max |U^T U - I| below it
-  virtual int pending_factor(int k, double* t, int ldt)
+  double drop_final_tol = 0.0;     // > 0: the block stays pending only when the closing pass found max |U^T U - I| below it
+  double drop_final_stol = 1.0e-4; // ... and max |X^T U| of the stored block below this (three-pass schedule)
+  // *applied = 1: the chain's closing sweep HAS applied p to the block in memory (it ran without measuring anything): the block in
+  // memory is [X | U_measured] p, and what the caller still owes it is the k x k factor of its Gram matrix I - E^T E
+  virtual int pending_block(int m, int k, double* p, int ldp, int* applied)
   {
     for (int j = 0; j < k; ++j)
-      for (int i = 0; i < k; ++i) t[(size_t)i + (size_t)j * ldt] = (i == j) ? 1.0 : 0.0;
+      for (int i = 0; i < m + k; ++i) p[(size_t)i + (size_t)j * ldp] = (i == m + j) ? 1.0 : 0.0;
+    if (applied) *applied = 0;
     return 0;
   }
   int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests
@@ -330,10 +335,11 @@ struct dla_ctx {
   int callback_order = 1;    // DLA_OPT_CALLBACK_ORDER (default: host-synchronised, safe for callbacks on any stream)
   int p2p_timeout_ms = 5000; // DLA_OPT_P2P_TIMEOUT_MS
   int run_ahead = 1;         // DLA_OPT_RUN_AHEAD
+  int pending_blocks = 1;    // DLA_OPT_PENDING_BLOCKS
   long long n_global = -1;   // -1: single shard, n_global == n
   long long row0 = 0;
-  std::vector<double> pending_t;   // dla_expand_project mode 3: the factor the last call left pending (k x k, ld k)
-  int pending_k = 0;
+  std::vector<double> pending_p;   // dla_expand_project modes 3 / 4: the block [E ; T] the last call left pending ((m + k) x k, ld m + k)
+  int pending_k = 0, pending_m = 0, pending_applied = 0;
   std::string err;
   // pinned staging buffers for host-mode callbacks
   double* stage_x = nullptr;

@@ -100,6 +100,8 @@ struct GramArgs {
   int noskip;        // A/B: issue the loads of fully padded column groups too (gram_lds_kernel)
   const double* wp;  // gram_lds_kernel WP: pending factor of the U block, packed [16][16] (wp[16 p + j] = W(p, j)); nullptr = identity
   double* uw;        // gram_lds_kernel WP: when set, the transformed tiles U W are also written back (the panel address of U)
+  const double* cx;  // gram_lds_kernel WP == 2: the coefficient block C' of a projection sweep, packed [l4][16] (rows 0 .. l-1 belong to
+                     // the columns of X, rows l .. l+k-1 to the columns of U, zero padded): the staged U tile is replaced by [X | U] C'
 };
 
 // A launch of a device-driven chain is speculative: the step it belongs to may not be the one the device-side state
@@ -277,11 +279,17 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a)
 // X^T U and the Gram matrix of U in one sweep over [X | U].  With GramArgs::uw the transformed tiles are written back as well
 // (full 128-byte column segments, straight from the staged image): the triangular update, the Gram matrix of its result
 // and X^T of its result in ONE sweep, all three taken from the very values that reach memory.
+// WP == 2 (one U tile, the whole of X in this one pass): the projection sweep of ortho_vs_x itself, U <- [X | U] C' (reference
+// diaglib.f90:3544 with the pending triangular factor folded in, see OP_COMBOX).  A wave's 16 (32) rows of ALL columns of [X | U]
+// sit in its staged image, so the new U tile is (l + k) / 4 MFMAs away (D^T = C'^T [X | U]^T, the coefficients C'(4 s + g, c) in
+// registers for the whole sweep); it replaces the U tile in the image, goes to memory, and X^T U_new / U_new^T U_new are formed from
+// the very values that were stored -- the measurement the NEXT projection (or the closing one) needs, without another pass over X.
 template <int TLW, int KT, int NT = 1, int R = 16, int SELF = 0, int QT = 0, int LOW = 0, int WP = 0>
 __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
 {
   DLA_PREDICATED(a);
   static_assert(!WP || (QT == 0 && LOW == 0 && KT <= 3 && (KT == 1 || (!SELF && R == 16))), "pending factor: up to three U tiles");
+  static_assert(WP != 2 || (KT == 1 && !SELF), "projection sweep: one U tile beside the X tiles");
   constexpr int UU = (WP && !SELF) ? KT * (KT + 1) / 2 : 0;   // extra output slots: the tiles (qi >= qj) of (U W)^T (U W)
   constexpr int NSLOT = TLW * KT + UU;
   // R rows per wave tile (16 or 32): R/2 lanes cover one column segment, 128/R columns per load instruction
@@ -357,8 +365,18 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   for (int e = 0; e < (UU > 0 ? UU : 1); ++e) accuu[e] = (v4d){0.0, 0.0, 0.0, 0.0};
   // A operands of the tile transform: W(16 p + 4 s + g, 16 q + c) for the tile pairs p <= q (W is upper triangular).
   // One tile: wp is the 16 x 16 image ortho_tail16 writes; more: the packed [KT][k4][16] image of ortho_tail (rows >= k4 are not there)
-  double wa[WP ? KT * (KT + 1) / 2 : 1][WP ? 4 : 1];
-  if constexpr (WP) {
+  double wa[WP == 1 ? KT * (KT + 1) / 2 : 1][WP == 1 ? 4 : 1];
+  // WP == 2: A operands of the projection, C'(row of staged column 4 s + g, c); staged columns beyond the block get a zero
+  double ca[WP == 2 ? 4 * (TLW + 1) : 1];
+  if constexpr (WP == 2) {
+#pragma unroll
+    for (int s = 0; s < 4 * (TLW + 1); ++s) {
+      const int sc = 4 * s + g;
+      const int row = sc < 16 * TLW ? (sc < a.l ? sc : -1) : (sc - 16 * TLW < a.k ? a.l + sc - 16 * TLW : -1);
+      ca[s] = row >= 0 ? a.cx[(size_t)row * 16 + c] : 0.0;
+    }
+  }
+  if constexpr (WP == 1) {
     const int k4w = ((a.k + 3) / 4) * 4;
 #pragma unroll
     for (int q = 0; q < KT; ++q)
@@ -403,10 +421,25 @@ __global__ __launch_bounds__(256) void gram_lds_kernel(GramArgs a)
   // WP: staged U tile <- (U tile) W, 16 rows at a time
   auto apply_w = [&](long long r0w, bool rows_ok) {
     if constexpr (WP) {
-      if (a.wp == nullptr && a.uw == nullptr) return;      // nothing pending: the staged tile is the block itself
+      if (WP == 1 && a.wp == nullptr && a.uw == nullptr) return;      // nothing pending: the staged tile is the block itself
       // (all fragment reads first, then the MFMA chains of the R / 16 row groups side by side, then the stores)
       double* ut = my + (size_t)UOFF * RS + c;
-      if constexpr (KT == 1) {
+      if constexpr (WP == 2) {
+        // U_new[row c][g + 4 r] = sum over the staged columns j of [X | U][row c][j] C'(j, g + 4 r)
+        v4d d[R / 16];
+#pragma unroll
+        for (int h = 0; h < R / 16; ++h) d[h] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4 * (TLW + 1); ++s)
+#pragma unroll
+          for (int h = 0; h < R / 16; ++h)
+            d[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[s], lds_load1(my + (size_t)(4 * s + g) * RS + c + 16 * h), d[h], 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < R / 16; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds_store1(ut + (size_t)(g + 4 * r) * RS + 16 * h, d[h][r]);
+      } else if constexpr (KT == 1) {
         double uin[R / 16][4];
 #pragma unroll
         for (int h = 0; h < R / 16; ++h)
@@ -1667,7 +1700,15 @@ __global__ void halo_pack_kernel(int n, int m, int halo, int nranks, int rank, c
 // wrong guess costs empty launches, never a wrong result.  One host wait at the end reads the state back.
 // OP_GRAMX / OP_GRAMW / OP_XW belong to the pending-factor schedule (k <= 16, even n; see ortho_tail16): X^T U and U^T U in one
 // sweep over [X | U]; the Gram matrix of U W formed on the fly; both at once
-enum { OP_NONE = 0, OP_GRAM_UU = 1, OP_TRMMG = 2, OP_XU = 3, OP_COMBO = 4, OP_FINAL = 5, OP_GRAMX = 6, OP_GRAMW = 7, OP_XW = 8 };
+// OP_COMBOX / OP_CLOSE belong to the three-pass schedule (OrthoTailArgs::x3, see ortho_tail16): the projection sweep that also
+// measures X^T U and U^T U of what it stores, and the closing projection that measures nothing
+enum { OP_NONE = 0, OP_GRAM_UU = 1, OP_TRMMG = 2, OP_XU = 3, OP_COMBO = 4, OP_FINAL = 5, OP_GRAMX = 6, OP_GRAMW = 7, OP_XW = 8,
+       OP_COMBOX = 9, OP_CLOSE = 10 };
+// the block a chain leaves pending, in pinned host memory: [row][PEND_LD] with the rows of E (the part that multiplies X: only the
+// three-pass schedule has one) followed by the k rows of the triangular factor T, then the header {sequence number, rows of E}
+#define PEND_LD 48
+#define PEND_ROWS 640
+#define PEND_HDR ((size_t)PEND_ROWS * PEND_LD)
 enum { OST_RUNNING = 0, OST_DONE = 1, OST_CD_MAXIT = 2, OST_FACTOR_FAIL = 3, OST_VSX_MAXIT = 4 };
 
 struct OrthoDev {
@@ -1706,13 +1747,14 @@ struct OrthoTailArgs {
   unsigned long long* dbg;   // $DIAGLIB_AMD_CHAIN_DEBUG: time stamps of the step (100 MHz ticks), 16 per executed sweep
   int xw_ok;           // blocks of 17..48 columns (ortho_tail): the storing sweep OP_XW exists for this shape -- a triangular update
                        // inside the loop is written together with X^T U and U^T U of what it stores (one sweep instead of two)
-  double* t_host;      // drop_final: pinned copy of the factor that stays pending, k x k column-major with ld 48, and behind it
-                       // (index 48 * 48) the chain's sequence number -- for callers that fold the factor into their small matrices
-                       // instead (LOBPCG's W block, dla_expand_project mode 3)
+  double* t_host;      // drop_final: pinned copy of the block that stays pending (layout: PEND_LD / PEND_HDR above; the header is
+                       // written last) -- for callers that fold it into their small matrices instead (dla_expand_project modes 3, 4)
   int t_seq;
+  double drop_stol;    // three-pass schedule: the closing block stays pending only when max |X^T U| of the stored block is below it
   double drop_tol;     // > 0: drop_final only when max |G - I| of the closing pass is below it (a block that STAYS in the basis may
                        // keep a pending factor only if later blocks can still be projected against it as if it were orthonormal:
                        // two passes leave (2 drop_tol)^2 of the component they remove)
+  int x3;              // three-pass schedule (ortho_tail16, fold == 1): every projection is OP_COMBOX, see there
   int drop_final;      // 1: the chain ends where it would ask for OP_FINAL -- the pending upper-triangular factor is NOT applied.
                        // For callers that B-orthonormalise the block by Cholesky-QR right behind the chain (dla_expand_project_metric:
                        // b_ortho, reference diaglib.f90:3094-3183): the Q factor of U W and of U is the same for any upper-triangular W
@@ -1826,7 +1868,7 @@ __device__ __forceinline__ void tail_publish(const OrthoTailArgs& a, const TailS
 // One step of the state machine, executed by the 64 lanes of one wave; lds: TAIL_LDS_DOUBLES doubles.
 // pre != nullptr: the caller has checked the phase and read the state already (fused into a reduction kernel);
 // g_in_lds: the caller has put the k x k Gram matrix into both LDS images (A and S) already.
-__device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const TailState* pre = nullptr, bool g_in_lds = false)
+__device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const TailState* pre = nullptr, bool g_in_lds = false)
 {
   OrthoDev* st = a.st;
   if (pre == nullptr) {
@@ -1847,12 +1889,17 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
   double* A = lds;
   double* S = lds + 48 * TLD;
   // C' = [-(xu W) ; W ; 0] packed for the combined sweep, W(pp, j) in the LDS image A (row pp), xu m x k with leading dimension ldx
-  auto assemble = [&](const double* xu, int ldx) {
+  // (to_host: the block stays pending -- the same rows also go to the caller's pinned buffer, the header last)
+  auto assemble = [&](const double* xu, int ldx, bool to_host) {
     const int l = m + k, l4 = ((l + 3) / 4) * 4;
     // rows that are not products: the W block, the zero padding of rows and columns
     for (int idx = lane; idx < kt * l4 * 16; idx += 64) {
       const int q = idx / (l4 * 16), p = (idx / 16) % l4, j = 16 * q + (idx % 16);
-      if (p >= m || j >= k) a.cpk[idx] = (p < l && j < k) ? lds_load1(A + (p - m) * TLD + j) : 0.0;
+      if (p >= m || j >= k) {
+        const double v = (p < l && j < k) ? lds_load1(A + (p - m) * TLD + j) : 0.0;
+        a.cpk[idx] = v;
+        if (to_host && p >= m && p < l && j < k) a.t_host[(size_t)p * PEND_LD + j] = v;
+      }
     }
     for (int p = lane; p < m; p += 64) {
       // row p of xu into the lane's own LDS row (the S image is free here), then the k dot products
@@ -1862,8 +1909,24 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
 #pragma unroll 4
         for (int pp = 0; pp <= j; ++pp) sacc += lds_load1(S + pp * 64 + lane) * lds_load1(A + pp * TLD + j);
         a.cpk[((size_t)(j / 16) * l4 + p) * 16 + (j % 16)] = -sacc;
+        if (to_host) a.t_host[(size_t)p * PEND_LD + j] = -sacc;
       }
     }
+    if (to_host) {
+      __threadfence_system();
+      if (lane == 0) { a.t_host[PEND_HDR + 1] = (double)m; a.t_host[PEND_HDR + 2] = 0.0; __threadfence_system(); a.t_host[PEND_HDR] = (double)a.t_seq; }
+    }
+  };
+  // A caller that folds pending blocks into its small matrices (drop_final + t_host) lets the chain END wherever X^T U has been
+  // measured on the stored block and the factor of that block's Gram matrix has converged: the closing pass of the reference
+  // (:3543-3544, then one macro-iteration with a near-identity factor) is then the block [-(xu W) ; W], which the caller applies
+  // to its coefficients exactly (dla_basis_admit) -- as long as xu is small enough for that algebra to be benign (drop_stol).
+  const bool may_pend = a.drop_final && a.t_host != nullptr && m > 0;
+  auto small_xu = [&](const double* xu, int ldx) {
+    double sm = 0.0;
+    for (int idx = lane; idx < m * k; idx += 64) sm = fmax(sm, fabs(xu[(size_t)(idx % m) + (size_t)(idx / m) * ldx]));
+    for (int off = 32; off > 0; off >>= 1) sm = fmax(sm, __shfl_xor(sm, off, 64));
+    return sm < a.drop_stol;
   };
 
   if (a.after == OP_FINAL) {
@@ -1872,10 +1935,12 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
     // C' = [-(xu W) ; W]  (host_logic.cpp ortho_vs_x_impl, X^T (U W) = (X^T U) W), packed for the combined sweep
     for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx % k) * TLD + idx / k, a.wfull[idx]);   // A[pp][j] = W(pp, j)
     TSYNC();
-    assemble(a.gsrc, m);
+    const bool pend = may_pend && small_xu(a.gsrc, m);
+    assemble(a.gsrc, m, pend);
     t.it_macro = 0;           // the ortho_cd that follows the combined sweep starts afresh (*growth = 1, it = 0)
     t.growth = 1.0;
-    t.phase = OP_COMBO;
+    if (pend) t.status = OST_DONE;
+    else t.phase = OP_COMBO;
   } else {
     // one macro-iteration of ortho_cd on the Gram matrix the sweep left in gsrc
     ++t.it_macro;
@@ -1942,7 +2007,7 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
         // OP_XW measured X^T U and U^T U on the block it stored.  When this factor ends the ortho_cd pass and ortho_vs_x goes on
         // (growth eps >= tol, :3562-3564), the next projection has its coefficients already: C' = [-(xu W) ; W] with the
         // factor of this step pending -- exactly what the separate X^T U sweep (OP_XU) would have produced
-        const bool xw_project = a.after == OP_XW && macro_done && can_defer && (t.sloppy || t.growth * eps >= tol) && t.it_outer <= maxit;
+        const bool xw_project = a.after == OP_XW && macro_done && can_defer && (t.sloppy || t.growth * eps >= tol || may_pend) && t.it_outer <= maxit;
         if ((a.after == OP_GRAMX && lead) || xw_project) {
           // X^T U came with the Gram matrix: the first projection follows at once, C' = [-(xu W) ; W] (one factorisation step
           // in front of the loop, closing pass mandatory after a factor that is not near the identity: see lead_once above)
@@ -1954,16 +2019,21 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
           TSYNC();
           for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx / k) * TLD + idx % k, lds_load1(S + (idx / k) * TLD + idx % k));
           TSYNC();
-          assemble(a.gsrc, m + k);
+          const bool pend = xw_project && may_pend && small_xu(a.gsrc, m + k);
+          assemble(a.gsrc, m + k, pend);
           t.sloppy = (!xw_project && t.growth * eps >= tol) ? 1 : 0;      // (a measured X^T U of the stored block is not sloppy)
           ++t.it_outer;
           t.it_macro = 0; t.growth = 1.0;
-          t.phase = OP_COMBO;
+          if (pend) t.status = OST_DONE;
+          else t.phase = OP_COMBO;
         } else if (!macro_done) {
           // inside the loop, without a level shift: the update is stored together with X^T U and U^T U of what it stores
           t.phase = (a.xw_ok && can_defer && !force_defer && it_micro == 0) ? OP_XW : OP_TRMMG;
-        } else if (can_defer && (force_defer || t.sloppy || t.growth * eps >= tol)) {
+        } else if (can_defer && (force_defer || t.sloppy || t.growth * eps >= tol || (a.drop_tol > 0.0 && t.it_outer < 2))) {
           // the pass ends with W pending; ortho_vs_x goes on with a projection pass (xu_norm = growth eps >= tol)
+          // (drop_tol > 0: the caller's stored basis may carry pending blocks -- it is orthonormal to drop_tol only, and ONE
+          //  projection against it leaves that share of the component it removes (round-4 advisor): there are always two, the
+          //  second one on a measured X^T U)
           if (!force_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;     // :3568
           else {
             // (a first projection whose pending factor is not the near-identity one of a converged macro-iteration leaves
@@ -1987,10 +2057,10 @@ __device__ void ortho_tail(const OrthoTailArgs& a, double* lds, int lane, const 
               // the factor that stays pending: W of this step (everything before it has been written by the sweeps)
               for (int idx = lane; idx < k * k; idx += 64) {
                 const int pp = idx % k, j = idx / k;
-                a.t_host[(size_t)pp + (size_t)j * 48] = (pp <= j) ? lds_load1(A + j * TLD + pp) : 0.0;
+                a.t_host[(size_t)pp * PEND_LD + j] = (pp <= j) ? lds_load1(A + j * TLD + pp) : 0.0;
               }
               __threadfence_system();
-              if (lane == 0) a.t_host[48 * 48] = (double)a.t_seq;
+              if (lane == 0) { a.t_host[PEND_HDR + 1] = 0.0; a.t_host[PEND_HDR + 2] = 0.0; a.t_host[PEND_HDR] = (double)a.t_seq; }
             }
           }
           else t.phase = OP_FINAL;
@@ -2225,7 +2295,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // One step of the state machine for k <= 16, called by ALL 256 threads of a block (wave 0 does the serial part, all four
 // waves assemble the coefficient block of a projection sweep).  g_in_lds: lds[64 r + lane] already holds the Gram matrix
 // in C-layout (a single-tile reduction hands it over from its registers).
-__device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailState* pre, bool g_in_lds, unsigned long long t_entry = 0)
+__device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailState* pre, bool g_in_lds, unsigned long long t_entry = 0)
 {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -2233,7 +2303,9 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
   __shared__ int s_go;
   if (pre == nullptr) {
     const int ph = __hip_atomic_load(&st->phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int need = a.after == OP_GRAMX ? (int)OP_GRAM_UU : a.after;     // (the first sweep of any chain answers the start phase)
+    // (the first sweep of any chain answers the start phase; in a three-pass chain the plain projection sweep may stand in for the
+    //  measuring one -- the host picks the one the previous chain of this kind could have used, see ortho_chain_begin)
+    const int need = a.after == OP_GRAMX ? (int)OP_GRAM_UU : (a.x3 && a.after == OP_COMBO) ? (int)OP_COMBOX : a.after;
     if (ph != need) {
       if (a.publish && tid == 0 && st->nops > 0) *a.st_host = *st;
       return;
@@ -2243,7 +2315,8 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
   const double eps = 2.220446049250313e-16, tol = 2.0 * eps;
   const int maxit = a.maxit, can_defer = a.can_defer;
   const int after = a.after;
-  const bool sweep_xu = (after == OP_GRAMX || after == OP_XW);          // this sweep formed xu (and G) in xug, on the stored block
+  const bool sweep_xu = (after == OP_GRAMX || after == OP_XW || after == OP_COMBOX);   // this sweep formed xu (and G) in xug, on the stored block
+  const int op_project = a.x3 ? (int)OP_COMBOX : (int)OP_COMBO;       // the projection sweep of this chain
   // coefficient source of a possible assembly: rows of xu, prefetched by every wave (tiles wave, wave + 4, ...)
   const double* xsrc = (after == OP_XU || sweep_xu) ? a.gsrc : a.xug;
   const int ldx = (after == OP_XU) ? m : m + k;
@@ -2260,6 +2333,40 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
     }
   double* lds_d = lds + 272;
   double* lds_p = lds + 528;
+  // max |X^T U| of the stored block (three-pass schedule: what a closing projection on the small side has to be small against)
+  __shared__ double s_smax[4];
+  __shared__ double s_colsq[4][16];            // sum over this wave's rows of S(row, col)^2
+  const bool meas_sweep = a.x3 && (after == OP_COMBOX || after == OP_XW);    // S = X^T U and G = U^T U measured on the block the sweep stored
+  // a caller that folds pending blocks into its small matrices: the chain ends wherever X^T U has been measured on the stored block
+  // and the factor of that block has converged (see ortho_tail) -- for the sweep-per-update schedule that is the step behind OP_XU
+  const bool may_pend = a.drop_final && a.t_host != nullptr && m > 0;
+  if (meas_sweep || (may_pend && after == OP_XU)) {
+    double sm = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sm = fmax(sm, fabs(xa[q][s]));
+    for (int t0 = 16 * (wave + 16); t0 < m; t0 += 64)          // (m > 256: the rows beyond the prefetched ones)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int row = t0 + c, col = 4 * s + g;
+        if (row < m && col < k) sm = fmax(sm, fabs(__hip_atomic_load(xsrc + (size_t)row + (size_t)col * ldx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sm = fmax(sm, __shfl_xor(sm, off, 64));
+    if (lane == 0) s_smax[wave] = sm;
+    // column 4 s + g: the 16 lanes of row group g hold its rows (m <= 256 here: the measuring sweeps take m <= 192)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double sq = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sq += xa[q][s] * xa[q][s];
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+      if (c == 0) s_colsq[wave][4 * s + g] = sq;
+    }
+    __syncthreads();
+  }
   if (wave == 0) {
     TailState t = pre ? *pre : TailState{st->it_macro, st->it_outer, st->macro_total, st->shifts, st->nops, OP_NONE, OST_RUNNING, st->growth, st->have_xu, st->sloppy};
     t.phase = OP_NONE; t.status = OST_RUNNING;
@@ -2269,15 +2376,15 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
     const int dslot = t.nops;
     if (lane == 0 && a.dbg != nullptr && dslot < 48) { a.dbg[dslot * 16 + 8] = t_entry; a.dbg[dslot * 16 + 9] = (unsigned long long)after; }
     if (lane == 0) TSTAMP(a, dslot, 0);
-    if (after == OP_FINAL) {
+    if (after == OP_FINAL || after == OP_CLOSE) {
       t.status = OST_DONE;
     } else if (after == OP_XU) {
       // the block in memory is U_mem with Wp pending: C' = [-(X^T U_mem) Wp ; Wp]
 #pragma unroll
       for (int r = 0; r < 4; ++r) { pnew[r] = a.wst[512 + 64 * r + lane]; dnew[r] = pnew[r]; }
       t.it_macro = 0; t.growth = 1.0; t.have_xu = 0; t.sloppy = 0;
-      t.phase = OP_COMBO;
-      go = 1;
+      if (may_pend && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) < a.drop_stol) { t.status = OST_DONE; go = 2; }
+      else { t.phase = op_project; go = 1; }
     } else {
       ++t.it_macro;
       if (t.it_macro > maxit) {
@@ -2398,7 +2505,72 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
           // keeps the reference's order of operations (see ortho_tail), because its weakest columns are amplified rounding
           // noise whose realisation depends on that order and the solvers' convergence history on the noise.
           const bool macro_done = (eps * rcond * rcond < tol) || (stage0 && a.lead_once && a.fold == 1 && after == OP_GRAMX && it_micro == 0);      // :3331-3332
-          if (!macro_done) {
+          // Three-pass schedule (x3).  OP_COMBOX (and OP_XW) have measured S = X^T U and G = U^T U on the block they stored, so their
+          // step never needs a sweep that only measures:
+          //   * factor not converged (the block that comes out of the first projection is as ill-conditioned as the expansion
+          //     vectors are dependent -- 1e7 on the benchmark): the next projection follows at once, C' = [-(S W) ; W].  It removes
+          //     what the last one left (S is measured, not carried) and applies W in the same sweep -- the reference's second pass
+          //     over X (:3543-3544) moved in front of the second macro-iteration of ortho_cd instead of behind it.  Its result
+          //     carries an X component of order eps ||W||: the closing projection is mandatory (sloppy).  (After a level shift the
+          //     reference's order is kept, as everywhere: written update, then OP_XW.)
+          //   * factor converged: the reference's closing pass is  S = X^T U (:3543), U -= X S (:3544), one macro-iteration of
+          //     ortho_cd with a near-identity factor (:3256-3327).  S and G are already here, measured on the stored block.
+          //       - a caller that folds pending blocks into its small matrices (drop_final + t_host) gets [-(S W) ; W] and the chain
+          //         ENDS: no sweep at all.  The caller finishes the algebra exactly (dla_basis_admit: the Gram matrix of the
+          //         projected block is G - S^T S, which it corrects with a k x k factor of its own), so S only has to be small
+          //         enough for that correction to be well conditioned and for the stored basis to stay a good one for the
+          //         projections of later blocks: max |S| below drop_stol, max |G - I| below drop_tol;
+          //       - otherwise the pass is the single sweep U <- [X | U] [-(S W) ; W] (OP_CLOSE, nothing measured behind it -- the
+          //         reference does not measure behind its last update either), when it is due (sloppy, growth eps >= tol_ortho,
+          //         :3562-3564).  G was measured before the projection instead of after it: the two differ by S^T S, so this
+          //         takes place only for max |S| < 1e-9 (m |S|^2 below eps); a larger S gets one more measured projection.
+          const bool cx_step = meas_sweep && !stage0 && it_micro == 0;
+          const double smax = cx_step ? fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) : 0.0;
+          bool pend = false, pend_e = false, pend_r = false;
+          // (X^T U too large to stay on the small side of a basis that has to remain orthonormal in memory, but small enough for the
+          //  Gram matrix of the projected block, I - (S W)^T (S W), to be factored by the caller: the closing sweep runs without
+          //  measuring anything and the caller gets [-(S W) ; W] marked APPLIED -- it owes the block only the k x k factor)
+          if (cx_step && macro_done && may_pend && smax >= a.drop_stol && t.it_outer <= maxit) {
+            // |(S^T S)_ij| <= max_j sum_i S_ij^2: what the block's Gram matrix in memory will be off the identity by
+            double cs = lane < 16 ? ((s_colsq[0][lane] + s_colsq[1][lane]) + s_colsq[2][lane]) + s_colsq[3][lane] : 0.0;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) cs = fmax(cs, __shfl_xor(cs, off, 64));
+            cs = rlane(cs, 0);
+            pend_r = 2.0 * cs < (a.drop_tol > 0.0 ? a.drop_tol : 1.0e-8);
+            if (lane == 0 && a.dbg != nullptr && dslot < 48) a.dbg[dslot * 16 + 14] = (unsigned long long)__double_as_longlong(cs);
+          }
+          if (cx_step && macro_done && may_pend && smax < a.drop_stol) {
+            double dev = 0.0;              // max |G - I| of this pass (g0: the Gram matrix, identity beyond k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dev = fmax(dev, fabs(g0[r] - ((g + 4 * r == c) ? 1.0 : 0.0)));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dev = fmax(dev, __shfl_xor(dev, off, 64));
+            pend = a.drop_tol <= 0.0 || dev < a.drop_tol;
+            pend_e = !pend;
+          }
+          if (lane == 0 && a.dbg != nullptr && dslot < 48) a.dbg[dslot * 16 + 13] = (unsigned long long)__double_as_longlong(smax);
+          if (pend) {
+            t.status = OST_DONE; go = 2;                          // the closing block stays pending
+          } else if (pend_e) {
+            // X^T U is small enough to stay on the small side, the factor is not (a block that stays in the caller's basis has to
+            // be orthonormal to drop_tol in memory): the projection stays pending, [-(S W) ; I], and the factor is applied by the
+            // cheapest sweep there is (U <- U W, nothing of X is read)
+            t.phase = OP_FINAL; go = 3;
+          } else if (pend_r) {
+            t.phase = OP_CLOSE; go = 4;
+          } else if (cx_step && (!macro_done || smax >= 1.0e-9)) {
+            if (t.it_outer > maxit) t.status = OST_VSX_MAXIT;     // :3568
+            else {
+              ++t.it_outer;
+              t.sloppy = macro_done ? 0 : 1;
+              t.it_macro = 0; t.growth = 1.0; t.have_xu = 0; t.phase = OP_COMBOX; go = 1;
+            }
+          } else if (cx_step) {
+            const bool need_proj = t.sloppy || t.growth * eps >= tol || may_pend;
+            if (t.it_outer > maxit && need_proj) t.status = OST_VSX_MAXIT;
+            else if (need_proj || smax >= 64.0 * eps) { t.phase = OP_CLOSE; go = 1; }
+            else t.phase = OP_FINAL;
+          } else if (!macro_done) {
             // another macro-iteration.  In front of the loop its Gram matrix comes from U_mem Wp on the fly -- unless the
             // factorisation needed a level shift (rank-deficient block: the update is written); inside the loop the update is
             // written, together with X^T U and U^T U of what is stored (OP_XW) when it is expected to be the last one
@@ -2409,14 +2581,15 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
             //  what it stores on its way, a wrong guess costs one more sweep over X)
             else if (it_micro == 0) t.phase = OP_XW;
             else { t.phase = OP_TRMMG; t.have_xu = 0; }
-          } else if (can_defer && (force_defer || t.sloppy || t.growth * eps >= tol)) {
+          } else if (can_defer && (force_defer || t.sloppy || t.growth * eps >= tol || (a.drop_tol > 0.0 && t.it_outer < 2))) {
             // ortho_vs_x goes on with a projection pass (xu_norm = growth eps >= tol, :3562-3564)
+            // (drop_tol > 0: always two projections against a basis that may carry pending blocks, see ortho_tail)
             if (!force_defer && t.it_outer > maxit) t.status = OST_VSX_MAXIT;     // :3568
             else {
               ++t.it_outer;
               if (t.have_xu) {
                 t.sloppy = (stage0 && t.growth * eps >= tol) ? 1 : 0;
-                t.it_macro = 0; t.growth = 1.0; t.have_xu = 0; t.phase = OP_COMBO; go = 1;
+                t.it_macro = 0; t.growth = 1.0; t.have_xu = 0; t.phase = op_project; go = 1;
               }
               else t.phase = OP_XU;
             }
@@ -2434,10 +2607,10 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const int pp = g + 4 * r;
-                  if (pp < k && c < k) a.t_host[(size_t)pp + (size_t)c * 48] = pnew[r];
+                  if (pp < k && c < k) a.t_host[(size_t)pp * PEND_LD + c] = pnew[r];
                 }
                 __threadfence_system();
-                if (lane == 0) a.t_host[48 * 48] = (double)a.t_seq;
+                if (lane == 0) { a.t_host[PEND_HDR + 1] = 0.0; a.t_host[PEND_HDR + 2] = 0.0; a.t_host[PEND_HDR] = (double)a.t_seq; }
               }
             }
             else t.phase = OP_FINAL;
@@ -2454,6 +2627,11 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
   __syncthreads();
   if (!s_go) return;
   // C' = [-(xu Wd) ; Wp ; 0], packed [l4][16] for the projection sweep; 16 rows of xu per MFMA quadruple
+  // (s_go >= 2: the block stays pending -- it also goes to the caller's pinned buffer, the header last; 3: only its projection
+  //  part does, the factor is applied in memory by the OP_FINAL sweep that follows)
+  const bool to_host = s_go >= 2;
+  const bool t_ident = s_go == 3;
+  const double applied = s_go == 4 ? 1.0 : 0.0;     // 4: the whole block is applied in memory by the OP_CLOSE sweep that follows
   const int l = m + k, l4 = ((l + 3) / 4) * 4;
   double db[4];
 #pragma unroll
@@ -2469,6 +2647,7 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
     for (int r = 0; r < 4; ++r) {
       const int p_ = t0 + g + 4 * r;
       if (p_ < m) a.cpk[(size_t)p_ * 16 + c] = (c < k) ? -acc[r] : 0.0;
+      if (to_host && p_ < m && c < k) a.t_host[(size_t)p_ * PEND_LD + c] = -acc[r];
     }
   }
   // (m > 256: the tiles beyond the prefetched ones)
@@ -2484,6 +2663,7 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
     for (int r = 0; r < 4; ++r) {
       const int p_ = t0 + g + 4 * r;
       if (p_ < m) a.cpk[(size_t)p_ * 16 + c] = (c < k) ? -acc[r] : 0.0;
+      if (to_host && p_ < m && c < k) a.t_host[(size_t)p_ * PEND_LD + c] = -acc[r];
     }
   }
   if (wave == 0) {
@@ -2491,9 +2671,15 @@ __device__ void ortho_tail16(const OrthoTailArgs& a, double* lds, const TailStat
     for (int r = 0; r < 4; ++r) {
       const int pp = g + 4 * r;
       if (pp < k) a.cpk[(size_t)(m + pp) * 16 + c] = (c < k) ? lds_load1(lds_p + 64 * r + lane) : 0.0;
+      if (to_host && pp < k && c < k) a.t_host[(size_t)(m + pp) * PEND_LD + c] = t_ident ? (pp == c ? 1.0 : 0.0) : lds_load1(lds_p + 64 * r + lane);
     }
     for (int idx = lane; idx < (l4 - l) * 16; idx += 64) a.cpk[(size_t)l * 16 + idx] = 0.0;
     if (lane == 0 && pre != nullptr) TSTAMP(a, pre->nops, 7);
+  }
+  if (to_host) {
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) { a.t_host[PEND_HDR + 1] = (double)m; a.t_host[PEND_HDR + 2] = applied; __threadfence_system(); a.t_host[PEND_HDR] = (double)a.t_seq; }
   }
 }
 
@@ -2592,7 +2778,7 @@ struct P2PArgs {
 };
 
 // the exchange itself, executed by the 256 threads of ONE block (ends with a block barrier); false: a peer timed out
-__device__ bool p2p_exchange(const P2PArgs& a)
+__device__ __forceinline__ bool p2p_exchange(const P2PArgs& a)
 {
   const unsigned long long seq = *a.executed + 1;
   const int tid = threadIdx.x, par = (int)(seq & 1ULL);
@@ -3412,6 +3598,8 @@ struct HipEngine : dla::Engine {
   bool chain_reduced = false;        // the last RCCL all-reduce of a chain went out of place (d_red_small / d_red_xug)
   double* chain_red_dst = nullptr;   // ... to this buffer
   bool chain_xw = false;             // the chain being enqueued may use the storing sweep OP_XW for its wide block (ortho_tail)
+  bool chain_x3 = false;             // the chain being enqueued runs the three-pass schedule (OP_COMBOX / OP_CLOSE, ortho_tail16)
+  int x3_cooldown = 0;               // > 0: a recent chain needed a level shift -- that many chains run the five-sweep schedule
   // ---- one-shot peer-to-peer all-reduce (p2p_allreduce_kernel)
   struct P2P {
     bool on = false;
@@ -3614,9 +3802,9 @@ struct HipEngine : dla::Engine {
     HIPCHK(hipMalloc((void**)&d_wst, sizeof(double) * 768));
     if (chain_debug) { HIPCHK(hipMalloc((void**)&d_dbg, sizeof(unsigned long long) * 48 * 16)); HIPCHK(hipMemsetAsync(d_dbg, 0, sizeof(unsigned long long) * 48 * 16, st)); }
     HIPCHK(hipMalloc((void**)&d_xug, sizeof(double) * XUG_DOUBLES));
-    HIPCHK(hipHostMalloc((void**)&h_tpend, sizeof(double) * (48 * 48 + 8), hipHostMallocMapped));
+    HIPCHK(hipHostMalloc((void**)&h_tpend, sizeof(double) * (PEND_HDR + 8), hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&h_tpend_dev, h_tpend, 0));
-    h_tpend[48 * 48] = 0.0;
+    h_tpend[PEND_HDR] = 0.0; h_tpend[PEND_HDR + 1] = 0.0; h_tpend[PEND_HDR + 2] = 0.0;
     HIPCHK(hipMalloc((void**)&d_red_small, sizeof(double) * RED_DOUBLES));
     HIPCHK(hipMalloc((void**)&d_red_xug, sizeof(double) * RED_DOUBLES));
     return DLA_OK;
@@ -3650,14 +3838,17 @@ struct HipEngine : dla::Engine {
   {
     pending_tail = OrthoTailArgs{d_ost, h_ost_dev, d_small, d_wpk, d_wfull, d_cpk2, op, m, k, m > 0 ? 1 : 0, ortho_maxit, publish ? 1 : 0,
                                  fold, tune[6] == 7 ? 0 : 1, d_xug, d_wst, d_dbg, chain_xw ? 1 : 0};
-    if ((fold == 1 && op == OP_GRAMX) || op == OP_XW) pending_tail.gsrc = d_xug;
+    if ((fold == 1 && op == OP_GRAMX) || op == OP_XW || op == OP_COMBOX) pending_tail.gsrc = d_xug;
+    pending_tail.x3 = chain_x3 ? 1 : 0;
     pending_tail.drop_final = (drop_final && m > 0) ? 1 : 0;
-    pending_tail.t_host = (pending_tail.drop_final && publish_pending) ? h_tpend_dev : nullptr;
+    pending_tail.t_host = (pending_tail.drop_final && publish_pending && m + k <= PEND_ROWS) ? h_tpend_dev : nullptr;
     pending_tail.t_seq = t_seq;
     pending_tail.drop_tol = drop_final_tol;
+    pending_tail.drop_stol = drop_final_stol;
     fuse_tail = p2p.on ? tune[6] != 4 : (nranks <= 1 && !comm);     // (knob 6 = 4: the exchange as a launch of its own)
     tail_fused = false;
-    pred_phase = &d_ost->phase; pred_want = (op == OP_GRAMX) ? (int)OP_GRAM_UU : op;   // the first sweep answers the start phase
+    pred_phase = &d_ost->phase;
+    pred_want = (op == OP_GRAMX) ? (int)OP_GRAM_UU : (chain_x3 && op == OP_COMBO) ? (int)OP_COMBOX : op;   // the first sweep answers the start phase
     int stc = DLA_OK;
     switch (op) {
       case OP_GRAM_UU: stc = gram_dev_once(n, k, u, k, u, DLA_OP_GRAM, false); break;
@@ -3677,6 +3868,9 @@ struct HipEngine : dla::Engine {
         if (!stc) stc = fused_reduce(k);
         break;
       case OP_FINAL:   stc = gemm_chunk(n, 0, k, u, k, nullptr, 0, u, 2, DLA_OP_TRMM, false, d_wpk); break;
+      // three-pass schedule: the projection that measures what it stores, and the closing one that measures nothing
+      case OP_COMBOX:  stc = gram_wp_once(n, m, bx, k, u, nullptr, u, d_cpk2); break;
+      case OP_CLOSE:   stc = gemm_chunk(n, 0, m + k, x, k, nullptr, 0, u, 0, DLA_OP_GEMM, false, d_cpk2); break;
       default: err = "ortho_chain: bad op"; stc = DLA_ERR_ARG;
     }
     pred_phase = nullptr; pred_want = 0;
@@ -3700,6 +3894,17 @@ struct HipEngine : dla::Engine {
   template <int TLW, int KT, int R>
   int launch_gram_wp(const GramArgs& a, dim3 grid, bool self)
   {
+    if (a.cx != nullptr) {
+      // the projection sweep (WP == 2): one U tile
+      if constexpr (KT == 1) {
+        auto kfn = gram_lds_kernel<TLW, 1, 1, R, 0, 0, 0, 2>;
+        const size_t lds = sizeof(double) * 4 * 16 * (TLW + 1) * (R + 2);
+        if (!raise_lds((const void*)kfn, lds)) return DLA_ERR_RUNTIME;
+        DLA_LAUNCH(kfn, grid, dim3(256), lds, st, a);
+        return DLA_OK;
+      }
+      err = "gram_wp: the projection sweep takes one-tile blocks"; return DLA_ERR_ARG;
+    }
     if (self) {
       if constexpr (TLW == 1 && KT == 1) {
         auto kfn = gram_lds_kernel<1, 1, 1, 32, 1, 0, 0, 1>;
@@ -3717,9 +3922,11 @@ struct HipEngine : dla::Engine {
   // widest X pass of the pending-factor sweeps: 12 X tiles beside one U tile, 8 beside two (16 + 3 accumulator tiles), 5 beside
   // three (15 + 6)
   static int wp_max_tlw(int kt) { return kt <= 1 ? 12 : kt == 2 ? 8 : 5; }
-  int gram_wp_once(int n, int m, const double* x, int k, const double* u, const double* wp, double* uw)
+  //   cx != nullptr (m > 0, uw = u, one pass): U <- [X | U] C' stored, X^T U and U^T U of the stored result (OP_COMBOX)
+  int gram_wp_once(int n, int m, const double* x, int k, const double* u, const double* wp, double* uw, const double* cx = nullptr)
   {
     const bool self = (m == 0);
+    if (cx != nullptr && (self || uw == nullptr || wp != nullptr || k > 16)) { err = "gram_wp: bad projection sweep"; return DLA_ERR_ARG; }
     const int kt = (k + 15) / 16;
     if (kt > 3 || (self && kt > 1)) { err = "gram_wp: block too wide"; return DLA_ERR_ARG; }
     const int tx = self ? 1 : (m + 15) / 16;
@@ -3745,13 +3952,15 @@ struct HipEngine : dla::Engine {
     if (!self && (m + k) * k > XUG_DOUBLES) { err = "gram_wp: basis too wide for the chain's buffer"; return DLA_ERR_ARG; }
     // (written-back tiles: every pass would transform the block again, and passes run side by side)
     if (uw != nullptr && passes != 1) { err = "gram_wp: the storing sweep takes one pass"; return DLA_ERR_ARG; }
-    GramArgs a{self ? u : x, u, d_partial, (long long)n, self ? k : m, k, passes, 0, pred_phase, pred_want, 0, wp, uw};
+    GramArgs a{self ? u : x, u, d_partial, (long long)n, self ? k : m, k, passes, 0, pred_phase, pred_want, 0, wp, uw, cx};
     dim3 grid(blocks, passes);
     {
       char kn[64];
-      std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d, %d, 0, 0, 1>", tlw, kt, self ? 32 : R, self ? 1 : 0);
-      // reference-schedule flops: the Gram matrix (2 n k^2), X^T U (2 n m k), and the triangular update the sweep applies on the fly (n k^2)
-      Scope s(this, DLA_OP_GRAM, 8.0 * (double)n * (double)(m + k + (uw ? k : 0)), 2.0 * (double)n * (m + k) * k + (wp ? 1.0 * (double)n * k * k : 0.0), kn);
+      std::snprintf(kn, sizeof kn, "gram_lds_kernel<%d, %d, 1, %d, %d, 0, 0, %d>", tlw, kt, self ? 32 : R, self ? 1 : 0, cx ? 2 : 1);
+      // reference-schedule flops: the Gram matrix (2 n k^2), X^T U (2 n m k), and the triangular update the sweep applies on the fly
+      // (n k^2) -- or, for the projection sweep, the update U -= X (X^T U) (2 n m k) with the pending factor (n k^2)
+      Scope s(this, cx ? DLA_OP_GEMM : DLA_OP_GRAM, 8.0 * (double)n * (double)(m + k + (uw ? k : 0)),
+              2.0 * (double)n * (m + k) * k + ((wp || cx) ? 1.0 * (double)n * k * k : 0.0) + (cx ? 2.0 * (double)n * m * k : 0.0), kn);
       int r_ = DLA_ERR_RUNTIME;
 #define GWP(T, K, RR) if (tlw == T && kt == K) r_ = launch_gram_wp<T, K, RR>(a, grid, self); else
       GWP(1, 1, 32) GWP(2, 1, 32) GWP(3, 1, 16) GWP(4, 1, 16) GWP(5, 1, 16) GWP(6, 1, 16) GWP(7, 1, 16) GWP(8, 1, 16) GWP(10, 1, 16) GWP(12, 1, 16)
@@ -3794,18 +4003,26 @@ struct HipEngine : dla::Engine {
     double* u = nullptr;
     long long key = 0, key_last = 0;
     bool xw = false;                 // wide block with the storing sweep OP_XW (see ortho_chain_begin)
+    bool x3 = false;                 // three-pass schedule
     std::vector<int> plan, launched;
     std::vector<SpecRec> recs;
   } run;
 
-  // the factor the last chain left pending (drop_final + publish_pending), or the identity; fetching it clears it
-  int pending_factor(int k, double* t, int ldt) override
+  // the block the last chain left pending (drop_final + publish_pending): p = [E ; T], (m + k) x k -- the finished block is
+  // [X | U_stored] p -- or [0 ; I] when nothing is pending; fetching it clears it
+  int pending_block(int m, int k, double* p, int ldp, int* applied) override
   {
     for (int j = 0; j < k; ++j)
-      for (int i = 0; i < k; ++i) t[(size_t)i + (size_t)j * ldt] = (i == j) ? 1.0 : 0.0;
+      for (int i = 0; i < m + k; ++i) p[(size_t)i + (size_t)j * ldp] = (i == m + j) ? 1.0 : 0.0;
+    if (applied) *applied = 0;
     if (t_pending_k == k && h_tpend) {
-      for (int j = 0; j < k; ++j)
-        for (int i = 0; i <= j; ++i) t[(size_t)i + (size_t)j * ldt] = h_tpend[(size_t)i + (size_t)j * 48];
+      if (applied) *applied = h_tpend[PEND_HDR + 2] != 0.0 ? 1 : 0;
+      const int er = (int)h_tpend[PEND_HDR + 1];
+      if (er != 0 && er != m) { t_pending_k = 0; err = "pending_block: the chain's basis width is not the caller's"; return DLA_ERR_ARG; }
+      for (int j = 0; j < k; ++j) {
+        for (int i = 0; i < er; ++i) p[(size_t)i + (size_t)j * ldp] = h_tpend[(size_t)i * PEND_LD + j];
+        for (int i = 0; i <= j; ++i) p[(size_t)(m + i) + (size_t)j * ldp] = h_tpend[(size_t)(er + i) * PEND_LD + j];
+      }
     }
     t_pending_k = 0;
     return DLA_OK;
@@ -3820,6 +4037,7 @@ struct HipEngine : dla::Engine {
   int ortho_chain_begin(int n, int m, int k, const double* x, const double* bx, double* u, dla::OrthoReport* rep) override
   {
     rep->handled = 0;
+    t_pending_k = 0;                 // (whatever an earlier chain left: nobody fetched it, it belongs to no later call)
     if (run.active) { err = "ortho_chain: a chain is already in flight"; return DLA_ERR_RUNTIME; }
     if (tune[6] == 3) return DLA_OK;                               // A/B: host-driven loop
     if (hook || local_only || k <= 0 || k > 48) return DLA_OK;     // hook reductions need the host between sweeps
@@ -3831,6 +4049,15 @@ struct HipEngine : dla::Engine {
     const bool vec2 = even_rows(n) && (((uintptr_t)u | (uintptr_t)x | (uintptr_t)bx) % 16 == 0);
     int fold = (k <= 16 && tune[6] != 5) ? 2 : 0;
     if (fold && vsx && vec2 && m <= 192 && tune[6] != 6 && lds_limit > (size_t)128 * 1024) fold = 1;
+    // ... and with the standard inner product (bx == x: the panel the projection subtracts is the panel it measures against) the
+    // three-pass schedule: projections that measure X^T U and U^T U of what they store (tune knob 6 = 12: the five-sweep one)
+    // Not while expansion blocks come out of their first projection numerically rank deficient (level shifts: the benchmark
+    // operator's rank-4 coupling leaves 4 new directions per 13-column block): there the written update and the storing sweep
+    // follow whatever the projection measured, the closing projection only needs its Gram matrix, and a basis that carries pending
+    // projections of 1e-9 is not tight enough -- the next block's leftover is amplified by 1e10 on its way through the shifted
+    // factors (measured r05, interleaved: 17.0 against 16.35 ms per benchmark solve; 138.5 against 144.3 ms on the random-guess
+    // leg, which never shifts).  A chain that reports a level shift switches the schedule off for the next 16 chains.
+    const bool x3 = fold == 1 && bx == x && tune[6] != 12 && (x3_cooldown <= 0 || tune[6] == 13);
     // wider blocks (LDS-loop tail): X^T U and U^T U in ONE sweep when [X | U] fits one pass of the Gram kernel (the plain
     // product with the contiguous panel [X | U] on the left: U follows X, bx == x) and the leading ortho_cd takes one step
     const int ktw = (k + 15) / 16;
@@ -3848,14 +4075,16 @@ struct HipEngine : dla::Engine {
     // refused request for more than 64 KiB of LDS shows up before anything has touched U).  After a refusal the engine's LDS
     // limit is down and the host-driven loop, which redoes single operations under it, takes the call.
     {
-      const long long vkey = (long long)k * 1000000 + m + fold * 500000000000LL + (vsx ? 0 : 250000000000LL) + (wide_xw ? 125000000000LL : 0LL);
+      const long long vkey = (long long)k * 1000000 + m + fold * 500000000000LL + (vsx ? 0 : 250000000000LL) + (wide_xw ? 125000000000LL : 0LL) +
+                             (x3 ? 31250000000LL : 0LL);
       if (!chain_verified.count(vkey)) {
-        static const int every_op[] = {OP_GRAM_UU, OP_GRAMX, OP_GRAMW, OP_XW, OP_XU, OP_TRMMG, OP_COMBO, OP_FINAL};
+        static const int every_op[] = {OP_GRAM_UU, OP_GRAMX, OP_GRAMW, OP_XW, OP_XU, OP_TRMMG, OP_COMBO, OP_FINAL, OP_COMBOX, OP_CLOSE};
         std::vector<SpecRec> dummy;
-        dry_launch = true; spec_rec = &dummy; lds_retry = false; chain_xw = wide_xw;
+        dry_launch = true; spec_rec = &dummy; lds_retry = false; chain_xw = wide_xw; chain_x3 = x3;
         int std_ = DLA_OK;
         for (int op : every_op) {
           if (!vsx && (op == OP_GRAMX || op == OP_XW || op == OP_XU || op == OP_COMBO || op == OP_GRAMW)) continue;
+          if ((op == OP_COMBOX || op == OP_CLOSE) && !x3) continue;
           if (fold != 1 && (op == OP_GRAMW || (op == OP_XW && !wide_xw))) continue;
           if (fold != 1 && op == OP_GRAMX && !wide_gramx) continue;
           std_ = launch_op(op, n, m, k, x, bx, u, false, fold);
@@ -3890,15 +4119,16 @@ struct HipEngine : dla::Engine {
     t_pending_k = 0;
     t_seq = t_seq >= 1000000 ? 1 : t_seq + 1;
     const long long key = (long long)k * 1000000 + m + fold * 500000000000LL + (wide_gramx ? 250000000000LL : 0LL) + (wide_xw ? 125000000000LL : 0LL) +
-                          (dropf ? 62500000000LL : 0LL);
+                          (dropf ? 62500000000LL : 0LL) + (x3 ? 31250000000LL : 0LL);
     std::vector<int>& hist = ortho_history[key];
     std::vector<int> plan = hist;
-    const long long kind_key = -(long long)(64 * k + (vsx ? 1 : 0) + 2 * fold + (wide_gramx ? 8 : 0) + (wide_xw ? 16 : 0) + (dropf ? 32 : 0)) - 1;
+    const long long kind_key = -(long long)(128 * k + (vsx ? 1 : 0) + 2 * fold + (wide_gramx ? 8 : 0) + (wide_xw ? 16 : 0) + (dropf ? 32 : 0) + (x3 ? 64 : 0)) - 1;
     std::vector<int>& last_k = ortho_history[kind_key];   // most recent call of this kind and width
     if (plan.empty()) plan = last_k;
     if (plan.empty()) {
       // the schedule measured on the reference: cd x2, [projection, cd x2], [projection, cd x1]
-      if (fold == 1) plan = {OP_GRAMX, OP_COMBO, OP_TRMMG, OP_XW, OP_COMBO, OP_FINAL};
+      if (x3) plan = {OP_GRAMX, OP_COMBOX, OP_COMBOX, OP_CLOSE, OP_FINAL};
+      else if (fold == 1) plan = {OP_GRAMX, OP_COMBO, OP_TRMMG, OP_XW, OP_COMBO, OP_FINAL};
       else if (wide_xw) plan = {OP_GRAMX, OP_COMBO, OP_XW, OP_COMBO, OP_FINAL};
       else if (wide_gramx) plan = {OP_GRAMX, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
       else if (vsx) plan = {OP_GRAM_UU, OP_TRMMG, OP_XU, OP_COMBO, OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL};
@@ -3908,11 +4138,33 @@ struct HipEngine : dla::Engine {
     // fused tail is skipped together with a sweep whose turn it is not).  With drop_final the machine never asks for the sweep
     // itself, and the executed list a plan is remembered from does not contain it
     if (plan.empty() || plan.back() != OP_FINAL) plan.push_back(OP_FINAL);
+    // (three-pass schedule: whether a chain ends with its closing block pending or with the closing sweep depends on the last bits
+    //  of a Gram matrix -- a plan remembered from a chain that ended pending keeps the sweep in place: an empty launch when it
+    //  is not needed, against a host round trip and a repeated operator call when it is)
+    if (x3 && std::find(plan.begin(), plan.end(), (int)OP_CLOSE) == plan.end()) plan.insert(plan.end() - 1, (int)OP_CLOSE);
+    // (... and which projection sweep stands for the phase "projection": the one that also measures X^T U of what it stores costs
+    //  4 m / 16 more MFMAs per 16 rows (5.0-5.4 TB/s against 5.7), and its measurement is thrown away when the block it produced
+    //  needs a level shift -- the written update comes next, then the storing sweep measures again.  The previous chain of this
+    //  kind tells: a projection that was followed by the written update is planned as the plain sweep, a plain one that was
+    //  followed by the storing sweep as the measuring one (which would have made that sweep the closing projection).)
+    //  A chain whose first projection needed the written update ends, after the storing sweep, with a projection whose Gram matrix
+    //  is all that is needed behind it (X^T U of the stored block is of order 1e-5 ... 1e-3 there, and what the projection leaves
+    //  is rounding): the plain sweep again.
+    if (x3) {
+      bool shifted = false;
+      for (size_t i = 0; i + 1 < plan.size(); ++i) {
+        if ((plan[i] == OP_COMBOX || plan[i] == OP_COMBO) && plan[i + 1] == OP_TRMMG) shifted = true;
+        if (shifted && plan[i] == OP_COMBOX) plan[i] = OP_COMBO;
+        if (!shifted && plan[i] == OP_COMBO && plan[i + 1] == OP_XW) { plan[i] = OP_COMBOX; plan[i + 1] = OP_COMBOX; }
+      }
+    }
     run.n = n; run.m = m; run.k = k; run.fold = fold; run.vsx = vsx; run.x = x; run.bx = bx; run.u = u;
     run.key = key;
     run.key_last = kind_key;
     run.xw = wide_xw;
+    run.x3 = x3;
     chain_xw = wide_xw;
+    chain_x3 = x3;
     run.plan = plan; run.launched.clear(); run.recs.clear();
     stc = chain_enqueue();
     if (stc) return stc;
@@ -3954,6 +4206,7 @@ struct HipEngine : dla::Engine {
   {
     spec_rec = &run.recs;
     chain_xw = run.xw;
+    chain_x3 = run.x3;
     int stc = DLA_OK;
     for (size_t pi = 0; pi < run.plan.size(); ++pi) {
       spec_tag = (int)run.launched.size();
@@ -3998,7 +4251,19 @@ struct HipEngine : dla::Engine {
       if (sres.status != OST_RUNNING) break;
       // the device went another way than expected: continue from where it stands with the most likely tail
       // (a launch whose turn it is not costs ~2 us, a host round trip ~25: the continuation lists what may follow, in order)
-      if (fold == 1) {
+      if (run.x3) {
+        switch (sres.phase) {
+          case OP_TRMMG: plan = sres.it_outer == 0 ? std::vector<int>{OP_TRMMG, OP_GRAMW, OP_COMBOX, OP_COMBOX, OP_CLOSE, OP_FINAL}
+                                                   : std::vector<int>{OP_TRMMG, OP_XW, OP_XU, OP_COMBOX, OP_CLOSE, OP_FINAL}; break;
+          case OP_GRAMW:  plan = {OP_GRAMW, OP_GRAMW, OP_COMBOX, OP_COMBOX, OP_CLOSE, OP_FINAL}; break;
+          case OP_COMBOX: plan = {OP_COMBOX, OP_COMBOX, OP_CLOSE, OP_FINAL}; break;
+          case OP_XW:     plan = {OP_XW, OP_COMBOX, OP_CLOSE, OP_FINAL}; break;
+          case OP_XU:     plan = {OP_XU, OP_COMBOX, OP_COMBOX, OP_CLOSE, OP_FINAL}; break;
+          case OP_CLOSE:  plan = {OP_CLOSE, OP_FINAL}; break;
+          case OP_FINAL:  plan = {OP_FINAL}; break;
+          default: err = "ortho_chain: device state machine in an unexpected phase"; return DLA_ERR_RUNTIME;
+        }
+      } else if (fold == 1) {
         switch (sres.phase) {
           case OP_TRMMG: plan = sres.it_outer == 0 ? std::vector<int>{OP_TRMMG, OP_GRAMW, OP_COMBO, OP_XW, OP_COMBO, OP_FINAL}
                                                    : std::vector<int>{OP_TRMMG, OP_XU, OP_COMBO, OP_FINAL}; break;
@@ -4024,6 +4289,7 @@ struct HipEngine : dla::Engine {
     }
     if (sres.status == OST_RUNNING) { err = "ortho_chain: no progress"; return DLA_ERR_RUNTIME; }
     chain_armed = true;              // a terminal tail has put the machine back to its initial state
+    if (vsx && fold == 1) { if (sres.shifts > 0) x3_cooldown = 16; else if (x3_cooldown > 0) --x3_cooldown; }
     if (chain_debug) {
       std::printf("  [dla] chain k=%d m=%d: %zu launches enqueued, executed:", k, m, launched.size());
       for (int i = 0; i < std::min(sres.nops, 48); ++i) std::printf(" %d", sres.log[i]);
@@ -4034,9 +4300,9 @@ struct HipEngine : dla::Engine {
         for (int i = 0; i < std::min(sres.nops, 48); ++i) {
           const unsigned long long* q = &hs[i * 16];
           auto us = [&](int a_, int b_) { return (q[a_] && q[b_]) ? (double)(long long)(q[b_] - q[a_]) * 0.01 : -1.0; };
-          double rc, gdev; std::memcpy(&rc, &q[10], 8); std::memcpy(&gdev, &q[12], 8);
-          std::printf("    op %llu (err est %.2e, max|G-I| %.2e, chol %llu cycles = %.2f GHz): kernel entry->tail %.2f us | G load %.2f | chol+inv %.2f | norms %.2f | products+stores %.2f | decide %.2f | publish %.2f | assemble %.2f\n",
-                      q[9], 2.2e-16 * rc * rc, gdev, q[11], us(1, 2) > 0 ? (double)q[11] / (us(1, 2) * 1e3) : 0.0, us(8, 0), us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7));
+          double rc, gdev, sdev, csq; std::memcpy(&rc, &q[10], 8); std::memcpy(&gdev, &q[12], 8); std::memcpy(&sdev, &q[13], 8); std::memcpy(&csq, &q[14], 8);
+          std::printf("    op %llu (err est %.2e, max|G-I| %.2e, max|X^T U| %.2e (col sq %.2e), chol %llu cycles = %.2f GHz): kernel entry->tail %.2f us | G load %.2f | chol+inv %.2f | norms %.2f | products+stores %.2f | decide %.2f | publish %.2f | assemble %.2f\n",
+                      q[9], 2.2e-16 * rc * rc, gdev, sdev, csq, q[11], us(1, 2) > 0 ? (double)q[11] / (us(1, 2) * 1e3) : 0.0, us(8, 0), us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7));
         }
         (void)hipMemset(d_dbg, 0, sizeof(unsigned long long) * 48 * 16);
       }
@@ -4053,7 +4319,7 @@ struct HipEngine : dla::Engine {
       if (sres.status == OST_DONE && sres.nops <= 48) { hist.assign(sres.log, sres.log + nlog); last_k = hist; }
     }
     // a chain that ended with its last factor pending has left it in the pinned buffer (the tail wrote the sequence number last)
-    if (sres.status == OST_DONE && drop_final && publish_pending && vsx && h_tpend[48 * 48] == (double)t_seq) t_pending_k = k;
+    if (sres.status == OST_DONE && drop_final && publish_pending && vsx && h_tpend[PEND_HDR] == (double)t_seq) t_pending_k = k;
     rep->handled = 1;
     rep->status = sres.status;
     rep->growth = sres.growth;

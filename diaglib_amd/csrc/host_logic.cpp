@@ -110,6 +110,7 @@ int dla_create(dla_ctx** out, int device)
   }
   dla_ctx* c = new dla_ctx();
   c->eng = e;
+  if (std::getenv("DIAGLIB_AMD_NO_PENDING") != nullptr) c->pending_blocks = 0;     // (default of new contexts; DLA_OPT_PENDING_BLOCKS)
   *out = c;
   return DLA_OK;
 }
@@ -189,6 +190,10 @@ int dla_set_option(dla_ctx* c, int option, int value)
       if (value < 0 || value > 2) return fail(c, DLA_ERR_ARG, "callback order must be 0, 1 or 2");
       c->callback_order = value;
       break;
+    case DLA_OPT_PENDING_BLOCKS:
+      if (value < 0 || value > 1) return fail(c, DLA_ERR_ARG, "pending blocks must be 0 or 1");
+      c->pending_blocks = value;
+      break;
     default:
       if (option >= DLA_OPT_TUNE0 && option < DLA_OPT_TUNE0 + 8) { c->eng->set_tune(option - DLA_OPT_TUNE0, value); break; }
       return fail(c, DLA_ERR_ARG, "unknown option");
@@ -210,6 +215,7 @@ int dla_get_option(dla_ctx* c, int option)
     case DLA_OPT_STAGE_CHUNKS: return c->stage_chunks;
     case DLA_OPT_P2P_TIMEOUT_MS: return c->p2p_timeout_ms;
     case DLA_OPT_RUN_AHEAD: return c->run_ahead;
+    case DLA_OPT_PENDING_BLOCKS: return c->pending_blocks;
     default: return -1;
   }
 }
@@ -1131,74 +1137,172 @@ static int expand_apply_project(dla_ctx* c, int mode, int n, int m, int k, doubl
 static int expand_project_impl(dla_ctx* c, int mode, int n, int m, int k, double* basis, double* abasis, dla_matvec_fn fn,
                                double shift, double* h, int ldh);
 
+// The closing pass of ortho_vs_x on the small side.  A device chain that ends with a pending block hands over p = [E' ; T]: the
+// stored block U_c has the measured products S = X_c^T U_c and G = U_c^T U_c, T is the inverse Cholesky factor of G
+// (T^T G T = I) and E' = -S T -- the reference's closing pass (diaglib.f90:3543-3544, then one macro-iteration of ortho_cd,
+// :3256-3327) written as coefficients of the stored columns.  Two things are still open and are settled here, exactly:
+//   * the stored columns X_c are themselves unfinished blocks, X = X_c D with D upper triangular (dmat; nullptr: D = I), so
+//     X_c^T X_c = (D D^T)^-1 and the projection that makes the new block orthogonal to X is E = -(X_c^T X_c)^-1 S T = D D^T E';
+//   * the Gram matrix of U_c T + X_c E is I - F^T F with F = D^T E' (G was measured before the projection, not after it):
+//     one more k x k Cholesky factor R, R^T (I - F^T F) R = I.
+// Out: p = [E ; T] R -- the finished block is [X_c | U_c] p, orthogonal to X_c D and orthonormal, to the accuracy S and G were
+// measured with.  E' = 0 (nothing but a triangular factor pending) is left alone.
+// applied: the chain's closing sweep has already applied [E' ; T] to the block in memory (it measured nothing behind it); what is
+// still owed is the difference, [E - E' ; I] R.
+// y(0:rows) += D(0:rows, 0:rows)^T-or-not times x, for the upper-triangular D = I + N of a basis with pending blocks, in the
+// cache- and SIMD-friendly order: column q of D is contiguous.  trans: y_q += D(0:q, q) . x(0:q)  (dot products: four partial
+// sums, so that the compiler may keep them in one vector register); otherwise y(0:q) += D(0:q, q) x_q.
+static inline double dot4(const double* a, const double* b, int n)
+{
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = 0;
+  for (; i + 4 <= n; i += 4) { s0 += a[i] * b[i]; s1 += a[i + 1] * b[i + 1]; s2 += a[i + 2] * b[i + 2]; s3 += a[i + 3] * b[i + 3]; }
+  for (; i < n; ++i) s0 += a[i] * b[i];
+  return (s0 + s1) + (s2 + s3);
+}
+
+static int close_pending_block(int m, int k, double* p, int ldp, const double* dmat, int ld, int applied)
+{
+  double emax = 0.0;
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < m; ++i) emax = std::max(emax, std::fabs(p[(size_t)i + (size_t)j * ldp]));
+  if (emax == 0.0) return DLA_OK;
+  // (D = I + N: the products with N matter only when |N| |E'| m reaches rounding level in E -- skip them otherwise)
+  double nmax = 0.0;
+  if (dmat)
+    for (int q = 0; q < m; ++q) {
+      const double* dq = dmat + (size_t)q * ld;
+      for (int i = 0; i < q; ++i) nmax = std::max(nmax, std::fabs(dq[i]));
+      nmax = std::max(nmax, std::fabs(dq[q] - 1.0));
+    }
+  const bool with_d = dmat != nullptr && nmax * emax * (double)m > 1.0e-19;
+  std::vector<double> f((size_t)m * k), mm((size_t)k * k), e((size_t)m * k, 0.0);
+  for (int j = 0; j < k; ++j) {
+    const double* ej = p + (size_t)j * ldp;
+    double* fj = &f[(size_t)j * m];
+    if (with_d) for (int r = 0; r < m; ++r) fj[r] = dot4(dmat + (size_t)r * ld, ej, r + 1);      // F = D^T E'
+    else for (int r = 0; r < m; ++r) fj[r] = ej[r];
+  }
+  for (int j = 0; j < k; ++j)
+    for (int i = j; i < k; ++i)
+      mm[(size_t)i + (size_t)j * k] = (i == j ? 1.0 : 0.0) - dot4(&f[(size_t)i * m], &f[(size_t)j * m], m);
+  if (dla_potrf_lower(k, mm.data(), k) != 0) return DLA_ERR_ORTHO;
+  if (dla_trtri_lower(k, mm.data(), k) != 0) return DLA_ERR_ORTHO;          // mm = L^-1 (lower); R = L^-T
+  for (int j = 0; j < k; ++j) {                  // E = D F
+    const double* fj = &f[(size_t)j * m];
+    double* ej = &e[(size_t)j * m];
+    if (with_d) {
+      for (int q = 0; q < m; ++q) {
+        const double fq = fj[q];
+        if (fq == 0.0) continue;
+        const double* dq = dmat + (size_t)q * ld;
+        for (int i = 0; i <= q; ++i) ej[i] += dq[i] * fq;
+      }
+    } else {
+      for (int i = 0; i < m; ++i) ej[i] = fj[i];
+    }
+  }
+  for (int j = 0; j < k; ++j) {
+    for (int i = 0; i < m; ++i) p[(size_t)i + (size_t)j * ldp] = e[(size_t)i + (size_t)j * m] - (applied ? p[(size_t)i + (size_t)j * ldp] : 0.0);
+    if (applied) for (int i = 0; i < k; ++i) p[(size_t)(m + i) + (size_t)j * ldp] = (i == j) ? 1.0 : 0.0;
+  }
+  // p <- p R, R(q, j) = Linv(j, q) for q <= j: columns from the right, in place
+  const int l = m + k;
+  for (int j = k - 1; j >= 0; --j) {
+    double* pj = p + (size_t)j * ldp;
+    const double rjj = mm[(size_t)j + (size_t)j * k];
+    for (int i = 0; i < l; ++i) pj[i] *= rjj;
+    for (int q = 0; q < j; ++q) {
+      const double rq = mm[(size_t)j + (size_t)q * k];
+      if (rq == 0.0) continue;
+      const double* pq = p + (size_t)q * ldp;
+      for (int i = 0; i < l; ++i) pj[i] += pq[i] * rq;
+    }
+  }
+  return DLA_OK;
+}
+
 int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis, double* abasis, dla_matvec_fn fn,
                        double shift, double* h, int ldh)
 {
   DLA_T("dla_expand_project");
   if (!c || !basis || !abasis || !h || !fn || mode < 0 || mode == 2 || mode > 4 || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
     return fail(c, DLA_ERR_ARG, "dla_expand_project: bad argument (n > 0, m >= 0, k > 0, ldh >= m + k)");
-  c->pending_k = 0;
-  // (A/B switch: $DIAGLIB_AMD_NO_PENDING makes modes 3 / 4 behave like 1 / 0 -- the factor is applied by the chain's last sweep)
-  static const bool no_pending = std::getenv("DIAGLIB_AMD_NO_PENDING") != nullptr;
-  if (mode == 3 && no_pending) mode = 1;
-  if (mode == 4 && no_pending) mode = 0;
+  c->pending_k = 0; c->pending_m = 0; c->pending_applied = 0;
+  // (DLA_OPT_PENDING_BLOCKS = 0 makes modes 3 / 4 behave like 1 / 0: the chain finishes the block in memory)
+  if (mode == 3 && !c->pending_blocks) mode = 1;
+  if (mode == 4 && !c->pending_blocks) mode = 0;
+  // a chain that failed behind a finished orthogonalisation must not leave its block to the next call (round-4 advisor)
+  struct Forget { dla_ctx* c; int m, k; bool keep = false; ~Forget() { if (!keep) { std::vector<double> junk((size_t)(m + k) * k); (void)c->eng->pending_block(m, k, junk.data(), m + k, nullptr); } } };
   if (mode == 4) {
-    // mode 4 = mode 0 for a block that STAYS in the basis (Davidson, reference diaglib.f90:1790 + 1685 + 1691): the last factor T
-    // stays pending only when the closing pass found the block orthonormal to 1e-8 -- later blocks are projected against the
-    // stored block as if it were orthonormal, and two passes leave (2e-8)^2 of what they remove.  h_host comes back RAW, for the
-    // stored block: the caller keeps the factors of all its blocks (D = diag(T_1, T_2, ...)) and forms D^T h T itself, as it
-    // multiplies the rows of its coefficient blocks by D before any product with the panel (dla_pending_factor)
-    struct Flags { dla::Engine* e; explicit Flags(dla::Engine* e_) : e(e_) { e->drop_final = true; e->publish_pending = true; e->drop_final_tol = 1.0e-8; }
-                   ~Flags() { e->drop_final = false; e->publish_pending = false; e->drop_final_tol = 0.0; } } flags(c->eng);
+    // mode 4 = mode 0 for a block that STAYS in the basis (Davidson, reference diaglib.f90:1790 + 1685 + 1691): what the chain
+    // left undone stays pending only when the closing pass found the block orthonormal to 1e-8 -- later blocks are projected
+    // against the stored block as if it were orthonormal, twice, the second time on a measured product.  h_host comes back RAW,
+    // for the stored block: the caller keeps the pending blocks of its whole basis (an upper-triangular D, dla_basis_admit) and
+    // multiplies the rows of its coefficient blocks by D before any product with the panel (dla_basis_fold)
+    // (1e-8 / 1e-9: a later block's first projection against the stored columns leaves that share of what it removes, and the block
+    //  that comes out of it can be as ill-conditioned as 1e7 -- the leftover must stay below its smallest directions)
+    struct Flags { dla::Engine* e; explicit Flags(dla::Engine* e_) : e(e_) { e->drop_final = true; e->publish_pending = true; e->drop_final_tol = 1.0e-8; e->drop_final_stol = 1.0e-9; }
+                   ~Flags() { e->drop_final = false; e->publish_pending = false; e->drop_final_tol = 0.0; e->drop_final_stol = 1.0e-4; } } flags(c->eng);
+    Forget forget{c, m, k};
     const int st = expand_project_impl(c, 0, n, m, k, basis, abasis, fn, shift, h, ldh);
     if (st) return st;
-    c->pending_t.assign((size_t)k * k, 0.0);
-    const int stp = c->eng->pending_factor(k, c->pending_t.data(), k);
+    forget.keep = true;
+    c->pending_p.assign((size_t)(m + k) * k, 0.0);
+    const int stp = c->eng->pending_block(m, k, c->pending_p.data(), m + k, &c->pending_applied);
     if (stp) return engfail(c, stp);
-    c->pending_k = k;
+    c->pending_k = k; c->pending_m = m;
     return DLA_OK;
   }
   if (mode != 3) return expand_project_impl(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
-  // mode 3 = mode 1 for a block that is used once and rebuilt (LOBPCG's W, reference diaglib.f90:518-529, 394-403): the chain's last
-  // factor T (upper triangular, near the identity) is not applied to the block; the projection of the stored block is
-  // corrected here, H <- D^T H D with D = diag(I, T), and the caller folds T into the W rows of every coefficient block it
-  // multiplies the panel with (dla_pending_factor) -- the sweep U <- U T (16 n k bytes) is never run
+  // mode 3 = mode 1 for a block that is used once and rebuilt (LOBPCG's W, reference diaglib.f90:518-529, 394-403): what the chain
+  // left undone -- its last triangular factor T (near the identity) and, with the three-pass schedule, the closing projection E --
+  // is not applied to the block; the projection of the stored blocks is corrected here, H <- D^T H D with D = [I E ; 0 T], and the
+  // caller folds D into every coefficient block it multiplies the panel with (dla_pending_block): the closing sweeps are never run
   {
     struct Flags { dla::Engine* e; explicit Flags(dla::Engine* e_) : e(e_) { e->drop_final = true; e->publish_pending = true; }
                    ~Flags() { e->drop_final = false; e->publish_pending = false; } } flags(c->eng);
+    Forget forget{c, m, k};
     const int st = expand_project_impl(c, 1, n, m, k, basis, abasis, fn, shift, h, ldh);
     if (st) return st;
+    forget.keep = true;
   }
-  c->pending_t.assign((size_t)k * k, 0.0);
-  int st = c->eng->pending_factor(k, c->pending_t.data(), k);
+  const int l = m + k;
+  c->pending_p.assign((size_t)l * k, 0.0);
+  int st = c->eng->pending_block(m, k, c->pending_p.data(), l, &c->pending_applied);
   if (st) return engfail(c, st);
-  c->pending_k = k;
-  const double* t = c->pending_t.data();
+  c->pending_k = k; c->pending_m = m;
+  st = close_pending_block(m, k, c->pending_p.data(), l, nullptr, 0, c->pending_applied);       // ([X P] is a finished block: D = I)
+  c->pending_applied = 0;
+  if (st) return fail(c, st, "dla_expand_project: the pending block's closing factor is not positive definite");
+  const double* p = c->pending_p.data();
   bool ident = true;
   for (int j = 0; j < k && ident; ++j)
-    for (int i = 0; i <= j; ++i) if (t[(size_t)i + (size_t)j * k] != (i == j ? 1.0 : 0.0)) { ident = false; break; }
+    for (int i = 0; i < l; ++i) if (p[(size_t)i + (size_t)j * l] != (i == m + j ? 1.0 : 0.0)) { ident = false; break; }
   if (ident) return DLA_OK;
-  const int l = m + k;
-  // rows m .. l-1 of the lower triangle: [H_wx | H_ww] <- T^T [H_wx | H_ww T]
-  std::vector<double> ww((size_t)k * k), tmp((size_t)k * l);
-  for (int j = 0; j < k; ++j)
-    for (int i = 0; i < k; ++i) ww[(size_t)i + (size_t)j * k] = (i >= j) ? h[(size_t)(m + i) + (size_t)(m + j) * ldh] : h[(size_t)(m + j) + (size_t)(m + i) * ldh];
-  // tmp = [H_wx | H_ww T]   (k x l)
-  for (int b = 0; b < m; ++b)
-    for (int i = 0; i < k; ++i) tmp[(size_t)i + (size_t)b * k] = h[(size_t)(m + i) + (size_t)b * ldh];
-  for (int j = 0; j < k; ++j)
-    for (int i = 0; i < k; ++i) {
-      double acc = 0.0;
-      for (int p = 0; p <= j; ++p) acc += ww[(size_t)i + (size_t)p * k] * t[(size_t)p + (size_t)j * k];
-      tmp[(size_t)i + (size_t)(m + j) * k] = acc;
+  // lower triangle of H (l x l): the W rows become  p^T H_full [I_x | p]  (H_xx is untouched)
+  std::vector<double> hf((size_t)l * l), g((size_t)l * k);
+  for (int j = 0; j < l; ++j)
+    for (int i = 0; i < l; ++i) hf[(size_t)i + (size_t)j * l] = (i >= j) ? h[(size_t)i + (size_t)j * ldh] : h[(size_t)j + (size_t)i * ldh];
+  // g = H_full p  (l x k)
+  for (int j = 0; j < k; ++j) {
+    double* gj = &g[(size_t)j * l];
+    for (int q = 0; q < l; ++q) {
+      const double pq = p[(size_t)q + (size_t)j * l];
+      if (pq == 0.0) continue;
+      const double* hq = &hf[(size_t)q * l];
+      for (int i = 0; i < l; ++i) gj[i] += hq[i] * pq;
     }
-  for (int b = 0; b < l; ++b)
-    for (int i = 0; i < k; ++i) {
-      if (b >= m && b - m > i) continue;                       // (lower triangle only)
+  }
+  // rows m .. l-1, columns 0 .. m-1:  (p^T H_full)(:, x) = g(x, :)^T by symmetry;  columns m .. : p^T g
+  for (int i = 0; i < k; ++i) {
+    for (int b = 0; b < m; ++b) h[(size_t)(m + i) + (size_t)b * ldh] = g[(size_t)b + (size_t)i * l];
+    for (int j = 0; j <= i; ++j) {
       double acc = 0.0;
-      for (int p = 0; p <= i; ++p) acc += t[(size_t)p + (size_t)i * k] * tmp[(size_t)p + (size_t)b * k];
-      h[(size_t)(m + i) + (size_t)b * ldh] = acc;
+      for (int q = 0; q < l; ++q) acc += p[(size_t)q + (size_t)i * l] * g[(size_t)q + (size_t)j * l];
+      h[(size_t)(m + i) + (size_t)(m + j) * ldh] = acc;
     }
+  }
   return DLA_OK;
 }
 
@@ -1207,9 +1311,89 @@ int dla_pending_factor(dla_ctx* c, int k, double* t, int ldt)
   if (!c || !t || k <= 0 || ldt < k) return fail(c, DLA_ERR_ARG, "dla_pending_factor: bad argument");
   for (int j = 0; j < k; ++j)
     for (int i = 0; i < k; ++i) t[(size_t)i + (size_t)j * ldt] = (i == j) ? 1.0 : 0.0;
-  if (c->pending_k == k)
+  if (c->pending_k == k) {
+    const int l = c->pending_m + k;
     for (int j = 0; j < k; ++j)
-      for (int i = 0; i <= j; ++i) t[(size_t)i + (size_t)j * ldt] = c->pending_t[(size_t)i + (size_t)j * k];
+      for (int i = 0; i <= j; ++i) t[(size_t)i + (size_t)j * ldt] = c->pending_p[(size_t)(c->pending_m + i) + (size_t)j * l];
+  }
+  return DLA_OK;
+}
+
+int dla_pending_block(dla_ctx* c, int m, int k, double* p, int ldp, int* applied)
+{
+  if (!c || !p || k <= 0 || m < 0 || ldp < m + k) return fail(c, DLA_ERR_ARG, "dla_pending_block: bad argument");
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < m + k; ++i) p[(size_t)i + (size_t)j * ldp] = (i == m + j) ? 1.0 : 0.0;
+  if (applied) *applied = 0;
+  if (c->pending_k == k && c->pending_m == m) {
+    for (int j = 0; j < k; ++j)
+      for (int i = 0; i < m + k; ++i) p[(size_t)i + (size_t)j * ldp] = c->pending_p[(size_t)i + (size_t)j * (m + k)];
+    if (applied) *applied = c->pending_applied;
+  }
+  return DLA_OK;
+}
+
+// ---- pending blocks of a basis that grows block by block (Davidson, dla_expand_project mode 4).  The panel holds the blocks as the
+// device chains left them; the orthonormal basis is panel * D with D upper triangular: column block i of D is the pending block
+// [E_i ; T_i] of block i (the identity where nothing stayed pending).  All matrices are column-major host arrays with leading
+// dimension ld; no device work, no context.
+//   dla_basis_admit: a block of k columns has come in behind m stored ones with the pending block p ((m + k) x k).  hcols = columns
+//   m .. m+k-1 of the caller's projected matrix h hold the RAW product [X | U]_stored^T A U_stored (rows 0 .. m+k-1); they are
+//   recorded in hraw (both triangles), p goes into D, and hcols become the columns of D^T hraw D -- the projected matrix of the
+//   orthonormal basis.
+int dla_basis_admit(int m, int k, double* p, int ldp, int applied, double* hraw, double* dmat, double* h, int ld)
+{
+  DLA_T("dla_basis_admit");
+  if (m < 0 || k <= 0 || !p || !hraw || !dmat || !h || ldp < m + k || ld < m + k) return DLA_ERR_ARG;
+  const int l = m + k;
+  {
+    const int stc = close_pending_block(m, k, p, ldp, dmat, ld, applied);      // the closing pass against X = X_c D, exactly (p in / out)
+    if (stc) return stc;
+  }
+  double* hc = h + (size_t)m * ld;
+  for (int j = 0; j < k; ++j) {
+    for (int i = 0; i < l; ++i) hraw[(size_t)i + (size_t)(m + j) * ld] = hc[(size_t)i + (size_t)j * ld];
+    for (int i = 0; i < m; ++i) hraw[(size_t)(m + j) + (size_t)i * ld] = hc[(size_t)i + (size_t)j * ld];
+    for (int i = 0; i < k; ++i)        // (the diagonal block arrives complete; keep it symmetric to the last bit)
+      if (i < j) hraw[(size_t)(m + j) + (size_t)(m + i) * ld] = hraw[(size_t)(m + i) + (size_t)(m + j) * ld];
+    for (int i = 0; i < l; ++i) dmat[(size_t)i + (size_t)(m + j) * ld] = p[(size_t)i + (size_t)j * ldp];
+  }
+  // g = hraw(0:l, 0:l) p
+  std::vector<double> g((size_t)l * k, 0.0);
+  for (int j = 0; j < k; ++j) {
+    double* gj = &g[(size_t)j * l];
+    for (int q = 0; q < l; ++q) {
+      const double pq = p[(size_t)q + (size_t)j * ldp];
+      if (pq == 0.0) continue;
+      const double* hq = hraw + (size_t)q * ld;
+      for (int i = 0; i < l; ++i) gj[i] += hq[i] * pq;
+    }
+  }
+  // hcols = D(0:l, 0:l)^T g: row r of the result is column r of D against g
+  for (int j = 0; j < k; ++j) {
+    const double* gj = &g[(size_t)j * l];
+    for (int r = 0; r < l; ++r) hc[(size_t)r + (size_t)j * ld] = dot4(dmat + (size_t)r * ld, gj, r + 1);
+  }
+  return DLA_OK;
+}
+
+//   dla_basis_fold: c(0:rows, 0:ncol) <- D(0:rows, 0:rows) c -- coefficients for the STORED blocks, before every product with the panel
+int dla_basis_fold(int rows, int ncol, const double* dmat, int ld, double* cf, int ldc)
+{
+  DLA_T("dla_basis_fold");
+  if (rows < 0 || ncol < 0 || !dmat || !cf || ld < rows || ldc < rows) return DLA_ERR_ARG;
+  std::vector<double> t((size_t)rows);
+  for (int j = 0; j < ncol; ++j) {
+    double* cj = cf + (size_t)j * ldc;
+    std::fill(t.begin(), t.end(), 0.0);
+    for (int q = 0; q < rows; ++q) {
+      const double cq = cj[q];
+      if (cq == 0.0) continue;
+      const double* dq = dmat + (size_t)q * ld;
+      for (int i = 0; i <= q; ++i) t[i] += dq[i] * cq;
+    }
+    for (int i = 0; i < rows; ++i) cj[i] = t[i];
+  }
   return DLA_OK;
 }
 

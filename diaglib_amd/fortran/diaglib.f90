@@ -258,11 +258,24 @@ module diaglib
       real(c_double) :: h(*)
       integer(c_int) :: st
     end function
-    function dla_pending_factor(ctx,k,t,ldt) bind(C,name='dla_pending_factor') result(st)
+    function dla_pending_block(ctx,m,k,p,ldp,applied) bind(C,name='dla_pending_block') result(st)
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: ctx
-      integer(c_int), value :: k, ldt
-      real(c_double) :: t(*)
+      integer(c_int), value :: m, k, ldp
+      real(c_double) :: p(*)
+      integer(c_int) :: applied
+      integer(c_int) :: st
+    end function
+    function dla_basis_admit(m,k,p,ldp,applied,hraw,dmat,h,ld) bind(C,name='dla_basis_admit') result(st)
+      import :: c_int, c_double
+      integer(c_int), value :: m, k, ldp, applied, ld
+      real(c_double) :: p(*), hraw(*), dmat(*), h(*)
+      integer(c_int) :: st
+    end function
+    function dla_basis_fold(rows,ncol,dmat,ld,c,ldc) bind(C,name='dla_basis_fold') result(st)
+      import :: c_int, c_double
+      integer(c_int), value :: rows, ncol, ld, ldc
+      real(c_double) :: dmat(*), c(*)
       integer(c_int) :: st
     end function
     function dla_expand_project_metric(ctx,mode,n,m,k,basis,bbasis,abasis,fn,bfn,shift,h,ldh) &
@@ -668,12 +681,12 @@ contains
     type(stopwatch) :: w
     type(solve_env) :: e
     type(c_ptr)     :: basis, abasis, bbasis, resid, britz
-    real(dp), allocatable :: h(:,:), y(:,:), theta(:), dmat(:,:), tblk(:,:)
-    integer,  allocatable :: bfirst(:)      ! first column of the block a basis column belongs to (dmat is block diagonal)
-    logical :: any_pending                  ! some block of the basis lacks its last triangular factor (see fold_* below)
+    real(dp), allocatable :: h(:,:), y(:,:), theta(:), dmat(:,:), hraw(:,:), pblk(:,:)
+    logical :: any_pending                  ! some block of the basis is not finished in memory (see admit_pending below)
     real(dp)        :: t_begin(2), t_end(2)
     integer         :: it, sweeps, kept, col, first, j, ritz_cols
-    logical         :: patch_kept, projected
+    logical         :: patch_kept, projected, mirror_raw
+    integer(c_int)  :: applied
 !
     call env_open(e, n, n_max, evec)
     ritz_cols = 0
@@ -690,7 +703,7 @@ contains
       bbasis = dev_panel(e%ctx, n, s%ld, 'bspace')
       britz  = dev_panel(e%ctx, n, n_max, 'b_evec')
     end if
-    allocate (h(s%ld,s%ld), y(s%ld,s%ld), theta(s%ld), dmat(s%ld,s%ld), tblk(n_max,n_max), bfirst(s%ld))
+    allocate (h(s%ld,s%ld), y(s%ld,s%ld), theta(s%ld), dmat(s%ld,s%ld), hraw(s%ld,s%ld), pblk(s%ld,n_max))
     call reset_pending()
 !
 !   The reference zero-fills both n x lda panels (:1632-1633).  On the device no column is read before it has been
@@ -738,6 +751,7 @@ contains
 !
         call chk(e%ctx, dla_gram(e%ctx, n, s%cols, basis, s%act, colp(abasis,n,col), h(1,col), s%ld), 'projection')
       end if
+      mirror_raw = .not.projected
       projected = .false.
       e%op_cols = e%op_cols + s%act
       if (patch_kept) then
@@ -747,6 +761,14 @@ contains
         patch_kept = .false.
         kept = 0
       end if
+!     (a block that came through the separate calls -- the first one, the one after a restart -- is finished in memory and so is
+!      everything in front of it: h is the raw projected matrix, kept for the pending blocks that may follow)
+      if (mirror_raw) then
+        do j = 1, s%cols
+          hraw(1:j,j) = h(1:j,j)
+          hraw(j,1:j) = h(1:j,j)
+        end do
+      end if
 !
 !     Rayleigh-Ritz: the lowest n_max pairs of the upper triangle (:1703-1708)
 !
@@ -755,7 +777,8 @@ contains
       call need_eigensolver(dla_syev_lowest('u', s%cols, y, s%ld, theta, n_max))
       call lap_charge(w, w%diag)
       eig = theta(1:n_max)
-      if (any_pending) call fold_rows(y, s%cols, n_max)      ! coefficients for the STORED blocks: every product with the panel
+!     (coefficients for the STORED blocks: every product with the panel takes D y)
+      if (any_pending) call need_ok(dla_basis_fold(s%cols, n_max, dmat, s%ld, y, s%ld), 'basis fold')
 !
 !     Ritz vectors, residuals of the wanted roots that are still open, and their norms: one sweep (:1717-1732)
 !
@@ -825,14 +848,15 @@ contains
 !
           if (it.lt.max_iter) then
 !
-!           mode 4: a block that the closing pass found orthonormal to 1e-8 keeps its last triangular factor pending (the sweep
-!           U <- U T is not run); its columns of the projected matrix come back for the stored block and are corrected here,
-!           D^T h T with D = diag(T_1, T_2, ...) over the blocks of the basis
+!           mode 4: a block that the closing pass found orthonormal to 1e-8 keeps its closing projection and its last triangular
+!           factor pending (the sweeps of :3543-3544 and :3327 are not run on it): the finished block is [X | U] p for the STORED
+!           columns; its columns of the projected matrix come back for the stored block and are corrected here, D^T h_raw D with
+!           the upper-triangular D that collects the pending blocks of the whole basis
 !
             call chk(e%ctx, dla_expand_project(e%ctx, 4_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
                                                h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
-            call chk(e%ctx, dla_pending_factor(e%ctx, s%act, tblk, n_max), 'pending factor')
-            call admit_factor(s%head, s%act)
+            call chk(e%ctx, dla_pending_block(e%ctx, s%cols, s%act, pblk, s%ld, applied), 'pending block')
+            call admit_pending(s%cols, s%act)
             projected = .true.
           else
 !           (last sweep allowed: nobody will read the operator's image of this block -- the caller's routine is not called)
@@ -889,81 +913,54 @@ contains
 !
   contains
 !
-!   Blocks whose last triangular factor was left pending (dla_expand_project mode 4): the panel holds U_i T_i^-1 for block i, the
-!   orthonormal basis is basis * D with D = diag(T_1, T_2, ...) -- block diagonal, upper triangular, identity where nothing is
-!   pending.  The projected matrix and the coefficients of every product with the panel take D in k x k pieces.
+!   Blocks the device chain did not finish in memory (dla_expand_project mode 4): block i of the orthonormal basis is
+!   [X_stored | U_stored] p_i -- p_i = [E_i ; T_i], the closing projection and the last triangular factor of its orthogonalisation.
+!   The orthonormal basis is panel * D with D upper triangular (column block i = p_i, the identity where nothing is pending): the
+!   projected matrix is D^T hraw D (hraw: the raw products of the stored columns) and every coefficient block takes D before a
+!   product with the panel.  The algebra is host-size (dla_basis_admit / dla_basis_fold).
 !
     subroutine reset_pending()
       integer :: j
       dmat = zero
+      hraw = zero
       do j = 1, s%ld
         dmat(j,j) = one
-        bfirst(j) = j
       end do
       any_pending = .false.
     end subroutine reset_pending
 !
-!   the block that starts at column c0 (k columns) has come back with the factor tblk pending: record it and turn the raw columns
-!   of the projected matrix, h(1:c0+k-1, c0:c0+k-1) = [X_c | U_c]^T A U_c, into D^T h T
+!   a block of k columns has come in behind m stored ones with pblk pending
 !
-    subroutine admit_factor(c0, k)
-      integer, intent(in) :: c0, k
-      integer :: i, j, p, rows
+    subroutine admit_pending(m, k)
+      integer, intent(in) :: m, k
+      integer :: i, j
       logical :: ident
       ident = .true.
       do j = 1, k
-        do i = 1, j
-          if (tblk(i,j).ne.merge(one, zero, i.eq.j)) ident = .false.
+        do i = 1, m + k
+          if (pblk(i,j).ne.merge(one, zero, i.eq.m+j)) ident = .false.
         end do
-      end do
-      bfirst(c0:c0+k-1) = c0
-      dmat(c0:c0+k-1,c0:c0+k-1) = zero
-      do j = 1, k
-        dmat(c0:c0+j-1,c0+j-1) = tblk(1:j,j)
       end do
       if (.not.ident) any_pending = .true.
-      if (.not.any_pending) return
-      rows = c0 + k - 1
-      if (.not.ident) then
-        do j = k, 1, -1
-          h(1:rows,c0+j-1) = h(1:rows,c0+j-1)*tblk(j,j)
-          do p = 1, j - 1
-            h(1:rows,c0+j-1) = h(1:rows,c0+j-1) + h(1:rows,c0+p-1)*tblk(p,j)
-          end do
+      if (.not.any_pending) then
+!       (nothing pending anywhere: h is the projected matrix as it came; the raw copy is kept for later blocks)
+        hraw(1:m+k,m+1:m+k) = h(1:m+k,m+1:m+k)
+        do j = 1, k
+          hraw(m+j,1:m+k) = hraw(1:m+k,m+j)
         end do
+        return
       end if
-      call fold_rows_t(h(:,c0:c0+k-1), rows, k)
-    end subroutine admit_factor
+      call need_ok(dla_basis_admit(m, k, pblk, s%ld, applied, hraw, dmat, h, s%ld), 'basis admit')
+    end subroutine admit_pending
 !
-!   g(1:nrow,:) <- D^T g
-!
-    subroutine fold_rows_t(g, nrow, ncol)
-      integer,  intent(in)    :: nrow, ncol
-      real(dp), intent(inout) :: g(s%ld,ncol)
-      integer :: r, p
-      do r = nrow, 1, -1
-        if (bfirst(r).eq.r .and. dmat(r,r).eq.one) cycle          ! (first column of a block: only its diagonal entry)
-        g(r,1:ncol) = g(r,1:ncol)*dmat(r,r)
-        do p = bfirst(r), r - 1
-          g(r,1:ncol) = g(r,1:ncol) + dmat(p,r)*g(p,1:ncol)
-        end do
-      end do
-    end subroutine fold_rows_t
-!
-!   c(1:nrow,:) <- D c
-!
-    subroutine fold_rows(c, nrow, ncol)
-      integer,  intent(in)    :: nrow, ncol
-      real(dp), intent(inout) :: c(s%ld,ncol)
-      integer :: r, p
-      do p = 1, nrow
-        c(p,1:ncol) = c(p,1:ncol)*dmat(p,p)
-        do r = p + 1, nrow
-          if (bfirst(r).ne.bfirst(p)) exit
-          c(p,1:ncol) = c(p,1:ncol) + dmat(p,r)*c(r,1:ncol)
-        end do
-      end do
-    end subroutine fold_rows
+    subroutine need_ok(st, what)
+      integer(c_int),   intent(in) :: st
+      character(len=*), intent(in) :: what
+      if (st.ne.0) then
+        write(6,*) ' diaglib: ', what, ' failed'
+        error stop 1
+      end if
+    end subroutine need_ok
   end subroutine davidson_core
 !
   subroutine davidson_driver(verbose,n,n_targ,n_max,max_iter,tol,max_dav,shift,matvec,precnd,eig,evec,ok)
@@ -1014,11 +1011,13 @@ contains
     type(c_funptr)  :: op, prec, metric
     type(c_ptr)     :: sp(2), asp(2), bsp(2), resid, latest
     integer         :: rd, wr              ! the copy the basis is read from / the copy that receives the new X and P
-    real(dp), allocatable :: h(:,:), theta(:), cx(:,:), cp(:,:), ycp(:,:), seen(:,:,:), tfac(:,:), yf(:,:)
-    integer :: tw                  ! > 0: the W block in memory still lacks the triangular factor tfac(1:tw,1:tw) (see orthogonalise_w)
+    real(dp), allocatable :: h(:,:), theta(:), cx(:,:), cp(:,:), ycp(:,:), seen(:,:,:), pfac(:,:), yf(:,:)
+    integer :: tw                  ! > 0: the W block in memory (tw columns) is not finished: the orthonormal block is
+                                   ! [X P | W_stored] pfac(1:width,1:tw) (see orthogonalise_w)
     real(dp)        :: t_begin(2), t_end(2)
     integer         :: it, sweeps, width, live, c_x, c_p, c_w, wide, bet
     logical         :: projected           ! the W block already has its operator image and S^T A S is in h (dla_expand_project)
+    integer(c_int)  :: applied_w
 !
     op     = c_funloc(matvec)
     prec   = c_funloc(precnd)
@@ -1036,7 +1035,7 @@ contains
     resid = dev_panel(e%ctx, n, n_max, 'r')
     rd = 1
     wr = 2
-    allocate (h(wide,wide), theta(wide), seen(2,n_max,2), tfac(n_max,n_max))
+    allocate (h(wide,wide), theta(wide), seen(2,n_max,2), pfac(wide,n_max))
     tw = 0
     h    = zero
     seen = zero
@@ -1107,7 +1106,8 @@ contains
       if (.not.gen_eig) then
         if (tw.gt.0) then
 !
-!         the W block in memory is W T^-1 (orthogonalise_w): products with the panel take T on the W rows of their coefficients
+!         the W block in memory lacks its closing steps (orthogonalise_w): products with the panel take D = [I E ; 0 T] on
+!         their coefficients
 !
           allocate (yf(width,n_max))
           yf = h(1:width,1:n_max)
@@ -1252,13 +1252,19 @@ contains
       open = max(1, n_max - front)
     end function open_roots_expected
 !
-!   rows of the W block (the last tw of the current width) of a coefficient block times the pending factor
+!   cf <- D cf with D = [I E ; 0 T]: the W rows (the last tw of the current width) of a coefficient block reach every row through
+!   the pending block pfac = [E ; T]
 !
     subroutine fold_pending(cf, ncol)
       integer,  intent(in)    :: ncol
       real(dp), intent(inout) :: cf(width,ncol)
+      real(dp) :: wrows(tw,ncol)
+      integer  :: mx
       if (tw.le.0 .or. ncol.le.0) return
-      cf(width-tw+1:width,1:ncol) = matmul(tfac(1:tw,1:tw), cf(width-tw+1:width,1:ncol))
+      mx = width - tw
+      wrows = cf(mx+1:width,1:ncol)
+      cf(mx+1:width,1:ncol) = matmul(pfac(mx+1:width,1:tw), wrows)
+      if (mx.gt.0) cf(1:mx,1:ncol) = cf(1:mx,1:ncol) + matmul(pfac(1:mx,1:tw), wrows)
     end subroutine fold_pending
 !
     subroutine turn_over()
@@ -1288,12 +1294,13 @@ contains
 !       (the operator on the W block and S^T A S -- the head of the next sweep -- in the same call: dla_expand_project)
         if (it.lt.max_iter) then
 !
-!         mode 3: W is used by one sweep and then rebuilt, so the last triangular factor of its orthogonalisation is not
-!         applied to it -- the projection comes back corrected, and the sweep's coefficients take the factor (fold_pending)
+!         mode 3: W is used by one sweep and then rebuilt, so the closing projection and the last triangular factor of its
+!         orthogonalisation are not applied to it -- the projection comes back corrected, and the sweep's coefficients take the
+!         pending block (fold_pending)
 !
           call chk(e%ctx, dla_expand_project(e%ctx, 3_c_int, n, m, k, sp(rd), asp(rd), op, shift, h, wide), &
                    'ortho_vs_x + matvec + projection')
-          call chk(e%ctx, dla_pending_factor(e%ctx, k, tfac, n_max), 'pending factor')
+          call chk(e%ctx, dla_pending_block(e%ctx, m, k, pfac, wide, applied_w), 'pending block')
           tw = k
           projected = .true.
         else

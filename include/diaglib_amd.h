@@ -95,6 +95,11 @@ enum {
                                       2: also for the caller's device-mode callbacks (ordering contract 0 or 2) -- the caller
                                          states that the operator keeps no state between calls;
                                       0: never (one call after the other; A/B and debugging)                                  */
+  DLA_OPT_PENDING_BLOCKS = 11,     /* dla_expand_project modes 3 / 4 (what the drivers call): 1 (default) the orthogonalisation chain may
+                                      leave its closing projection and its last triangular factor to the caller's small matrices
+                                      (dla_pending_block); 0: every block is finished in memory (modes 3 / 4 behave like 1 / 0) --
+                                      same eigenpairs either way, for A/B runs and tests in one process.  New contexts start
+                                      with 0 when $DIAGLIB_AMD_NO_PENDING is set                                              */
   DLA_OPT_TUNE0 = 100              /* 100..107: kernel-shape experiment knobs for the interleaved A/B tools
                                       (tools/tune_*.py, tools/kernel_bench.py); 0 = the shipped default          */
 };
@@ -241,17 +246,36 @@ int  dla_ritz_residual2(dla_ctx* ctx, int n, int l, int m, const double* v_dev, 
  * operator must therefore be a pure function of its input (it is called a second time for the same block then). */
 int  dla_expand_project(dla_ctx* ctx, int mode, int n, int m, int k, double* basis_dev, double* abasis_dev,
                         dla_matvec_fn matvec, double shift, double* h_host, int ldh);
-/* mode 3 = mode 1 for a block that is used once and then rebuilt -- LOBPCG's W block (diaglib.f90:518-529, 394-403): the last
- * triangular factor T of the orthogonalisation (upper triangular, near the identity) is NOT applied to the stored block.  h_host
- * is the projection for the orthonormal block U T (corrected on the host, D^T H D with D = diag(I, T)); the caller multiplies
- * the rows of every coefficient block that belong to the new block by T before it forms products with the panel
- * (S [y | cp] = S_stored D [y | cp]).  dla_pending_factor returns T of the last mode-3 call (k x k, upper triangular; the
- * identity when nothing stayed pending: host-driven loops, a chain that took the long way).  16 n k bytes less per iteration.
- * mode 4 = mode 0 for a block that STAYS in the basis (Davidson): T stays pending only when the closing pass of the
- * orthogonalisation found max |U^T U - I| < 1e-8 (later blocks are projected against the stored block as if it were orthonormal;
- * two passes leave (2e-8)^2 of what they remove), and h_host comes back RAW, for the stored block -- the caller keeps the factors
- * of all its blocks, D = diag(T_1, T_2, ...), forms D^T h T itself and multiplies the rows of its coefficient blocks by D. */
+/* mode 3 = mode 1 for a block that is used once and then rebuilt -- LOBPCG's W block (diaglib.f90:518-529, 394-403).  The device
+ * chain ends as soon as it holds S = X^T U and G = U^T U MEASURED on the stored block together with the converged factor T of G
+ * (T^T G T = I): the reference's closing pass -- U -= X S (:3543-3544), one macro-iteration of ortho_cd with a near-identity factor
+ * (:3256-3327) -- is then a matter of coefficients.  The finished block is [X | U_stored] p with p = [E ; T'] ((m + k) x k), formed on
+ * the host from what the chain hands over: E = -S T R, T' = T R with the k x k factor R that makes the projected block orthonormal
+ * (its Gram matrix is I - (S T)^T (S T): G was measured before the projection).  h_host is the projection for the FINISHED block
+ * (D^T H D with D = [I E ; 0 T']); the caller multiplies every coefficient block by D before it forms products with the panel
+ * (S [y | cp] = S_stored D [y | cp]).  dla_pending_block returns p of the last mode-3 / mode-4 call ([0 ; I] when nothing stayed
+ * pending: host-driven loops, a chain that had to finish in memory); dla_pending_factor returns its T' part.
+ * mode 4 = mode 0 for a block that STAYS in the basis (Davidson): the same, but h_host comes back RAW, for the stored block, and
+ * dla_pending_block returns the chain's own [-S T ; T] -- the caller keeps the pending blocks of its whole basis in an upper-
+ * triangular D and dla_basis_admit completes the closing pass against the FINISHED basis X_stored D (E = -D D^T S T: the stored
+ * columns are not orthonormal, X_stored^T X_stored = (D D^T)^-1), records the block in D and turns the raw columns into those of
+ * D^T H D; dla_basis_fold multiplies coefficient rows by D.  A block that stays in the basis must keep later device projections
+ * against the stored columns effective (the block that comes out of a first projection can be as ill-conditioned as 1e7: what the
+ * projection leaves behind has to stay below its smallest directions): the projection part stays pending only for max |S| < 1e-9,
+ * the factor only for max |G - I| < 1e-8 -- otherwise the factor is applied in memory (U <- U T, nothing of X is read) or the chain
+ * finishes the block there.  (mode 3: max |S| < 1e-4; the block is rebuilt in the next iteration.)  *applied = 1 (mode 4, for
+ * 1e-9 <= max |S| < 1e-5): the chain's closing sweep HAS applied [-S T ; T] to the block in memory, without measuring anything behind
+ * it -- the block in memory is what h_host belongs to, and dla_basis_admit owes it only the difference to the exact closing pass and
+ * the k x k factor of its Gram matrix I - (S T)^T (S T). */
 int  dla_pending_factor(dla_ctx* ctx, int k, double* t_host, int ldt);
+int  dla_pending_block(dla_ctx* ctx, int m, int k, double* p_host, int ldp, int* applied);
+/* Host-size algebra of a basis with pending blocks (no device work; all arrays column-major, leading dimension ld):
+ * dla_basis_admit: a block of k columns came in behind m stored ones with the chain's pending block p (in: [-S T ; T], out: the
+ * completed [E ; T']); columns m .. m+k-1 of h hold the raw product [X | U]_stored^T A U_stored (reference :1691 on the stored
+ * block).  Records them in hraw (both triangles) and p in the upper-triangular dmat, and replaces the columns of h by those of
+ * dmat^T hraw dmat.  dla_basis_fold: c <- dmat(0:rows,0:rows) c. */
+int  dla_basis_admit(int m, int k, double* p_host, int ldp, int applied, double* hraw, double* dmat, double* h, int ld);
+int  dla_basis_fold(int rows, int ncol, const double* dmat, int ld, double* c, int ldc);
 /* The expansion step with a metric B (gen_david_driver diaglib.f90:2170-2190, lobpcg_driver with gen_eig :523-529): on
  * basis = [X | U], bbasis = [BX | BU], abasis = [AX | AU]:  b_ortho_vs_x(X, BX, U) (:3576-3663),  BU = B U (the caller's bvec),
  * b_ortho(U, BU) (:3094-3183),  AU = A U [+ shift U],  and the projection as in dla_expand_project (mode 0 / 1).  Same result as

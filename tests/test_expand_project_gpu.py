@@ -253,44 +253,48 @@ def test_expand_project_metric_equals_the_separate_calls(ctx, rng, mode, n, m, k
 
 
 @pytest.mark.parametrize("n,m,k,kind", [(4000, 26, 13, "random"), (4000, 52, 11, "near_span"), (2500, 74, 37, "random"),
-                                        (6000, 42, 21, "random"), (3001, 21, 8, "random")])
+                                        (6000, 42, 21, "random"), (3001, 21, 8, "random"), (5000, 208, 13, "random")])
 @pytest.mark.parametrize("ahead", [True, False])
-def test_expand_project_with_the_last_factor_pending(ctx, rng, n, m, k, kind, ahead):
-    """mode 3 (LOBPCG's W block): the chain's last triangular factor T is handed to the host instead of being applied.  The stored
-    block times T is the orthonormal block mode 1 delivers; the operator's image of the stored block times T is mode 1's; the
-    projection comes back already corrected; T is upper triangular and near the identity."""
+def test_expand_project_with_the_closing_block_pending(ctx, rng, n, m, k, kind, ahead):
+    """mode 3 (LOBPCG's W block): the chain ends where it holds X^T U and U^T U measured on the stored block and the converged
+    factor; the closing pass of the reference (diaglib.f90:3543-3544 + one macro-iteration of ortho_cd) comes back as the block
+    p = [E ; T] ((m + k) x k).  [X | U_stored] p is the orthonormal block mode 1 delivers; the operator's image follows by
+    linearity; the projection comes back already corrected; T is upper triangular with a positive diagonal."""
     try:
         _setup(ctx, n)
         x, u = _blocks(rng, n, m, k, kind)
-        ax = _apply(ctx, x)
-        b1, a1, h1, _ = _run(ctx, 1, x, u, ax, 0.25, ahead)
-        b3, a3, h3, _ = _run(ctx, 3, x, u, ax, 0.25, ahead)
-        t = ctx.pending_factor(k)
+        shift = 0.25
+        axs = np.asfortranarray(_apply(ctx, x) + shift * x)          # (the X block of A S carries the shift like every block, :397)
+        b1, a1, h1, _ = _run(ctx, 1, x, u, axs, shift, ahead)
+        b3, a3, h3, _ = _run(ctx, 3, x, u, axs, shift, ahead)
+        p = ctx.pending_block(m, k)
+        e, t = p[:m], p[m:]
+        assert np.array_equal(ctx.pending_factor(k), t)
         assert np.array_equal(np.tril(t, -1), np.zeros_like(t)) and np.all(np.diag(t) > 0)
         if n % 2 == 0:                                    # (an odd row count takes the host-driven schedule: nothing stays pending)
-            assert not np.array_equal(t, np.eye(k))       # the device chain did leave a factor pending
-            assert np.abs(t - np.eye(k)).max() < 0.2, np.abs(t - np.eye(k)).max()   # (the factor of the pass that found U^T U = I + small)
-        w1, w3 = b1[:, m:], b3[:, m:] @ t
+            assert not np.array_equal(t, np.eye(k))       # the device chain did leave its closing block pending
+            assert np.abs(e).max() < 1e-3 and np.abs(t - np.eye(k)).max() < 0.5
+        w1, w3 = b1[:, m:], x @ e + b3[:, m:] @ t
         assert np.abs(w3.T @ w3 - np.eye(k)).max() < 50 * EPS and np.abs(x.T @ w3).max() < 50 * EPS
         assert np.abs(w3 - w1).max() < 1e-12                                       # the same block (rounding apart)
-        assert np.abs(a3[:, m:] @ t - a1[:, m:]).max() < 1e-11 * max(1.0, np.abs(a1).max())
+        assert np.abs(axs @ e + a3[:, m:] @ t - a1[:, m:]).max() < 1e-11 * max(1.0, np.abs(a1).max())
         l1, l3 = np.tril(h1), np.tril(h3)
         assert np.abs(l3 - l1).max() < 1e-11 * max(1.0, np.abs(l1).max())
         assert np.array_equal(b3[:, :m], x)
-        # a second fetch returns the identity: the factor belongs to the call that left it
-        assert np.array_equal(ctx.pending_factor(k), t)
+        # a second fetch returns the same block: it belongs to the call that left it
+        assert np.array_equal(ctx.pending_block(m, k), p)
     finally:
         ctx.set_option(capi.OPT_RUN_AHEAD, 1)
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
         ctx.set_shard(-1, 0)
 
 
-@pytest.mark.parametrize("n,m,k", [(4000, 26, 13), (6000, 42, 21), (4000, 52, 8)])
-def test_expand_project_keeps_the_factor_of_a_block_that_stays(ctx, rng, n, m, k):
-    """mode 4 (a Davidson block): the factor stays pending only when the closing pass found the block orthonormal to 1e-8.  A block
-    that is orthonormal to 1e-10 on entry keeps it: the stored block times T is orthonormal to rounding, the projection comes back
-    raw (for the stored block), and T^T-corrected it equals mode 0's.  A random block (closing deviation far above 1e-8 or the
-    usual two passes) gets its sweep and returns the identity -- both ways the pair (stored block, T) describes the same basis."""
+@pytest.mark.parametrize("n,m,k", [(4000, 26, 13), (6000, 42, 21), (4000, 52, 8), (4000, 208, 13), (5000, 74, 37)])
+def test_expand_project_keeps_the_closing_block_of_a_block_that_stays(ctx, rng, n, m, k):
+    """mode 4 (a Davidson block): the projection comes back RAW, for the stored block, together with the chain's pending block
+    [-S T ; T]; dla_basis_admit completes the closing pass against the caller's basis (here D = I: X is a finished block) and
+    turns the raw columns into those of the orthonormal block -- equal to mode 0's.  Both a nearly orthonormal block and a random
+    one end pending; either way the pair (stored block, p) describes the block mode 0 stores."""
     try:
         _setup(ctx, n)
         x = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, m)))[0])
@@ -299,18 +303,26 @@ def test_expand_project_keeps_the_factor_of_a_block_that_stays(ctx, rng, n, m, k
             ax = _apply(ctx, x)
             b0, a0, h0, _ = _run(ctx, 0, x, u, ax, 0.0, True)
             b4, a4, h4, _ = _run(ctx, 4, x, u, ax, 0.0, True)
-            t = ctx.pending_factor(k)
+            p = ctx.pending_block(m, k)
+            assert np.any(p[:m] != 0.0)                     # the chain ended with its closing pass pending
+            l = m + k
+            hraw = np.zeros((l, l), order="F"); dmat = np.asfortranarray(np.eye(l)); h = np.zeros((l, l), order="F")
+            hraw[:m, :m] = x.T @ ax
+            h[:, m:] = h4
+            ctx.basis_admit(m, k, p, hraw, dmat, h, applied=ctx.pending_applied)
+            e, t = p[:m], p[m:]
             assert np.array_equal(np.tril(t, -1), np.zeros_like(t)) and np.all(np.diag(t) > 0)
-            w4 = b4[:, m:] @ t
+            assert np.array_equal(dmat[:, m:], p) and np.array_equal(dmat[:m, :m], np.eye(m))
+            w4 = x @ e + b4[:, m:] @ t
             assert np.abs(w4.T @ w4 - np.eye(k)).max() < 50 * EPS and np.abs(x.T @ w4).max() < 50 * EPS
             assert np.abs(w4 - b0[:, m:]).max() < 1e-12
-            # raw projection for the stored block; with D = diag(I, T): D^T h4 T = h0
-            d = np.eye(m + k); d[m:, m:] = t
-            assert np.abs(d.T @ h4 @ t - h0).max() < 1e-11 * max(1.0, np.abs(h0).max())
-            assert np.abs(a4[:, m:] @ t - a0[:, m:]).max() < 1e-11 * max(1.0, np.abs(a0).max())
-            pending = not np.array_equal(t, np.eye(k))
-            if u is not None and np.abs(u.T @ u - np.eye(k)).max() < 1e-8:
-                assert pending and np.abs(t - np.eye(k)).max() < 1e-8        # the nearly orthonormal block keeps its factor
+            assert np.abs(h[:, m:] - h0).max() < 1e-11 * max(1.0, np.abs(h0).max())
+            assert np.abs(ax @ e + a4[:, m:] @ t - a0[:, m:]).max() < 1e-11 * max(1.0, np.abs(a0).max())
+            # coefficients for the stored columns: D c
+            cfull = np.asfortranarray(rng.standard_normal((l, 3)))
+            want = dmat @ cfull
+            ctx.basis_fold(l, dmat, cfull)
+            assert np.abs(cfull - want).max() < 1e-13
     finally:
         ctx.set_option(capi.OPT_RUN_AHEAD, 1)
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
