@@ -238,6 +238,9 @@ class Context:
     def set_option(self, opt: int, val: int) -> None:
         self._chk(self.lib.dla_set_option(self.h, opt, int(val)))
 
+    def get_option(self, opt: int) -> int:
+        return int(self.lib.dla_get_option(self.h, opt))
+
     def sync(self) -> None:
         self._chk(self.lib.dla_sync(self.h))
 

@@ -1722,6 +1722,7 @@ struct OrthoDev {
   int have_xu;        // pending-factor schedule: X^T U of the block in memory is known (xug) up to the factors in wst
   double growth;      // prod ||L^-1||_est of the current ortho_cd pass
   int sloppy;         // pending-factor schedule: the last projection used an X^T U carried through ill-conditioned factors
+  double gdev;        // max |G - I| of the last Gram matrix that was factored (how far the pending factor is from the identity)
   int last_status;    // how the last chain ended (OST_*), kept when the machine re-arms: what runs behind a chain on the device
                       // without the host in between (bortho_tail_kernel) continues only after OST_DONE
   int log[48];        // the sweeps executed, in order
@@ -1832,7 +1833,7 @@ __device__ __forceinline__ double lds_norm_est(int k, const double* A, int lane)
   return dn + sqrt(on);
 }
 
-struct TailState { int it_macro, it_outer, macro_total, shifts, nops, phase, status; double growth; int have_xu, sloppy; };
+struct TailState { int it_macro, it_outer, macro_total, shifts, nops, phase, status; double growth; int have_xu, sloppy; double gdev; };
 #define TAIL_LDS_DOUBLES (48 * TLD + 48 * 64)   // image A, then image S (also used as 48 x 64 scratch)
 
 // what one lane does at the end of a step: log the sweep, report to the host when the chain ends (or the plan does), leave the
@@ -1853,13 +1854,13 @@ __device__ __forceinline__ void tail_publish(const OrthoTailArgs& a, const TailS
   }
   if (t.status != OST_RUNNING) {
     // finished (or failed): re-arm the machine for the next chain, so that no initial state has to be copied in
-    st->it_macro = 0; st->it_outer = 0; st->nops = 0; st->macro_total = 0; st->shifts = 0; st->growth = 1.0; st->have_xu = 0; st->sloppy = 0;
+    st->it_macro = 0; st->it_outer = 0; st->nops = 0; st->macro_total = 0; st->shifts = 0; st->growth = 1.0; st->have_xu = 0; st->sloppy = 0; st->gdev = 1.0;
     st->last_status = t.status;
     st->status = OST_RUNNING;
     __hip_atomic_store(&st->phase, (int)OP_GRAM_UU, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     st->it_macro = t.it_macro; st->it_outer = t.it_outer; st->nops = nops + 1; st->macro_total = t.macro_total;
-    st->shifts = t.shifts; st->growth = t.growth; st->status = t.status; st->have_xu = t.have_xu; st->sloppy = t.sloppy;
+    st->shifts = t.shifts; st->growth = t.growth; st->status = t.status; st->have_xu = t.have_xu; st->sloppy = t.sloppy; st->gdev = t.gdev;
     __hip_atomic_store(&st->phase, ph_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -1884,7 +1885,7 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
   const int kt = (k + 15) / 16, k4 = ((k + 3) / 4) * 4;
   const double eps = 2.220446049250313e-16, tol = 2.0 * eps;   // epsilon(one), tol_ortho (diaglib.f90:151)
   const int maxit = a.maxit, can_defer = a.can_defer;
-  TailState t = pre ? *pre : TailState{st->it_macro, st->it_outer, st->macro_total, st->shifts, st->nops, OP_NONE, OST_RUNNING, st->growth, 0, st->sloppy};
+  TailState t = pre ? *pre : TailState{st->it_macro, st->it_outer, st->macro_total, st->shifts, st->nops, OP_NONE, OST_RUNNING, st->growth, 0, st->sloppy, st->gdev};
   const int force_defer = can_defer && t.it_outer == 0;   // the ortho_cd that precedes the loop always leaves W pending
   double* A = lds;
   double* S = lds + 48 * TLD;
@@ -1935,7 +1936,7 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
     // C' = [-(xu W) ; W]  (host_logic.cpp ortho_vs_x_impl, X^T (U W) = (X^T U) W), packed for the combined sweep
     for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx % k) * TLD + idx / k, a.wfull[idx]);   // A[pp][j] = W(pp, j)
     TSYNC();
-    const bool pend = may_pend && small_xu(a.gsrc, m);
+    const bool pend = may_pend && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) && small_xu(a.gsrc, m);
     assemble(a.gsrc, m, pend);
     t.it_macro = 0;           // the ortho_cd that follows the combined sweep starts afresh (*growth = 1, it = 0)
     t.growth = 1.0;
@@ -1956,6 +1957,15 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
           const int i = idx % k, j = idx / k;
           if (i >= j) { const double v = a.gsrc[(size_t)(roff + i) + (size_t)j * ldg]; lds_store1(A + i * TLD + j, v); lds_store1(S + i * TLD + j, v); }
         }
+      }
+      {
+        double dv = 0.0;                  // max |G - I| of the Gram matrix about to be factored
+        for (int idx = lane; idx < k * k; idx += 64) {
+          const int i = idx % k, j = idx / k;
+          if (i >= j) dv = fmax(dv, fabs(lds_load1(S + i * TLD + j) - (i == j ? 1.0 : 0.0)));
+        }
+        for (int off = 32; off > 0; off >>= 1) dv = fmax(dv, __shfl_xor(dv, off, 64));
+        t.gdev = dv;
       }
       int info = lds_potrf(k, A, lane);
       int it_micro = 0;
@@ -2019,7 +2029,7 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
           TSYNC();
           for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx / k) * TLD + idx % k, lds_load1(S + (idx / k) * TLD + idx % k));
           TSYNC();
-          const bool pend = xw_project && may_pend && small_xu(a.gsrc, m + k);
+          const bool pend = xw_project && may_pend && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) && small_xu(a.gsrc, m + k);
           assemble(a.gsrc, m + k, pend);
           t.sloppy = (!xw_project && t.growth * eps >= tol) ? 1 : 0;      // (a measured X^T U of the stored block is not sloppy)
           ++t.it_outer;
@@ -2368,7 +2378,7 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
     __syncthreads();
   }
   if (wave == 0) {
-    TailState t = pre ? *pre : TailState{st->it_macro, st->it_outer, st->macro_total, st->shifts, st->nops, OP_NONE, OST_RUNNING, st->growth, st->have_xu, st->sloppy};
+    TailState t = pre ? *pre : TailState{st->it_macro, st->it_outer, st->macro_total, st->shifts, st->nops, OP_NONE, OST_RUNNING, st->growth, st->have_xu, st->sloppy, st->gdev};
     t.phase = OP_NONE; t.status = OST_RUNNING;
     const int force_defer = can_defer && t.it_outer == 0;
     int go = 0;
@@ -2383,7 +2393,9 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
 #pragma unroll
       for (int r = 0; r < 4; ++r) { pnew[r] = a.wst[512 + 64 * r + lane]; dnew[r] = pnew[r]; }
       t.it_macro = 0; t.growth = 1.0; t.have_xu = 0; t.sloppy = 0;
-      if (may_pend && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) < a.drop_stol) { t.status = OST_DONE; go = 2; }
+      // (the block stays pending when the caller takes pending blocks and both X^T U, just measured, and the distance of the
+      //  pending factor from the identity -- the Gram matrix it came from -- are within the caller's bounds)
+      if (may_pend && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) < a.drop_stol && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol)) { t.status = OST_DONE; go = 2; }
       else { t.phase = op_project; go = 1; }
     } else {
       ++t.it_macro;
@@ -2414,6 +2426,14 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
             else v = __hip_atomic_load(a.gsrc + (size_t)(roff + hi) + (size_t)lo * ldg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           g0[r] = v;
+        }
+        {
+          double dv = 0.0;                // max |G - I| (identity beyond k)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dv = fmax(dv, fabs(g0[r] - ((g + 4 * r == c) ? 1.0 : 0.0)));
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) dv = fmax(dv, __shfl_xor(dv, off, 64));
+          t.gdev = dv;
         }
         v4d am = g0, x;
         double dmax, xmax;
@@ -2894,7 +2914,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
   if constexpr (TAIL) {
     if (threadIdx.x < 64)
       pre = TailState{a.tail.st->it_macro, a.tail.st->it_outer, a.tail.st->macro_total, a.tail.st->shifts, a.tail.st->nops,
-                      OP_NONE, OST_RUNNING, a.tail.st->growth, a.tail.st->have_xu, a.tail.st->sloppy};
+                      OP_NONE, OST_RUNNING, a.tail.st->growth, a.tail.st->have_xu, a.tail.st->sloppy, a.tail.st->gdev};
   }
   // loads are issued in batches of 32 / 8 (independent), the adds stay in index order
   double s = 0.0;
@@ -3599,7 +3619,8 @@ struct HipEngine : dla::Engine {
   double* chain_red_dst = nullptr;   // ... to this buffer
   bool chain_xw = false;             // the chain being enqueued may use the storing sweep OP_XW for its wide block (ortho_tail)
   bool chain_x3 = false;             // the chain being enqueued runs the three-pass schedule (OP_COMBOX / OP_CLOSE, ortho_tail16)
-  int x3_cooldown = 0;               // > 0: a recent chain needed a level shift -- that many chains run the five-sweep schedule
+  int x3_cooldown = 8;               // > 0: a recent chain needed a level shift (or the context is new: no evidence yet) -- that many
+                                     // chains run the five-sweep schedule
   // ---- one-shot peer-to-peer all-reduce (p2p_allreduce_kernel)
   struct P2P {
     bool on = false;
@@ -4106,7 +4127,7 @@ struct HipEngine : dla::Engine {
       // first chain (or the previous one was abandoned on an error): copy the initial state in.  Afterwards the
       // tail that ends a chain re-arms the machine itself.
       OrthoDev init{};
-      init.phase = OP_GRAM_UU; init.status = OST_RUNNING; init.growth = 1.0;
+      init.phase = OP_GRAM_UU; init.status = OST_RUNNING; init.growth = 1.0; init.gdev = 1.0;
       *h_ost_init = init;
       HIPCHK(hipMemcpyAsync(d_ost, h_ost_init, sizeof(OrthoDev), hipMemcpyHostToDevice, st));
     }

@@ -259,9 +259,12 @@ def test_expand_project_with_the_closing_block_pending(ctx, rng, n, m, k, kind, 
     """mode 3 (LOBPCG's W block): the chain ends where it holds X^T U and U^T U measured on the stored block and the converged
     factor; the closing pass of the reference (diaglib.f90:3543-3544 + one macro-iteration of ortho_cd) comes back as the block
     p = [E ; T] ((m + k) x k).  [X | U_stored] p is the orthonormal block mode 1 delivers; the operator's image follows by
-    linearity; the projection comes back already corrected; T is upper triangular with a positive diagonal."""
+    linearity; the projection comes back already corrected; T is upper triangular with a positive diagonal.
+    (Tune knob 6 = 13: the three-pass schedule from the first chain on -- a new context runs the five-sweep one until eight chains
+    in a row have needed no level shift.)"""
     try:
         _setup(ctx, n)
+        ctx.set_option(100 + 6, 13)
         x, u = _blocks(rng, n, m, k, kind)
         shift = 0.25
         axs = np.asfortranarray(_apply(ctx, x) + shift * x)          # (the X block of A S carries the shift like every block, :397)
@@ -284,6 +287,7 @@ def test_expand_project_with_the_closing_block_pending(ctx, rng, n, m, k, kind, 
         # a second fetch returns the same block: it belongs to the call that left it
         assert np.array_equal(ctx.pending_block(m, k), p)
     finally:
+        ctx.set_option(100 + 6, 0)
         ctx.set_option(capi.OPT_RUN_AHEAD, 1)
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
         ctx.set_shard(-1, 0)
@@ -297,6 +301,7 @@ def test_expand_project_keeps_the_closing_block_of_a_block_that_stays(ctx, rng, 
     one end pending; either way the pair (stored block, p) describes the block mode 0 stores."""
     try:
         _setup(ctx, n)
+        ctx.set_option(100 + 6, 13)
         x = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, m)))[0])
         q = rng.standard_normal((n, k)); q -= x @ (x.T @ q); q = np.linalg.qr(q)[0]
         for u in (np.asfortranarray(q @ (np.eye(k) + 1e-10 * rng.standard_normal((k, k)))), np.asfortranarray(rng.standard_normal((n, k)))):
@@ -304,7 +309,8 @@ def test_expand_project_keeps_the_closing_block_of_a_block_that_stays(ctx, rng, 
             b0, a0, h0, _ = _run(ctx, 0, x, u, ax, 0.0, True)
             b4, a4, h4, _ = _run(ctx, 4, x, u, ax, 0.0, True)
             p = ctx.pending_block(m, k)
-            assert np.any(p[:m] != 0.0)                     # the chain ended with its closing pass pending
+            if k <= 16 and m <= 192:
+                assert np.any(p[:m] != 0.0)                 # the three-pass chain ended with its closing pass pending
             l = m + k
             hraw = np.zeros((l, l), order="F"); dmat = np.asfortranarray(np.eye(l)); h = np.zeros((l, l), order="F")
             hraw[:m, :m] = x.T @ ax
@@ -324,6 +330,7 @@ def test_expand_project_keeps_the_closing_block_of_a_block_that_stays(ctx, rng, 
             ctx.basis_fold(l, dmat, cfull)
             assert np.abs(cfull - want).max() < 1e-13
     finally:
+        ctx.set_option(100 + 6, 0)
         ctx.set_option(capi.OPT_RUN_AHEAD, 1)
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
         ctx.set_shard(-1, 0)

@@ -1,0 +1,90 @@
+"""A basis that grows block by block through dla_expand_project mode 4 (the Davidson drivers' expansion step, reference
+diaglib.f90:1790 + 1685 + 1691) with the blocks' closing passes left pending: the panel holds what the device chains stored, the
+caller's upper-triangular D (dla_basis_admit) holds what they left undone.  Whatever schedule a chain took -- three-pass, five-sweep,
+sweep-per-update beyond 192 columns, level shifts -- and whatever it left pending,
+
+    (panel D)^T (panel D) = I      and      h = (panel D)^T A (panel D)
+
+to rounding: the property the round-4 review asked for (the stored basis alone need not be orthonormal)."""
+import numpy as np
+import pytest
+
+from diaglib_amd import capi
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+def _grow(ctx, rng, n, k, nb, kind, pending):
+    mv = capi.fn_address("dla_synth_matvec")
+    ld = nb * k
+    x0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, k)))[0])
+    basis = ctx.panel(np.asfortranarray(np.hstack([x0, np.zeros((n, ld - k))])))
+    abasis = ctx.panel(np.zeros((n, ld), order="F"))
+    ctx.synth_matvec(basis.col(0, k), abasis.col(0, k))
+    hraw = np.zeros((ld, ld), order="F"); dmat = np.asfortranarray(np.eye(ld)); h = np.zeros((ld, ld), order="F")
+    b = basis.download(); ab = abasis.download()
+    hraw[:k, :k] = b[:, :k].T @ ab[:, :k]; h[:k, :k] = hraw[:k, :k]
+    n_pending = 0
+    for blk in range(1, nb):
+        m = blk * k
+        if kind == "inside":          # mostly inside span(X): the projection removes almost everything
+            u = b[:, :m] @ rng.standard_normal((m, k)) + 1e-6 * rng.standard_normal((n, k))
+        elif kind == "dependent":     # numerically rank deficient after the projection: level shifts
+            u = b[:, :m] @ rng.standard_normal((m, k)) + 0.3 * rng.standard_normal((n, k))
+            u[:, -1] = u[:, 0] * (1.0 + 1e-13) + 1e-14 * rng.standard_normal(n)
+        else:
+            u = b[:, :m] @ rng.standard_normal((m, k)) + 0.3 * rng.standard_normal((n, k))
+        basis.col(m, k).upload(np.asfortranarray(u))
+        h4 = ctx.expand_project(4 if pending else 0, basis, abasis, m, k, mv, 0.0)
+        p = ctx.pending_block(m, k) if pending else np.asfortranarray(np.vstack([np.zeros((m, k)), np.eye(k)]))
+        applied = ctx.pending_applied if pending else False
+        n_pending += int(np.any(p[:m] != 0.0) or not np.array_equal(p[m:], np.eye(k)))
+        h[:m + k, m:m + k] = h4
+        ctx.basis_admit(m, k, p, hraw, dmat, h, applied=applied)
+        b = basis.download()
+    ab = abasis.download()
+    return b, ab, dmat, h, n_pending
+
+
+@pytest.mark.parametrize("knob", [0, 12, 13])
+@pytest.mark.parametrize("k,nb,kind", [(1, 8, "random"), (3, 8, "random"), (13, 6, "random"), (13, 18, "random"), (13, 6, "inside"),
+                                       (13, 6, "dependent"), (8, 10, "dependent"), (21, 5, "random"), (37, 4, "random")])
+def test_basis_with_pending_blocks_is_orthonormal_and_projects_exactly(ctx, rng, knob, k, nb, kind):
+    n = 6000
+    try:
+        ctx.set_shard(n, 0); ctx.synth_setup(n, 0, n); ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+        ctx.set_option(100 + 6, knob)
+        b, ab, dmat, h, n_pending = _grow(ctx, rng, n, k, nb, kind, True)
+        l = nb * k
+        v = b @ dmat
+        assert np.abs(v.T @ v - np.eye(l)).max() < 50 * EPS, (np.abs(v.T @ v - np.eye(l)).max(), n_pending)
+        href = v.T @ (ab @ dmat)
+        assert np.abs(np.triu(h - href)).max() < 1e-13 * np.abs(href).max()
+        if knob == 13 and k <= 16 and kind == "random":
+            assert n_pending >= min(nb - 1, 192 // k - 1) // 2      # the three-pass chains do leave their closing passes pending
+    finally:
+        ctx.set_option(100 + 6, 0)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
+
+
+def test_pending_blocks_can_be_switched_off_per_context(ctx, rng):
+    """DLA_OPT_PENDING_BLOCKS = 0: modes 3 / 4 finish every block in memory (nothing comes back pending); same basis either way."""
+    n, k, nb = 6000, 13, 5
+    try:
+        ctx.set_shard(n, 0); ctx.synth_setup(n, 0, n); ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+        ctx.set_option(100 + 6, 13)
+        outs = []
+        for on in (1, 0):
+            ctx.set_option(capi.OPT_PENDING_BLOCKS, on)
+            assert ctx.get_option(capi.OPT_PENDING_BLOCKS) == on
+            b, ab, dmat, h, n_pending = _grow(ctx, np.random.default_rng(7), n, k, nb, "random", True)
+            assert (n_pending > 0) == bool(on)
+            outs.append(b @ dmat)
+        assert np.abs(outs[0] - outs[1]).max() < 1e-12
+    finally:
+        ctx.set_option(capi.OPT_PENDING_BLOCKS, 1)
+        ctx.set_option(100 + 6, 0)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
