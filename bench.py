@@ -15,7 +15,9 @@ the only cross-rank traffic is the RCCL all-reduce of the small m x m products.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  `value` = reference-schedule GFLOP (the flops of the
-BLAS calls the reference would issue for the iterations performed) / wall time of the solves,
+BLAS calls the reference would issue for the iterations performed -- counted per logical operation
+at the library's entry points, dla_stats.ref_flops, so that a fused / pending / skipped sweep raises
+it; `value_launched` is the per-launch count of what the engine ran) / wall time of the solves,
 inputs resident in HBM.  `roofline` is the dominant kernel class measured with HIP events on the
 engine's stream during the timed region; `cpu_baseline` times the UNMODIFIED reference
 (oracle/_ref, flang+MKL) -- or the oracle's C port when that library cannot be loaded -- on this
@@ -131,7 +133,8 @@ def cpu_baseline(n_sample: int, n_targ: int, n_max: int, max_dav: int, tol: floa
                      f"n={n_sample} rows, whole call incl. the reference's allocation + zero-fill of its panels, "
                      f"{dt:.2f} s on {CPU_THREADS} threads (MKL + OpenMP callbacks; {CPU_THREADS} = the cores this process may use: "
                      f"affinity mask / cgroup CPU quota of the box, which has {HOST_CPUS}), converged={bool(ok)}; "
-                     "flops = GPU run's reference-schedule flops per row x n_sample"}
+                     "flops = the GPU run's reference-schedule flops per row (dla_stats.ref_flops: the BLAS calls of the reference "
+                     "for the iterations performed, independent of what the engine launched) x n_sample"}
     if buckets and buckets.get("total"):
         # the reference's own timers (diaglib.f90:1835-1841): in-loop wall time and its three buckets; the rest of the
         # loop (projection, Ritz vectors, residuals) is un-bucketed in the reference
@@ -363,9 +366,13 @@ def main() -> None:
         dist.all_gather_object(rows_per_rank, n_loc)
     # ---- flops / bytes (each rank counted its local rows; shards are equal up to 64 rows)
     classes = ["gram", "gemm", "trmm", "ritz", "elem"]
-    flops_local = sum(stats[c]["flops"] for c in classes)
-    flops_total = flops_local * (n / n_loc)
+    # "GFLOP/s = reference-schedule flops of the iterations performed / wall time", the numerator from the solve's own
+    # record of LOGICAL operations (dla_stats.ref_flops: per entry point the flops of the BLAS calls the reference issues there --
+    # projection 2nLk, Ritz + residual 4nLM + 5nT, ortho_vs_x 2n(4Lk) + 15nk^2, ...), so that a sweep that is fused, left pending or
+    # skipped RAISES the figure.  `value_launched` keeps the per-launch count of what the engine ran (it shrinks with every fusion).
+    flops_total = stats["ref_flops"] * (n / n_loc)
     value = flops_total / dt / 1e9
+    flops_launched = sum(stats[c]["flops"] for c in classes) * (n / n_loc)
     kst = ctx_kernel_stats
     # dominant kernel = the single kernel symbol with the largest HIP-event time in the timed region
     main = {k: v for k, v in kst.items() if v["alg_bytes"] > 0 and v["ms"] > 0}
@@ -394,13 +401,17 @@ def main() -> None:
     # kernel symbol is quoted -- profiles/pmc_traffic.json is keyed by the workload string; anything else stays null
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    traffic_source = None
     if os.path.exists(tfile) and world == 1:      # the PMC passes were taken at N = 1 (whole problem on one GPU)
         try:
-            traffic = json.load(open(tfile)).get(workload_key, {}).get(dom)
+            tj = json.load(open(tfile))
+            traffic = tj.get(workload_key, {}).get(dom)
+            if traffic is not None:       # (a separate rocprofv3 --pmc pass of this workload, not a counter of THIS run)
+                traffic_source = "profiles/pmc_traffic.json (" + str(tj.get("_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.py")) + ")"
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "launches": dk["launches"], "event_steps": ev_steps,
                 "avg_launch_ms": round(dk["ms"] / max(1, dk["launches"]), 4),
                 "alg_bytes_per_launch": round(dk["alg_bytes"] / max(1, dk["launches"]), 1)}
@@ -446,6 +457,7 @@ def main() -> None:
     out = {
         "metric": "eigensolver GFLOP/s + iters-to-converge, n=2e6 m=8 Davidson, 1/2/4/8 GPU",
         "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value_launched": round(flops_launched / dt / 1e9, 2), "gflop_per_solve": round(flops_total / args.steps / 1e9, 3),
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.solver} n={n} roots={n_targ} n_max={n_max} max_dav={args.max_dav} tol={args.tol:g} "

@@ -50,10 +50,10 @@ EXPORTS = [
 
 class Stats(C.Structure):
     _fields_ = [("launches", C.c_longlong * 7), ("alg_bytes", C.c_double * 7), ("flops", C.c_double * 7),
-                ("ms", C.c_double * 7), ("allreduces", C.c_longlong), ("host_syncs", C.c_longlong)]
+                ("ms", C.c_double * 7), ("allreduces", C.c_longlong), ("host_syncs", C.c_longlong), ("ref_flops", C.c_double)]
 
     def as_dict(self) -> dict:
-        d = {"allreduces": int(self.allreduces), "host_syncs": int(self.host_syncs)}
+        d = {"allreduces": int(self.allreduces), "host_syncs": int(self.host_syncs), "ref_flops": float(self.ref_flops)}
         for i, nm in enumerate(OP_NAMES):
             d[nm] = {"launches": int(self.launches[i]), "alg_bytes": float(self.alg_bytes[i]),
                      "flops": float(self.flops[i]), "ms": float(self.ms[i])}

@@ -340,6 +340,7 @@ struct dla_ctx {
   long long row0 = 0;
   std::vector<double> pending_p;   // dla_expand_project modes 3 / 4: the block [E ; T] the last call left pending ((m + k) x k, ld m + k)
   int pending_k = 0, pending_m = 0, pending_applied = 0;
+  int ref_depth = 0;         // nesting of entry points (reference-schedule flops are counted at the outermost one)
   std::string err;
   // pinned staging buffers for host-mode callbacks
   double* stage_x = nullptr;

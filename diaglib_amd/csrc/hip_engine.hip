@@ -5372,6 +5372,14 @@ struct HipEngine : dla::Engine {
     }
     if (expect != n_global) { err = "spmm_setup_csr_sharded: the shards do not cover n_global rows"; return DLA_ERR_ARG; }
     if (halo > 4096) { err = "spmm_setup_csr_sharded: halo wider than 4096 rows (not a banded matrix)"; return DLA_ERR_ARG; }
+    // one right-hand side of the halo exchange is nranks x 2 x halo doubles and has to fit a mailbox slot when the mailboxes are the
+    // only transport (round-4 advisor: beyond it the product had nowhere to go, and its abort left the peers in their exchange
+    // until the timeout).  Same numbers on every rank: refused by all of them, here.
+    if (p2p.on && !comm && !hook && (long long)nr * 2 * halo > (long long)P2P_MAX_DOUBLES) {
+      err = "spmm_setup_csr_sharded: nranks x 2 x halo = " + std::to_string((long long)nr * 2 * halo) + " doubles per column exceed a peer-to-peer mailbox slot (" +
+            std::to_string(P2P_MAX_DOUBLES) + "); attach RCCL (dla_comm_init) or a reduction hook beside the mailboxes";
+      return DLA_ERR_ARG;
+    }
     dla::ShardedEll e;
     dla::sharded_ell_build(n, row0, rowptr, colind, values, (int)halo, e);
     bind();

@@ -347,9 +347,24 @@ int dla_trim(dla_ctx* c, size_t* released) { if (!c) return DLA_ERR_ARG; return 
 int dla_sync(dla_ctx* c) { DLA_T("dla_sync"); return engfail(c, c->eng->sync()); }
 
 // ------------------------------------------------------------------ block algebra
+// Reference-schedule flops ("the flops of the BLAS calls the reference would issue for the iterations performed"): counted
+// per LOGICAL operation at the entry point the driver calls -- the dgemm / dtrmm / daxpy / dnrm2 calls of the reference routine
+// that entry stands for -- whatever the engine launches for it (fused, left pending, skipped).  Entry points that call other entry
+// points count once, at the outermost level.  dla_stats::ref_flops; bench.py's `value` numerator.
+namespace {
+struct RefFlops {
+  dla_ctx* c;
+  RefFlops(dla_ctx* c_, double f) : c(c_) { if (c && c->ref_depth++ == 0) c->eng->stats.ref_flops += f; }
+  ~RefFlops() { if (c) --c->ref_depth; }
+};
+// ortho_vs_x with the schedule measured on the reference: 5 x (Gram + dtrmm) on U, 2 x (X^T U, U -= X C)
+inline double ortho_vs_x_flops(double n, double m, double k) { return 2.0 * n * (4.0 * m * k) + 15.0 * n * k * k; }
+}  // namespace
+
 int dla_gram(dla_ctx* c, int n, int l, const double* x, int k, const double* u, double* ch, int ldc)
 {
   DLA_T("dla_gram");
+  RefFlops rf(c, 2.0 * n * (double)l * k);                       // dgemm 't','n' (:1691, 3543)
   if (l <= 0 || k <= 0) return DLA_OK;
   return engfail(c, c->eng->gram(n, l, x, k, u, ch, ldc));
 }
@@ -357,6 +372,7 @@ int dla_gram(dla_ctx* c, int n, int l, const double* x, int k, const double* u, 
 int dla_gram_lower(dla_ctx* c, int n, int l, const double* x, const double* u, double* ch, int ldc)
 {
   DLA_T("dla_gram_lower");
+  RefFlops rf(c, 2.0 * n * (double)l * l);                       // the reference forms the full product (:403)
   if (l <= 0) return DLA_OK;
   return engfail(c, c->eng->gram_lower(n, l, x, u, ch, ldc));
 }
@@ -364,6 +380,7 @@ int dla_gram_lower(dla_ctx* c, int n, int l, const double* x, const double* u, d
 int dla_panel_gemm(dla_ctx* c, int n, int l, const double* x, int k, const double* ch, int ldc, double* z)
 {
   DLA_T("dla_panel_gemm");
+  RefFlops rf(c, 2.0 * n * (double)l * k);
   if (k <= 0) return DLA_OK;
   return engfail(c, c->eng->gemm(n, l, x, k, ch, ldc, z, 0));
 }
@@ -371,6 +388,7 @@ int dla_panel_gemm(dla_ctx* c, int n, int l, const double* x, int k, const doubl
 int dla_panel_update(dla_ctx* c, int n, int l, const double* x, int k, const double* ch, int ldc, double* u)
 {
   DLA_T("dla_panel_update");
+  RefFlops rf(c, 2.0 * n * (double)l * k);
   if (k <= 0 || l <= 0) return DLA_OK;
   return engfail(c, c->eng->gemm(n, l, x, k, ch, ldc, u, 1));
 }
@@ -414,6 +432,12 @@ int dla_ritz_residual(dla_ctx* c, int n, int l, int m, const double* v, const do
                       double* rnorm)
 {
   DLA_T("dla_ritz_residual");
+  {
+    int act = 0;
+    for (int i = 0; i < n_res; ++i) if (!(skip && skip[i])) ++act;
+    // two dgemms (:1717, 1721) + daxpy / dnrm2 / maxval per open root (:1723-1732): the reference forms the Ritz vectors every time
+    RefFlops rf(c, 4.0 * n * (double)l * m + 5.0 * n * (double)act);
+  }
   std::vector<double> sm((size_t)2 * (n_res > 0 ? n_res : 1), 0.0);
   int st = c->eng->ritz_residual(n, l, m, v, av, y, ldy, eig, n_res, skip, evec, r, avy, sm.data());
   if (st) return engfail(c, st);
@@ -431,6 +455,11 @@ int dla_ritz_residual_p(dla_ctx* c, int n, int l, int m, const double* v, const 
                         double* rnorm, int k2, const double* c2, int ldc2, double* p, double* ap)
 {
   DLA_T("dla_ritz_residual_p");
+  {
+    int act = 0;
+    for (int i = 0; i < n_res; ++i) if (!(skip && skip[i])) ++act;
+    RefFlops rf(c, 4.0 * n * (double)l * m + 5.0 * n * (double)act + 4.0 * n * (double)l * (k2 > 0 ? k2 : 0));     // + P = S cp, AP = AS cp (:495-501)
+  }
   if (k2 < 0 || (k2 > 0 && (!c2 || !p || !ap || ldc2 < l))) return fail(c, DLA_ERR_ARG, "ritz_residual_p: bad extra block");
   std::vector<double> sm((size_t)2 * (n_res > 0 ? n_res : 1), 0.0);
   int st = c->eng->ritz_residual_p(n, l, m, v, av, y, ldy, eig, n_res, skip, evec, r, avy, sm.data(), k2, c2, ldc2, p, ap);
@@ -449,6 +478,11 @@ int dla_ritz_residual2(dla_ctx* c, int n, int l, int m, const double* v, const d
                        double* t_work, double* junk, double* rnorm)
 {
   DLA_T("dla_ritz_residual2");
+  if (c && n > 0 && l > 0 && m > 0) {
+    int act = 0;
+    for (int i = 0; i < n_res; ++i) if (!(skip && skip[i])) ++act;
+    RefFlops rf(c, 4.0 * n * (double)l * m + 5.0 * n * (double)act);
+  }
   if (!c || !v || !av || !y1 || !y2 || !eig || !e || !r || !t_work || !junk || !rnorm || n <= 0 || l <= 0 || m <= 0 || ldy1 < l || ldy2 < l ||
       n_res < 0 || n_res > m)
     return fail(c, DLA_ERR_ARG, "dla_ritz_residual2: bad argument");
@@ -467,12 +501,14 @@ int dla_ritz_residual2(dla_ctx* c, int n, int l, int m, const double* v, const d
 int dla_axpy(dla_ctx* c, size_t len, double alpha, const double* x, double* y)
 {
   DLA_T("dla_axpy");
+  RefFlops rf(c, 2.0 * (double)len);
   return engfail(c, c->eng->axpy(len, alpha, x, y));
 }
 
 int dla_nrm2(dla_ctx* c, size_t len, const double* x, double* out)
 {
   DLA_T("dla_nrm2");
+  RefFlops rf(c, 2.0 * (double)len);
   double s = 0.0;
   int st = c->eng->sumsq(len, x, &s);
   if (st) return engfail(c, st);
@@ -588,6 +624,7 @@ static int ortho_cd_impl(dla_ctx* c, dla::BlockOps* ops, int n, int k, double* u
 int dla_ortho_cd(dla_ctx* c, int n, int k, double* u, double* growth, int* ok)
 {
   DLA_T("dla_ortho_cd");
+  RefFlops rf(c, 6.0 * n * (double)k * k);                       // two macro-iterations of (dgemm 't','n' + dtrmm), :3256, 3327
   if (k > 0) {
     dla::OrthoReport rep;
     int stc = c->eng->ortho_chain(n, 0, k, nullptr, nullptr, u, &rep);
@@ -871,12 +908,14 @@ static int ortho_vs_x_after_chain(dla_ctx* c, dla::BlockOps* ops, long long row0
 int dla_ortho_vs_x(dla_ctx* c, int n, int m, int k, const double* x, double* u)
 {
   DLA_T("dla_ortho_vs_x");
+  RefFlops rf(c, ortho_vs_x_flops(n, m, k));
   return ortho_vs_x_impl(c, c->eng, c->row0, global_rows(c, n), n, m, k, x, x, u);
 }
 
 int dla_b_ortho_vs_x(dla_ctx* c, int n, int m, int k, const double* x, const double* bx, double* u)
 {
   DLA_T("dla_b_ortho_vs_x");
+  RefFlops rf(c, ortho_vs_x_flops(n, m, k));
   return ortho_vs_x_impl(c, c->eng, c->row0, global_rows(c, n), n, m, k, x, bx, u);
 }
 
@@ -887,6 +926,7 @@ int dla_b_ortho_vs_x(dla_ctx* c, int n, int m, int k, const double* x, const dou
 int dla_b_ortho(dla_ctx* c, int n, int m, double* u, double* bu)
 {
   DLA_T("dla_b_ortho");
+  RefFlops rf(c, 4.0 * n * (double)m * m);                       // U^T BU + two dtrsm (:3170-3178)
   if (m <= 0) return DLA_OK;
   std::vector<double> metric((size_t)m * m);
   int st = c->eng->gram(n, m, u, m, bu, metric.data(), m);
@@ -902,6 +942,7 @@ int dla_b_ortho(dla_ctx* c, int n, int m, double* u, double* bu)
 int dla_check_guess(dla_ctx* c, int n, int m, double* evec)
 {
   DLA_T("dla_check_guess");
+  RefFlops rf(c, 2.0 * n * (double)m * m);                       // the Gram matrix of the guess (:3762)
   double growth;
   int ok;
   // one reduction serves both tests of the reference: ||evec||_F (dnrm2 at :3749) is sqrt(trace) of the Gram matrix (:3762)
@@ -1226,6 +1267,9 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
                        double shift, double* h, int ldh)
 {
   DLA_T("dla_expand_project");
+  // ortho_vs_x (:1790 / 523-529) + the projection (:1691 / 401-403) [+ daxpy :397]; the operator is the caller's
+  RefFlops rf(c, c && n > 0 && k > 0 ? ortho_vs_x_flops(n, m, k) + (shift != 0.0 ? 2.0 * n * (double)k : 0.0) +
+                                       ((mode == 0 || mode == 4) ? 2.0 * n * (double)(m + k) * k : 2.0 * n * (double)(m + k) * (m + k)) : 0.0);
   if (!c || !basis || !abasis || !h || !fn || mode < 0 || mode == 2 || mode > 4 || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
     return fail(c, DLA_ERR_ARG, "dla_expand_project: bad argument (n > 0, m >= 0, k > 0, ldh >= m + k)");
   c->pending_k = 0; c->pending_m = 0; c->pending_applied = 0;
@@ -1475,6 +1519,9 @@ int dla_expand_project_metric(dla_ctx* c, int mode, int n, int m, int k, double*
                               dla_matvec_fn metric, double shift, double* h, int ldh)
 {
   DLA_T("dla_expand_project_metric");
+  // b_ortho_vs_x + b_ortho [+ the projection]
+  RefFlops rf(c, c && n > 0 && k > 0 ? ortho_vs_x_flops(n, m, k) + 4.0 * n * (double)k * k + (shift != 0.0 ? 2.0 * n * (double)k : 0.0) +
+                                       (mode == 0 ? 2.0 * n * (double)(m + k) * k : mode == 1 ? 2.0 * n * (double)(m + k) * (m + k) : 0.0) : 0.0);
   // mode 2: b_ortho_vs_x -> metric -> b_ortho only (abasis, op, h unused) -- the expansion of caslr_eff_driver, whose blocks are
   // made orthonormal in the metric (A+B) resp. (A-B) right after they have been orthogonalised against the basis (reference
   // diaglib.f90:1417-1424)

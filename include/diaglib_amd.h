@@ -123,6 +123,9 @@ typedef struct {
   double    ms[DLA_OP_COUNT];         /* HIP-event time (only with DLA_OPT_PROFILE)         */
   long long allreduces;               /* cross-rank reductions issued                       */
   long long host_syncs;               /* stream synchronisations for host-visible results   */
+  double    ref_flops;                /* reference-schedule flops of the LOGICAL operations the caller asked for (SURVEY 8d:
+                                         what the reference's BLAS calls would execute for them), counted at the entry points --
+                                         independent of what was launched, fused, left pending or skipped                 */
 } dla_stats;
 
 /* per-kernel statistics: name as rocprofv3 prints it (without namespace and argument list), launches,

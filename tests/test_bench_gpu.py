@@ -79,6 +79,25 @@ def test_bench_two_ranks_started_without_a_launcher():
     assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_value_counts_the_reference_schedule_not_the_launches():
+    """`value` = reference-schedule flops of the iterations performed / wall time.  Two schedules of the orthogonalisation
+    that launch different sweeps (tune knob 6: 12 = the five-sweep schedule, 13 = the three-pass one) converge in the same number
+    of iterations and must report the SAME flops per solve -- while the per-launch count (`value_launched` x time) differs."""
+    outs = []
+    for knob in ("12", "13"):
+        env = dict(os.environ, DIAGLIB_BENCH_TUNE="6=" + knob)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--no-cpu-baseline",
+                            "--no-random-leg"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        outs.append(_line(p.stdout))
+    a, b = outs
+    assert a["config"]["iters"] == b["config"]["iters"] == 9
+    assert a["gflop_per_solve"] == pytest.approx(b["gflop_per_solve"], rel=1e-12)
+    la = a["value_launched"] * a["ms_per_step"]; lb = b["value_launched"] * b["ms_per_step"]
+    assert abs(la - lb) > 1e-3 * la                  # the engine did launch different work
+    assert a["value"] * a["ms_per_step"] == pytest.approx(a["gflop_per_solve"] * 1e3, rel=1e-3)
+
+
 def test_headline_line_finds_its_counters():
     """On the headline workload the dominant kernel's HBM traffic must come from profiles/pmc_traffic.json: the file is keyed by
     workload and by the kernel name with every template argument, so a kernel whose template list changed without a new PMC

@@ -54,6 +54,8 @@ diags, offs = [2.0 + i / 50.0], [0]
 for d in range(1, hb + 1):
     v = 0.3 / d * np.cos(i[:n - d] + d)
     diags += [v, v]; offs += [d, -d]
+if spec.get("reach"):                       # one more pair of diagonals far out: the halo has to be that wide
+    d = spec["reach"]; v = 0.01 * np.cos(i[:n - d]); diags += [v, v]; offs += [d, -d]
 a = sp.diags(diags, offs, shape=(n, n), format="lil")
 if spec.get("far"):
     a[0, n - 1] = 0.1; a[n - 1, 0] = 0.1
@@ -170,3 +172,12 @@ def test_sharded_operator_wide_block_exchanges_in_column_chunks(tmp_path):
     not fit one mailbox slot (16384) -- the product goes through in column chunks"""
     spec = dict(backend="hip", transport="p2p", n=100_000, n_targ=8, n_max=37, half_band=120, tol=1e-9)
     _check(tmp_path, spec, 2)
+
+
+@pytest.mark.gpu
+def test_sharded_operator_refuses_a_halo_beyond_a_mailbox_slot_on_every_rank(tmp_path):
+    """Round-4 advisor: three ranks on the peer-to-peer mailboxes and a 3000-row halo need 3 x 2 x 3000 = 18000 doubles per column,
+    more than a slot (16384): every rank refuses the layout at setup (nothing is left waiting in an exchange)."""
+    spec = dict(backend="hip", transport="p2p", n=30_000, n_targ=2, n_max=4, half_band=2, reach=3000, tol=1e-6)
+    res, _ = _run_world(tmp_path, spec, 3)
+    assert all(r["status"].startswith("refused") and "mailbox slot" in r["status"] for r in res), res
