@@ -253,6 +253,10 @@ struct Engine : BlockOps {
   virtual int kernel_stats(dla_kernel_stat*, int) { return 0; }
   virtual void reset_kernel_stats() {}
   virtual void set_tune(int, int) {}
+  virtual int get_tune(int) { return 0; }
+  // a driver call starts: whatever the engine adapts from what earlier chains did is put back to its initial state, so that a solve's
+  // sequence of sweeps -- and with it every bit of its result -- is a function of that solve alone
+  virtual void begin_solve() {}
 };
 
 // $DIAGLIB_AMD_HOSTTIME=1: wall time spent inside each C-ABI entry point (printed by dla_destroy)

@@ -3059,6 +3059,8 @@ struct HipEngine : dla::Engine {
   // 4 = gram blocks-per-pass override (0 = built-in choice everywhere)
   int tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void set_tune(int i, int v) override { if (i >= 0 && i < 8) tune[i] = v; }
+  int get_tune(int i) override { return (i >= 0 && i < 8) ? tune[i] : 0; }
+  void begin_solve() override { x3_cooldown = X3_COOLDOWN_START; }
   // per-kernel statistics (names as rocprofv3 prints them, without namespace / argument list)
   struct KStat { long long launches = 0; double alg_bytes = 0.0, ms = 0.0, flops = 0.0; };
   std::map<std::string, KStat> kstats;
@@ -3619,8 +3621,10 @@ struct HipEngine : dla::Engine {
   double* chain_red_dst = nullptr;   // ... to this buffer
   bool chain_xw = false;             // the chain being enqueued may use the storing sweep OP_XW for its wide block (ortho_tail)
   bool chain_x3 = false;             // the chain being enqueued runs the three-pass schedule (OP_COMBOX / OP_CLOSE, ortho_tail16)
-  int x3_cooldown = 8;               // > 0: a recent chain needed a level shift (or the context is new: no evidence yet) -- that many
-                                     // chains run the five-sweep schedule
+  static const int X3_COOLDOWN_START = 2;
+  int x3_cooldown = X3_COOLDOWN_START;   // > 0: a recent chain needed a level shift (or the solve is new: no evidence yet) -- that many
+                                     // chains run the five-sweep schedule.  Reset at every driver call (begin_solve): the schedule of
+                                     // a solve depends on that solve alone, repeated solves give identical bits
   // ---- one-shot peer-to-peer all-reduce (p2p_allreduce_kernel)
   struct P2P {
     bool on = false;
@@ -4077,7 +4081,8 @@ struct HipEngine : dla::Engine {
     // follow whatever the projection measured, the closing projection only needs its Gram matrix, and a basis that carries pending
     // projections of 1e-9 is not tight enough -- the next block's leftover is amplified by 1e10 on its way through the shifted
     // factors (measured r05, interleaved: 17.0 against 16.35 ms per benchmark solve; 138.5 against 144.3 ms on the random-guess
-    // leg, which never shifts).  A chain that reports a level shift switches the schedule off for the next 16 chains.
+    // leg, which never shifts).  A chain that reports a level shift switches the schedule off for the next 16 chains, and every
+    // solve starts with two chains of the five-sweep schedule (on the benchmark the first one shifts).
     const bool x3 = fold == 1 && bx == x && tune[6] != 12 && (x3_cooldown <= 0 || tune[6] == 13);
     // wider blocks (LDS-loop tail): X^T U and U^T U in ONE sweep when [X | U] fits one pass of the Gram kernel (the plain
     // product with the contiguous panel [X | U] on the left: U follows X, bx == x) and the leading ortho_cd takes one step

@@ -201,9 +201,17 @@ int dla_set_option(dla_ctx* c, int option, int value)
   return DLA_OK;
 }
 
+int dla_begin_solve(dla_ctx* c)
+{
+  if (!c) return DLA_ERR_ARG;
+  c->eng->begin_solve();
+  return DLA_OK;
+}
+
 int dla_get_option(dla_ctx* c, int option)
 {
   if (!c) return -1;
+  if (option >= DLA_OPT_TUNE0 && option < DLA_OPT_TUNE0 + 8) return c->eng->get_tune(option - DLA_OPT_TUNE0);
   switch (option) {
     case DLA_OPT_CALLBACKS_ON_DEVICE: return c->callbacks_on_device;
     case DLA_OPT_EVEC_ON_DEVICE: return c->evec_on_device;

@@ -229,6 +229,11 @@ module diaglib
       integer(c_int), value :: n, m, k
       integer(c_int) :: st
     end function
+    function dla_begin_solve(ctx) bind(C,name='dla_begin_solve') result(st)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx
+      integer(c_int) :: st
+    end function
     function dla_check_guess(ctx,n,m,evec) bind(C,name='dla_check_guess') result(st)
       import :: c_ptr, c_int
       type(c_ptr), value :: ctx, evec
@@ -477,6 +482,7 @@ contains
     integer,          intent(in)  :: rows, width
     real(dp), target, intent(in)  :: evec(rows,width)
     e%ctx   = dla_default_ctx()
+    call chk(e%ctx, dla_begin_solve(e%ctx), 'begin_solve')
     e%rows  = rows
     e%width = width
     e%ritz_is_callers = dla_get_option(e%ctx, opt_evec_dev) .ne. 0

@@ -146,6 +146,10 @@ dla_ctx* dla_default_ctx(void);                      /* the context the Fortran 
                                                         options), so two host threads can solve at the same time.  The
                                                         reference cannot: module-level state, diaglib.f90:155-161 */
 int  dla_set_option(dla_ctx* ctx, int option, int value);
+/* A driver call starts (the Fortran drivers call it first): adaptive choices of the engine -- which sweep schedule the
+ * orthogonalisation chains take, decided from what earlier chains of the SAME solve reported -- go back to their initial state, so
+ * that a solve's results do not depend on the solves before it (repeated solves are bit-identical). */
+int  dla_begin_solve(dla_ctx* ctx);
 int  dla_get_option(dla_ctx* ctx, int option);
 const char* dla_last_error(dla_ctx* ctx);
 const char* dla_backend_name(dla_ctx* ctx);          /* "hip:gfx950" for the product */

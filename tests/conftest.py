@@ -38,6 +38,31 @@ def ctx():
     return c
 
 
+# every option of the session context and its default (include/diaglib_amd.h)
+_CTX_DEFAULTS = {1: 0, 2: 0, 3: 0, 4: 0, 5: 1, 6: 10, 7: 0, 8: 0, 9: 5000, 10: 1, 11: 1}
+
+
+@pytest.fixture(autouse=True)
+def _clean_ctx(request):
+    """The HIP context is shared by the whole session; a test that leaves a shard, an option, a tune knob or a reduction hook behind
+    silently changes the semantics of every later test (round 4: a forgotten shard turned rms norms into sums).  After every
+    test that used it the context is put back and checked against its defaults."""
+    yield
+    if "ctx" not in request.fixturenames:
+        return
+    c = request.getfixturevalue("ctx")
+    c.set_allreduce_hook(None, 1, 0)
+    c.set_shard(-1, 0)
+    for opt, val in _CTX_DEFAULTS.items():
+        c.set_option(opt, val)
+    for knob in range(8):
+        c.set_option(100 + knob, 0)
+    for opt, val in _CTX_DEFAULTS.items():
+        assert c.get_option(opt) == val, (opt, c.get_option(opt))
+    assert all(c.get_option(100 + knob) == 0 for knob in range(8))
+    assert c.comm_info() == (1, 0), c.comm_info()
+
+
 @pytest.fixture()
 def rng():
     return np.random.default_rng(12345)

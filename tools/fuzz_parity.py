@@ -77,6 +77,26 @@ for it in range(cases):
     cmv, cpc, cbv = MV_T(mvf), PC_T(pcf), MV_T(bvf)
     pmv, ppc, pbv = (C.cast(f, C.c_void_p).value for f in (cmv, cpc, cbv))
     spec = dict(n=n, t=t, m=m, solver=solver, max_dav=max_dav, tol=tol, shift=shift, guess=guess)
+    # every case also with the pending blocks switched off (DLA_OPT_PENDING_BLOCKS = 0: each block finished in memory) and with the
+    # three-pass schedule forced from the first chain (tune knob 6 = 13), in this process: same ok, same eigenvalues, same history
+    variants = {}
+    try:
+        for vname, (pend, knob) in (("no_pending", (0, 0)), ("three_pass", (1, 13)), ("five_sweep", (1, 12))):
+            ctx.set_option(capi.OPT_PENDING_BLOCKS, pend); ctx.set_option(100 + 6, knob)
+            if solver == "davidson":
+                variants[vname] = ctx.davidson_driver(n, t, m, 300, tol, max_dav, shift, mv, pc, g.copy(order="F"))
+            elif solver == "lobpcg":
+                variants[vname] = ctx.lobpcg_driver(n, t, m, 300, tol, shift, mv, pc, g.copy(order="F"))
+            elif solver == "gen_david":
+                variants[vname] = ctx.gen_david_driver(n, t, m, 300, tol, max_dav, shift, mv, pc, bv, g.copy(order="F"))
+            else:
+                variants[vname] = ctx.lobpcg_driver(n, t, m, 300, tol, shift, mv, pc, g.copy(order="F"), bvec=bv)
+    except Exception as ex:   # noqa: BLE001
+        bad += 1
+        print("FAIL (exception in a variant)", spec, str(ex)[:200], flush=True)
+        continue
+    finally:
+        ctx.set_option(capi.OPT_PENDING_BLOCKS, 1); ctx.set_option(100 + 6, 0)
     try:
         if solver == "davidson":
             e, v, ok, info = ctx.davidson_driver(n, t, m, 300, tol, max_dav, shift, mv, pc, g)
@@ -108,6 +128,10 @@ for it in range(cases):
         slack = max(3, tr.iters // 6)               #  which the last roots lock moves the count by 10 %, with or without the pending factor)
     lim = max(1e-9, 50.0 * tol * tol)          # eigenvalue error ~ residual^2; both sides stop anywhere below tol
     good = ok == oko == okr and (not ok or (res["d_oracle"] < lim and res["d_ref"] < lim)) and abs(info["iters"] - tr.iters) <= slack
+    for vname, (ev_, _, okv, infov) in variants.items():
+        dv = float(np.abs(ev_[:t] - e[:t]).max() / scale)
+        res[vname] = (bool(okv), dv, infov["iters"])
+        good = good and okv == ok and (not ok or dv < max(1e-10, lim)) and abs(infov["iters"] - info["iters"]) <= max(1, slack)
     if not good:
         bad += 1
         print("FAIL", dict(spec, case=it), res, flush=True)
