@@ -4083,7 +4083,10 @@ struct HipEngine : dla::Engine {
     // factors (measured r05, interleaved: 17.0 against 16.35 ms per benchmark solve; 138.5 against 144.3 ms on the random-guess
     // leg, which never shifts).  A chain that reports a level shift switches the schedule off for the next 16 chains, and every
     // solve starts with two chains of the five-sweep schedule (on the benchmark the first one shifts).
-    const bool x3 = fold == 1 && bx == x && tune[6] != 12 && (x3_cooldown <= 0 || tune[6] == 13);
+    // (A block that is used once and rebuilt -- LOBPCG's W, dla_expand_project mode 3: pending blocks without a bound on the Gram
+    //  matrix -- leaves nothing in a basis: the three-pass schedule always; measured r05, n = 2e6, 8 roots: 15.99 against 17.07 ms.)
+    const bool rebuilt = drop_final && publish_pending && drop_final_tol <= 0.0;
+    const bool x3 = fold == 1 && bx == x && tune[6] != 12 && (x3_cooldown <= 0 || tune[6] == 13 || rebuilt);
     // wider blocks (LDS-loop tail): X^T U and U^T U in ONE sweep when [X | U] fits one pass of the Gram kernel (the plain
     // product with the contiguous panel [X | U] on the left: U follows X, bx == x) and the leading ortho_cd takes one step
     const int ktw = (k + 15) / 16;
