@@ -5085,7 +5085,11 @@ struct HipEngine : dla::Engine {
       char kn[64];
       // (the name rocprofv3 prints: the last argument is the scheduling variant of the wide sweeps, tune knob 0 = 7 ... 11)
       const int t0 = tune[0];
+#ifdef DLA_AB_VARIANTS
       const int sched = (k2 > 0 && qt == 0 && kt >= 4) ? (t0 == 7 ? 1 : t0 == 8 ? 2 : t0 == 11 ? 5 : (kt == 5 && t0 == 9) ? 3 : (kt == 5 && t0 == 10) ? 4 : 0) : 0;
+#else
+      const int sched = 0; (void)t0;
+#endif
       std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d, %s, %d>", kt, vec2 ? 2 : 1, kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt, k2 > 0 ? "true" : "false", sched);
       // (flops: the two Ritz products and, with extra columns, the two panel products they replace)
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + ((avy ? 2.0 : 1.0) + (evec ? 1.0 : 0.0)) * m + 2.0 * k2),
@@ -5098,6 +5102,9 @@ struct HipEngine : dla::Engine {
         else if (kt == 1) RZ((ritz_kernel<1, 2, 3, 0, 0, true>));
         else if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 0, true>));
         else if (kt == 3) RZ((ritz_kernel<3, 2, 3, 3, 0, true>));
+#ifdef DLA_AB_VARIANTS
+        // (the hand-scheduled variants of round 4 -- iglp_opt, two sched_group_barrier pipelines, role-swapping stages: none faster
+        //  than the compiler's order, profiles/r04/ritz_sched_ab.txt -- are built only with -DDLA_AB_VARIANTS, for tools/ritz_sched_ab.py)
         else if (kt == 4 && tune[0] == 7) RZ((ritz_kernel<4, 2, 3, 3, 0, true, 1>));
         else if (kt == 4 && tune[0] == 8) RZ((ritz_kernel<4, 2, 3, 3, 0, true, 2>));
         else if (kt == 5 && tune[0] == 7) RZ((ritz_kernel<5, 2, 3, 3, 0, true, 1>));
@@ -5106,6 +5113,7 @@ struct HipEngine : dla::Engine {
         else if (kt == 5 && tune[0] == 11) RZ((ritz_kernel<5, 2, 3, 3, 0, true, 5>));
         else if (kt == 5 && tune[0] == 9) RZ((ritz_kernel<5, 2, 3, 3, 0, true, 3>));
         else if (kt == 5 && tune[0] == 10) RZ((ritz_kernel<5, 2, 3, 3, 0, true, 4>));
+#endif
         else if (kt == 4) RZ((ritz_kernel<4, 2, 3, 3, 0, true>));
         else RZ((ritz_kernel<5, 2, 3, 3, 0, true>));        // (pipeline depth 2 / 4 measured: 8.9 / 7.9 ms against 7.5 at 37 + 37 columns)
       } else if (vec2 && kt >= 2 && tune[0] == 1) {

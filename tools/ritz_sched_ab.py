@@ -3,6 +3,7 @@
 tune knob 0 = 0 (compiler's schedule), 7 / 9 (__builtin_amdgcn_iglp_opt(0) / (1)), 8 / 10 (two explicit sched_group_barrier
 pipelines; 9 and 10 exist for five tiles only), 11 (two stages per loop trip, the register sets changing roles).
 Checks that the three variants give the same bits, then times them in one process on one device.
+Needs a library built with -DDLA_AB_VARIANTS (the variants are not part of the product build since round 5).
 
     python tools/ritz_sched_ab.py [n] [rounds]
 """
