@@ -3966,7 +3966,10 @@ struct HipEngine : dla::Engine {
     const int R = (kt == 1 && tlw <= 2) ? 32 : 16;
     const long long nchunks = ((long long)n + 31) / 32;
     const long long want = (nchunks + 15) / 16;
-    int blocks = (int)std::max(1LL, std::min((long long)ncu * (self ? 2 : 1), want));
+    // (one U tile beside up to five X tiles: at most 212 / 252 registers and 55 KB of LDS per block -- two blocks per CU, two waves
+    //  per SIMD: measured r05 at n = 2e6, interleaved: +5 ... 11 % for the projection sweep, +3 ... 9 % for the storing one; beyond
+    //  five tiles the kernels need more than 256 registers and a second block per CU only runs behind the first)
+    int blocks = (int)std::max(1LL, std::min((long long)ncu * ((self || (kt == 1 && tlw <= 5 && tune[4] != -1)) ? 2 : 1), want));   // (knob 4 = -1: A/B)
     if (tune[4] > 0) blocks = (int)std::max(1LL, std::min((long long)tune[4], want));
     const int extra = self ? 0 : kt * (kt + 1) / 2;          // tiles (qi >= qj) of the Gram matrix of the U block
     const int slots = self ? 1 : tlw * kt + extra;
