@@ -32,7 +32,7 @@ OP_NAMES = ["gram", "gemm", "trmm", "ritz", "elem", "matvec", "precnd"]
 
 # every symbol include/diaglib_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "dla_create", "dla_destroy", "dla_default_ctx", "dla_set_option", "dla_get_option", "dla_begin_solve", "dla_last_error",
+    "dla_create", "dla_destroy", "dla_default_ctx", "dla_set_option", "dla_get_option", "dla_begin_solve", "dla_class_times", "dla_last_error",
     "dla_backend_name", "dla_get_stats", "dla_reset_stats", "dla_get_kernel_stats", "dla_stream",
     "dla_comm_unique_id", "dla_comm_init", "dla_comm_finalize", "dla_comm_info", "dla_p2p_export", "dla_p2p_attach", "dla_p2p_detach", "dla_set_allreduce_hook", "dla_set_shard",
     "dla_alloc", "dla_free", "dla_trim", "dla_zero", "dla_upload", "dla_download", "dla_copy", "dla_sync",
@@ -93,7 +93,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     sig = {
         "dla_create": (i, [C.POINTER(vp), i]), "dla_destroy": (i, [vp]), "dla_default_ctx": (vp, []),
         "dla_trim": (i, [vp, C.POINTER(sz)]),
-        "dla_set_option": (i, [vp, i, i]), "dla_get_option": (i, [vp, i]), "dla_begin_solve": (i, [vp]),
+        "dla_set_option": (i, [vp, i, i]), "dla_get_option": (i, [vp, i]), "dla_begin_solve": (i, [vp]), "dla_class_times": (i, [vp, vp]),
         "dla_last_error": (C.c_char_p, [vp]), "dla_backend_name": (C.c_char_p, [vp]),
         "dla_get_stats": (i, [vp, C.POINTER(Stats)]), "dla_reset_stats": (i, [vp]), "dla_stream": (vp, [vp]),
         "dla_get_kernel_stats": (i, [vp, C.POINTER(KernelStat), i]),

@@ -238,6 +238,7 @@ struct Engine : BlockOps {
   bool even_rows(long long n) const { return n % 2 == 0 && peers_even; }
   // all-reduce of a few HOST values over the small-product transport (setup-time agreement between the ranks); collective
   virtual int allreduce_host(double* /*v*/, int /*count*/, int /*op: 0 sum, 1 max*/) { return nranks > 1 ? DLA_ERR_COMM : DLA_OK; }
+  virtual bool has_transport() const { return hook != nullptr; }     // something that can carry a cross-rank reduction is attached
   bool local_only = false;   // true while working on data that is replicated on every rank (no reductions)
   dla_allreduce_fn hook = nullptr;
   void* hook_user = nullptr;
@@ -344,6 +345,7 @@ struct dla_ctx {
   long long row0 = 0;
   std::vector<double> pending_p;   // dla_expand_project modes 3 / 4: the block [E ; T] the last call left pending ((m + k) x k, ld m + k)
   int pending_k = 0, pending_m = 0, pending_applied = 0;
+  int agree_seq = 0;         // agreements on the shard layout this context has taken part in (agree_on_shards)
   int ref_depth = 0;         // nesting of entry points (reference-schedule flops are counted at the outermost one)
   std::string err;
   // pinned staging buffers for host-mode callbacks

@@ -5344,6 +5344,7 @@ struct HipEngine : dla::Engine {
   double* d_halo = nullptr; size_t halo_doubles = 0;
   std::vector<double> h_halo;        // host mirror for the hook transport
   // all-reduce of a few host values through the engine's small-product transport (setup-time agreement between the ranks)
+  bool has_transport() const override { return hook != nullptr || comm != nullptr || p2p.on; }
   int allreduce_host(double* v, int count, int op) override
   {
     std::vector<double> t(v, v + count);

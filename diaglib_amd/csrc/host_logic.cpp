@@ -240,6 +240,16 @@ int dla_get_stats(dla_ctx* c, dla_stats* out)
   return DLA_OK;
 }
 
+// HIP-event time per kernel class in milliseconds (DLA_OPT_PROFILE must be on while the work runs), in the order of the DLA_OP_*
+// ids -- the door through which a Fortran caller reaches the breakdown SURVEY section 5 asks for beside the reference's four timers
+int dla_class_times(dla_ctx* c, double* ms)
+{
+  if (!c || !ms) return DLA_ERR_ARG;
+  c->eng->collect_times();
+  for (int i = 0; i < DLA_OP_COUNT; ++i) ms[i] = c->eng->stats.ms[i];
+  return DLA_OK;
+}
+
 int dla_reset_stats(dla_ctx* c)
 {
   if (!c) return DLA_ERR_ARG;
@@ -260,17 +270,23 @@ int dla_comm_unique_id(char id[128]) { return dla::engine_unique_id(id); }
 
 static int agree_on_shards(dla_ctx* c);
 
+// Attaching a transport after the shard has been announced ends with the collective agreement on the shard layout
+// (agree_on_shards); when THAT fails -- a layout the ranks refuse, or ranks that announce in different orders -- the transport just
+// attached is taken down again, so that "failed" means "nothing attached" on every rank (round-4 advisor).
 int dla_comm_init(dla_ctx* c, int nranks, int rank, const char id[128])
 {
   if (!c) return DLA_ERR_ARG;
-  const int st = engfail(c, c->eng->comm_init(nranks, rank, id));
-  return st ? st : agree_on_shards(c);
+  int st = engfail(c, c->eng->comm_init(nranks, rank, id));
+  if (st) return st;
+  st = agree_on_shards(c);
+  if (st) { const std::string keep = c->err; (void)c->eng->comm_finalize(); c->eng->peers_even = true; c->err = keep; }
+  return st;
 }
 
 int dla_comm_finalize(dla_ctx* c)
 {
   if (!c) return DLA_ERR_ARG;
-  c->eng->peers_even = true;
+  c->eng->peers_even = true;       // (comm_finalize takes every transport down: one rank again)
   return engfail(c, c->eng->comm_finalize());
 }
 
@@ -284,15 +300,23 @@ int dla_p2p_export(dla_ctx* c, int nranks, char handles[128])
 int dla_p2p_attach(dla_ctx* c, int nranks, int rank, const char* all_handles)
 {
   if (!c || !all_handles) return DLA_ERR_ARG;
-  const int st = engfail(c, c->eng->p2p_attach(nranks, rank, all_handles));
-  return st ? st : agree_on_shards(c);
+  int st = engfail(c, c->eng->p2p_attach(nranks, rank, all_handles));
+  if (st) return st;
+  st = agree_on_shards(c);
+  if (st) { const std::string keep = c->err; (void)c->eng->p2p_detach(); c->err = keep; }
+  return st;
 }
 
+// The mailboxes go; another transport (RCCL, a hook) may stay attached: what the ranks agreed on (Engine::peers_even) belongs to the
+// layout, not to the transport, and is agreed again over what is left -- collectively, like the detach itself.
 int dla_p2p_detach(dla_ctx* c)
 {
   if (!c) return DLA_ERR_ARG;
+  const int st = engfail(c, c->eng->p2p_detach());
+  if (st) return st;
+  if (c->eng->has_transport()) return agree_on_shards(c);
   c->eng->peers_even = true;
-  return engfail(c, c->eng->p2p_detach());
+  return DLA_OK;
 }
 
 int dla_comm_info(dla_ctx* c, int* nranks, int* rank)
@@ -310,7 +334,15 @@ int dla_set_allreduce_hook(dla_ctx* c, dla_allreduce_fn fn, void* user, int nran
   c->eng->hook_user = user;
   c->eng->nranks = nranks;
   c->eng->rank = rank;
-  return fn ? agree_on_shards(c) : DLA_OK;
+  if (fn) {
+    const int st = agree_on_shards(c);
+    if (st) { c->eng->hook = nullptr; c->eng->hook_user = nullptr; c->eng->nranks = 1; c->eng->rank = 0; c->eng->peers_even = true; }
+    return st;
+  }
+  // the hook goes: whatever is still attached carries the agreement from now on
+  if (c->eng->has_transport()) return agree_on_shards(c);
+  c->eng->peers_even = true;
+  return DLA_OK;
 }
 
 // The ranks agree on what every schedule decision may depend on (dla_internal.h: Engine::peers_even): the shard heights, gathered
@@ -320,10 +352,25 @@ static int agree_on_shards(dla_ctx* c)
   dla::Engine* e = c->eng;
   e->peers_even = true;
   if (e->nranks <= 1 || c->n_global <= 0) return DLA_OK;
-  std::vector<double> r0((size_t)e->nranks, 0.0);
+  // [row0 of every rank | a tag per rank | n_global per rank]: the tag = a fixed word + the number of agreements this context has
+  // taken part in.  Ranks that announce their shards in different orders relative to attaching the transport, or one that announces
+  // once more than its peers, pair exchanges that do not belong together: the tags then differ and every rank that sees it says so
+  // (round-4 advisor) instead of adopting a layout made of unrelated numbers.  Required order: every rank makes the same sequence
+  // of dla_set_shard / dla_comm_init / dla_p2p_attach / dla_set_allreduce_hook calls.
+  const int nr = e->nranks;
+  const double tag = 4.0e15 + (double)(++c->agree_seq);
+  std::vector<double> r0((size_t)3 * nr, 0.0);
   r0[e->rank] = (double)c->row0;
-  const int st = e->allreduce_host(r0.data(), e->nranks, 0);
+  r0[(size_t)nr + e->rank] = tag;
+  r0[(size_t)2 * nr + e->rank] = (double)c->n_global;
+  const int st = e->allreduce_host(r0.data(), 3 * nr, 0);
   if (st) return engfail(c, st);
+  for (int r = 0; r < nr; ++r) {
+    if (r0[(size_t)nr + r] != tag)
+      return fail(c, DLA_ERR_COMM, "dla_set_shard: the ranks are not at the same agreement (shards announced / transports attached in different orders)");
+    if (r0[(size_t)2 * nr + r] != (double)c->n_global)
+      return fail(c, DLA_ERR_ARG, "dla_set_shard: the ranks announce different global row counts");
+  }
   bool even = true;
   for (int r = 0; r < e->nranks; ++r) {
     const long long lo = (long long)r0[r], hi = r + 1 < e->nranks ? (long long)r0[r + 1] : c->n_global;
@@ -1563,8 +1610,12 @@ int dla_expand_project_metric(dla_ctx* c, int mode, int n, int m, int k, double*
       if (sta) return sta;
       if (rep.status == 1 && rep.clean && bst < 0) return fail(c, DLA_ERR_LAPACK, "b_ortho: metric not positive definite");
       if (good) return DLA_OK;
-      // the chain took another route (or stopped): nothing behind it has touched U (the factorisation did not go on);
-      // finish the orthogonalisation and repeat the rest on the finished block
+      // The chain took another route than planned (or stopped).  When it stopped half way the device step of b_ortho did not go on
+      // and nothing behind the chain has touched U.  When it ENDED WELL, only later than planned -- continuation launches, enqueued by
+      // ortho_chain_finish, completed it -- the b_ortho step that was already in the queue may have seen a finished chain and applied
+      // U <- U W, BU <- BU W to a block the operator had already read unfinished (round-4 advisor): U is then B-orthonormal against
+      // a stale BU.  Either way everything behind the chain is repeated on the block as it stands: the metric image is formed
+      // again, and b_ortho on a block that is already B-orthonormal is a factorisation of the identity.
       st = ortho_vs_x_after_chain(c, c->eng, c->row0, nglob, n, m, k, basis, bbasis, u, &rep);
       if (st) return st;
       return metric_tail_steps(c, mode, n, m, k, basis, bbasis, abasis, op, metric, shift, h, ldh, false, false, &b_handled);

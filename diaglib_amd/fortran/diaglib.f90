@@ -28,7 +28,7 @@ module diaglib
 !
   public :: lobpcg_driver, davidson_driver, gen_david_driver, ortho, b_ortho, ortho_cd, ortho_vs_x, b_ortho_vs_x
   public :: caslr_eff_driver, caslr_driver
-  public :: diaglib_amd_config
+  public :: diaglib_amd_config, diaglib_amd_timings
 !
   real(dp), parameter :: zero = 0.0_dp, one = 1.0_dp, ten = 10.0_dp
   integer,  parameter :: min_dav = 10          ! smallest basis, in blocks (reference diaglib.f90:1544)
@@ -229,6 +229,17 @@ module diaglib
       integer(c_int), value :: n, m, k
       integer(c_int) :: st
     end function
+    function dla_class_times(ctx,ms) bind(C,name='dla_class_times') result(st)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx
+      real(c_double) :: ms(*)
+      integer(c_int) :: st
+    end function
+    function dla_reset_stats(ctx) bind(C,name='dla_reset_stats') result(st)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx
+      integer(c_int) :: st
+    end function
     function dla_begin_solve(ctx) bind(C,name='dla_begin_solve') result(st)
       import :: c_ptr, c_int
       type(c_ptr), value :: ctx
@@ -376,6 +387,44 @@ contains
       if (release_context) st = dla_destroy(ctx)
     end if
   end subroutine diaglib_amd_config
+!
+! ---------------------------------------------------------------------------------------
+! Device time per kind of work (extension).  The reference prints four buckets -- matvec, diagonalization, orthogonalization, total
+! (diaglib.f90:1835-1841) -- and leaves the projection, the Ritz vectors and the residuals un-bucketed; the drivers here print the
+! same four (byte-compatible tables).  This routine gives a caller the rest: seconds of HIP-event time on the engine's stream since
+! the last reset, per kernel class.
+!   call diaglib_amd_timings(profile=.true.)              ! switch the event timing on (about 4 us per launch) and clear the counters
+!   call davidson_driver(...)
+!   call diaglib_amd_timings(t_proj=tp, t_ritz=tr, ...)    ! read; reset=.true. clears the counters afterwards
+! t_proj: every X^T U product (projection :1691, the Gram matrices of the orthogonalisation :3256, :3543); t_update: U -= X C and
+! Z = V Y sweeps (:3544); t_trmm: triangular updates (:3327); t_ritz: Ritz vectors + residuals + norms, one fused sweep
+! (:1717-1732); t_elem: copies / axpy / fills; t_matvec, t_precnd: the library's OWN device operators (a caller's callbacks are
+! timed by the reference's matvec bucket, which the drivers still print).
+! ---------------------------------------------------------------------------------------
+  subroutine diaglib_amd_timings(profile, reset, t_proj, t_update, t_trmm, t_ritz, t_elem, t_matvec, t_precnd)
+    logical,  intent(in),  optional :: profile, reset
+    real(dp), intent(out), optional :: t_proj, t_update, t_trmm, t_ritz, t_elem, t_matvec, t_precnd
+    type(c_ptr)    :: ctx
+    integer(c_int) :: st
+    real(c_double) :: ms(8)
+    ctx = dla_default_ctx()
+    if (present(profile)) then
+      st = dla_set_option(ctx, 3_c_int, merge(1_c_int,0_c_int,profile))
+      if (profile) st = dla_reset_stats(ctx)
+    end if
+    ms = 0.0_c_double
+    st = dla_class_times(ctx, ms)
+    if (present(t_proj))   t_proj   = ms(1)*1.0e-3_dp
+    if (present(t_update)) t_update = ms(2)*1.0e-3_dp
+    if (present(t_trmm))   t_trmm   = ms(3)*1.0e-3_dp
+    if (present(t_ritz))   t_ritz   = ms(4)*1.0e-3_dp
+    if (present(t_elem))   t_elem   = ms(5)*1.0e-3_dp
+    if (present(t_matvec)) t_matvec = ms(6)*1.0e-3_dp
+    if (present(t_precnd)) t_precnd = ms(7)*1.0e-3_dp
+    if (present(reset)) then
+      if (reset) st = dla_reset_stats(ctx)
+    end if
+  end subroutine diaglib_amd_timings
 !
 ! ---------------------------------------------------------------------------------------
 ! small plumbing

@@ -11,7 +11,7 @@
 program device_caller
   use real_precision
   use iso_c_binding
-  use diaglib, only : davidson_driver, lobpcg_driver, diaglib_amd_config
+  use diaglib, only : davidson_driver, lobpcg_driver, diaglib_amd_config, diaglib_amd_timings
   implicit none
   interface
     function dla_default_ctx() bind(C,name='dla_default_ctx') result(ctx)
@@ -42,6 +42,7 @@ program device_caller
   integer  :: n_eig, i
   logical  :: ok
   real(dp), allocatable :: eig(:), evec(:,:)
+  real(dp) :: tt(6)
 !
   if (dla_synth_setup(dla_default_ctx(), int(n,c_long_long), 0_c_long_long, n, 4, 0.5_dp).ne.0) stop 'setup failed'
   call diaglib_amd_config(callbacks_on_device=.true., evec_on_device=.false.)
@@ -51,7 +52,10 @@ program device_caller
   do i = 1, n_eig
     evec(i,i) = 1.0_dp
   end do
+  call diaglib_amd_timings(profile=.true.)         ! device time per kind of work (the reference leaves projection / Ritz / residual un-bucketed)
   call davidson_driver(.false.,n,n_want,n_eig,itmax,tol,m_max,0.0_dp,dla_synth_matvec,dla_synth_precnd,eig,evec,ok)
+  call diaglib_amd_timings(profile=.false., t_proj=tt(1), t_update=tt(2), t_trmm=tt(3), t_ritz=tt(4), t_matvec=tt(5), t_precnd=tt(6))
+  write(6,'(a,6f12.6)') 'DEVICE DAVIDSON seconds (proj update trmm ritz matvec precnd):', tt
   write(6,'(a,l2)') 'DEVICE DAVIDSON ok:', ok
   write(6,'(a,8f14.9)') 'DEVICE DAVIDSON eig:', eig(1:n_want)
   evec = 0.0_dp

@@ -155,6 +155,10 @@ const char* dla_last_error(dla_ctx* ctx);
 const char* dla_backend_name(dla_ctx* ctx);          /* "hip:gfx950" for the product */
 int  dla_get_stats(dla_ctx* ctx, dla_stats* out);
 int  dla_reset_stats(dla_ctx* ctx);
+/* HIP-event time per kernel class since the last reset, ms[DLA_OP_COUNT] in the order of the DLA_OP_* ids (needs DLA_OPT_PROFILE = 1
+ * while the work runs).  What the Fortran module's diaglib_amd_timings returns: the reference prints four buckets (matvec,
+ * diagonalization, orthogonalization, total; diaglib.f90:1835-1841) and leaves projection / Ritz vectors / residuals un-bucketed. */
+int  dla_class_times(dla_ctx* ctx, double* ms);
 int  dla_get_kernel_stats(dla_ctx* ctx, dla_kernel_stat* out, int cap);   /* returns the number of entries */
 void* dla_stream(dla_ctx* ctx);                      /* hipStream_t the kernels run on */
 

@@ -80,6 +80,9 @@ def test_fortran_caller_device_mode(tmp_path, ctx, oracle):
         vals = [float(v) for v in re.search("DEVICE " + tag + r" eig:(.*)", out).group(1).split()]
         assert np.allclose(vals, eo[:t], atol=2e-8), (tag, vals, eo[:t])
     assert abs(float(re.search(r"DEVICE \|x1\|:\s+([0-9.]+)", out).group(1)) - 1.0) < 1e-9
+    # diaglib_amd_timings: the per-class device times SURVEY section 5 asks for reach a Fortran caller (all of them ran, none took a second)
+    secs = [float(v) for v in re.search(r"DEVICE DAVIDSON seconds .*:(.*)", out).group(1).split()]
+    assert len(secs) == 6 and all(0.0 < v < 1.0 for v in secs), secs
 
 
 def test_fortran_caller_sparse_device_operator(tmp_path, ctx):
