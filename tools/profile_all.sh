@@ -5,11 +5,15 @@
 # counter passes), the same counter passes on the cfg 5 shape, tools/profile_extra.sh (cfg 3 / 4 / 5 bench lines, 250 k-row
 # shard), the shard rehearsal, the linear-response / generalised runs, the host-time report, the k x k step's time stamps, the
 # host-mode probe and the HIP legs of the floor probes.  Results are collected in gpurun_out/profiles_<tag>/ (copy to profiles/<tag>/).
+# A gpurun call is limited to 20 minutes: the pass can be cut in three -- bash tools/profile_all.sh r05 A | B | C (default: all).
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
+PART=${2:-ABC}
 OUT=gpurun_out/profiles_$TAG
-rm -rf $OUT; mkdir -p $OUT
+[[ $PART == *A* ]] && rm -rf $OUT
+mkdir -p $OUT
 P=gpurun_out/profile_$TAG
+if [[ $PART == *A* ]]; then
 bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
 cp $P/bench_default.json $P/pmc_traffic.txt $P/mfma_util.json $P/mfma_util.txt $OUT/
 cp $P/kt/run_kernel_stats.csv $OUT/kernel_stats_bench_steps5.csv
@@ -28,6 +32,19 @@ bash tools/profile_extra.sh $TAG > $OUT/profile_extra.log 2>&1
 cp $P/bench_lobpcg_cfg5shape_1gpu.json $P/bench_davidson_cfg4shape_1gpu.json $P/bench_lobpcg_cfg3.json $P/bench_250k_rows.json \
    $P/kernel_stats_lobpcg_cfg5shape.csv $P/kernel_trace_one_solve_250k_rows.txt $OUT/
 echo "extra done"
+fi
+if [[ $PART == *B* ]]; then
+# the sweep schedules of ortho_vs_x, interleaved in one call: tune knob 6 = 0 (shipped: three-pass unless a chain shifted), 12 (five-sweep),
+# 13 (three-pass always) -- headline + random-guess leg, LOBPCG cfg 3, and the cfg 4 / cfg 5 shapes
+for r in 1 2; do for t in 0 12 13; do
+  DIAGLIB_BENCH_TUNE="6=$t" python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('davidson n=2e6 8 roots  knob6=$t:', d['ms_per_step'], 'ms,', d['config']['iters'], 'iterations,', d['roofline']['solve']['alg_GB'], 'GB, step', d['roofline']['step']['frac'], '| random-guess leg', d['config']['random_guess_leg']['ms'], 'ms,', d['config']['random_guess_leg']['iters'], 'iterations')"
+done; done > $OUT/three_pass_ab.txt 2>&1 || true
+for r in 1 2; do for t in 0 12; do
+  DIAGLIB_BENCH_TUNE="6=$t" python3 bench.py --solver lobpcg --steps 10 --warmup 3 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lobpcg n=2e6 8 roots    knob6=$t:', d['ms_per_step'], 'ms,', d['config']['iters'], 'iterations,', d['roofline']['solve']['alg_GB'], 'GB')"
+done; done >> $OUT/three_pass_ab.txt 2>&1 || true
+for r in 1 2; do for t in 0 12; do
+  DIAGLIB_BENCH_TUNE="6=$t" python3 bench.py --solver lobpcg --n 10000000 --roots 32 --tol 1e-12 --steps 3 --warmup 1 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lobpcg n=1e7 32 roots   knob6=$t:', d['ms_per_step'], 'ms,', d['config']['iters'], 'iterations,', d['roofline']['solve']['alg_GB'], 'GB')"
+done; done >> $OUT/three_pass_ab.txt 2>&1 || true
 bash tools/shard_rehearsal.sh 1 2 4 > $OUT/shard_rehearsal_2e6.txt 2>&1
 python3 tools/lr_gen_bench.py > $OUT/bench_lr_gen_2e6.jsonl 2> $OUT/lr_gen.err
 DIAGLIB_AMD_HOSTTIME=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --n 250000 --steps 20 --warmup 3 --no-cpu-baseline --no-random-leg > $OUT/hosttime_250k_rows.txt 2>&1
@@ -46,10 +63,11 @@ for r in 1 2 3; do
   DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('davidson n=2e6 8 roots, pending factors on :', d['ms_per_step'], 'ms,', d['iters'], 'iterations')"
   DIAGLIB_AMD_NO_PENDING=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('davidson n=2e6 8 roots, pending factors off:', d['ms_per_step'], 'ms,', d['iters'], 'iterations')"
 done > $OUT/davidson_pending_ab.txt 2>&1 || true
-(python3 tools/lobpcg_pending_ab.py 2000000 8 2e-13; python3 tools/lobpcg_pending_ab.py 10000000 32 1e-11; python3 tools/lobpcg_pending_ab.py 10000000 32 1e-12) 2>/dev/null | grep "pending factor" > $OUT/lobpcg_pending_ab.txt || true
-python3 tools/ritz_sched_ab.py 2000000 5 2>/dev/null | grep -v amdgpu.ids > $OUT/ritz_sched_ab.txt || true
+(python3 tools/lobpcg_pending_ab.py 2000000 8 2e-13; python3 tools/lobpcg_pending_ab.py 10000000 32 1e-12) 2>/dev/null | grep "pending" > $OUT/lobpcg_pending_ab.txt || true
 hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/rr_probe.hip -Ldiaglib_amd/lib -ldiaglib_amd -Wl,-rpath,$PWD/diaglib_amd/lib -o tools/bin/rr_probe && timeout -k 5 120 tools/bin/rr_probe 20 > $OUT/rr_device_probe.txt 2>&1 || true
 echo "rehearsal / lr / host done"
+fi
+if [[ $PART == *C* ]]; then
 bash tools/profile_stalls.sh headline > /dev/null 2>&1 && cp gpurun_out/stall_counters_headline.txt $OUT/stall_counters_headline.txt
 bash tools/profile_stalls.sh cfg5 --solver lobpcg --n 10000000 --roots 32 --tol 1e-12 > /dev/null 2>&1 && cp gpurun_out/stall_counters_cfg5.txt $OUT/stall_counters_cfg5shape.txt
 rm -rf gpurun_out/stalls_headline gpurun_out/stalls_cfg5
@@ -58,6 +76,8 @@ python3 tools/floor_probe.py --n 10000000 --roots 32 --solver lobpcg --iters 30 
 python3 tools/floor_probe.py --n 2000000 --roots 8 --solver davidson --iters 16 --impl hip > $OUT/floor_probe_davidson_n2e6_8roots_hip.txt 2>/dev/null
 python3 tools/floor_probe.py --n 1000000 --roots 32 --solver lobpcg --iters 40 --impl hip,oracle,reference > $OUT/floor_probe_lobpcg_n1e6_32roots.txt 2>/dev/null
 rm -f $OUT/lr_gen.err
+fi
+if [[ $PART == *A* ]]; then
 python3 - <<PY
 import json
 a = json.load(open("$OUT/pmc_traffic_headline.json")); c = json.load(open("$OUT/pmc_traffic_cfg5shape.json"))
@@ -66,4 +86,5 @@ json.dump({k1: a[k1], k5: c[k5]}, open("$OUT/pmc_traffic.json", "w"), indent=1, 
 PY
 rm -f $OUT/pmc_traffic_headline.json $OUT/pmc_traffic_cfg5shape.json
 rm -rf $P/kt $P/mfma $P/fetch $P/write gpurun_out/profile_${TAG}c5
+fi
 ls $OUT
