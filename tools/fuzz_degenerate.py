@@ -21,6 +21,7 @@ bad = 0
 errors = 0
 kinds = ["duplicate", "zero", "in_span_x", "low_rank", "few_rows", "scales", "mixed"]
 for it in range(cases):
+    ctx.set_option(100 + 6, (0, 12, 13)[it % 3])      # sweep schedule of ortho_vs_x: shipped choice / five-sweep / three-pass always
     kind = kinds[it % len(kinds)]
     k = int(rng.choice([rng.integers(2, 17), rng.integers(17, 40)]))
     m = int(rng.choice([0, rng.integers(1, 30), rng.integers(30, 120)]))

@@ -17,6 +17,7 @@ ctx = capi.Context()
 o = Oracle()
 bad = 0
 for it in range(cases):
+    ctx.set_option(100 + 6, (0, 12, 13)[it % 3])      # sweep schedule of ortho_vs_x: shipped choice / five-sweep / three-pass always
     k = int(rng.choice([rng.integers(1, 17), rng.integers(17, 49)]))
     m = int(rng.choice([0, rng.integers(1, 40), rng.integers(40, 200)]))
     n = int(rng.integers(max(m + k, 8) * 2, max(m + k, 8) * 2 + 6000))
