@@ -42,7 +42,7 @@ EXPORTS = [
     "dla_call_matvec", "dla_call_precnd", "dla_expand_project", "dla_expand_project_metric",
     "dla_syev", "dla_syev_lowest", "dla_potrf_lower", "dla_trtri_lower", "dla_norm_est",
     "dla_synth_setup", "dla_synth_matvec", "dla_synth_precnd", "dla_synth_apbmul", "dla_synth_ambmul", "dla_synth_spdmul", "dla_synth_smdmul",
-    "dla_synth_metric", "dla_synth_lrprec1", "dla_synth_lrprec2", "dla_pending_factor", "dla_pending_block", "dla_basis_admit", "dla_basis_fold", "dla_spmm_setup_csr", "dla_spmm_setup_csr_sharded", "dla_spmm_matvec", "dla_spmm_precnd",
+    "dla_synth_metric", "dla_synth_lrprec1", "dla_synth_lrprec2", "dla_pending_factor", "dla_pending_block", "dla_basis_admit", "dla_basis_fold", "dla_basis_sync", "dla_spmm_setup_csr", "dla_spmm_setup_csr_sharded", "dla_spmm_matvec", "dla_spmm_precnd",
     "dla_davidson_driver", "dla_gen_david_driver", "dla_lobpcg_driver", "dla_caslr_eff_driver", "dla_caslr_driver", "dla_call_lrprec",
     "dla_last_solve_info", "dla_set_solve_info",
 ]
@@ -133,6 +133,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "dla_pending_block": (i, [vp, i, i, vp, i, vp]),
         "dla_basis_admit": (i, [i, i, vp, i, i, vp, vp, vp, i]),
         "dla_basis_fold": (i, [i, i, vp, i, vp, i]),
+        "dla_basis_sync": (i, [vp, i, i, vp, i]),
         "dla_spmm_setup_csr": (i, [vp, i, vp, vp, vp]),
         "dla_spmm_setup_csr_sharded": (i, [vp, i, C.c_longlong, C.c_longlong, vp, vp, vp]),
         "dla_davidson_driver": (None, [i, i, i, i, i, d, i, d, vp, vp, vp, vp, c_ip]),
@@ -462,10 +463,18 @@ class Context:
         assert dmat.flags.f_contiguous and c.flags.f_contiguous
         self._chk(self.lib.dla_basis_fold(rows, c.shape[1], _dp(dmat), dmat.shape[0], _dp(c), c.shape[0]))
 
+    def basis_sync(self, m: int, k: int, dmat: np.ndarray = None) -> None:
+        """dla_basis_sync: columns m .. m+k-1 of the caller's D to the device (k <= 0: forget everything)"""
+        if k <= 0:
+            self._chk(self.lib.dla_basis_sync(self.h, 0, 0, None, 0))
+            return
+        assert dmat.flags.f_contiguous
+        self._chk(self.lib.dla_basis_sync(self.h, m, k, _dp(dmat), dmat.shape[0]))
+
     def expand_project(self, mode: int, basis: DevPanel, abasis: DevPanel, m: int, k: int, matvec: int, shift: float = 0.0) -> np.ndarray:
         """dla_expand_project on the leading m + k columns of the two panels: ortho_vs_x(X, U), AU = A U + shift U, then the
         projection -- mode 0: [X | U]^T AU ((m+k) x k), mode 1: lower triangle of [X | U]^T [AX | AU]"""
-        h = np.zeros((m + k, k if mode in (0, 4) else m + k), order="F")       # (modes 3 / 4: 1 / 0 with the last factor pending)
+        h = np.zeros((m + k, k if mode in (0, 4, 5) else m + k), order="F")       # (modes 3 / 4 / 5: 1 / 0 / 0 with the last factor pending)
         self._chk(self.lib.dla_expand_project(self.h, mode, basis.n, m, k, basis.ptr, abasis.ptr, matvec, shift, _dp(h), m + k))
         return h
 

@@ -94,6 +94,12 @@ struct BlockOps {
     if (applied) *applied = 0;
     return 0;
   }
+  // basis_exact (dla_expand_project mode 5): the stored columns X are not a finished basis but X D is, with the caller's upper-
+  // triangular D kept on the device block by block (basis_sync; m = columns in front of the block, k <= 0: forget everything).
+  // Device chains then project with X (D D^T) X^T, and a block may stay pending however far the stored columns are from orthonormal.
+  bool basis_exact = false;
+  virtual int basis_sync(int /*m*/, int /*k*/, const double* /*dmat*/, int /*ld*/) { return 0; }
+  virtual bool basis_exact_ok() const { return false; }   // the device-driven chain takes one-tile blocks on this context
   int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests
   std::string err;
 };

@@ -1701,9 +1701,11 @@ __global__ void halo_pack_kernel(int n, int m, int halo, int nranks, int rank, c
 // OP_GRAMX / OP_GRAMW / OP_XW belong to the pending-factor schedule (k <= 16, even n; see ortho_tail16): X^T U and U^T U in one
 // sweep over [X | U]; the Gram matrix of U W formed on the fly; both at once
 // OP_COMBOX / OP_CLOSE belong to the three-pass schedule (OrthoTailArgs::x3, see ortho_tail16): the projection sweep that also
-// measures X^T U and U^T U of what it stores, and the closing projection that measures nothing
+// measures X^T U and U^T U of what it stores, and the closing projection that measures nothing.  OP_TRMMC is OP_TRMMG (the written
+// update U <- U W with the Gram matrix of what it stores) behind a measuring sweep whose X^T U is carried through it, S W: the
+// macro-iteration of ortho_cd that a caller with pending blocks gets instead of one more projection (see ortho_tail16)
 enum { OP_NONE = 0, OP_GRAM_UU = 1, OP_TRMMG = 2, OP_XU = 3, OP_COMBO = 4, OP_FINAL = 5, OP_GRAMX = 6, OP_GRAMW = 7, OP_XW = 8,
-       OP_COMBOX = 9, OP_CLOSE = 10 };
+       OP_COMBOX = 9, OP_CLOSE = 10, OP_TRMMC = 11 };
 // the block a chain leaves pending, in pinned host memory: [row][PEND_LD] with the rows of E (the part that multiplies X: only the
 // three-pass schedule has one) followed by the k rows of the triangular factor T, then the header {sequence number, rows of E}
 #define PEND_LD 48
@@ -1756,6 +1758,9 @@ struct OrthoTailArgs {
                        // keep a pending factor only if later blocks can still be projected against it as if it were orthonormal:
                        // two passes leave (2 drop_tol)^2 of the component they remove)
   int x3;              // three-pass schedule (ortho_tail16, fold == 1): every projection is OP_COMBOX, see there
+  const double* dmat;  // != nullptr: the stored columns X are not a finished basis -- the finished one is X D with this upper-triangular
+  int dmat_ld;         // D (m x m, column-major, the caller's pending blocks: dla_basis_sync).  The projector onto span(X) is then
+                       // X (D D^T) X^T, and the projection coefficients are -(D D^T)(xu W) instead of -(xu W) (ortho_tail16)
   int drop_final;      // 1: the chain ends where it would ask for OP_FINAL -- the pending upper-triangular factor is NOT applied.
                        // For callers that B-orthonormalise the block by Cholesky-QR right behind the chain (dla_expand_project_metric:
                        // b_ortho, reference diaglib.f90:3094-3183): the Q factor of U W and of U is the same for any upper-triangular W
@@ -2301,6 +2306,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // LDS use of ortho_tail16 (doubles): [0,256) G hand-over / transpose scratch (16 x 17), [272,528) Wd for the assembly,
 // [528,784) Wp for the assembly
 #define T16_LDS_DOUBLES 784
+#define T16_ZS_ROWS 288                    // rows of the coefficient block the exact projection (OrthoTailArgs::dmat) keeps in LDS behind them
 
 // One step of the state machine for k <= 16, called by ALL 256 threads of a block (wave 0 does the serial part, all four
 // waves assemble the coefficient block of a projection sweep).  g_in_lds: lds[64 r + lane] already holds the Gram matrix
@@ -2330,7 +2336,7 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
   // coefficient source of a possible assembly: rows of xu, prefetched by every wave (tiles wave, wave + 4, ...)
   const double* xsrc = (after == OP_XU || sweep_xu) ? a.gsrc : a.xug;
   const int ldx = (after == OP_XU) ? m : m + k;
-  const bool may_assemble = m > 0 && (after == OP_XU || sweep_xu || after == OP_GRAMW || after == OP_TRMMG);
+  const bool may_assemble = m > 0 && (after == OP_XU || sweep_xu || after == OP_GRAMW || after == OP_TRMMG || after == OP_TRMMC);
   double xa[4][4];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -2356,19 +2362,24 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int s = 0; s < 4; ++s) sm = fmax(sm, fabs(xa[q][s]));
+    double sq_far[4] = {0.0, 0.0, 0.0, 0.0};
     for (int t0 = 16 * (wave + 16); t0 < m; t0 += 64)          // (m > 256: the rows beyond the prefetched ones)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int row = t0 + c, col = 4 * s + g;
-        if (row < m && col < k) sm = fmax(sm, fabs(__hip_atomic_load(xsrc + (size_t)row + (size_t)col * ldx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        if (row < m && col < k) {
+          const double v = __hip_atomic_load(xsrc + (size_t)row + (size_t)col * ldx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sm = fmax(sm, fabs(v));
+          sq_far[s] += v * v;
+        }
       }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sm = fmax(sm, __shfl_xor(sm, off, 64));
     if (lane == 0) s_smax[wave] = sm;
-    // column 4 s + g: the 16 lanes of row group g hold its rows (m <= 256 here: the measuring sweeps take m <= 192)
+    // column 4 s + g: the 16 lanes of row group g hold its rows
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      double sq = 0.0;
+      double sq = sq_far[s];
 #pragma unroll
       for (int q = 0; q < 4; ++q) sq += xa[q][s] * xa[q][s];
 #pragma unroll
@@ -2377,6 +2388,16 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
     }
     __syncthreads();
   }
+  // max_j sum_i S_ij^2 >= |(S^T S)_ij|: what the Gram matrix of the projected block differs from G by (wave 0, every lane)
+  auto colsq_max = [&]() {
+    double cs = lane < 16 ? ((s_colsq[0][lane] + s_colsq[1][lane]) + s_colsq[2][lane]) + s_colsq[3][lane] : 0.0;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) cs = fmax(cs, __shfl_xor(cs, off, 64));
+    return rlane(cs, 0);
+  };
+  // (a pending block's projection is closed on the caller's k x k matrices through the Cholesky factor of I - F^T F, F = D^T S T:
+  //  that stays well conditioned while the columns' sums of squares do)
+  const double CS_CAP = 0.02;
   if (wave == 0) {
     TailState t = pre ? *pre : TailState{st->it_macro, st->it_outer, st->macro_total, st->shifts, st->nops, OP_NONE, OST_RUNNING, st->growth, st->have_xu, st->sloppy, st->gdev};
     t.phase = OP_NONE; t.status = OST_RUNNING;
@@ -2395,7 +2416,8 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
       t.it_macro = 0; t.growth = 1.0; t.have_xu = 0; t.sloppy = 0;
       // (the block stays pending when the caller takes pending blocks and both X^T U, just measured, and the distance of the
       //  pending factor from the identity -- the Gram matrix it came from -- are within the caller's bounds)
-      if (may_pend && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) < a.drop_stol && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol)) { t.status = OST_DONE; go = 2; }
+      if (may_pend && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) < a.drop_stol && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) &&
+          colsq_max() < CS_CAP) { t.status = OST_DONE; go = 2; }
       else { t.phase = op_project; go = 1; }
     } else {
       ++t.it_macro;
@@ -2545,17 +2567,18 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
           //         :3562-3564).  G was measured before the projection instead of after it: the two differ by S^T S, so this
           //         takes place only for max |S| < 1e-9 (m |S|^2 below eps); a larger S gets one more measured projection.
           const bool cx_step = meas_sweep && !stage0 && it_micro == 0;
+          // (behind OP_TRMMC: the carried product is good for a pending block when this step's factor has converged without a
+          //  level shift; otherwise the chain goes on as behind any written update, on measured products only)
+          const bool carried_pend = after == OP_TRMMC && macro_done && it_micro == 0 && may_pend && t.have_xu;
+          if (after == OP_TRMMC && !carried_pend) t.have_xu = 0;
           const double smax = cx_step ? fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) : 0.0;
           bool pend = false, pend_e = false, pend_r = false;
           // (X^T U too large to stay on the small side of a basis that has to remain orthonormal in memory, but small enough for the
           //  Gram matrix of the projected block, I - (S W)^T (S W), to be factored by the caller: the closing sweep runs without
           //  measuring anything and the caller gets [-(S W) ; W] marked APPLIED -- it owes the block only the k x k factor)
-          if (cx_step && macro_done && may_pend && smax >= a.drop_stol && t.it_outer <= maxit) {
+          if (cx_step && macro_done && may_pend && smax >= a.drop_stol && t.it_outer <= maxit && a.dmat == nullptr) {
             // |(S^T S)_ij| <= max_j sum_i S_ij^2: what the block's Gram matrix in memory will be off the identity by
-            double cs = lane < 16 ? ((s_colsq[0][lane] + s_colsq[1][lane]) + s_colsq[2][lane]) + s_colsq[3][lane] : 0.0;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) cs = fmax(cs, __shfl_xor(cs, off, 64));
-            cs = rlane(cs, 0);
+            const double cs = colsq_max();
             pend_r = 2.0 * cs < (a.drop_tol > 0.0 ? a.drop_tol : 1.0e-8);
             if (lane == 0 && a.dbg != nullptr && dslot < 48) a.dbg[dslot * 16 + 14] = (unsigned long long)__double_as_longlong(cs);
           }
@@ -2567,6 +2590,7 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
             for (int off = 32; off > 0; off >>= 1) dev = fmax(dev, __shfl_xor(dev, off, 64));
             pend = a.drop_tol <= 0.0 || dev < a.drop_tol;
             pend_e = !pend;
+            if (pend && colsq_max() >= CS_CAP) pend = false;      // (one more measured projection: the branch for a large S below)
           }
           if (lane == 0 && a.dbg != nullptr && dslot < 48) a.dbg[dslot * 16 + 13] = (unsigned long long)__double_as_longlong(smax);
           if (pend) {
@@ -2578,8 +2602,25 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
             t.phase = OP_FINAL; go = 3;
           } else if (pend_r) {
             t.phase = OP_CLOSE; go = 4;
-          } else if (cx_step && (!macro_done || smax >= 1.0e-9)) {
+          } else if (carried_pend) {
+            // (the update behind a measured X^T U has been written and its Gram matrix measured: S W was carried, see below)
+            double dev = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dev = fmax(dev, fabs(g0[r] - ((g + 4 * r == c) ? 1.0 : 0.0)));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dev = fmax(dev, __shfl_xor(dev, off, 64));
+            if (a.drop_tol <= 0.0 || dev < a.drop_tol) { t.status = OST_DONE; go = 2; }
+            else { t.phase = OP_FINAL; go = 3; }
+          } else if (cx_step && (!macro_done || smax >= 1.0e-9 || (may_pend && smax < a.drop_stol && macro_done && !pend_e))) {
+            // A caller with pending blocks, a factor that has not converged but is close (eps rcond^2 < 1e-10: W is within a few
+            // hundred of the identity) and an X^T U so small that S W stays far inside the caller's bound: the next macro-iteration
+            // of ortho_cd does not need X.  U <- U W is written with the Gram matrix of what it stores (OP_TRMMC), X^T (U W) = S W
+            // is carried exactly as the first projection's product is (Wd), and when that Gram matrix's factor has converged the
+            // block stays pending as [-(S W) T ; T].  What the written update adds to X^T U is its rounding, eps ||W|| at most --
+            // the reference's own last update (dtrsm behind its last projection, :3327) leaves the same.
+            const bool carry = may_pend && !macro_done && eps * rcond * rcond < 1.0e-10 && 4.0 * smax * linv_norm < a.drop_stol;
             if (t.it_outer > maxit) t.status = OST_VSX_MAXIT;     // :3568
+            else if (carry) { t.sloppy = 1; t.phase = OP_TRMMC; }
             else {
               ++t.it_outer;
               t.sloppy = macro_done ? 0 : 1;
@@ -2653,6 +2694,10 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
   const bool t_ident = s_go == 3;
   const double applied = s_go == 4 ? 1.0 : 0.0;     // 4: the whole block is applied in memory by the OP_CLOSE sweep that follows
   const int l = m + k, l4 = ((l + 3) / 4) * 4;
+  // Exact projection against an unfinished basis (a.dmat): Z = xu Wd goes to LDS first, the coefficients become -(D D^T) Z.  The
+  // block that goes to the HOST stays -Z: the caller applies D D^T itself (dla_basis_admit).
+  const bool dfix = a.dmat != nullptr && m <= T16_ZS_ROWS;
+  double* zs = lds + T16_LDS_DOUBLES;               // [16 ceil(m / 16)][16]
   double db[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) db[s] = lds_load1(lds_d + 64 * s + lane);
@@ -2666,7 +2711,8 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int p_ = t0 + g + 4 * r;
-      if (p_ < m) a.cpk[(size_t)p_ * 16 + c] = (c < k) ? -acc[r] : 0.0;
+      if (dfix) lds_store1(zs + (size_t)p_ * 16 + c, (p_ < m && c < k) ? acc[r] : 0.0);
+      else if (p_ < m) a.cpk[(size_t)p_ * 16 + c] = (c < k) ? -acc[r] : 0.0;
       if (to_host && p_ < m && c < k) a.t_host[(size_t)p_ * PEND_LD + c] = -acc[r];
     }
   }
@@ -2682,8 +2728,56 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int p_ = t0 + g + 4 * r;
-      if (p_ < m) a.cpk[(size_t)p_ * 16 + c] = (c < k) ? -acc[r] : 0.0;
+      if (dfix) lds_store1(zs + (size_t)p_ * 16 + c, (p_ < m && c < k) ? acc[r] : 0.0);
+      else if (p_ < m) a.cpk[(size_t)p_ * 16 + c] = (c < k) ? -acc[r] : 0.0;
       if (to_host && p_ < m && c < k) a.t_host[(size_t)p_ * PEND_LD + c] = -acc[r];
+    }
+  }
+  if (dfix) {
+    // Z' = D (D^T Z), 16 x 16 tiles on the matrix cores; D is upper triangular: D(Q, R) = 0 for Q > R.  A wave owns the row tiles
+    // R = wave, wave + 4, ...; products D = A B with the contraction index p = g + 4 s: A[c][p], B[p][c] (see mfma16 above)
+    const int nt = (m + 15) / 16, ld = a.dmat_ld;
+    __syncthreads();
+    v4d y1[5];
+#pragma unroll
+    for (int qq = 0; qq < 5; ++qq) {
+      const int R = wave + 4 * qq;
+      y1[qq] = (v4d){0.0, 0.0, 0.0, 0.0};
+      if (R < nt)
+        for (int Q = 0; Q <= R; ++Q)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int rowd = 16 * Q + g + 4 * s, cold = 16 * R + c;        // A[c][p] = D(16 Q + p, 16 R + c)
+            const double av = (rowd < m && cold < m) ? a.dmat[(size_t)rowd + (size_t)cold * ld] : 0.0;
+            y1[qq] = mfma16(av, lds_load1(zs + (size_t)rowd * 16 + c), y1[qq]);
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 5; ++qq) {
+      const int R = wave + 4 * qq;
+      if (R < nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds_store1(zs + (size_t)(16 * R + g + 4 * r) * 16 + c, y1[qq][r]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 5; ++qq) {
+      const int R = wave + 4 * qq;
+      if (R >= nt) continue;
+      v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+      for (int Q = R; Q < nt; ++Q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int rowd = 16 * R + c, cold = 16 * Q + g + 4 * s;          // A[c][p] = D(16 R + c, 16 Q + p)
+          const double av = (rowd < m && cold < m) ? a.dmat[(size_t)rowd + (size_t)cold * ld] : 0.0;
+          acc = mfma16(av, lds_load1(zs + (size_t)cold * 16 + c), acc);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p_ = 16 * R + g + 4 * r;
+        if (p_ < m) a.cpk[(size_t)p_ * 16 + c] = (c < k) ? -acc[r] : 0.0;
+      }
     }
   }
   if (wave == 0) {
@@ -2753,7 +2847,7 @@ __global__ __launch_bounds__(64) void ortho_tail_kernel(OrthoTailArgs a)
 
 __global__ __launch_bounds__(256) void ortho_tail16_kernel(OrthoTailArgs a)
 {
-  __shared__ __attribute__((aligned(16))) double lds[T16_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double lds[T16_LDS_DOUBLES + T16_ZS_ROWS * 16];
   ortho_tail16(a, lds, nullptr, false);
 }
 
@@ -3865,6 +3959,8 @@ struct HipEngine : dla::Engine {
                                  fold, tune[6] == 7 ? 0 : 1, d_xug, d_wst, d_dbg, chain_xw ? 1 : 0};
     if ((fold == 1 && op == OP_GRAMX) || op == OP_XW || op == OP_COMBOX) pending_tail.gsrc = d_xug;
     pending_tail.x3 = chain_x3 ? 1 : 0;
+    pending_tail.dmat = (basis_exact && fold && m > 0 && dmat_nontrivial && dmat_cols == m && m <= DMAT_LD) ? d_dmat : nullptr;
+    pending_tail.dmat_ld = DMAT_LD;
     pending_tail.drop_final = (drop_final && m > 0) ? 1 : 0;
     pending_tail.t_host = (pending_tail.drop_final && publish_pending && m + k <= PEND_ROWS) ? h_tpend_dev : nullptr;
     pending_tail.t_seq = t_seq;
@@ -3885,6 +3981,7 @@ struct HipEngine : dla::Engine {
       case OP_XW:      stc = gram_wp_once(n, m, bx, k, u, d_wpk, u); break;
       case OP_GRAMW:   stc = gram_wp_once(n, 0, nullptr, k, u, d_wpk, nullptr); break;
       case OP_TRMMG:
+      case OP_TRMMC:
         stc = gemm_chunk(n, 0, k, u, k, nullptr, 0, u, 2, DLA_OP_TRMM, true, d_wpk);
         if (!stc) stc = fused_reduce(k);
         break;
@@ -4036,6 +4133,40 @@ struct HipEngine : dla::Engine {
     std::vector<SpecRec> recs;
   } run;
 
+  // ---- the caller's pending blocks on the device (dla_basis_sync): D, upper triangular, column-major with leading dimension
+  // DMAT_LD -- what the exact projection of ortho_tail16 multiplies with.  Columns arrive in order, block by block.
+  static const int DMAT_LD = T16_ZS_ROWS;
+  double* d_dmat = nullptr;
+  int dmat_cols = 0;                 // columns described so far (-1: the basis has outgrown the buffer)
+  bool dmat_nontrivial = false;      // some entry differs from the identity by more than 1e-10
+  bool basis_exact_ok() const override { return !hook && !local_only && tune[6] != 3 && tune[6] != 5 && tune[6] != 14 && lds_limit > (size_t)128 * 1024; }   // (knob 6 = 14: A/B, mode 5 behaves like mode 4)
+  int basis_sync(int m, int k, const double* dmat, int ld) override
+  {
+    if (k <= 0) { dmat_cols = 0; dmat_nontrivial = false; return DLA_OK; }
+    if (dmat_cols < 0) return DLA_OK;
+    if (m != dmat_cols) { err = "basis_sync: the blocks of D arrive in order (" + std::to_string(dmat_cols) + " columns known, block starts at " + std::to_string(m) + ")"; return DLA_ERR_ARG; }
+    if (m + k > DMAT_LD) { dmat_cols = -1; return DLA_OK; }
+    bind();
+    if (!d_dmat) {
+      HIPCHK(hipMalloc((void**)&d_dmat, sizeof(double) * (size_t)DMAT_LD * DMAT_LD));
+      HIPCHK(hipMemsetAsync(d_dmat, 0, sizeof(double) * (size_t)DMAT_LD * DMAT_LD, st));
+    }
+    double* h = nullptr;
+    int slot = 0;
+    const size_t bytes = sizeof(double) * (size_t)k * DMAT_LD;
+    const int stc = stage_slot(bytes, &h, &slot);
+    if (stc) return stc;
+    std::memset(h, 0, bytes);
+    for (int j = 0; j < k; ++j)
+      for (int i = 0; i <= m + j; ++i) {
+        const double v = dmat[(size_t)i + (size_t)(m + j) * ld];
+        h[(size_t)j * DMAT_LD + i] = v;
+        if (v != (i == m + j ? 1.0 : 0.0)) dmat_nontrivial = true;
+      }
+    dmat_cols = m + k;
+    return stage_commit(slot, bytes, d_dmat + (size_t)m * DMAT_LD);
+  }
+
   // the block the last chain left pending (drop_final + publish_pending): p = [E ; T], (m + k) x k -- the finished block is
   // [X | U_stored] p -- or [0 ; I] when nothing is pending; fetching it clears it
   int pending_block(int m, int k, double* p, int ldp, int* applied) override
@@ -4067,10 +4198,17 @@ struct HipEngine : dla::Engine {
     rep->handled = 0;
     t_pending_k = 0;                 // (whatever an earlier chain left: nobody fetched it, it belongs to no later call)
     if (run.active) { err = "ortho_chain: a chain is already in flight"; return DLA_ERR_RUNTIME; }
-    if (tune[6] == 3) return DLA_OK;                               // A/B: host-driven loop
-    if (hook || local_only || k <= 0 || k > 48) return DLA_OK;     // hook reductions need the host between sweeps
+    // (basis_exact: the stored columns are not orthonormal, only the device chain projects with the caller's D -- the host-driven
+    //  loop, which ends on the reference's growth test, must not take such a block)
+    auto not_handled = [&]() {
+      if (!(basis_exact && m > 0)) return (int)DLA_OK;
+      err = "ortho_chain: dla_expand_project mode 5 needs the device-driven chain with the caller's pending blocks on the device (dla_basis_sync after every block; blocks of at most 16 columns, at most 288 basis columns, no all-reduce hook)";
+      return (int)DLA_ERR_ARG;
+    };
+    if (tune[6] == 3) return not_handled();                               // A/B: host-driven loop
+    if (hook || local_only || k <= 0 || k > 48) return not_handled();     // hook reductions need the host between sweeps
     const bool vsx = m > 0;
-    if (vsx && !(u == x + (size_t)n * m && can_combo(m, k))) return DLA_OK;
+    if (vsx && !(u == x + (size_t)n * m && can_combo(m, k))) return not_handled();
     if (!vsx && fused_lds(k, k) > lds_limit) return DLA_OK;
     // k x k steps on the matrix cores (ortho_tail16) for one-tile blocks; with them, on the 16-byte path and while X^T U fits one
     // pass of the storing sweep (12 tiles), the pending-factor schedule (fold = 1); otherwise the sweep-per-update one (fold = 2)
@@ -4089,7 +4227,10 @@ struct HipEngine : dla::Engine {
     // (A block that is used once and rebuilt -- LOBPCG's W, dla_expand_project mode 3: pending blocks without a bound on the Gram
     //  matrix -- leaves nothing in a basis: the three-pass schedule always; measured r05, n = 2e6, 8 roots: 15.99 against 17.07 ms.)
     const bool rebuilt = drop_final && publish_pending && drop_final_tol <= 0.0;
-    const bool x3 = fold == 1 && bx == x && tune[6] != 12 && (x3_cooldown <= 0 || tune[6] == 13 || rebuilt);
+    // (basis_exact: the caller keeps its pending blocks on the device (dla_basis_sync) and every projection of this chain is exact
+    //  against the FINISHED basis -- a loose stored basis costs later chains nothing, so the schedule that ends soonest always)
+    if (basis_exact && vsx && (fold == 0 || dmat_cols != m)) return not_handled();
+    const bool x3 = fold == 1 && bx == x && tune[6] != 12 && (x3_cooldown <= 0 || tune[6] == 13 || rebuilt || basis_exact);
     // wider blocks (LDS-loop tail): X^T U and U^T U in ONE sweep when [X | U] fits one pass of the Gram kernel (the plain
     // product with the contiguous panel [X | U] on the left: U follows X, bx == x) and the leading ortho_cd takes one step
     const int ktw = (k + 15) / 16;
@@ -4110,13 +4251,13 @@ struct HipEngine : dla::Engine {
       const long long vkey = (long long)k * 1000000 + m + fold * 500000000000LL + (vsx ? 0 : 250000000000LL) + (wide_xw ? 125000000000LL : 0LL) +
                              (x3 ? 31250000000LL : 0LL);
       if (!chain_verified.count(vkey)) {
-        static const int every_op[] = {OP_GRAM_UU, OP_GRAMX, OP_GRAMW, OP_XW, OP_XU, OP_TRMMG, OP_COMBO, OP_FINAL, OP_COMBOX, OP_CLOSE};
+        static const int every_op[] = {OP_GRAM_UU, OP_GRAMX, OP_GRAMW, OP_XW, OP_XU, OP_TRMMG, OP_COMBO, OP_FINAL, OP_COMBOX, OP_CLOSE, OP_TRMMC};
         std::vector<SpecRec> dummy;
         dry_launch = true; spec_rec = &dummy; lds_retry = false; chain_xw = wide_xw; chain_x3 = x3;
         int std_ = DLA_OK;
         for (int op : every_op) {
           if (!vsx && (op == OP_GRAMX || op == OP_XW || op == OP_XU || op == OP_COMBO || op == OP_GRAMW)) continue;
-          if ((op == OP_COMBOX || op == OP_CLOSE) && !x3) continue;
+          if ((op == OP_COMBOX || op == OP_CLOSE || op == OP_TRMMC) && !x3) continue;
           if (fold != 1 && (op == OP_GRAMW || (op == OP_XW && !wide_xw))) continue;
           if (fold != 1 && op == OP_GRAMX && !wide_gramx) continue;
           std_ = launch_op(op, n, m, k, x, bx, u, false, fold);
@@ -4124,7 +4265,7 @@ struct HipEngine : dla::Engine {
         }
         dry_launch = false; spec_rec = nullptr;
         if (std_) {
-          if (lds_retry) { lds_retry = false; return DLA_OK; }        // rep->handled stays 0: host-driven loop
+          if (lds_retry) { lds_retry = false; return not_handled(); }        // rep->handled stays 0: host-driven loop
           return std_;
         }
         chain_verified.insert(vkey);
@@ -4174,22 +4315,11 @@ struct HipEngine : dla::Engine {
     //  of a Gram matrix -- a plan remembered from a chain that ended pending keeps the sweep in place: an empty launch when it
     //  is not needed, against a host round trip and a repeated operator call when it is)
     if (x3 && std::find(plan.begin(), plan.end(), (int)OP_CLOSE) == plan.end()) plan.insert(plan.end() - 1, (int)OP_CLOSE);
-    // (... and which projection sweep stands for the phase "projection": the one that also measures X^T U of what it stores costs
-    //  4 m / 16 more MFMAs per 16 rows (5.0-5.4 TB/s against 5.7), and its measurement is thrown away when the block it produced
-    //  needs a level shift -- the written update comes next, then the storing sweep measures again.  The previous chain of this
-    //  kind tells: a projection that was followed by the written update is planned as the plain sweep, a plain one that was
-    //  followed by the storing sweep as the measuring one (which would have made that sweep the closing projection).)
-    //  A chain whose first projection needed the written update ends, after the storing sweep, with a projection whose Gram matrix
-    //  is all that is needed behind it (X^T U of the stored block is of order 1e-5 ... 1e-3 there, and what the projection leaves
-    //  is rounding): the plain sweep again.
-    if (x3) {
-      bool shifted = false;
-      for (size_t i = 0; i + 1 < plan.size(); ++i) {
-        if ((plan[i] == OP_COMBOX || plan[i] == OP_COMBO) && plan[i + 1] == OP_TRMMG) shifted = true;
-        if (shifted && plan[i] == OP_COMBOX) plan[i] = OP_COMBO;
-        if (!shifted && plan[i] == OP_COMBO && plan[i + 1] == OP_XW) { plan[i] = OP_COMBOX; plan[i + 1] = OP_COMBOX; }
-      }
-    }
+    // (The plain projection sweep never stands in for the measuring one, although it is faster -- 4 m / 16 fewer MFMAs per 16 rows,
+    //  5.7 against 5.0-5.4 TB/s -- and its measurement is thrown away whenever the block it stored needs a level shift: which
+    //  sweep ran would decide what the step behind it knows, the chain's path would depend on the plan, the plan on the chains
+    //  this context has seen before, and two identical solves would differ in their last bits.  r05: tried, 0.02 ms per shifted
+    //  chain of the benchmark; tests/test_solver_gpu.py compares repeated solves bit for bit.)
     run.n = n; run.m = m; run.k = k; run.fold = fold; run.vsx = vsx; run.x = x; run.bx = bx; run.u = u;
     run.key = key;
     run.key_last = kind_key;
@@ -4226,7 +4356,7 @@ struct HipEngine : dla::Engine {
       // reference-schedule flops of what the fused sweeps fold in (same bookkeeping as trmm_gram / combo_gram)
       for (size_t i = 0; i < cd.launched.size(); ++i) {
         if (!ran[i]) continue;
-        if (cd.launched[i] == OP_TRMMG) stats.flops[DLA_OP_GRAM] += 2.0 * (double)cd.n * cd.k * cd.k;
+        if (cd.launched[i] == OP_TRMMG || cd.launched[i] == OP_TRMMC) stats.flops[DLA_OP_GRAM] += 2.0 * (double)cd.n * cd.k * cd.k;
         if (cd.launched[i] == OP_COMBO) { stats.flops[DLA_OP_GRAM] += 2.0 * (double)cd.n * cd.k * cd.k; stats.flops[DLA_OP_GEMM] -= 1.0 * (double)cd.n * cd.k * cd.k; }
       }
     }
@@ -4287,6 +4417,7 @@ struct HipEngine : dla::Engine {
         switch (sres.phase) {
           case OP_TRMMG: plan = sres.it_outer == 0 ? std::vector<int>{OP_TRMMG, OP_GRAMW, OP_COMBOX, OP_COMBOX, OP_CLOSE, OP_FINAL}
                                                    : std::vector<int>{OP_TRMMG, OP_XW, OP_XU, OP_COMBOX, OP_CLOSE, OP_FINAL}; break;
+          case OP_TRMMC:  plan = {OP_TRMMC, OP_XW, OP_XU, OP_COMBOX, OP_CLOSE, OP_FINAL}; break;
           case OP_GRAMW:  plan = {OP_GRAMW, OP_GRAMW, OP_COMBOX, OP_COMBOX, OP_CLOSE, OP_FINAL}; break;
           case OP_COMBOX: plan = {OP_COMBOX, OP_COMBOX, OP_CLOSE, OP_FINAL}; break;
           case OP_XW:     plan = {OP_XW, OP_COMBOX, OP_CLOSE, OP_FINAL}; break;

@@ -1325,12 +1325,17 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
   // ortho_vs_x (:1790 / 523-529) + the projection (:1691 / 401-403) [+ daxpy :397]; the operator is the caller's
   RefFlops rf(c, c && n > 0 && k > 0 ? ortho_vs_x_flops(n, m, k) + (shift != 0.0 ? 2.0 * n * (double)k : 0.0) +
                                        ((mode == 0 || mode == 4) ? 2.0 * n * (double)(m + k) * k : 2.0 * n * (double)(m + k) * (m + k)) : 0.0);
-  if (!c || !basis || !abasis || !h || !fn || mode < 0 || mode == 2 || mode > 4 || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
+  if (!c || !basis || !abasis || !h || !fn || mode < 0 || mode == 2 || mode > 5 || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
     return fail(c, DLA_ERR_ARG, "dla_expand_project: bad argument (n > 0, m >= 0, k > 0, ldh >= m + k)");
   c->pending_k = 0; c->pending_m = 0; c->pending_applied = 0;
-  // (DLA_OPT_PENDING_BLOCKS = 0 makes modes 3 / 4 behave like 1 / 0: the chain finishes the block in memory)
+  // (DLA_OPT_PENDING_BLOCKS = 0 makes modes 3 / 4 / 5 behave like 1 / 0 / 0: the chain finishes the block in memory)
   if (mode == 3 && !c->pending_blocks) mode = 1;
-  if (mode == 4 && !c->pending_blocks) mode = 0;
+  if ((mode == 4 || mode == 5) && !c->pending_blocks) mode = 0;
+  // mode 5 = mode 4 with the caller's pending blocks kept on the device as well (dla_basis_sync after every block): the chain's
+  // projections are exact against the FINISHED basis X D, so what a block leaves pending is bounded only by what keeps the host
+  // algebra well conditioned (max |S| < 0.05, Gram matrix factorable in one step) -- not by what later projections could absorb
+  const bool exact = mode == 5 && c->eng->basis_exact_ok() && k <= 16 && m + k <= 288;   // (otherwise: mode 4, the tight bounds)
+  if (mode == 5) mode = 4;
   // a chain that failed behind a finished orthogonalisation must not leave its block to the next call (round-4 advisor)
   struct Forget { dla_ctx* c; int m, k; bool keep = false; ~Forget() { if (!keep) { std::vector<double> junk((size_t)(m + k) * k); (void)c->eng->pending_block(m, k, junk.data(), m + k, nullptr); } } };
   if (mode == 4) {
@@ -1341,8 +1346,8 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
     // multiplies the rows of its coefficient blocks by D before any product with the panel (dla_basis_fold)
     // (1e-8 / 1e-9: a later block's first projection against the stored columns leaves that share of what it removes, and the block
     //  that comes out of it can be as ill-conditioned as 1e7 -- the leftover must stay below its smallest directions)
-    struct Flags { dla::Engine* e; explicit Flags(dla::Engine* e_) : e(e_) { e->drop_final = true; e->publish_pending = true; e->drop_final_tol = 1.0e-8; e->drop_final_stol = 1.0e-9; }
-                   ~Flags() { e->drop_final = false; e->publish_pending = false; e->drop_final_tol = 0.0; e->drop_final_stol = 1.0e-4; } } flags(c->eng);
+    struct Flags { dla::Engine* e; Flags(dla::Engine* e_, bool ex) : e(e_) { e->drop_final = true; e->publish_pending = true; e->drop_final_tol = ex ? 0.0 : 1.0e-8; e->drop_final_stol = ex ? 5.0e-2 : 1.0e-9; e->basis_exact = ex; }
+                   ~Flags() { e->drop_final = false; e->publish_pending = false; e->drop_final_tol = 0.0; e->drop_final_stol = 1.0e-4; e->basis_exact = false; } } flags(c->eng, exact);
     Forget forget{c, m, k};
     const int st = expand_project_impl(c, 0, n, m, k, basis, abasis, fn, shift, h, ldh);
     if (st) return st;
@@ -1403,6 +1408,12 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
     }
   }
   return DLA_OK;
+}
+
+int dla_basis_sync(dla_ctx* c, int m, int k, const double* dmat, int ld)
+{
+  if (!c || (k > 0 && (!dmat || m < 0 || ld < m + k))) return fail(c, DLA_ERR_ARG, "dla_basis_sync: bad argument");
+  return engfail(c, c->eng->basis_sync(m, k, dmat, ld));
 }
 
 int dla_pending_factor(dla_ctx* c, int k, double* t, int ldt)

@@ -294,6 +294,13 @@ module diaglib
       real(c_double) :: dmat(*), c(*)
       integer(c_int) :: st
     end function
+    function dla_basis_sync(ctx,m,k,dmat,ld) bind(C,name='dla_basis_sync') result(st)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr),    value :: ctx
+      integer(c_int), value :: m, k, ld
+      real(c_double) :: dmat(*)
+      integer(c_int) :: st
+    end function
     function dla_expand_project_metric(ctx,mode,n,m,k,basis,bbasis,abasis,fn,bfn,shift,h,ldh) &
              bind(C,name='dla_expand_project_metric') result(st)
       import :: c_ptr, c_funptr, c_int, c_double
@@ -741,6 +748,8 @@ contains
     real(dp)        :: t_begin(2), t_end(2)
     integer         :: it, sweeps, kept, col, first, j, ritz_cols
     logical         :: patch_kept, projected, mirror_raw
+    logical         :: exact_basis          ! the pending blocks are kept on the device as well (dla_expand_project mode 5)
+    integer         :: synced               ! columns of dmat the device knows
     integer(c_int)  :: applied
 !
     call env_open(e, n, n_max, evec)
@@ -759,6 +768,7 @@ contains
       britz  = dev_panel(e%ctx, n, n_max, 'b_evec')
     end if
     allocate (h(s%ld,s%ld), y(s%ld,s%ld), theta(s%ld), dmat(s%ld,s%ld), hraw(s%ld,s%ld), pblk(s%ld,n_max))
+    exact_basis = (.not.with_metric) .and. n_max.le.16 .and. s%ld.le.288
     call reset_pending()
 !
 !   The reference zero-fills both n x lda panels (:1632-1633).  On the device no column is read before it has been
@@ -906,12 +916,27 @@ contains
 !           mode 4: a block that the closing pass found orthonormal to 1e-8 keeps its closing projection and its last triangular
 !           factor pending (the sweeps of :3543-3544 and :3327 are not run on it): the finished block is [X | U] p for the STORED
 !           columns; its columns of the projected matrix come back for the stored block and are corrected here, D^T h_raw D with
-!           the upper-triangular D that collects the pending blocks of the whole basis
+!           the upper-triangular D that collects the pending blocks of the whole basis.
+!           mode 5 (blocks of up to 16 columns, up to 288 basis columns): the device holds D as well and projects with
+!           X (D D^T) X^T -- what may stay pending is then bounded by the conditioning of the k x k algebra only
 !
-            call chk(e%ctx, dla_expand_project(e%ctx, 4_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
-                                               h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
+            if (exact_basis) then
+              if (synced.lt.s%cols) then
+                call chk(e%ctx, dla_basis_sync(e%ctx, synced, s%cols - synced, dmat, s%ld), 'basis sync')
+                synced = s%cols
+              end if
+              call chk(e%ctx, dla_expand_project(e%ctx, 5_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
+                                                 h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
+            else
+              call chk(e%ctx, dla_expand_project(e%ctx, 4_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
+                                                 h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
+            end if
             call chk(e%ctx, dla_pending_block(e%ctx, s%cols, s%act, pblk, s%ld, applied), 'pending block')
             call admit_pending(s%cols, s%act)
+            if (exact_basis) then
+              call chk(e%ctx, dla_basis_sync(e%ctx, s%cols, s%act, dmat, s%ld), 'basis sync')
+              synced = s%cols + s%act
+            end if
             projected = .true.
           else
 !           (last sweep allowed: nobody will read the operator's image of this block -- the caller's routine is not called)
@@ -982,6 +1007,8 @@ contains
         dmat(j,j) = one
       end do
       any_pending = .false.
+      synced = 0
+      if (exact_basis) call chk(e%ctx, dla_basis_sync(e%ctx, 0_c_int, 0_c_int, dmat, s%ld), 'basis sync')
     end subroutine reset_pending
 !
 !   a block of k columns has come in behind m stored ones with pblk pending

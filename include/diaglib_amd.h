@@ -277,7 +277,13 @@ int  dla_expand_project(dla_ctx* ctx, int mode, int n, int m, int k, double* bas
  * finishes the block there.  (mode 3: max |S| < 1e-4; the block is rebuilt in the next iteration.)  *applied = 1 (mode 4, for
  * 1e-9 <= max |S| < 1e-5): the chain's closing sweep HAS applied [-S T ; T] to the block in memory, without measuring anything behind
  * it -- the block in memory is what h_host belongs to, and dla_basis_admit owes it only the difference to the exact closing pass and
- * the k x k factor of its Gram matrix I - (S T)^T (S T). */
+ * the k x k factor of its Gram matrix I - (S T)^T (S T).
+ * mode 5 = mode 4 with the caller's D kept on the DEVICE as well (dla_basis_sync after every block, blocks of at most 16 columns, at
+ * most 288 basis columns): every projection of the chain is then X (D D^T) X^T U, exact against the finished basis, and the bounds
+ * on what may stay pending are those of the host algebra alone -- max |S| < 0.05 with column sums of squares below 0.02, nothing on
+ * G (its factor has converged) -- so the chain ends behind the first sweep that has measured S and G on what it stored.  Where the
+ * device-driven chain does not run at all (an all-reduce hook, the A/B knobs for the host loop) or the shape is beyond the device
+ * copy, the call behaves like mode 4; it fails (DLA_ERR_ARG) when the device copy does not describe the m columns in front of it. */
 int  dla_pending_factor(dla_ctx* ctx, int k, double* t_host, int ldt);
 int  dla_pending_block(dla_ctx* ctx, int m, int k, double* p_host, int ldp, int* applied);
 /* Host-size algebra of a basis with pending blocks (no device work; all arrays column-major, leading dimension ld):
@@ -287,6 +293,10 @@ int  dla_pending_block(dla_ctx* ctx, int m, int k, double* p_host, int ldp, int*
  * dmat^T hraw dmat.  dla_basis_fold: c <- dmat(0:rows,0:rows) c. */
 int  dla_basis_admit(int m, int k, double* p_host, int ldp, int applied, double* hraw, double* dmat, double* h, int ld);
 int  dla_basis_fold(int rows, int ncol, const double* dmat, int ld, double* c, int ldc);
+/* Device copy of the caller's D for dla_expand_project mode 5: columns m .. m+k-1 of dmat (upper triangular, leading dimension ld;
+ * rows 0 .. m+k-1 are read) follow the m columns sent so far -- blocks arrive in order, every block of the basis, identity ones
+ * included; k <= 0 forgets everything (new solve, restart).  Asynchronous: the host array may be changed when the call returns. */
+int  dla_basis_sync(dla_ctx* ctx, int m, int k, const double* dmat, int ld);
 /* The expansion step with a metric B (gen_david_driver diaglib.f90:2170-2190, lobpcg_driver with gen_eig :523-529): on
  * basis = [X | U], bbasis = [BX | BU], abasis = [AX | AU]:  b_ortho_vs_x(X, BX, U) (:3576-3663),  BU = B U (the caller's bvec),
  * b_ortho(U, BU) (:3094-3183),  AU = A U [+ shift U],  and the projection as in dla_expand_project (mode 0 / 1).  Same result as

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 EPS = np.finfo(np.float64).eps
 
 
-def _grow(ctx, rng, n, k, nb, kind, pending):
+def _grow(ctx, rng, n, k, nb, kind, pending, mode=4):
     mv = capi.fn_address("dla_synth_matvec")
     ld = nb * k
     x0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, k)))[0])
@@ -26,6 +26,9 @@ def _grow(ctx, rng, n, k, nb, kind, pending):
     b = basis.download(); ab = abasis.download()
     hraw[:k, :k] = b[:, :k].T @ ab[:, :k]; h[:k, :k] = hraw[:k, :k]
     n_pending = 0
+    if mode == 5:                     # the device keeps D as well: every block is announced, identity ones included
+        ctx.basis_sync(0, 0)
+        ctx.basis_sync(0, k, dmat)
     for blk in range(1, nb):
         m = blk * k
         if kind == "inside":          # mostly inside span(X): the projection removes almost everything
@@ -36,12 +39,14 @@ def _grow(ctx, rng, n, k, nb, kind, pending):
         else:
             u = b[:, :m] @ rng.standard_normal((m, k)) + 0.3 * rng.standard_normal((n, k))
         basis.col(m, k).upload(np.asfortranarray(u))
-        h4 = ctx.expand_project(4 if pending else 0, basis, abasis, m, k, mv, 0.0)
+        h4 = ctx.expand_project(mode if pending else 0, basis, abasis, m, k, mv, 0.0)
         p = ctx.pending_block(m, k) if pending else np.asfortranarray(np.vstack([np.zeros((m, k)), np.eye(k)]))
         applied = ctx.pending_applied if pending else False
         n_pending += int(np.any(p[:m] != 0.0) or not np.array_equal(p[m:], np.eye(k)))
         h[:m + k, m:m + k] = h4
         ctx.basis_admit(m, k, p, hraw, dmat, h, applied=applied)
+        if mode == 5:
+            ctx.basis_sync(m, k, dmat)
         b = basis.download()
     ab = abasis.download()
     return b, ab, dmat, h, n_pending
@@ -65,6 +70,55 @@ def test_basis_with_pending_blocks_is_orthonormal_and_projects_exactly(ctx, rng,
             assert n_pending >= min(nb - 1, 192 // k - 1) // 2      # the three-pass chains do leave their closing passes pending
     finally:
         ctx.set_option(100 + 6, 0)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
+
+
+@pytest.mark.parametrize("k,nb,kind", [(1, 8, "random"), (3, 8, "random"), (13, 6, "random"), (13, 22, "random"), (16, 18, "random"), (13, 6, "inside"),
+                                       (13, 6, "dependent"), (8, 10, "dependent"), (13, 20, "dependent"), (13, 20, "inside")])
+def test_basis_kept_on_the_device_projects_exactly(ctx, rng, k, nb, kind):
+    """mode 5: the chains project with X (D D^T) X^T, so the stored columns may be as far from orthonormal as the host algebra
+    tolerates (max |S| < 0.05) -- the finished basis panel D is orthonormal to rounding all the same, over every basis width the device
+    copy takes (288 columns: the last blocks run the sweep-per-update schedule beyond 192)."""
+    n = 6000
+    try:
+        ctx.set_shard(n, 0); ctx.synth_setup(n, 0, n); ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+        b, ab, dmat, h, n_pending = _grow(ctx, rng, n, k, nb, kind, True, mode=5)
+        l = nb * k
+        v = b @ dmat
+        assert np.abs(v.T @ v - np.eye(l)).max() < 50 * EPS, (np.abs(v.T @ v - np.eye(l)).max(), n_pending)
+        href = v.T @ (ab @ dmat)
+        assert np.abs(np.triu(h - href)).max() < 1e-13 * np.abs(href).max()
+        if kind == "random":
+            assert n_pending >= (nb - 1) // 2
+    finally:
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
+
+
+def test_mode_5_refuses_a_basis_the_device_copy_does_not_describe(ctx, rng):
+    n, k = 4000, 8
+    mv = capi.fn_address("dla_synth_matvec")
+    try:
+        ctx.set_shard(n, 0); ctx.synth_setup(n, 0, n); ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+        x0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, 2 * k)))[0])
+        basis = ctx.panel(np.asfortranarray(np.hstack([x0, rng.standard_normal((n, k))])))
+        abasis = ctx.panel(np.zeros((n, 3 * k), order="F"))
+        ctx.basis_sync(0, 0)
+        ctx.basis_sync(0, k, np.asfortranarray(np.eye(3 * k)))          # one block announced, two stored
+        with pytest.raises(capi.DlaError):
+            ctx.expand_project(5, basis, abasis, 2 * k, k, mv, 0.0)
+        with pytest.raises(capi.DlaError):                                # blocks arrive in order
+            ctx.basis_sync(2 * k, k, np.asfortranarray(np.eye(3 * k)))
+        ctx.basis_sync(k, k, np.asfortranarray(np.eye(3 * k)))
+        ctx.expand_project(5, basis, abasis, 2 * k, k, mv, 0.0)
+        p = ctx.pending_block(2 * k, k)
+        b = basis.download()
+        v = b[:, :2 * k] @ p[:2 * k] + b[:, 2 * k:] @ p[2 * k:]
+        # (identity D: the closing block the chain hands over is completed by dla_basis_admit; here only its T part is checked)
+        assert np.abs(np.triu(p[2 * k:], 0) - p[2 * k:]).max() == 0.0 and np.isfinite(v).all()
+    finally:
+        ctx.basis_sync(0, 0)
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
         ctx.set_shard(-1, 0)
 
