@@ -1928,11 +1928,14 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
   // (:3543-3544, then one macro-iteration with a near-identity factor) is then the block [-(xu W) ; W], which the caller applies
   // to its coefficients exactly (dla_basis_admit) -- as long as xu is small enough for that algebra to be benign (drop_stol).
   const bool may_pend = a.drop_final && a.t_host != nullptr && m > 0;
-  auto small_xu = [&](const double* xu, int ldx) {
+  // (wn: norm estimate of the factor that is pending on the measured block -- what has to be small is xu W.  A block of LOBPCG
+  //  residuals of norm 1e-8 measured in front of its first projection has a tiny X^T U and a factor of 1e8: found by
+  //  tools/fuzz_multirank.py, seed 78)
+  auto small_xu = [&](const double* xu, int ldx, double wn) {
     double sm = 0.0;
     for (int idx = lane; idx < m * k; idx += 64) sm = fmax(sm, fabs(xu[(size_t)(idx % m) + (size_t)(idx / m) * ldx]));
     for (int off = 32; off > 0; off >>= 1) sm = fmax(sm, __shfl_xor(sm, off, 64));
-    return sm < a.drop_stol;
+    return sm * fmax(wn, 1.0) < a.drop_stol;
   };
 
   if (a.after == OP_FINAL) {
@@ -1941,7 +1944,7 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
     // C' = [-(xu W) ; W]  (host_logic.cpp ortho_vs_x_impl, X^T (U W) = (X^T U) W), packed for the combined sweep
     for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx % k) * TLD + idx / k, a.wfull[idx]);   // A[pp][j] = W(pp, j)
     TSYNC();
-    const bool pend = may_pend && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) && small_xu(a.gsrc, m);
+    const bool pend = may_pend && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) && small_xu(a.gsrc, m, t.growth);
     assemble(a.gsrc, m, pend);
     t.it_macro = 0;           // the ortho_cd that follows the combined sweep starts afresh (*growth = 1, it = 0)
     t.growth = 1.0;
@@ -2034,7 +2037,7 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
           TSYNC();
           for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx / k) * TLD + idx % k, lds_load1(S + (idx / k) * TLD + idx % k));
           TSYNC();
-          const bool pend = xw_project && may_pend && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) && small_xu(a.gsrc, m + k);
+          const bool pend = xw_project && may_pend && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) && small_xu(a.gsrc, m + k, linv_norm);
           assemble(a.gsrc, m + k, pend);
           t.sloppy = (!xw_project && t.growth * eps >= tol) ? 1 : 0;      // (a measured X^T U of the stored block is not sloppy)
           ++t.it_outer;
@@ -2413,11 +2416,12 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
       // the block in memory is U_mem with Wp pending: C' = [-(X^T U_mem) Wp ; Wp]
 #pragma unroll
       for (int r = 0; r < 4; ++r) { pnew[r] = a.wst[512 + 64 * r + lane]; dnew[r] = pnew[r]; }
+      const double wn = fmax(t.growth, 1.0);     // norm estimate of Wp: what has to be small is (X^T U_mem) Wp
       t.it_macro = 0; t.growth = 1.0; t.have_xu = 0; t.sloppy = 0;
       // (the block stays pending when the caller takes pending blocks and both X^T U, just measured, and the distance of the
       //  pending factor from the identity -- the Gram matrix it came from -- are within the caller's bounds)
-      if (may_pend && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) < a.drop_stol && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) &&
-          colsq_max() < CS_CAP) { t.status = OST_DONE; go = 2; }
+      if (may_pend && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) * wn < a.drop_stol && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) &&
+          colsq_max() * wn * wn < CS_CAP) { t.status = OST_DONE; go = 2; }
       else { t.phase = op_project; go = 1; }
     } else {
       ++t.it_macro;

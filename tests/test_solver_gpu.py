@@ -657,6 +657,25 @@ def test_two_host_threads_solve_at_the_same_time(oracle):
             assert np.array_equal(eig, outs[0][0])   # the same thread gets the same bits every time
 
 
+def test_lobpcg_residual_block_of_tiny_norm_is_not_left_pending_unprojected(ctx):
+    """Found by tools/fuzz_multirank.py (seed 78): near convergence LOBPCG's block of preconditioned residuals has norm 1e-8, so
+    X^T U measured IN FRONT of the first projection is tiny although the block lies mostly inside span(X); with the pending factor
+    (1e8) it is not.  The chain has to test (X^T U) W against the caller's bound, not X^T U: before the fix the closing block came
+    back with a Gram matrix that was not positive definite and the driver stopped."""
+    n, t, m = 235_047, 29, 36
+    try:
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+        ctx.synth_setup(n, 0, n)
+        g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
+        ev = ctx.panel(g)
+        eig, _, ok, info = ctx.lobpcg_driver(n, t, m, 200, 1e-8, 0.0, capi.fn_address("dla_synth_matvec"), capi.fn_address("dla_synth_precnd"), ev)
+        assert ok and info["iters"] < 30
+        v = ev.download()[:, :t]
+        assert np.abs(v.T @ v - np.eye(t)).max() < 1e-12
+    finally:
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+
+
 def test_short_lived_threads_release_their_contexts():
     """The drivers' context belongs to the calling thread and goes away with it: 30 threads that each solve once and end
     leave device memory where it started (each of them holds ~0.25 GB of cached panels while it lives)."""

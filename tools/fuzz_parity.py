@@ -97,6 +97,8 @@ for it in range(cases):
         continue
     finally:
         ctx.set_option(capi.OPT_PENDING_BLOCKS, 1); ctx.set_option(100 + 6, 0)
+    for kv in filter(None, os.environ.get("FUZZ_TUNE", "").split(",")):       # e.g. FUZZ_TUNE=6=3: the main run on the host-driven loops
+        ctx.set_option(100 + int(kv.split("=")[0]), int(kv.split("=")[1]))
     try:
         if solver == "davidson":
             e, v, ok, info = ctx.davidson_driver(n, t, m, 300, tol, max_dav, shift, mv, pc, g)
@@ -124,7 +126,7 @@ for it in range(cases):
     # unit guesses: the history is robust to rounding; random guesses and tolerances near the rounding floor of max|r| (1e-11 on
     # these spectra: DESIGN 11.7) end a few sweeps earlier or later with the last bits of the small eigensolver
     slack = 1 if (guess == "unit" and tol >= 1e-10) else max(3, tr.iters // 8)
-    if "lobpcg" in solver and (m > 24 or m == t):   # (wide LOBPCG blocks, or no guard vectors behind the wanted roots: the order in
+    if "lobpcg" in solver and (m > 24 or m <= t + 1):   # (wide LOBPCG blocks, or at most one guard vector behind the wanted roots: the order in
         slack = max(3, tr.iters // 6)               #  which the last roots lock moves the count by 10 %, with or without the pending factor)
     lim = max(1e-9, 50.0 * tol * tol)          # eigenvalue error ~ residual^2; both sides stop anywhere below tol
     good = ok == oko == okr and (not ok or (res["d_oracle"] < lim and res["d_ref"] < lim)) and abs(info["iters"] - tr.iters) <= slack
