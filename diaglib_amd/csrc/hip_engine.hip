@@ -1761,6 +1761,8 @@ struct OrthoTailArgs {
   const double* dmat;  // != nullptr: the stored columns X are not a finished basis -- the finished one is X D with this upper-triangular
   int dmat_ld;         // D (m x m, column-major, the caller's pending blocks: dla_basis_sync).  The projector onto span(X) is then
                        // X (D D^T) X^T, and the projection coefficients are -(D D^T)(xu W) instead of -(xu W) (ortho_tail16)
+  int gp;              // 1: the first projection's triangular factor comes from the Gram matrix of the PROJECTED block, G - Y^T Y with
+                       // Y = D^T (X^T U), both measured by OP_GRAMX -- instead of the block's own (see ortho_tail16)
   int drop_final;      // 1: the chain ends where it would ask for OP_FINAL -- the pending upper-triangular factor is NOT applied.
                        // For callers that B-orthonormalise the block by Cholesky-QR right behind the chain (dla_expand_project_metric:
                        // b_ortho, reference diaglib.f90:3094-3183): the Q factor of U W and of U is the same for any upper-triangular W
@@ -2391,6 +2393,71 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
     }
     __syncthreads();
   }
+  // zs <- D^T zs for the caller's upper-triangular D (a.dmat), 16 x 16 tiles on the matrix cores: D(Q, R) = 0 for Q > R.  A wave owns
+  // the row tiles R = wave, wave + 4, ...; products with the contraction index p = g + 4 s: A[c][p], B[p][c] (see mfma16).
+  // Called by all 256 threads; zs holds [16 nt][16] doubles.
+  double* zs = lds + T16_LDS_DOUBLES;
+  auto dt_times_zs = [&](int nt) {
+    const int ld = a.dmat_ld;
+    __syncthreads();
+    v4d y1[5];
+#pragma unroll
+    for (int qq = 0; qq < 5; ++qq) {
+      const int R = wave + 4 * qq;
+      y1[qq] = (v4d){0.0, 0.0, 0.0, 0.0};
+      if (R < nt)
+        for (int Q = 0; Q <= R; ++Q)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int rowd = 16 * Q + g + 4 * s, cold = 16 * R + c;        // A[c][p] = D(16 Q + p, 16 R + c)
+            const double av = (rowd < m && cold < m) ? a.dmat[(size_t)rowd + (size_t)cold * ld] : 0.0;
+            y1[qq] = mfma16(av, lds_load1(zs + (size_t)rowd * 16 + c), y1[qq]);
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 5; ++qq) {
+      const int R = wave + 4 * qq;
+      if (R < nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds_store1(zs + (size_t)(16 * R + g + 4 * r) * 16 + c, y1[qq][r]);
+    }
+    __syncthreads();
+  };
+  // The first projection (the step behind OP_GRAMX in a three-pass chain) takes its triangular factor from the Gram matrix of the
+  // block it is about to STORE: (U - X (D D^T) S)^T (U - X (D D^T) S) = G - Y^T Y with Y = D^T S, all of it measured by the sweep in
+  // front of this step.  The reference factors U^T U there (its ortho_cd in front of the loop, :3533) and finds, behind the
+  // projection, a block whose columns have lost most of their norm and some of their independence -- on the benchmark a Gram
+  // matrix 1.0 off the identity, a second projection with its factor, a third factor.  With the projected block's own factor the
+  // stored block comes out near orthonormal (to eps cond^2 of the PROJECTED block), and its measured S and G usually end the chain:
+  // two passes over X instead of three.  Same Q factor as the reference's in exact arithmetic (every factor is upper triangular
+  // with a positive diagonal); a Gram matrix that is not positive definite, or has lost 13 digits to the subtraction, leaves the
+  // reference's order in place (level shifts included).
+  const int it_outer_in = pre ? pre->it_outer : st->it_outer;
+  const bool gp_step = a.gp && a.x3 && a.fold == 1 && after == OP_GRAMX && m > 0 && m <= 256 && a.lead_once && can_defer && it_outer_in == 0;
+  v4d gp_p = (v4d){0.0, 0.0, 0.0, 0.0};
+  if (gp_step) {
+    const int nt = (m + 15) / 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t0 = 16 * (wave + 4 * q);
+      if (t0 < 16 * nt) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) lds_store1(zs + (size_t)(t0 + c) * 16 + 4 * s + g, xa[q][s]);      // (zero beyond m and k)
+      }
+    }
+    if (a.dmat != nullptr) dt_times_zs(nt);
+    else __syncthreads();
+    if (wave == 0) {
+      for (int R = 0; R < nt; ++R)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double v = lds_load1(zs + (size_t)(16 * R + 4 * s + g) * 16 + c);     // A[c][p] = B[p][c] = Y(16 R + p, c)
+          gp_p = mfma16(v, v, gp_p);
+        }
+    }
+    __syncthreads();     // (the assembly below reuses zs)
+  }
   // max_j sum_i S_ij^2 >= |(S^T S)_ij|: what the Gram matrix of the projected block differs from G by (wave 0, every lane)
   auto colsq_max = [&]() {
     double cs = lane < 16 ? ((s_colsq[0][lane] + s_colsq[1][lane]) + s_colsq[2][lane]) + s_colsq[3][lane] : 0.0;
@@ -2467,9 +2534,42 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
         const unsigned long long cyc0 = a.dbg ? __builtin_readcyclecounter() : 0ULL;
         // factorisation; on a non-positive pivot the level-shift ladder (:3265-3295): shift = max(eps alpha ||U||_F, 2 eps),
         // alpha = 100, 1000, ...  (one call site: the factorisation loop exists once in the code)
-        int info, it_micro = 0;
+        int info = 1, it_micro = 0;
         double alpha = 100.0, unorm = -1.0;
-        for (;;) {
+        bool used_gp = false;
+        if (gp_step) {
+          v4d amp;
+          double lost = 1.0;           // smallest ratio of a projected column's squared norm to the column's own
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool in = (g + 4 * r < k && c < k);
+            amp[r] = in ? g0[r] - gp_p[r] : g0[r];
+            if (in && g + 4 * r == c) lost = fmin(lost, g0[r] > 0.0 ? amp[r] / g0[r] : 0.0);
+          }
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) lost = fmin(lost, __shfl_xor(lost, off, 64));
+          if (lost > 1.0e-13) {
+            // (a projected block that is numerically rank deficient gets the reference's level shifts, :3265-3295, on ITS Gram
+            //  matrix: the factor is then only approximate, and everything behind it is measured on what it stored)
+            const v4d amp0 = amp;
+            double trp = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (g + 4 * r == c && c < k) trp += amp0[r];
+            const double tr = wave_sum(trp), un = sqrt(tr > 0.0 ? tr : 0.0);
+            double al = 100.0;
+            int itm = 0;
+            for (;;) {
+              info = chol_inv16(k, amp, x, dmax, xmax, lane);
+              if (info == 0 || ++itm > maxit || a.gp < 2) break;
+              const double shift = fmax(eps * al * un, tol);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) amp[r] = amp0[r] + ((g + 4 * r == c && c < k) ? shift : 0.0);
+              al *= 10.0;
+            }
+            if (info == 0) { used_gp = true; am = amp; t.shifts += itm; }
+          }
+        }
+        if (!used_gp) for (;;) {
           info = chol_inv16(k, am, x, dmax, xmax, lane);
           if (info == 0) break;
           if (unorm < 0.0) {
@@ -2700,8 +2800,7 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
   const int l = m + k, l4 = ((l + 3) / 4) * 4;
   // Exact projection against an unfinished basis (a.dmat): Z = xu Wd goes to LDS first, the coefficients become -(D D^T) Z.  The
   // block that goes to the HOST stays -Z: the caller applies D D^T itself (dla_basis_admit).
-  const bool dfix = a.dmat != nullptr && m <= T16_ZS_ROWS;
-  double* zs = lds + T16_LDS_DOUBLES;               // [16 ceil(m / 16)][16]
+  const bool dfix = a.dmat != nullptr && m <= T16_ZS_ROWS;          // (zs: [16 ceil(m / 16)][16])
   double db[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) db[s] = lds_load1(lds_d + 64 * s + lane);
@@ -2738,33 +2837,9 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
     }
   }
   if (dfix) {
-    // Z' = D (D^T Z), 16 x 16 tiles on the matrix cores; D is upper triangular: D(Q, R) = 0 for Q > R.  A wave owns the row tiles
-    // R = wave, wave + 4, ...; products D = A B with the contraction index p = g + 4 s: A[c][p], B[p][c] (see mfma16 above)
+    // Z' = D (D^T Z): the first product through dt_times_zs, the second one the same way with D's rows
     const int nt = (m + 15) / 16, ld = a.dmat_ld;
-    __syncthreads();
-    v4d y1[5];
-#pragma unroll
-    for (int qq = 0; qq < 5; ++qq) {
-      const int R = wave + 4 * qq;
-      y1[qq] = (v4d){0.0, 0.0, 0.0, 0.0};
-      if (R < nt)
-        for (int Q = 0; Q <= R; ++Q)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int rowd = 16 * Q + g + 4 * s, cold = 16 * R + c;        // A[c][p] = D(16 Q + p, 16 R + c)
-            const double av = (rowd < m && cold < m) ? a.dmat[(size_t)rowd + (size_t)cold * ld] : 0.0;
-            y1[qq] = mfma16(av, lds_load1(zs + (size_t)rowd * 16 + c), y1[qq]);
-          }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int qq = 0; qq < 5; ++qq) {
-      const int R = wave + 4 * qq;
-      if (R < nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds_store1(zs + (size_t)(16 * R + g + 4 * r) * 16 + c, y1[qq][r]);
-    }
-    __syncthreads();
+    dt_times_zs(nt);
 #pragma unroll
     for (int qq = 0; qq < 5; ++qq) {
       const int R = wave + 4 * qq;
@@ -3963,6 +4038,10 @@ struct HipEngine : dla::Engine {
                                  fold, tune[6] == 7 ? 0 : 1, d_xug, d_wst, d_dbg, chain_xw ? 1 : 0};
     if ((fold == 1 && op == OP_GRAMX) || op == OP_XW || op == OP_COMBOX) pending_tail.gsrc = d_xug;
     pending_tail.x3 = chain_x3 ? 1 : 0;
+    // (knob 6 = 15: A/B, the first factor from U^T U as the reference's; 16: A/B, level shifts on the projected block's Gram matrix
+    //  instead of the reference's order for a numerically rank-deficient block -- 14.2-14.36 against 14.37-14.46 ms on the benchmark,
+    //  but such a block's weakest columns then depend on the schedule: not shipped)
+    pending_tail.gp = tune[6] == 15 ? 0 : tune[6] == 16 ? 2 : 1;
     pending_tail.dmat = (basis_exact && fold && m > 0 && dmat_nontrivial && dmat_cols == m && m <= DMAT_LD) ? d_dmat : nullptr;
     pending_tail.dmat_ld = DMAT_LD;
     pending_tail.drop_final = (drop_final && m > 0) ? 1 : 0;
