@@ -2406,13 +2406,23 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
       const int R = wave + 4 * qq;
       y1[qq] = (v4d){0.0, 0.0, 0.0, 0.0};
       if (R < nt)
-        for (int Q = 0; Q <= R; ++Q)
+        for (int Q0 = 0; Q0 <= R; Q0 += 4) {
+          // (four tiles of D per round: sixteen loads in flight, then sixteen MFMAs)
+          double av[4][4];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int rowd = 16 * Q + g + 4 * s, cold = 16 * R + c;        // A[c][p] = D(16 Q + p, 16 R + c)
-            const double av = (rowd < m && cold < m) ? a.dmat[(size_t)rowd + (size_t)cold * ld] : 0.0;
-            y1[qq] = mfma16(av, lds_load1(zs + (size_t)rowd * 16 + c), y1[qq]);
-          }
+          for (int dq = 0; dq < 4; ++dq)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const int rowd = 16 * (Q0 + dq) + g + 4 * s, cold = 16 * R + c;        // A[c][p] = D(16 Q + p, 16 R + c)
+              av[dq][s] = (Q0 + dq <= R && rowd < m && cold < m) ? a.dmat[(size_t)rowd + (size_t)cold * ld] : 0.0;
+            }
+#pragma unroll
+          for (int dq = 0; dq < 4; ++dq)
+            if (Q0 + dq <= R)
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+                y1[qq] = mfma16(av[dq][s], lds_load1(zs + (size_t)(16 * (Q0 + dq) + g + 4 * s) * 16 + c), y1[qq]);
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -2800,10 +2810,26 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
   const int l = m + k, l4 = ((l + 3) / 4) * 4;
   // Exact projection against an unfinished basis (a.dmat): Z = xu Wd goes to LDS first, the coefficients become -(D D^T) Z.  The
   // block that goes to the HOST stays -Z: the caller applies D D^T itself (dla_basis_admit).
-  const bool dfix = a.dmat != nullptr && m <= T16_ZS_ROWS;          // (zs: [16 ceil(m / 16)][16])
+  // (the coefficients are only read by a sweep that follows: a block that stays pending needs none -- s_go 2, 3)
+  const bool dfix = a.dmat != nullptr && m <= T16_ZS_ROWS && (s_go == 1 || s_go == 4);          // (zs: [16 ceil(m / 16)][16])
+  // behind OP_GRAMX zs still holds Y = D^T S of the step's first phase: D^T (S Wd) = Y Wd, one product with D saved
+  const bool have_y = dfix && gp_step;
   double db[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) db[s] = lds_load1(lds_d + 64 * s + lane);
+  if (have_y) {
+    const int nt = (m + 15) / 16;
+#pragma unroll
+    for (int qq = 0; qq < 5; ++qq) {
+      const int R = wave + 4 * qq;
+      if (R >= nt) continue;
+      v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma16(lds_load1(zs + (size_t)(16 * R + c) * 16 + 4 * s + g), db[s], acc);    // A[c][p] = Y(16 R + c, p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds_store1(zs + (size_t)(16 * R + g + 4 * r) * 16 + c, acc[r]);      // (the wave's own tile rows)
+    }
+  } else {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int t0 = 16 * (wave + 4 * q);
@@ -2836,22 +2862,33 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
       if (to_host && p_ < m && c < k) a.t_host[(size_t)p_ * PEND_LD + c] = -acc[r];
     }
   }
+  }
   if (dfix) {
-    // Z' = D (D^T Z): the first product through dt_times_zs, the second one the same way with D's rows
+    // Z' = D (D^T Z): the first product through dt_times_zs (or Y Wd above), the second one the same way with D's rows
     const int nt = (m + 15) / 16, ld = a.dmat_ld;
-    dt_times_zs(nt);
+    if (have_y) __syncthreads();
+    else dt_times_zs(nt);
 #pragma unroll
     for (int qq = 0; qq < 5; ++qq) {
       const int R = wave + 4 * qq;
       if (R >= nt) continue;
       v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-      for (int Q = R; Q < nt; ++Q)
+      for (int Q0 = R; Q0 < nt; Q0 += 4) {
+        double av[4][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int rowd = 16 * R + c, cold = 16 * Q + g + 4 * s;          // A[c][p] = D(16 R + c, 16 Q + p)
-          const double av = (rowd < m && cold < m) ? a.dmat[(size_t)rowd + (size_t)cold * ld] : 0.0;
-          acc = mfma16(av, lds_load1(zs + (size_t)cold * 16 + c), acc);
-        }
+        for (int dq = 0; dq < 4; ++dq)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int rowd = 16 * R + c, cold = 16 * (Q0 + dq) + g + 4 * s;          // A[c][p] = D(16 R + c, 16 Q + p)
+            av[dq][s] = (Q0 + dq < nt && rowd < m && cold < m) ? a.dmat[(size_t)rowd + (size_t)cold * ld] : 0.0;
+          }
+#pragma unroll
+        for (int dq = 0; dq < 4; ++dq)
+          if (Q0 + dq < nt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              acc = mfma16(av[dq][s], lds_load1(zs + (size_t)(16 * (Q0 + dq) + g + 4 * s) * 16 + c), acc);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int p_ = 16 * R + g + 4 * r;
