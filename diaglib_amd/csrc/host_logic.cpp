@@ -1324,7 +1324,7 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
   DLA_T("dla_expand_project");
   // ortho_vs_x (:1790 / 523-529) + the projection (:1691 / 401-403) [+ daxpy :397]; the operator is the caller's
   RefFlops rf(c, c && n > 0 && k > 0 ? ortho_vs_x_flops(n, m, k) + (shift != 0.0 ? 2.0 * n * (double)k : 0.0) +
-                                       ((mode == 0 || mode == 4) ? 2.0 * n * (double)(m + k) * k : 2.0 * n * (double)(m + k) * (m + k)) : 0.0);
+                                       ((mode == 0 || mode == 4 || mode == 5) ? 2.0 * n * (double)(m + k) * k : 2.0 * n * (double)(m + k) * (m + k)) : 0.0);
   if (!c || !basis || !abasis || !h || !fn || mode < 0 || mode == 2 || mode > 5 || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
     return fail(c, DLA_ERR_ARG, "dla_expand_project: bad argument (n > 0, m >= 0, k > 0, ldh >= m + k)");
   c->pending_k = 0; c->pending_m = 0; c->pending_applied = 0;

@@ -84,14 +84,15 @@ def test_value_counts_the_reference_schedule_not_the_launches():
     that launch different sweeps (tune knob 6: 12 = the five-sweep schedule, 13 = the three-pass one) converge in the same number
     of iterations and must report the SAME flops per solve -- while the per-launch count (`value_launched` x time) differs."""
     outs = []
-    for knob in ("12", "13"):
+    for knob in ("12", "13", "14"):                  # (14: dla_expand_project mode 5 behaves like mode 4 -- the same logical operations again)
         env = dict(os.environ, DIAGLIB_BENCH_TUNE="6=" + knob)
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--no-cpu-baseline",
                             "--no-random-leg"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
         assert p.returncode == 0, p.stderr[-3000:]
         outs.append(_line(p.stdout))
-    a, b = outs
-    assert a["config"]["iters"] == b["config"]["iters"] == 9
+    a, b, c4 = outs
+    assert a["config"]["iters"] == b["config"]["iters"] == c4["config"]["iters"] == 9
+    assert c4["gflop_per_solve"] == pytest.approx(b["gflop_per_solve"], rel=2e-2)
     # (the same logical operations; the two schedules round differently, and a root whose residual sits at its threshold may leave
     #  the active block one iteration earlier or later: a column of one iteration is 1 % of the solve)
     assert a["gflop_per_solve"] == pytest.approx(b["gflop_per_solve"], rel=2e-2)
