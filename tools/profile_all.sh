@@ -5,10 +5,10 @@
 # counter passes), the same counter passes on the cfg 5 shape, tools/profile_extra.sh (cfg 3 / 4 / 5 bench lines, 250 k-row
 # shard), the shard rehearsal, the linear-response / generalised runs, the host-time report, the k x k step's time stamps, the
 # host-mode probe and the HIP legs of the floor probes.  Results are collected in gpurun_out/profiles_<tag>/ (copy to profiles/<tag>/).
-# A gpurun call is limited to 20 minutes: the pass can be cut in three -- bash tools/profile_all.sh r05 A | B | C (default: all).
+# A gpurun call is limited to 20 minutes: the pass can be cut in four -- bash tools/profile_all.sh r05 A | B | C | D (default: all).
 set -e
 TAG=${1:-r05}
-PART=${2:-ABC}
+PART=${2:-ABCD}
 OUT=gpurun_out/profiles_$TAG
 [[ $PART == *A* ]] && rm -rf $OUT
 mkdir -p $OUT
@@ -34,21 +34,10 @@ cp $P/bench_lobpcg_cfg5shape_1gpu.json $P/bench_davidson_cfg4shape_1gpu.json $P/
 echo "extra done"
 fi
 if [[ $PART == *B* ]]; then
-# the sweep schedules of ortho_vs_x, interleaved in one call: tune knob 6 = 0 (shipped: three-pass unless a chain shifted), 12 (five-sweep),
-# 13 (three-pass always) -- headline + random-guess leg, LOBPCG cfg 3, and the cfg 4 / cfg 5 shapes
-for r in 1 2; do for t in 0 12 13; do
-  DIAGLIB_BENCH_TUNE="6=$t" python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('davidson n=2e6 8 roots  knob6=$t:', d['ms_per_step'], 'ms,', d['config']['iters'], 'iterations,', d['roofline']['solve']['alg_GB'], 'GB, step', d['roofline']['step']['frac'], '| random-guess leg', d['config']['random_guess_leg']['ms'], 'ms,', d['config']['random_guess_leg']['iters'], 'iterations')"
-done; done > $OUT/three_pass_ab.txt 2>&1 || true
-for r in 1 2; do for t in 0 12; do
-  DIAGLIB_BENCH_TUNE="6=$t" python3 bench.py --solver lobpcg --steps 10 --warmup 3 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lobpcg n=2e6 8 roots    knob6=$t:', d['ms_per_step'], 'ms,', d['config']['iters'], 'iterations,', d['roofline']['solve']['alg_GB'], 'GB')"
-done; done >> $OUT/three_pass_ab.txt 2>&1 || true
-for r in 1 2; do for t in 0 12; do
-  DIAGLIB_BENCH_TUNE="6=$t" python3 bench.py --solver lobpcg --n 10000000 --roots 32 --tol 1e-12 --steps 3 --warmup 1 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lobpcg n=1e7 32 roots   knob6=$t:', d['ms_per_step'], 'ms,', d['config']['iters'], 'iterations,', d['roofline']['solve']['alg_GB'], 'GB')"
-done; done >> $OUT/three_pass_ab.txt 2>&1 || true
 bash tools/shard_rehearsal.sh 1 2 4 > $OUT/shard_rehearsal_2e6.txt 2>&1
 python3 tools/lr_gen_bench.py > $OUT/bench_lr_gen_2e6.jsonl 2> $OUT/lr_gen.err
 DIAGLIB_AMD_HOSTTIME=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --n 250000 --steps 20 --warmup 3 --no-cpu-baseline --no-random-leg > $OUT/hosttime_250k_rows.txt 2>&1
-DIAGLIB_AMD_CHAIN_DEBUG=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-random-leg 2>&1 | grep -A6 "chain k=13 m=52" | tail -7 | cut -c1-260 > $OUT/chain_timing_k13_m52.txt
+DIAGLIB_AMD_CHAIN_DEBUG=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-random-leg 2>&1 | grep -A4 "chain k=13 m=39" | tail -5 | cut -c1-260 > $OUT/chain_timing_k13_m39.txt
 python3 tools/host_mode_probe.py 2>&1 | tail -8 > $OUT/host_mode_probe.txt
 # drop-in mode: time inside the caller's routine / waiting for downloads / waiting for small results against the chunk count
 for c in 1 2 4 8; do
@@ -76,6 +65,24 @@ python3 tools/floor_probe.py --n 10000000 --roots 32 --solver lobpcg --iters 30 
 python3 tools/floor_probe.py --n 2000000 --roots 8 --solver davidson --iters 16 --impl hip > $OUT/floor_probe_davidson_n2e6_8roots_hip.txt 2>/dev/null
 python3 tools/floor_probe.py --n 1000000 --roots 32 --solver lobpcg --iters 40 --impl hip,oracle,reference > $OUT/floor_probe_lobpcg_n1e6_32roots.txt 2>/dev/null
 rm -f $OUT/lr_gen.err
+fi
+if [[ $PART == *D* ]]; then
+# the schedules of ortho_vs_x, interleaved in one call: tune knob 6 = 0 (shipped: pending blocks on the device too, first factor from the
+# projected block's Gram matrix), 15 (the same with the first factor from U^T U), 14 (dla_expand_project mode 5 behaves like mode 4: the
+# round's earlier state, tight bounds on what stays pending), 12 (five-sweep schedule) -- headline + random-guess leg, LOBPCG cfg 3, cfg 5 shape
+for r in 1 2 3; do for t in 0 15 14 12; do
+  DIAGLIB_BENCH_TUNE="6=$t" python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('davidson n=2e6 8 roots  knob6=$t:', d['ms_per_step'], 'ms,', d['config']['iters'], 'iterations,', d['roofline']['solve']['alg_GB'], 'GB, step', d['roofline']['step']['frac'], '| random-guess leg', d['config']['random_guess_leg']['ms'], 'ms,', d['config']['random_guess_leg']['iters'], 'iterations')"
+done; done > $OUT/schedule_ab.txt 2>&1 || true
+for r in 1 2; do for t in 0 15 12; do
+  DIAGLIB_BENCH_TUNE="6=$t" python3 bench.py --solver lobpcg --steps 10 --warmup 3 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lobpcg n=2e6 8 roots    knob6=$t:', d['ms_per_step'], 'ms,', d['config']['iters'], 'iterations,', d['roofline']['solve']['alg_GB'], 'GB')"
+done; done >> $OUT/schedule_ab.txt 2>&1 || true
+for r in 1 2; do for t in 0 12; do
+  DIAGLIB_BENCH_TUNE="6=$t" python3 bench.py --solver lobpcg --n 10000000 --roots 32 --tol 1e-12 --steps 3 --warmup 1 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lobpcg n=1e7 32 roots   knob6=$t:', d['ms_per_step'], 'ms,', d['config']['iters'], 'iterations,', d['roofline']['solve']['alg_GB'], 'GB')"
+done; done >> $OUT/schedule_ab.txt 2>&1 || true
+python3 tools/solve_jitter.py 30 > $OUT/solve_jitter.txt 2>/dev/null || true
+python3 tools/solve_jitter.py 30 14 >> $OUT/solve_jitter.txt 2>/dev/null || true
+DIAGLIB_AMD_CHAIN_DEBUG=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-random-leg 2>&1 | grep "chain k=" | tail -8 | cut -c1-120 > $OUT/chain_schedules_headline.txt
+echo "schedule A/B done"
 fi
 if [[ $PART == *A* ]]; then
 python3 - <<PY
