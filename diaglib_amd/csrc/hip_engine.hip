@@ -1711,6 +1711,11 @@ enum { OP_NONE = 0, OP_GRAM_UU = 1, OP_TRMMG = 2, OP_XU = 3, OP_COMBO = 4, OP_FI
 #define PEND_LD 48
 #define PEND_ROWS 640
 #define PEND_HDR ((size_t)PEND_ROWS * PEND_LD)
+// dla_expand_project mode 4: the caller's stored basis is orthonormal to 1e-8 per block only (pending factors and projections), and a
+// projection against it leaves (X_c^T X_c - I) S of what it removes -- up to m 1e-8 |S| over a basis of m columns.  A chain of that
+// mode may end behind a projection only when that projection removed less than this (tools/fuzz_pending_basis.py: 1e-6 left 1.7e-12
+// on a basis of 300 columns)
+#define TIGHT_REMOVES 1.0e-8
 enum { OST_RUNNING = 0, OST_DONE = 1, OST_CD_MAXIT = 2, OST_FACTOR_FAIL = 3, OST_VSX_MAXIT = 4 };
 
 struct OrthoDev {
@@ -1933,12 +1938,16 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
   // (wn: norm estimate of the factor that is pending on the measured block -- what has to be small is xu W.  A block of LOBPCG
   //  residuals of norm 1e-8 measured in front of its first projection has a tiny X^T U and a factor of 1e8: found by
   //  tools/fuzz_multirank.py, seed 78)
-  auto small_xu = [&](const double* xu, int ldx, double wn) {
+  auto xu_max = [&](const double* xu, int ldx, double wn) {
     double sm = 0.0;
     for (int idx = lane; idx < m * k; idx += 64) sm = fmax(sm, fabs(xu[(size_t)(idx % m) + (size_t)(idx / m) * ldx]));
     for (int off = 32; off > 0; off >>= 1) sm = fmax(sm, __shfl_xor(sm, off, 64));
-    return sm * fmax(wn, 1.0) < a.drop_stol;
+    return sm * fmax(wn, 1.0);
   };
+  auto small_xu = [&](const double* xu, int ldx, double wn) { return xu_max(xu, ldx, wn) < a.drop_stol; };
+  // (the caller's stored basis is orthonormal to drop_tol only, dla_expand_project mode 4: a projection against it leaves that share
+  //  of what it removes, so no chain may end behind a projection that removed more than TIGHT_REMOVES -- see ortho_tail16)
+  const bool tight = a.drop_tol > 0.0 && m > 0;
 
   if (a.after == OP_FINAL) {
     t.status = OST_DONE;
@@ -1947,6 +1956,7 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
     for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx % k) * TLD + idx / k, a.wfull[idx]);   // A[pp][j] = W(pp, j)
     TSYNC();
     const bool pend = may_pend && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) && small_xu(a.gsrc, m, t.growth);
+    if (!pend && tight && xu_max(a.gsrc, m, t.growth) >= TIGHT_REMOVES) t.sloppy = 1;
     assemble(a.gsrc, m, pend);
     t.it_macro = 0;           // the ortho_cd that follows the combined sweep starts afresh (*growth = 1, it = 0)
     t.growth = 1.0;
@@ -2042,6 +2052,7 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
           const bool pend = xw_project && may_pend && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) && small_xu(a.gsrc, m + k, linv_norm);
           assemble(a.gsrc, m + k, pend);
           t.sloppy = (!xw_project && t.growth * eps >= tol) ? 1 : 0;      // (a measured X^T U of the stored block is not sloppy)
+          if (!pend && tight && xu_max(a.gsrc, m + k, xw_project ? linv_norm : t.growth) >= TIGHT_REMOVES) t.sloppy = 1;
           ++t.it_outer;
           t.it_macro = 0; t.growth = 1.0;
           if (pend) t.status = OST_DONE;
@@ -2361,7 +2372,10 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
   // a caller that folds pending blocks into its small matrices: the chain ends wherever X^T U has been measured on the stored block
   // and the factor of that block has converged (see ortho_tail) -- for the sweep-per-update schedule that is the step behind OP_XU
   const bool may_pend = a.drop_final && a.t_host != nullptr && m > 0;
-  if (meas_sweep || (may_pend && after == OP_XU)) {
+  // (tight: the caller's stored basis is orthonormal to drop_tol only -- dla_expand_project mode 4 -- and a projection against it
+  //  leaves that share of what it removes: no chain may END behind a projection that removed more than TIGHT_REMOVES)
+  const bool tight = a.drop_tol > 0.0 && may_assemble;
+  if (meas_sweep || (may_pend && after == OP_XU) || tight) {
     double sm = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -2495,6 +2509,10 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
       for (int r = 0; r < 4; ++r) { pnew[r] = a.wst[512 + 64 * r + lane]; dnew[r] = pnew[r]; }
       const double wn = fmax(t.growth, 1.0);     // norm estimate of Wp: what has to be small is (X^T U_mem) Wp
       t.it_macro = 0; t.growth = 1.0; t.have_xu = 0; t.sloppy = 0;
+      // a projection against stored columns that are orthonormal to drop_tol = 1e-8 only leaves m 1e-8 of what it removes: when that
+      // is more than TIGHT_REMOVES the block needs another measured projection behind this one (fuzz_pending_basis.py: a block that lies in
+      // span(X) to 1e-9 came out orthogonal to the finished basis to 1.7e-10 only)
+      if (tight && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) * wn >= TIGHT_REMOVES) t.sloppy = 1;
       // (the block stays pending when the caller takes pending blocks and both X^T U, just measured, and the distance of the
       //  pending factor from the identity -- the Gram matrix it came from -- are within the caller's bounds)
       if (may_pend && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) * wn < a.drop_stol && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) &&
@@ -2764,6 +2782,7 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
               ++t.it_outer;
               if (t.have_xu) {
                 t.sloppy = (stage0 && t.growth * eps >= tol) ? 1 : 0;
+                if (tight && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) * fmax(t.growth, 1.0) >= TIGHT_REMOVES) t.sloppy = 1;    // (see OP_XU above)
                 t.it_macro = 0; t.growth = 1.0; t.have_xu = 0; t.phase = op_project; go = 1;
               }
               else t.phase = OP_XU;
@@ -3333,6 +3352,7 @@ struct HipEngine : dla::Engine {
     if (d_cpk2) (void)hipFree(d_cpk2);
     if (d_wst) (void)hipFree(d_wst);
     if (d_xug) (void)hipFree(d_xug);
+    if (d_dmat) (void)hipFree(d_dmat);
     if (d_red_small) (void)hipFree(d_red_small);
     if (d_red_xug) (void)hipFree(d_red_xug);
     if (d_bgo) (void)hipFree(d_bgo);

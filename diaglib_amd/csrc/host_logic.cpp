@@ -842,6 +842,12 @@ int dla_ortho_qr(dla_ctx* c, int n, int k, double* u)
 static int ortho_vs_x_after_chain(dla_ctx* c, dla::BlockOps* ops, long long row0, long long n_rows_global, int n, int m, int k,
                                   const double* x, const double* bx, double* u, const dla::OrthoReport* chain);
 
+// dla_expand_project mode 4: the stored basis is orthonormal to 1e-8 per block only, and a projection against it leaves that share of
+// what it removes.  The device chains know (TIGHT_REMOVES in hip_engine.hip); the host-driven loop follows the reference, whose
+// growth test ends after one projection -- there the whole ortho_vs_x runs a second time: its first product X^T U is then what the
+// first run left, 1e-8 |S|, and what the second run leaves of it is below rounding (tools/fuzz_pending_basis.py, FUZZ_WIDE).
+static bool tight_basis(const dla_ctx* c) { return c && c->eng && c->eng->drop_final && c->eng->drop_final_tol > 0.0; }
+
 static int ortho_vs_x_impl(dla_ctx* c, dla::BlockOps* ops, long long row0, long long n_rows_global, int n, int m, int k,
                            const double* x, const double* bx, double* u)
 {
@@ -850,7 +856,10 @@ static int ortho_vs_x_impl(dla_ctx* c, dla::BlockOps* ops, long long row0, long 
   dla::OrthoReport rep;
   int stc = ops->ortho_chain(n, m, k, x, bx, u, &rep);
   if (stc) return opsfail(c, ops, stc);
-  return ortho_vs_x_after_chain(c, ops, row0, n_rows_global, n, m, k, x, bx, u, rep.handled ? &rep : nullptr);
+  int st = ortho_vs_x_after_chain(c, ops, row0, n_rows_global, n, m, k, x, bx, u, rep.handled ? &rep : nullptr);
+  if (st == DLA_OK && m > 0 && tight_basis(c) && !(rep.handled && rep.status == 1))
+    st = ortho_vs_x_after_chain(c, ops, row0, n_rows_global, n, m, k, x, bx, u, nullptr);
+  return st;
 }
 
 static int ortho_vs_x_after_chain(dla_ctx* c, dla::BlockOps* ops, long long row0, long long n_rows_global, int n, int m, int k,
@@ -1334,8 +1343,10 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
   // mode 5 = mode 4 with the caller's pending blocks kept on the device as well (dla_basis_sync after every block): the chain's
   // projections are exact against the FINISHED basis X D, so what a block leaves pending is bounded only by what keeps the host
   // algebra well conditioned (max |S| < 0.05, Gram matrix factorable in one step) -- not by what later projections could absorb
-  const bool exact = mode == 5 && c->eng->basis_exact_ok() && k <= 16 && m + k <= 288;   // (otherwise: mode 4, the tight bounds)
-  if (mode == 5) mode = 4;
+  // (where the device cannot project with D -- wider blocks, a wider basis, an all-reduce hook -- the block is finished in memory,
+  //  mode 0: nothing of it stays pending in a basis that later blocks are projected against)
+  const bool exact = mode == 5 && c->eng->basis_exact_ok() && k <= 16 && m + k <= 288;
+  if (mode == 5) mode = exact ? 4 : 0;
   // a chain that failed behind a finished orthogonalisation must not leave its block to the next call (round-4 advisor)
   struct Forget { dla_ctx* c; int m, k; bool keep = false; ~Forget() { if (!keep) { std::vector<double> junk((size_t)(m + k) * k); (void)c->eng->pending_block(m, k, junk.data(), m + k, nullptr); } } };
   if (mode == 4) {
@@ -1541,10 +1552,12 @@ static int expand_project_impl(dla_ctx* c, int mode, int n, int m, int k, double
       // the chain took more launches than planned, or stopped: what ran behind it has read an unfinished block
       st = ortho_vs_x_after_chain(c, c->eng, c->row0, nglob, n, m, k, basis, basis, u, &rep);
       if (st) return st;
+      if (tight_basis(c) && rep.status != 1) { st = ortho_vs_x_after_chain(c, c->eng, c->row0, nglob, n, m, k, basis, basis, u, nullptr); if (st) return st; }
       return expand_apply_project(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
     }
     st = ortho_vs_x_after_chain(c, c->eng, c->row0, nglob, n, m, k, basis, basis, u, nullptr);
     if (st) return st;
+    if (tight_basis(c)) { st = ortho_vs_x_after_chain(c, c->eng, c->row0, nglob, n, m, k, basis, basis, u, nullptr); if (st) return st; }
     return expand_apply_project(c, mode, n, m, k, basis, abasis, fn, shift, h, ldh);
   }
   int st = ortho_vs_x_impl(c, c->eng, c->row0, nglob, n, m, k, basis, basis, u);

@@ -928,7 +928,8 @@ contains
               call chk(e%ctx, dla_expand_project(e%ctx, 5_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
                                                  h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
             else
-              call chk(e%ctx, dla_expand_project(e%ctx, 4_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
+!             (wider blocks / a wider basis: the device cannot project with D -- the block is finished in memory, nothing pending)
+              call chk(e%ctx, dla_expand_project(e%ctx, 0_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
                                                  h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
             end if
             call chk(e%ctx, dla_pending_block(e%ctx, s%cols, s%act, pblk, s%ld, applied), 'pending block')

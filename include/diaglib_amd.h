@@ -283,7 +283,11 @@ int  dla_expand_project(dla_ctx* ctx, int mode, int n, int m, int k, double* bas
  * on what may stay pending are those of the host algebra alone -- max |S| < 0.05 with column sums of squares below 0.02, nothing on
  * G (its factor has converged) -- so the chain ends behind the first sweep that has measured S and G on what it stored.  Where the
  * device-driven chain does not run at all (an all-reduce hook, the A/B knobs for the host loop) or the shape is beyond the device
- * copy, the call behaves like mode 4; it fails (DLA_ERR_ARG) when the device copy does not describe the m columns in front of it. */
+ * copy, the call behaves like mode 0 (the block is finished in memory, dla_pending_block answers [0 ; I]); it fails (DLA_ERR_ARG)
+ * when the device copy does not describe the m columns in front of it.
+ * (Mode 4's bounds cost later blocks a projection each time they remove more than 1e-8 from a block -- every chain of such a basis ends
+ * on a measured product below that --, so the drivers use mode 5 where it is available and mode 0 elsewhere; mode 4 stays for callers
+ * that keep D on the host only.) */
 int  dla_pending_factor(dla_ctx* ctx, int k, double* t_host, int ldt);
 int  dla_pending_block(dla_ctx* ctx, int m, int k, double* p_host, int ldp, int* applied);
 /* Host-size algebra of a basis with pending blocks (no device work; all arrays column-major, leading dimension ld):

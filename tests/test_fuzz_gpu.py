@@ -21,10 +21,12 @@ SLICES = [
     ("fuzz_parity_lr.py", ["12", "107"]),             # linear-response drivers against the reference
     ("fuzz_multirank.py", ["5", "108"]),             # 2 .. 4 ranks on one GPU against the single-rank run
     ("fuzz_spmm_sharded.py", ["3", "109"]),          # the sharded sparse sample operator
+    ("fuzz_pending_basis.py", ["60", "110"]),         # bases grown through dla_expand_project modes 4 / 5: (panel D) orthonormal, h exact
+    ("fuzz_pending_basis.py", ["40", "111", "-1", "wide"]),   # ... blocks of 17 .. 40 columns (mode 4, host-driven loops beyond 223 columns)
 ]
 
 
-@pytest.mark.parametrize("tool,args", SLICES, ids=[t for t, _ in SLICES])
+@pytest.mark.parametrize("tool,args", SLICES, ids=[t + ("-" + a[-1] if a[-1] == "wide" else "") for t, a in SLICES])
 def test_fuzz_slice(tool, args):
     env = dict(os.environ, OMP_NUM_THREADS="4", MKL_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)

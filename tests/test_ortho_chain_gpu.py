@@ -32,9 +32,10 @@ def _syncs(ctx):
     (1000, 26, 13, "rank_deficient"),                                                   # level-shift ladder
     (1000, 8, 5, "random"), (600, 3, 1, "random"),
 ])
-@pytest.mark.parametrize("schedule", [0, 12, 13])
+@pytest.mark.parametrize("schedule", [0, 12, 13, 15, 16])
 def test_chain_ortho_vs_x_vs_oracle(ctx, oracle, rng, n, m, k, kind, schedule):
-    """schedule = tune knob 6: 0 the shipped choice (three-pass unless a recent chain needed a level shift), 12 the five-sweep
+    """(15 / 16: the first factor from U^T U as in the reference / from the projected block's Gram matrix with level shifts: A/B knobs)
+    schedule = tune knob 6: 0 the shipped choice (three-pass unless a recent chain needed a level shift), 12 the five-sweep
     schedule, 13 the three-pass one from the first chain on (projection sweeps that measure X^T U of what they store, closing sweep
     without a measurement) -- same result to rounding under each."""
     ctx.set_option(TUNE_CHAIN, schedule)
