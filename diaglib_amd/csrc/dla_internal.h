@@ -100,6 +100,10 @@ struct BlockOps {
   bool basis_exact = false;
   virtual int basis_sync(int /*m*/, int /*k*/, const double* /*dmat*/, int /*ld*/) { return 0; }
   virtual bool basis_exact_ok() const { return false; }   // the device-driven chain takes one-tile blocks on this context
+  // xu <- D D^T xu (m x k, leading dimension ld) while basis_exact is set: what the host-driven loop multiplies X^T U with before a
+  // projection, so that it projects with X (D D^T) X^T as the device chain does (a chain that stopped half way -- ortho_cd out of
+  // iterations, Householder fallback -- is continued there)
+  virtual int basis_dd(int /*m*/, int /*k*/, double* /*xu*/, int /*ld*/) { return 0; }
   int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests
   std::string err;
 };

@@ -1955,7 +1955,7 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
     // C' = [-(xu W) ; W]  (host_logic.cpp ortho_vs_x_impl, X^T (U W) = (X^T U) W), packed for the combined sweep
     for (int idx = lane; idx < k * k; idx += 64) lds_store1(A + (idx % k) * TLD + idx / k, a.wfull[idx]);   // A[pp][j] = W(pp, j)
     TSYNC();
-    const bool pend = may_pend && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) && small_xu(a.gsrc, m, t.growth);
+    const bool pend = may_pend && t.gdev < (a.drop_tol > 0.0 ? a.drop_tol : 1.0) && small_xu(a.gsrc, m, t.growth);
     if (!pend && tight && xu_max(a.gsrc, m, t.growth) >= TIGHT_REMOVES) t.sloppy = 1;
     assemble(a.gsrc, m, pend);
     t.it_macro = 0;           // the ortho_cd that follows the combined sweep starts afresh (*growth = 1, it = 0)
@@ -2008,6 +2008,10 @@ __device__ __forceinline__ void ortho_tail(const OrthoTailArgs& a, double* lds, 
           ++t.shifts;
         }
       }
+      // (a factor that needed a level shift is not one a block may stay pending with: a zero block -- Davidson on a multiple of the
+      //  identity, residuals exactly zero -- "converges" with any shift, and the reference stops on it in ortho_vs_x after maxit
+      //  passes; the pending endings behind OP_XU look at gdev, tools/fuzz_degenerate_drivers.py)
+      if (it_micro > 0) t.gdev = fmax(t.gdev, 2.0);
       if (info != 0) {
         t.status = OST_FACTOR_FAIL;                             // reference: stop (:3283)
       } else {
@@ -2515,7 +2519,7 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
       if (tight && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) * wn >= TIGHT_REMOVES) t.sloppy = 1;
       // (the block stays pending when the caller takes pending blocks and both X^T U, just measured, and the distance of the
       //  pending factor from the identity -- the Gram matrix it came from -- are within the caller's bounds)
-      if (may_pend && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) * wn < a.drop_stol && (a.drop_tol <= 0.0 || t.gdev < a.drop_tol) &&
+      if (may_pend && fmax(fmax(s_smax[0], s_smax[1]), fmax(s_smax[2], s_smax[3])) * wn < a.drop_stol && t.gdev < (a.drop_tol > 0.0 ? a.drop_tol : 1.0) &&
           colsq_max() * wn * wn < CS_CAP) { t.status = OST_DONE; go = 2; }
       else { t.phase = op_project; go = 1; }
     } else {
@@ -2614,6 +2618,7 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
           alpha *= 10.0;
           ++t.shifts;
         }
+        if (it_micro > 0) t.gdev = fmax(t.gdev, 2.0);       // (no pending ending behind a shifted factor: see ortho_tail)
         if (info != 0) {
           t.status = OST_FACTOR_FAIL;
         } else {
@@ -4277,9 +4282,33 @@ struct HipEngine : dla::Engine {
   // DMAT_LD -- what the exact projection of ortho_tail16 multiplies with.  Columns arrive in order, block by block.
   static const int DMAT_LD = T16_ZS_ROWS;
   double* d_dmat = nullptr;
+  std::vector<double> h_dmat;        // the same on the host (basis_dd)
   int dmat_cols = 0;                 // columns described so far (-1: the basis has outgrown the buffer)
   bool dmat_nontrivial = false;      // some entry differs from the identity by more than 1e-10
   bool basis_exact_ok() const override { return !hook && !local_only && tune[6] != 3 && tune[6] != 5 && tune[6] != 14 && lds_limit > (size_t)128 * 1024; }   // (knob 6 = 14: A/B, mode 5 behaves like mode 4)
+  int basis_dd(int m, int k, double* xu, int ld) override
+  {
+    if (!basis_exact || m <= 0) return DLA_OK;
+    if (dmat_cols != m) { err = "ortho_vs_x: the copy of the caller's pending blocks does not describe this basis (dla_basis_sync after every block)"; return DLA_ERR_ARG; }
+    if (!dmat_nontrivial) return DLA_OK;
+    std::vector<double> y(m);
+    for (int j = 0; j < k; ++j) {
+      double* s = xu + (size_t)j * ld;
+      for (int r = 0; r < m; ++r) {                      // y = D^T s: column r of D, rows 0 .. r
+        const double* dr = &h_dmat[(size_t)r * DMAT_LD];
+        double acc = 0.0;
+        for (int i = 0; i <= r; ++i) acc += dr[i] * s[i];
+        y[r] = acc;
+      }
+      for (int i = 0; i < m; ++i) s[i] = 0.0;
+      for (int q = 0; q < m; ++q) {                      // s = D y
+        const double* dq = &h_dmat[(size_t)q * DMAT_LD];
+        const double yq = y[q];
+        for (int i = 0; i <= q; ++i) s[i] += dq[i] * yq;
+      }
+    }
+    return DLA_OK;
+  }
   int basis_sync(int m, int k, const double* dmat, int ld) override
   {
     if (k <= 0) { dmat_cols = 0; dmat_nontrivial = false; return DLA_OK; }
@@ -4297,10 +4326,12 @@ struct HipEngine : dla::Engine {
     const int stc = stage_slot(bytes, &h, &slot);
     if (stc) return stc;
     std::memset(h, 0, bytes);
+    if (h_dmat.empty()) h_dmat.assign((size_t)DMAT_LD * DMAT_LD, 0.0);
     for (int j = 0; j < k; ++j)
       for (int i = 0; i <= m + j; ++i) {
         const double v = dmat[(size_t)i + (size_t)(m + j) * ld];
         h[(size_t)j * DMAT_LD + i] = v;
+        h_dmat[(size_t)(m + j) * DMAT_LD + i] = v;
         if (v != (i == m + j ? 1.0 : 0.0)) dmat_nontrivial = true;
       }
     dmat_cols = m + k;
@@ -4341,8 +4372,8 @@ struct HipEngine : dla::Engine {
     // (basis_exact: the stored columns are not orthonormal, only the device chain projects with the caller's D -- the host-driven
     //  loop, which ends on the reference's growth test, must not take such a block)
     auto not_handled = [&]() {
-      if (!(basis_exact && m > 0)) return (int)DLA_OK;
-      err = "ortho_chain: dla_expand_project mode 5 needs the device-driven chain with the caller's pending blocks on the device (dla_basis_sync after every block; blocks of at most 16 columns, at most 288 basis columns, no all-reduce hook)";
+      if (!(basis_exact && m > 0) || dmat_cols == m) return (int)DLA_OK;     // (the host-driven loop projects with D as well: basis_dd)
+      err = "ortho_chain: dla_expand_project mode 5 needs the caller's pending blocks (dla_basis_sync after every block; at most 288 basis columns)";
       return (int)DLA_ERR_ARG;
     };
     if (tune[6] == 3) return not_handled();                               // A/B: host-driven loop

@@ -928,6 +928,9 @@ static int ortho_vs_x_after_chain(dla_ctx* c, dla::BlockOps* ops, long long row0
     if (m > 0) {
       st = ops->gram(n, m, bx, k, u, xu.data(), m);     // xu = X^T U  (:3543) / (BX)^T U (:3632)
       if (st) return opsfail(c, ops, st);
+      // (dla_expand_project mode 5: the stored columns are X_c with X = X_c D the finished basis -- project with X_c (D D^T) X_c^T)
+      st = ops->basis_dd(m, k, xu.data(), m);
+      if (st) return opsfail(c, ops, st);
       if (pending) {
         // xu <- xu W ; C' = [-xu ; W]
         const int ldc = m + k;

@@ -21,6 +21,7 @@ SLICES = [
     ("fuzz_parity_lr.py", ["12", "107"]),             # linear-response drivers against the reference
     ("fuzz_multirank.py", ["5", "108"]),             # 2 .. 4 ranks on one GPU against the single-rank run
     ("fuzz_spmm_sharded.py", ["3", "109"]),          # the sharded sparse sample operator
+    ("fuzz_degenerate_drivers.py", ["21", "112"]),    # the drivers on operators with multiple / zero / all-equal eigenvalues: never ok with a wrong answer
     ("fuzz_pending_basis.py", ["60", "110"]),         # bases grown through dla_expand_project modes 4 / 5: (panel D) orthonormal, h exact
     ("fuzz_pending_basis.py", ["40", "111", "-1", "wide"]),   # ... blocks of 17 .. 40 columns (mode 4, host-driven loops beyond 223 columns)
 ]

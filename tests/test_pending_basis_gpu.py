@@ -96,6 +96,53 @@ def test_basis_kept_on_the_device_projects_exactly(ctx, rng, k, nb, kind):
         ctx.set_shard(-1, 0)
 
 
+def test_a_chain_that_stops_half_way_is_continued_on_the_host_with_d(ctx, rng):
+    """mode 5 with ortho_cd's iteration limit at 2: the device chain stops (status 2: ortho_cd out of iterations), the reference's
+    Householder fallback runs (:3534 / :3549) and the host-driven loop goes on -- projecting with X (D D^T) X^T like the device
+    (BlockOps::basis_dd), because the stored columns are not orthonormal.  (Found by tests/test_spmm_sharded.py: a banded operator's
+    blocks do run into ortho_cd's limit.)"""
+    n, k, nb = 5000, 8, 7
+    mv = capi.fn_address("dla_synth_matvec")
+    try:
+        ctx.set_shard(n, 0); ctx.synth_setup(n, 0, n); ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+        ld = nb * k
+        x0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, k)))[0])
+        basis = ctx.panel(np.asfortranarray(np.hstack([x0, np.zeros((n, ld - k))])))
+        abasis = ctx.panel(np.zeros((n, ld), order="F"))
+        ctx.synth_matvec(basis.col(0, k), abasis.col(0, k))
+        hraw = np.zeros((ld, ld), order="F"); dmat = np.asfortranarray(np.eye(ld)); h = np.zeros((ld, ld), order="F")
+        b = basis.download(); ab = abasis.download()
+        hraw[:k, :k] = b[:, :k].T @ ab[:, :k]; h[:k, :k] = hraw[:k, :k]
+        ctx.basis_sync(0, 0); ctx.basis_sync(0, k, dmat)
+        stopped = 0
+        for blk in range(1, nb):
+            m = blk * k
+            u = b[:, :m] @ rng.standard_normal((m, k)) + 0.3 * rng.standard_normal((n, k))
+            if blk >= 4:                                   # (the first blocks leave pending parts behind: D is not the identity)
+                u[:, 1:] = u[:, :1] + 1e-9 * rng.standard_normal((n, k - 1))       # needs level shifts and several macro-iterations
+                ctx.set_option(capi.OPT_ORTHO_MAXIT, 2)
+            basis.col(m, k).upload(np.asfortranarray(u))
+            syncs = ctx.stats()["host_syncs"]
+            h4 = ctx.expand_project(5, basis, abasis, m, k, mv, 0.0)
+            stopped += int(blk >= 4 and ctx.stats()["host_syncs"] - syncs > 10)      # (the host-driven loop waits per operation)
+            ctx.set_option(capi.OPT_ORTHO_MAXIT, 10)
+            p = ctx.pending_block(m, k)
+            h[:m + k, m:m + k] = h4
+            ctx.basis_admit(m, k, p, hraw, dmat, h, applied=ctx.pending_applied)
+            ctx.basis_sync(m, k, dmat)
+            b = basis.download()
+        assert not np.array_equal(dmat, np.eye(ld)) and stopped >= 1
+        v = b @ dmat
+        assert np.abs(v.T @ v - np.eye(ld)).max() < 200 * EPS, np.abs(v.T @ v - np.eye(ld)).max()
+        href = v.T @ (abasis.download() @ dmat)
+        assert np.abs(np.triu(h - href)).max() < 1e-12 * np.abs(href).max()
+    finally:
+        ctx.set_option(capi.OPT_ORTHO_MAXIT, 10)
+        ctx.basis_sync(0, 0)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
+
+
 def test_mode_5_refuses_a_basis_the_device_copy_does_not_describe(ctx, rng):
     n, k = 4000, 8
     mv = capi.fn_address("dla_synth_matvec")
