@@ -143,6 +143,73 @@ def test_a_chain_that_stops_half_way_is_continued_on_the_host_with_d(ctx, rng):
         ctx.set_shard(-1, 0)
 
 
+def test_full_size_basis_of_twenty_blocks(ctx):
+    """The round-4 review's property test at the benchmark's size: n = 2e6, 13-column blocks, the basis filled to 20 blocks (260
+    columns) through dla_expand_project mode 5 with the caller's own D -- random blocks, blocks with most of their norm inside
+    span(X), blocks inside span(X) to 1e-7.  Checked through dla_gram on the device panels:  D^T (X_c^T X_c) D = I  to 50 eps and
+    h = D^T (X_c^T A X_c) D."""
+    n, k, nb = 2_000_000, 13, 20
+    mv = capi.fn_address("dla_synth_matvec")
+    rng = np.random.default_rng(11)
+    try:
+        ctx.set_shard(n, 0); ctx.synth_setup(n, 0, n); ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+        ld = nb * k
+        basis = ctx.panel(n, ld); abasis = ctx.panel(n, ld)
+        first = basis.col(0, k)
+        ctx.fill_guess(first, 3, 0)
+        ctx.check_guess(first)                                   # orthonormal first block
+        x0 = first.download()
+        ctx.synth_matvec(first, abasis.col(0, k))
+        hraw = np.zeros((ld, ld), order="F"); dmat = np.asfortranarray(np.eye(ld)); h = np.zeros((ld, ld), order="F")
+        hraw[:k, :k] = ctx.gram(first, abasis.col(0, k)); h[:k, :k] = hraw[:k, :k]
+        ctx.basis_sync(0, 0); ctx.basis_sync(0, k, dmat)
+        n_pending = 0
+        for blk in range(1, nb):
+            m = blk * k
+            u = rng.standard_normal((n, k)) * (1e-7 if blk % 5 == 4 else 0.3 / np.sqrt(n) * 30.0) + x0 @ rng.standard_normal((k, k))
+            basis.col(m, k).upload(np.asfortranarray(u))
+            h4 = ctx.expand_project(5, basis, abasis, m, k, mv, 0.0)
+            p = ctx.pending_block(m, k)
+            n_pending += int(np.any(p[:m] != 0.0) or not np.array_equal(p[m:], np.eye(k)))
+            h[:m + k, m:m + k] = h4
+            ctx.basis_admit(m, k, p, hraw, dmat, h, applied=ctx.pending_applied)
+            ctx.basis_sync(m, k, dmat)
+        g = ctx.gram(basis, basis)
+        e = np.abs(dmat.T @ g @ dmat - np.eye(ld)).max()
+        assert e < 50 * EPS, (e, n_pending)
+        assert n_pending >= nb // 2
+        ga = ctx.gram(basis, abasis)
+        href = dmat.T @ ga @ dmat
+        assert np.abs(np.triu(h - href)).max() < 1e-12 * np.abs(href).max()
+    finally:
+        ctx.basis_sync(0, 0)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
+
+
+def test_driver_with_restarts_returns_orthonormal_vectors_at_full_size(ctx):
+    """... and the driver itself on the benchmark's random-guess leg (42 iterations, two restarts: D is folded into the restart's
+    coefficients and reset): the Ritz vectors it returns are orthonormal to 1e-13 and the residuals below the tolerance."""
+    n, t, m = 2_000_000, 8, 13
+    try:
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+        ctx.synth_setup(n, 0, n)
+        ev = ctx.panel(n, m)
+        ctx.fill_guess(ev, 2, 2000)
+        eig, _, ok, info = ctx.davidson_driver(n, t, m, 100, 2e-13, 20, 0.0, capi.fn_address("dla_synth_matvec"),
+                                               capi.fn_address("dla_synth_precnd"), ev)
+        assert ok and info["restarts"] >= 1
+        g = ctx.gram(ev, ev)
+        assert np.abs(g - np.eye(m))[:t, :t].max() < 1e-13
+        ax = ctx.panel(n, m)
+        ctx.synth_matvec(ev, ax)
+        x_h, ax_h = ev.download(), ax.download()
+        res = np.sqrt(((ax_h - x_h * eig[None, :]) ** 2).sum(0))[:t] / np.abs(eig[:t])
+        assert res.max() < 1e-10, res
+    finally:
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+
+
 def test_mode_5_refuses_a_basis_the_device_copy_does_not_describe(ctx, rng):
     n, k = 4000, 8
     mv = capi.fn_address("dla_synth_matvec")
