@@ -3168,7 +3168,15 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
     for (int q = 0; q < 8; ++q) s += v[q];
   }
   for (; b < b1; ++b) s += p[(size_t)b * slots * 256];
-  if (turn != a.want) return;
+  if (turn != a.want) {
+    // not this launch's turn.  The last launch of a plan still tells the host where the machine stands (unless the chain has ended:
+    // a terminal step reported it and re-armed the machine, nops == 0) -- so that a plan need not end with a launch whose only
+    // purpose is to report
+    if constexpr (TAIL) {
+      if (a.do_tail && a.tail.publish && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.tail.st->nops > 0) *a.tail.st_host = *a.tail.st;
+    }
+    return;
+  }
   __shared__ int s_last;
   double tot = s;
   if (G > 1) {
@@ -4274,6 +4282,7 @@ struct HipEngine : dla::Engine {
     long long key = 0, key_last = 0;
     bool xw = false;                 // wide block with the storing sweep OP_XW (see ortho_chain_begin)
     bool x3 = false;                 // three-pass schedule
+    bool lean = false;               // the plan carries no closing / final sweep (the machine will not ask for them: see ortho_chain_begin)
     std::vector<int> plan, launched;
     std::vector<SpecRec> recs;
   } run;
@@ -4481,11 +4490,20 @@ struct HipEngine : dla::Engine {
     // every plan ends with OP_FINAL: its tail is a launch of its own that always runs and reports where the machine stands (a
     // fused tail is skipped together with a sweep whose turn it is not).  With drop_final the machine never asks for the sweep
     // itself, and the executed list a plan is remembered from does not contain it
+    // Callers that take the closing block on their small matrices without a bound on the factor (dla_expand_project modes 3 and 5: the
+    // machine ends with the block pending and never asks for OP_CLOSE / OP_FINAL) get plans without them: the fused step of the
+    // last planned sweep reports where the machine stands whether or not it was that sweep's turn (gram_reduce_kernel<true>).  Two
+    // predicated-off sweeps and two k x k launches less per chain: 19 us (r05 trace: 0.15 ms per benchmark solve, 0.23 per LOBPCG solve).
+    const bool fused_steps = p2p.on ? (tune[6] != 4 && (m + k) * k <= P2P_MAX_DOUBLES) : (nranks <= 1 && !comm);
+    const bool lean = vsx && drop_final && publish_pending && drop_final_tol <= 0.0 && m + k <= PEND_ROWS && fused_steps && tune[6] != 17;
+    if (lean) {
+      while (plan.size() > 1 && (plan.back() == OP_FINAL || plan.back() == OP_CLOSE)) plan.pop_back();
+    } else
     if (plan.empty() || plan.back() != OP_FINAL) plan.push_back(OP_FINAL);
     // (three-pass schedule: whether a chain ends with its closing block pending or with the closing sweep depends on the last bits
     //  of a Gram matrix -- a plan remembered from a chain that ended pending keeps the sweep in place: an empty launch when it
     //  is not needed, against a host round trip and a repeated operator call when it is)
-    if (x3 && std::find(plan.begin(), plan.end(), (int)OP_CLOSE) == plan.end()) plan.insert(plan.end() - 1, (int)OP_CLOSE);
+    if (x3 && !lean && std::find(plan.begin(), plan.end(), (int)OP_CLOSE) == plan.end()) plan.insert(plan.end() - 1, (int)OP_CLOSE);
     // (The plain projection sweep never stands in for the measuring one, although it is faster -- 4 m / 16 fewer MFMAs per 16 rows,
     //  5.7 against 5.0-5.4 TB/s -- and its measurement is thrown away whenever the block it stored needs a level shift: which
     //  sweep ran would decide what the step behind it knows, the chain's path would depend on the plan, the plan on the chains
@@ -4496,6 +4514,7 @@ struct HipEngine : dla::Engine {
     run.key_last = kind_key;
     run.xw = wide_xw;
     run.x3 = x3;
+    run.lean = lean;
     chain_xw = wide_xw;
     chain_x3 = x3;
     run.plan = plan; run.launched.clear(); run.recs.clear();
@@ -4619,6 +4638,8 @@ struct HipEngine : dla::Engine {
           default: err = "ortho_chain: device state machine in an unexpected phase"; return DLA_ERR_RUNTIME;
         }
       }
+      if (run.lean && sres.phase != OP_CLOSE && sres.phase != OP_FINAL)
+        while (plan.size() > 1 && (plan.back() == OP_FINAL || plan.back() == OP_CLOSE)) plan.pop_back();
       h_ost->status = -1;
     }
     if (sres.status == OST_RUNNING) { err = "ortho_chain: no progress"; return DLA_ERR_RUNTIME; }
