@@ -82,6 +82,7 @@ done; done >> $OUT/schedule_ab.txt 2>&1 || true
 python3 tools/solve_jitter.py 30 > $OUT/solve_jitter.txt 2>/dev/null || true
 python3 tools/solve_jitter.py 30 14 >> $OUT/solve_jitter.txt 2>/dev/null || true
 DIAGLIB_AMD_CHAIN_DEBUG=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-random-leg 2>&1 | grep "chain k=" | tail -8 | cut -c1-120 > $OUT/chain_schedules_headline.txt
+python3 tools/determinism_probe.py 2000000 10 > $OUT/determinism.txt 2>/dev/null || true
 echo "schedule A/B done"
 fi
 if [[ $PART == *A* ]]; then
