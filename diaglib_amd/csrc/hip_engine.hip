@@ -2326,7 +2326,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // LDS use of ortho_tail16 (doubles): [0,256) G hand-over / transpose scratch (16 x 17), [272,528) Wd for the assembly,
 // [528,784) Wp for the assembly
 #define T16_LDS_DOUBLES 784
-#define T16_ZS_ROWS 288                    // rows of the coefficient block the exact projection (OrthoTailArgs::dmat) keeps in LDS behind them
+#define T16_ZS_ROWS 320                    // rows of the coefficient block the exact projection (OrthoTailArgs::dmat) keeps in LDS behind them
 
 // One step of the state machine for k <= 16, called by ALL 256 threads of a block (wave 0 does the serial part, all four
 // waves assemble the coefficient block of a projection sweep).  g_in_lds: lds[64 r + lane] already holds the Gram matrix
@@ -3225,7 +3225,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramReduceArgs a)
     if (a.c_host) a.c_host[(size_t)xcol + (size_t)ucol * a.ldc] = tot;
   }
   if constexpr (!TAIL) return;
-  __shared__ __attribute__((aligned(16))) double tail_lds[TAIL ? TAIL_LDS_DOUBLES : 1];
+  __shared__ __attribute__((aligned(16))) double tail_lds[TAIL ? (TAIL_LDS_DOUBLES > T16_LDS_DOUBLES + T16_ZS_ROWS * 16 ? TAIL_LDS_DOUBLES : T16_LDS_DOUBLES + T16_ZS_ROWS * 16) : 1];
   if (!exchange && a.n_ps == 1 && a.tail.after != OP_XU) {
     // a single 16 x 16 tile, complete in this block's registers: it reaches the tail through LDS, no hand-over
     if (a.tail.fold) {
@@ -4382,7 +4382,7 @@ struct HipEngine : dla::Engine {
     //  loop, which ends on the reference's growth test, must not take such a block)
     auto not_handled = [&]() {
       if (!(basis_exact && m > 0) || dmat_cols == m) return (int)DLA_OK;     // (the host-driven loop projects with D as well: basis_dd)
-      err = "ortho_chain: dla_expand_project mode 5 needs the caller's pending blocks (dla_basis_sync after every block; at most 288 basis columns)";
+      err = "ortho_chain: dla_expand_project mode 5 needs the caller's pending blocks (dla_basis_sync after every block; at most 320 basis columns)";
       return (int)DLA_ERR_ARG;
     };
     if (tune[6] == 3) return not_handled();                               // A/B: host-driven loop

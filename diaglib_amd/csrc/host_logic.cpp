@@ -1348,7 +1348,7 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
   // algebra well conditioned (max |S| < 0.05, Gram matrix factorable in one step) -- not by what later projections could absorb
   // (where the device cannot project with D -- wider blocks, a wider basis, an all-reduce hook -- the block is finished in memory,
   //  mode 0: nothing of it stays pending in a basis that later blocks are projected against)
-  const bool exact = mode == 5 && c->eng->basis_exact_ok() && k <= 16 && m + k <= 288;
+  const bool exact = mode == 5 && c->eng->basis_exact_ok() && k <= 16 && m + k <= 320;
   if (mode == 5) mode = exact ? 4 : 0;
   // a chain that failed behind a finished orthogonalisation must not leave its block to the next call (round-4 advisor)
   struct Forget { dla_ctx* c; int m, k; bool keep = false; ~Forget() { if (!keep) { std::vector<double> junk((size_t)(m + k) * k); (void)c->eng->pending_block(m, k, junk.data(), m + k, nullptr); } } };

@@ -768,7 +768,7 @@ contains
       britz  = dev_panel(e%ctx, n, n_max, 'b_evec')
     end if
     allocate (h(s%ld,s%ld), y(s%ld,s%ld), theta(s%ld), dmat(s%ld,s%ld), hraw(s%ld,s%ld), pblk(s%ld,n_max))
-    exact_basis = (.not.with_metric) .and. n_max.le.16 .and. s%ld.le.288
+    exact_basis = (.not.with_metric) .and. n_max.le.16 .and. s%ld.le.320
     call reset_pending()
 !
 !   The reference zero-fills both n x lda panels (:1632-1633).  On the device no column is read before it has been
@@ -917,7 +917,7 @@ contains
 !           factor pending (the sweeps of :3543-3544 and :3327 are not run on it): the finished block is [X | U] p for the STORED
 !           columns; its columns of the projected matrix come back for the stored block and are corrected here, D^T h_raw D with
 !           the upper-triangular D that collects the pending blocks of the whole basis.
-!           mode 5 (blocks of up to 16 columns, up to 288 basis columns): the device holds D as well and projects with
+!           mode 5 (blocks of up to 16 columns, up to 320 basis columns): the device holds D as well and projects with
 !           X (D D^T) X^T -- what may stay pending is then bounded by the conditioning of the k x k algebra only
 !
             if (exact_basis) then

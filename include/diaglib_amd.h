@@ -279,7 +279,7 @@ int  dla_expand_project(dla_ctx* ctx, int mode, int n, int m, int k, double* bas
  * it -- the block in memory is what h_host belongs to, and dla_basis_admit owes it only the difference to the exact closing pass and
  * the k x k factor of its Gram matrix I - (S T)^T (S T).
  * mode 5 = mode 4 with the caller's D kept on the DEVICE as well (dla_basis_sync after every block, blocks of at most 16 columns, at
- * most 288 basis columns): every projection of the chain is then X (D D^T) X^T U, exact against the finished basis, and the bounds
+ * most 320 basis columns): every projection of the chain is then X (D D^T) X^T U, exact against the finished basis, and the bounds
  * on what may stay pending are those of the host algebra alone -- max |S| < 0.05 with column sums of squares below 0.02, nothing on
  * G (its factor has converged) -- so the chain ends behind the first sweep that has measured S and G on what it stored.  Where the
  * device-driven chain does not run at all (an all-reduce hook, the A/B knobs for the host loop) or the shape is beyond the device

@@ -74,12 +74,12 @@ def test_basis_with_pending_blocks_is_orthonormal_and_projects_exactly(ctx, rng,
         ctx.set_shard(-1, 0)
 
 
-@pytest.mark.parametrize("k,nb,kind", [(1, 8, "random"), (3, 8, "random"), (13, 6, "random"), (13, 22, "random"), (16, 18, "random"), (13, 6, "inside"),
+@pytest.mark.parametrize("k,nb,kind", [(1, 8, "random"), (3, 8, "random"), (13, 6, "random"), (13, 22, "random"), (16, 20, "random"), (13, 24, "dependent"), (13, 6, "inside"),
                                        (13, 6, "dependent"), (8, 10, "dependent"), (13, 20, "dependent"), (13, 20, "inside")])
 def test_basis_kept_on_the_device_projects_exactly(ctx, rng, k, nb, kind):
     """mode 5: the chains project with X (D D^T) X^T, so the stored columns may be as far from orthonormal as the host algebra
     tolerates (max |S| < 0.05) -- the finished basis panel D is orthonormal to rounding all the same, over every basis width the device
-    copy takes (288 columns: the last blocks run the sweep-per-update schedule beyond 192)."""
+    copy takes (320 columns: the last blocks run the sweep-per-update schedule beyond 192)."""
     n = 6000
     try:
         ctx.set_shard(n, 0); ctx.synth_setup(n, 0, n); ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised bases grown block by block through dla_expand_project modes 4 / 5 (the Davidson drivers' expansion step with the
 closing pass left to the caller's small matrices): random row counts (odd ones take the sweep-per-update
-schedule), block widths 1 .. 16, up to 288 columns, random / nearly dependent / inside-span(X) / tiny-norm blocks, every schedule
+schedule), block widths 1 .. 16, up to 320 columns, random / nearly dependent / inside-span(X) / tiny-norm blocks, every schedule
 knob.  Checked: (panel D)^T (panel D) = I to 100 eps and h = (panel D)^T A (panel D) to 1e-12.
 
     python tools/fuzz_pending_basis.py [cases] [seed] [only this case]      (FUZZ_WIDE=1 or a fourth argument `wide`: blocks of 17 .. 40 columns, mode 4)"""
@@ -25,7 +25,7 @@ for it in range(cases):
         continue
     rng = np.random.default_rng([seed, it])
     k = int(rng.integers(1, 17))
-    nb = int(rng.integers(3, max(4, min(24, 288 // k) + 1)))
+    nb = int(rng.integers(3, max(4, min(26, 320 // k) + 1)))
     mode = int(rng.choice([4, 5, 5]))
     if os.environ.get("FUZZ_WIDE") or (len(sys.argv) > 4 and sys.argv[4] == "wide"):             # blocks of two and three column tiles (the LDS-loop k x k step): mode 4 only
         k = int(rng.integers(17, 41)); nb = int(rng.integers(3, 11)); mode = 4
