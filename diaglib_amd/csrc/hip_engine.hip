@@ -2339,8 +2339,8 @@ __device__ __forceinline__ void ortho_tail16(const OrthoTailArgs& a, double* lds
   __shared__ int s_go;
   if (pre == nullptr) {
     const int ph = __hip_atomic_load(&st->phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (the first sweep of any chain answers the start phase; in a three-pass chain the plain projection sweep may stand in for the
-    //  measuring one -- the host picks the one the previous chain of this kind could have used, see ortho_chain_begin)
+    // (the first sweep of any chain answers the start phase; a plain projection sweep in a three-pass chain would answer the
+    //  measuring one's -- no plan contains one any more, see ortho_chain_begin)
     const int need = a.after == OP_GRAMX ? (int)OP_GRAM_UU : (a.x3 && a.after == OP_COMBO) ? (int)OP_COMBOX : a.after;
     if (ph != need) {
       if (a.publish && tid == 0 && st->nops > 0) *a.st_host = *st;
@@ -4397,13 +4397,13 @@ struct HipEngine : dla::Engine {
     if (fold && vsx && vec2 && m <= 192 && tune[6] != 6 && lds_limit > (size_t)128 * 1024) fold = 1;
     // ... and with the standard inner product (bx == x: the panel the projection subtracts is the panel it measures against) the
     // three-pass schedule: projections that measure X^T U and U^T U of what they store (tune knob 6 = 12: the five-sweep one)
-    // Not while expansion blocks come out of their first projection numerically rank deficient (level shifts: the benchmark
-    // operator's rank-4 coupling leaves 4 new directions per 13-column block): there the written update and the storing sweep
-    // follow whatever the projection measured, the closing projection only needs its Gram matrix, and a basis that carries pending
-    // projections of 1e-9 is not tight enough -- the next block's leftover is amplified by 1e10 on its way through the shifted
-    // factors (measured r05, interleaved: 17.0 against 16.35 ms per benchmark solve; 138.5 against 144.3 ms on the random-guess
-    // leg, which never shifts).  A chain that reports a level shift switches the schedule off for the next 16 chains, and every
-    // solve starts with two chains of the five-sweep schedule (on the benchmark the first one shifts).
+    // For callers that finish their blocks in memory (plain ortho_vs_x, dla_expand_project modes 0 / 1 / 4) not while expansion blocks
+    // come out of their first projection numerically rank deficient (level shifts: the benchmark operator's rank-4 coupling leaves 4
+    // new directions per 13-column block): there the written update and the storing sweep follow whatever the projection measured
+    // and the closing projection only needs its Gram matrix (measured r05, interleaved: 17.0 against 16.35 ms per benchmark solve;
+    // 138.5 against 144.3 ms on the random-guess leg, which never shifts).  A chain that reports a level shift switches the schedule
+    // off for the next 16 chains, and every solve starts with two chains of the five-sweep schedule (on the benchmark the first one
+    // shifts).  Callers that take the closing block on their small matrices (modes 3 and 5) always run it: `rebuilt`, `basis_exact`.
     // (A block that is used once and rebuilt -- LOBPCG's W, dla_expand_project mode 3: pending blocks without a bound on the Gram
     //  matrix -- leaves nothing in a basis: the three-pass schedule always; measured r05, n = 2e6, 8 roots: 15.99 against 17.07 ms.)
     const bool rebuilt = drop_final && publish_pending && drop_final_tol <= 0.0;
