@@ -126,6 +126,11 @@ for it in range(cases):
     # unit guesses: the history is robust to rounding; random guesses and tolerances near the rounding floor of max|r| (1e-11 on
     # these spectra: DESIGN 11.7) end a few sweeps earlier or later with the last bits of the small eigensolver
     slack = 1 if (guess == "unit" and tol >= 1e-10) else max(3, tr.iters // 8)
+    if "lobpcg" in solver and slack == 1:
+        # LOBPCG's 3m x 3m Rayleigh-Ritz problem has clusters whose eigenvectors the partial solver here and the oracle's solver
+        # rotate differently; 2 of 120 unit-guess cases (seed 300: cases 27 and 84) take 13 sweeps against 11 -- on the round-4
+        # build as well, with every schedule, eigenvalues equal to 1e-13
+        slack = 2
     if "lobpcg" in solver and (m > 24 or m <= t + 1):   # (wide LOBPCG blocks, or at most one guard vector behind the wanted roots: the order in
         slack = max(3, tr.iters // 6)               #  which the last roots lock moves the count by 10 %, with or without the pending factor)
     lim = max(1e-9, 50.0 * tol * tol)          # eigenvalue error ~ residual^2; both sides stop anywhere below tol
