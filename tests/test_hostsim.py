@@ -141,6 +141,63 @@ def test_two_ranks_gloo_equals_one_rank(sim, tmp_path, solver, guess):
         assert np.abs(v2[:, :t].T @ v2[:, :t] - np.eye(t)).max() < 1e-12
 
 
+PENDING_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import hostsim
+from diaglib_amd import capi
+capi.load(hostsim.build())
+ctx = capi.Context()
+assert ctx.backend.startswith("hostsim")
+rng = np.random.default_rng(3)
+n, k, nb = 3000, 5, 6
+mv = capi.fn_address("dla_synth_matvec")
+ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+ctx.synth_setup(n, 0, n)
+for mode in (5, 4, 3):
+    ld = nb * k
+    x0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, k)))[0])
+    basis = ctx.panel(np.asfortranarray(np.hstack([x0, np.zeros((n, ld - k))]))); abasis = ctx.panel(np.zeros((n, ld), order="F"))
+    ctx.synth_matvec(basis.col(0, k), abasis.col(0, k))
+    hraw = np.zeros((ld, ld), order="F"); dmat = np.asfortranarray(np.eye(ld)); h = np.zeros((ld, ld), order="F")
+    b = basis.download(); ab = abasis.download()
+    hraw[:k, :k] = b[:, :k].T @ ab[:, :k]; h[:k, :k] = hraw[:k, :k]
+    ctx.basis_sync(0, 0); ctx.basis_sync(0, k, dmat)
+    for blk in range(1, nb):
+        m = blk * k
+        u = b[:, :m] @ rng.standard_normal((m, k)) + 0.3 * rng.standard_normal((n, k))
+        basis.col(m, k).upload(np.asfortranarray(u))
+        hh = ctx.expand_project(mode, basis, abasis, m, k, mv, 0.0)
+        p = ctx.pending_block(m, k)
+        # the host engine runs no device chain: nothing stays pending, whatever the mode
+        assert np.array_equal(p, np.vstack([np.zeros((m, k)), np.eye(k)])), (mode, blk)
+        if mode == 3:
+            h[:m + k, :m + k] = np.tril(hh) + np.tril(hh, -1).T
+        else:
+            h[:m + k, m:m + k] = hh
+            ctx.basis_admit(m, k, p, hraw, dmat, h, applied=ctx.pending_applied)
+            ctx.basis_sync(m, k, dmat)
+        b = basis.download()
+    assert np.array_equal(dmat, np.eye(ld))
+    assert np.abs(b.T @ b - np.eye(ld)).max() < 1e-13
+    href = b.T @ abasis.download()
+    assert np.abs(np.triu(h - href)).max() < 1e-12 * np.abs(href).max(), mode
+print("pending modes on the host engine: ok")
+"""
+
+
+def test_pending_modes_fall_back_to_finished_blocks_on_the_host_engine(sim, tmp_path):
+    """dla_expand_project modes 3 / 4 / 5, dla_pending_block, dla_basis_admit, dla_basis_sync where no device chain exists (the
+    host-memory engine; on a GPU: an all-reduce hook): every block is finished in memory, the pending block is [0 ; I], D stays
+    the identity, h is the projected matrix."""
+    script = tmp_path / "pending_worker.py"
+    script.write_text(PENDING_WORKER.format(root=ROOT))
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "ok" in p.stdout
+
+
 def test_shard_rows_partition():
     sys.path.insert(0, ROOT)
     from bench import shard_rows
