@@ -4110,7 +4110,8 @@ struct HipEngine : dla::Engine {
     pending_tail.x3 = chain_x3 ? 1 : 0;
     // (knob 6 = 15: A/B, the first factor from U^T U as the reference's; 16: A/B, level shifts on the projected block's Gram matrix
     //  instead of the reference's order for a numerically rank-deficient block -- 14.2-14.36 against 14.37-14.46 ms on the benchmark,
-    //  but such a block's weakest columns then depend on the schedule: not shipped)
+    //  but such a block's weakest columns then depend on the schedule, and the reference's dense test matrix with unit guesses takes
+    //  another history (tests/test_trace_text.py::dav_n1000_unit fails with it, also when only the drivers' chains use it): not shipped)
     pending_tail.gp = tune[6] == 15 ? 0 : tune[6] == 16 ? 2 : 1;
     pending_tail.dmat = (basis_exact && fold && m > 0 && dmat_nontrivial && dmat_cols == m && m <= DMAT_LD) ? d_dmat : nullptr;
     pending_tail.dmat_ld = DMAT_LD;
