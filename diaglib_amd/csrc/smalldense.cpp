@@ -274,7 +274,8 @@ void tridiagonalize(int n, std::vector<double>& s, Tridiag& t)
 {
   t.n = n;
   t.d.assign(n, 0.0); t.e.assign(n, 0.0);
-  t.hv.assign((size_t)n * n, 0.0); t.hbeta.assign(n, 0.0);
+  if (t.hv.size() < (size_t)n * n) t.hv.resize((size_t)n * n);     // (row k is written where it is read: entries k+1 .. n-1, when beta_k != 0)
+  t.hbeta.assign(n, 0.0);
   std::vector<double> vbuf[2], pbuf[2], w(n + VW, 0.0);
   for (int q = 0; q < 2; ++q) { vbuf[q].assign(n + VW, 0.0); pbuf[q].assign(n + VW, 0.0); }
   if (n >= 3) {
@@ -505,7 +506,7 @@ void bisect_lowest(int n, const std::vector<double>& d, const std::vector<double
 // lowest m eigenpairs; zt rows 0..m-1 receive the eigenvectors of the ORIGINAL matrix
 int sym_eig_lowest(int n, std::vector<double>& s, int m, std::vector<double>& w_all, std::vector<double>& zt)
 {
-  Tridiag t;
+  static thread_local Tridiag t;             // (work arrays live as long as the thread: the solver runs once per iteration of every driver)
   tridiagonalize(n, s, t);
   double onenrm = 0.0;
   for (int i = 0; i < n; ++i) {
@@ -750,7 +751,9 @@ int dla_syev_lowest(char uplo, int n, double* a, int lda, double* w, int m)
   //  24 against 34 at n = 26, m = 13; below 20 the full one is 20-50 % faster)
   if (n <= 20 || m >= n) return dla_syev(uplo, n, a, lda, w);   // small or all wanted: full solve
   bool up = (uplo == 'u' || uplo == 'U');
-  std::vector<double> s((size_t)n * n), wall, zt((size_t)m * n);
+  static thread_local std::vector<double> s, wall, zt;
+  if (s.size() < (size_t)n * n) s.resize((size_t)n * n);
+  if (zt.size() < (size_t)m * n) zt.resize((size_t)m * n);
   for (int j = 0; j < n; ++j)
     for (int i = 0; i <= j; ++i) {
       double x = up ? at(a, lda, i, j) : at(a, lda, j, i);

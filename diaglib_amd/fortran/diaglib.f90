@@ -837,7 +837,9 @@ contains
 !
 !     Rayleigh-Ritz: the lowest n_max pairs of the upper triangle (:1703-1708)
 !
-      y(1:s%cols,1:s%cols) = h(1:s%cols,1:s%cols)       ! (only the leading block: the arrays are (ld,ld) = 0.5 MB at 20 blocks of 13)
+      do j = 1, s%cols                                  ! (only the upper triangle of the leading block: what the solver reads)
+        y(1:j,j) = h(1:j,j)
+      end do
       call lap_start(w)
       call need_eigensolver(dla_syev_lowest('u', s%cols, y, s%ld, theta, n_max))
       call lap_charge(w, w%diag)
