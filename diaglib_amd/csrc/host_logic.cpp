@@ -1483,8 +1483,22 @@ int dla_basis_admit(int m, int k, double* p, int ldp, int applied, double* hraw,
     for (int i = 0; i < l; ++i) dmat[(size_t)i + (size_t)(m + j) * ld] = p[(size_t)i + (size_t)j * ldp];
   }
   // g = hraw(0:l, 0:l) p
-  std::vector<double> g((size_t)l * k, 0.0);
-  for (int j = 0; j < k; ++j) {
+  // (four columns of p / g at a time: a column of hraw / of D is loaded once for the four -- the arithmetic of every entry, and its
+  //  order, is that of the plain loops; this runs in the Rayleigh-Ritz gap of every iteration while the device waits)
+  static thread_local std::vector<double> g;
+  g.assign((size_t)l * k, 0.0);
+  int j = 0;
+  for (; j + 4 <= k; j += 4) {
+    double* g0 = &g[(size_t)j * l]; double* g1 = g0 + l; double* g2 = g1 + l; double* g3 = g2 + l;
+    for (int q = 0; q < l; ++q) {
+      const double p0 = p[(size_t)q + (size_t)j * ldp], p1 = p[(size_t)q + (size_t)(j + 1) * ldp],
+                   p2 = p[(size_t)q + (size_t)(j + 2) * ldp], p3 = p[(size_t)q + (size_t)(j + 3) * ldp];
+      if (p0 == 0.0 && p1 == 0.0 && p2 == 0.0 && p3 == 0.0) continue;
+      const double* hq = hraw + (size_t)q * ld;
+      for (int i = 0; i < l; ++i) { const double hv = hq[i]; g0[i] += hv * p0; g1[i] += hv * p1; g2[i] += hv * p2; g3[i] += hv * p3; }
+    }
+  }
+  for (; j < k; ++j) {
     double* gj = &g[(size_t)j * l];
     for (int q = 0; q < l; ++q) {
       const double pq = p[(size_t)q + (size_t)j * ldp];
@@ -1494,7 +1508,20 @@ int dla_basis_admit(int m, int k, double* p, int ldp, int applied, double* hraw,
     }
   }
   // hcols = D(0:l, 0:l)^T g: row r of the result is column r of D against g
-  for (int j = 0; j < k; ++j) {
+  for (j = 0; j + 4 <= k; j += 4) {
+    const double* g0 = &g[(size_t)j * l]; const double* g1 = g0 + l; const double* g2 = g1 + l; const double* g3 = g2 + l;
+    for (int r = 0; r < l; ++r) {
+      const double* dr = dmat + (size_t)r * ld;
+      const int nn = r + 1;
+      double s[4][4] = {{0.0}};
+      int i = 0;
+      for (; i + 4 <= nn; i += 4)
+        for (int e = 0; e < 4; ++e) { const double dv = dr[i + e]; s[0][e] += dv * g0[i + e]; s[1][e] += dv * g1[i + e]; s[2][e] += dv * g2[i + e]; s[3][e] += dv * g3[i + e]; }
+      for (; i < nn; ++i) { const double dv = dr[i]; s[0][0] += dv * g0[i]; s[1][0] += dv * g1[i]; s[2][0] += dv * g2[i]; s[3][0] += dv * g3[i]; }
+      for (int c4 = 0; c4 < 4; ++c4) hc[(size_t)r + (size_t)(j + c4) * ld] = (s[c4][0] + s[c4][1]) + (s[c4][2] + s[c4][3]);
+    }
+  }
+  for (; j < k; ++j) {
     const double* gj = &g[(size_t)j * l];
     for (int r = 0; r < l; ++r) hc[(size_t)r + (size_t)j * ld] = dot4(dmat + (size_t)r * ld, gj, r + 1);
   }
