@@ -474,7 +474,7 @@ class Context:
     def expand_project(self, mode: int, basis: DevPanel, abasis: DevPanel, m: int, k: int, matvec: int, shift: float = 0.0) -> np.ndarray:
         """dla_expand_project on the leading m + k columns of the two panels: ortho_vs_x(X, U), AU = A U + shift U, then the
         projection -- mode 0: [X | U]^T AU ((m+k) x k), mode 1: lower triangle of [X | U]^T [AX | AU]"""
-        h = np.zeros((m + k, k if mode in (0, 4, 5) else m + k), order="F")       # (modes 3 / 4 / 5: 1 / 0 / 0 with the last factor pending)
+        h = np.zeros((m + k, k if mode in (0, 4, 5, 6) else m + k), order="F")    # (modes 3 / 4 / 5: 1 / 0 / 0 with the last factor pending; 6: 0 against the finished basis X D)
         self._chk(self.lib.dla_expand_project(self.h, mode, basis.n, m, k, basis.ptr, abasis.ptr, matvec, shift, _dp(h), m + k))
         return h
 

@@ -104,6 +104,14 @@ struct BlockOps {
   // projection, so that it projects with X (D D^T) X^T as the device chain does (a chain that stopped half way -- ortho_cd out of
   // iterations, Householder fallback -- is continued there)
   virtual int basis_dd(int /*m*/, int /*k*/, double* /*xu*/, int /*ld*/) { return 0; }
+  // What the engine's copy of the caller's D says about the m columns in front of a block: 0 = D is the identity there (the stored
+  // columns are finished: engines that never leave anything pending always answer this), 1 = the copy describes exactly these m
+  // columns and is NOT the identity (a projection against the stored columns alone would leave |X_c^T X_c - I| of what it removes),
+  // -1 = the copy does not describe them.
+  virtual int basis_state(int /*m*/) const { return 0; }
+  // the device-driven chain must not take the next calls: the host-driven loop runs (dla_expand_project mode 5 on a shape the device
+  // cannot project exactly, mode 6)
+  bool chain_off = false;
   int ortho_maxit = 10;      // maxit of ortho_cd / ortho_vs_x (diaglib.f90:3224,3521); DLA_OPT_ORTHO_MAXIT lowers it in tests
   std::string err;
 };

@@ -4294,7 +4294,10 @@ struct HipEngine : dla::Engine {
   double* d_dmat = nullptr;
   std::vector<double> h_dmat;        // the same on the host (basis_dd)
   int dmat_cols = 0;                 // columns described so far (-1: the basis has outgrown the buffer)
-  bool dmat_nontrivial = false;      // some entry differs from the identity by more than 1e-10
+  bool dmat_nontrivial = false;      // some entry differs from the identity at all (exact comparison: a rounding-level pending factor
+                                     // already switches the chains to the D D^T assembly -- two more k x k x m products per step --
+                                     // because a threshold would make the projections inexact by that threshold)
+  int basis_state(int m) const override { return m <= 0 ? 0 : dmat_cols != m ? -1 : dmat_nontrivial ? 1 : 0; }
   bool basis_exact_ok() const override { return !hook && !local_only && tune[6] != 3 && tune[6] != 5 && tune[6] != 14 && lds_limit > (size_t)128 * 1024; }   // (knob 6 = 14: A/B, mode 5 behaves like mode 4)
   int basis_dd(int m, int k, double* xu, int ld) override
   {
@@ -4324,7 +4327,19 @@ struct HipEngine : dla::Engine {
     if (k <= 0) { dmat_cols = 0; dmat_nontrivial = false; return DLA_OK; }
     if (dmat_cols < 0) return DLA_OK;
     if (m != dmat_cols) { err = "basis_sync: the blocks of D arrive in order (" + std::to_string(dmat_cols) + " columns known, block starts at " + std::to_string(m) + ")"; return DLA_ERR_ARG; }
-    if (m + k > DMAT_LD) { dmat_cols = -1; return DLA_OK; }
+    if (m + k > DMAT_LD) {
+      // beyond the copy's width: a basis whose blocks have all been finished in memory so far may go on that way (nothing to store:
+      // D = I), anything else is refused -- later projections could not be made exact and would silently lose orthogonality
+      // (round-5 advisor)
+      bool ident = !dmat_nontrivial;
+      for (int j = 0; j < k && ident; ++j)
+        for (int i = 0; i <= m + j; ++i)
+          if (dmat[(size_t)i + (size_t)(m + j) * ld] != (i == m + j ? 1.0 : 0.0)) { ident = false; break; }
+      if (ident) { dmat_cols = m + k; return DLA_OK; }
+      dmat_cols = -1;
+      err = "basis_sync: a basis with pending blocks cannot grow beyond " + std::to_string(DMAT_LD) + " columns (finish the blocks in memory: dla_expand_project mode 0 / 6)";
+      return DLA_ERR_ARG;
+    }
     bind();
     if (!d_dmat) {
       HIPCHK(hipMalloc((void**)&d_dmat, sizeof(double) * (size_t)DMAT_LD * DMAT_LD));
@@ -4386,7 +4401,7 @@ struct HipEngine : dla::Engine {
       err = "ortho_chain: dla_expand_project mode 5 needs the caller's pending blocks (dla_basis_sync after every block; at most 320 basis columns)";
       return (int)DLA_ERR_ARG;
     };
-    if (tune[6] == 3) return not_handled();                               // A/B: host-driven loop
+    if (tune[6] == 3 || chain_off) return not_handled();                  // A/B / the caller's request: host-driven loop
     if (hook || local_only || k <= 0 || k > 48) return not_handled();     // hook reductions need the host between sweeps
     const bool vsx = m > 0;
     if (vsx && !(u == x + (size_t)n * m && can_combo(m, k))) return not_handled();

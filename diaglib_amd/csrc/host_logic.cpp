@@ -1336,20 +1336,40 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
   DLA_T("dla_expand_project");
   // ortho_vs_x (:1790 / 523-529) + the projection (:1691 / 401-403) [+ daxpy :397]; the operator is the caller's
   RefFlops rf(c, c && n > 0 && k > 0 ? ortho_vs_x_flops(n, m, k) + (shift != 0.0 ? 2.0 * n * (double)k : 0.0) +
-                                       ((mode == 0 || mode == 4 || mode == 5) ? 2.0 * n * (double)(m + k) * k : 2.0 * n * (double)(m + k) * (m + k)) : 0.0);
-  if (!c || !basis || !abasis || !h || !fn || mode < 0 || mode == 2 || mode > 5 || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
+                                       ((mode == 0 || mode >= 4) ? 2.0 * n * (double)(m + k) * k : 2.0 * n * (double)(m + k) * (m + k)) : 0.0);
+  if (!c || !basis || !abasis || !h || !fn || mode < 0 || mode == 2 || mode > 6 || n <= 0 || m < 0 || k <= 0 || ldh < m + k)
     return fail(c, DLA_ERR_ARG, "dla_expand_project: bad argument (n > 0, m >= 0, k > 0, ldh >= m + k)");
   c->pending_k = 0; c->pending_m = 0; c->pending_applied = 0;
   // (DLA_OPT_PENDING_BLOCKS = 0 makes modes 3 / 4 / 5 behave like 1 / 0 / 0: the chain finishes the block in memory)
   if (mode == 3 && !c->pending_blocks) mode = 1;
-  if ((mode == 4 || mode == 5) && !c->pending_blocks) mode = 0;
+  if ((mode == 4 || mode == 5) && !c->pending_blocks && c->eng->basis_state(m) <= 0) mode = 0;
   // mode 5 = mode 4 with the caller's pending blocks kept on the device as well (dla_basis_sync after every block): the chain's
   // projections are exact against the FINISHED basis X D, so what a block leaves pending is bounded only by what keeps the host
   // algebra well conditioned (max |S| < 0.05, Gram matrix factorable in one step) -- not by what later projections could absorb
   // (where the device cannot project with D -- wider blocks, a wider basis, an all-reduce hook -- the block is finished in memory,
   //  mode 0: nothing of it stays pending in a basis that later blocks are projected against)
-  const bool exact = mode == 5 && c->eng->basis_exact_ok() && k <= 16 && m + k <= 320;
-  if (mode == 5) mode = exact ? 4 : 0;
+  const bool exact = mode == 5 && c->pending_blocks && c->eng->basis_exact_ok() && k <= 16 && m + k <= 320;
+  if (mode == 5 || mode == 6) {
+    // What the copy of the caller's D says about the m stored columns decides what a call that cannot be exact may do (round-5
+    // advisor: the device's ability can change between two calls of one solve -- a refused LDS request lowers the engine's limit --
+    // and earlier blocks of the basis may already be pending with max |S| up to 0.05, i.e. the stored columns are not orthonormal):
+    //   D = I there:         the stored columns are a finished basis; mode 0 is exact against it;
+    //   D != I:              the block is finished in memory by the host-driven loop, which multiplies every X^T U with D D^T
+    //                        (BlockOps::basis_dd) -- exact against the finished basis X D, nothing stays pending;
+    //   no copy of these m:  refused -- a plain projection against unfinished columns would lose orthogonality without a word.
+    // mode 6 asks for the second treatment outright: a block whose closing algebra the caller could not complete (dla_basis_admit
+    // answered DLA_ERR_ORTHO: I - F^T F not positive definite) is finished in memory from what the chain stored.
+    const int bs = c->eng->basis_state(m);
+    if (bs < 0)
+      return fail(c, DLA_ERR_ARG, "dla_expand_project: the engine's copy of the caller's pending blocks does not describe the columns in front of "
+                                  "this block (dla_basis_sync after every block; a basis with pending blocks holds at most 320 columns)");
+    if (mode == 6 || (!exact && bs > 0)) {
+      struct Flags { dla::Engine* e; explicit Flags(dla::Engine* e_) : e(e_) { e->basis_exact = true; e->chain_off = true; }
+                     ~Flags() { e->basis_exact = false; e->chain_off = false; } } flags(c->eng);
+      return expand_project_impl(c, 0, n, m, k, basis, abasis, fn, shift, h, ldh);
+    }
+    mode = exact ? 4 : 0;
+  }
   // a chain that failed behind a finished orthogonalisation must not leave its block to the next call (round-4 advisor)
   struct Forget { dla_ctx* c; int m, k; bool keep = false; ~Forget() { if (!keep) { std::vector<double> junk((size_t)(m + k) * k); (void)c->eng->pending_block(m, k, junk.data(), m + k, nullptr); } } };
   if (mode == 4) {
@@ -1392,7 +1412,13 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
   c->pending_k = k; c->pending_m = m;
   st = close_pending_block(m, k, c->pending_p.data(), l, nullptr, 0, c->pending_applied);       // ([X P] is a finished block: D = I)
   c->pending_applied = 0;
-  if (st) return fail(c, st, "dla_expand_project: the pending block's closing factor is not positive definite");
+  if (st) {
+    // I - (S T)^T (S T) is not positive definite: nothing bounds |T| where the chain ended (round-5 advisor).  The block in memory
+    // is intact -- what the chain stored -- so it is finished there: the orthogonalisation runs again on it, without anything left
+    // pending, and the operator and the projection are repeated on the finished block (p = [0 ; I]).
+    c->pending_k = 0; c->pending_m = 0;
+    return expand_project_impl(c, 1, n, m, k, basis, abasis, fn, shift, h, ldh);
+  }
   const double* p = c->pending_p.data();
   bool ident = true;
   for (int j = 0; j < k && ident; ++j)

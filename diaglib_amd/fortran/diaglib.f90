@@ -1019,6 +1019,7 @@ contains
     subroutine admit_pending(m, k)
       integer, intent(in) :: m, k
       integer :: i, j
+      integer(c_int) :: st
       logical :: ident
       ident = .true.
       do j = 1, k
@@ -1035,7 +1036,20 @@ contains
         end do
         return
       end if
-      call need_ok(dla_basis_admit(m, k, pblk, s%ld, applied, hraw, dmat, h, s%ld), 'basis admit')
+      st = dla_basis_admit(m, k, pblk, s%ld, applied, hraw, dmat, h, s%ld)
+      if (st.eq.5_c_int .and. exact_basis) then
+!
+!       the closing factor of the pending block is not positive definite (nothing bounds the chain's last triangular factor where it
+!       ended): the block in memory is what the chain stored, so it is finished there -- orthogonalised against the finished basis
+!       panel*D by the host-driven loop, operator and projection repeated on the result (dla_expand_project mode 6) -- and comes
+!       in with nothing pending
+!
+        call chk(e%ctx, dla_expand_project(e%ctx, 6_c_int, n, m, k, basis, abasis, op, zero, h(1,m+1), s%ld), &
+                 'ortho_vs_x + matvec + projection (block finished in memory)')
+        call chk(e%ctx, dla_pending_block(e%ctx, m, k, pblk, s%ld, applied), 'pending block')
+        st = dla_basis_admit(m, k, pblk, s%ld, applied, hraw, dmat, h, s%ld)
+      end if
+      call need_ok(st, 'basis admit')
     end subroutine admit_pending
 !
     subroutine need_ok(st, what)

@@ -282,9 +282,16 @@ int  dla_expand_project(dla_ctx* ctx, int mode, int n, int m, int k, double* bas
  * most 320 basis columns): every projection of the chain is then X (D D^T) X^T U, exact against the finished basis, and the bounds
  * on what may stay pending are those of the host algebra alone -- max |S| < 0.05 with column sums of squares below 0.02, nothing on
  * G (its factor has converged) -- so the chain ends behind the first sweep that has measured S and G on what it stored.  Where the
- * device-driven chain does not run at all (an all-reduce hook, the A/B knobs for the host loop) or the shape is beyond the device
- * copy, the call behaves like mode 0 (the block is finished in memory, dla_pending_block answers [0 ; I]); it fails (DLA_ERR_ARG)
- * when the device copy does not describe the m columns in front of it.
+ * device-driven chain cannot project exactly (an all-reduce hook, the A/B knobs for the host loop, a block wider than 16 columns,
+ * an engine whose LDS limit went down after a refused request -- which can happen between two calls of one solve) the block is
+ * finished in memory and dla_pending_block answers [0 ; I]: by mode 0 when the copy of D says the m stored columns are finished
+ * (D = I there), by the host-driven loop with every X^T U multiplied by D D^T when they are not -- never by a plain projection
+ * against unfinished columns.  The call fails (DLA_ERR_ARG) when the copy does not describe the m columns in front of the block;
+ * dla_basis_sync refuses a basis with pending blocks that grows beyond 320 columns.
+ * mode 6 = the block is finished in memory against the finished basis X D whatever the device could do (host-driven loop with D D^T),
+ * operator and projection on the result, nothing pending: the way out for a caller whose dla_basis_admit answered DLA_ERR_ORTHO (the
+ * closing factor I - F^T F of the pending block was not positive definite) -- called on the same block, which is still what the
+ * chain stored.  The operator is called a second time for that block.
  * (Mode 4's bounds cost later blocks a projection each time they remove more than 1e-8 from a block -- every chain of such a basis ends
  * on a measured product below that --, so the drivers use mode 5 where it is available and mode 0 elsewhere; mode 4 stays for callers
  * that keep D on the host only.) */

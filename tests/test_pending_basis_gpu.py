@@ -256,3 +256,62 @@ def test_pending_blocks_can_be_switched_off_per_context(ctx, rng):
         ctx.set_option(100 + 6, 0)
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
         ctx.set_shard(-1, 0)
+
+
+@pytest.mark.parametrize("how", ["host_loop_knob", "lds_limit_down", "wide_block", "mode6"])
+def test_a_call_that_cannot_be_exact_still_projects_against_the_finished_basis(ctx, rng, how):
+    """Round-5 advisor: a basis grown through mode 5 holds pending blocks (stored columns orthonormal to 0.05 only); when a later
+    call cannot use the device's exact projection -- the host-loop knob, an engine whose LDS limit went down between two calls of a
+    solve (basis_exact_ok() false), a block wider than 16 columns, or the caller's own request (mode 6) -- the block must still come
+    out orthogonal to the FINISHED basis panel*D, not to the stored columns: the host-driven loop multiplies X^T U by D D^T."""
+    n, k, nb = 6000, 13, 6
+    mv = capi.fn_address("dla_synth_matvec")
+    try:
+        ctx.set_shard(n, 0); ctx.synth_setup(n, 0, n); ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+        b, ab, dmat, h, n_pending = _grow(ctx, rng, n, k, nb, "random", True, mode=5)
+        assert n_pending >= 2 and not np.array_equal(dmat, np.eye(nb * k))
+        m = nb * k
+        kk = 17 if how == "wide_block" else k
+        v = b @ dmat
+        u = v @ rng.standard_normal((m, kk)) + 0.3 * rng.standard_normal((n, kk))
+        basis = ctx.panel(np.asfortranarray(np.hstack([b, u])))
+        abasis = ctx.panel(np.asfortranarray(np.hstack([ab, np.zeros((n, kk))])))
+        if how == "host_loop_knob":
+            ctx.set_option(100 + 6, 3)
+        if how == "lds_limit_down":
+            ctx.set_option(100 + 6, 14)                                   # (basis_exact_ok() answers false, like an engine under the 64 KiB limit)
+        h4 = ctx.expand_project(6 if how == "mode6" else 5, basis, abasis, m, kk, mv, 0.0)
+        p = ctx.pending_block(m, kk)
+        assert np.array_equal(p, np.vstack([np.zeros((m, kk)), np.eye(kk)]))          # finished in memory
+        unew = basis.download()[:, m:]
+        assert np.abs(v.T @ unew).max() < 50 * EPS, np.abs(v.T @ unew).max()
+        assert np.abs(unew.T @ unew - np.eye(kk)).max() < 50 * EPS
+        # ... and NOT merely against the stored columns (the defect: |X_c^T X_c - I| of what was removed stayed in the block)
+        aun = abasis.download()[:, m:]
+        href = np.vstack([b.T @ aun, unew.T @ aun])
+        assert np.abs(h4 - href).max() < 1e-12 * np.abs(href).max()
+    finally:
+        ctx.set_option(100 + 6, 0)
+        ctx.basis_sync(0, 0)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
+
+
+def test_a_basis_with_pending_blocks_is_refused_beyond_the_copy(ctx):
+    """dla_basis_sync past 320 columns: fine while every block so far was finished in memory (D = I: nothing to store), refused -- not
+    silently dropped -- once something is pending."""
+    ld = 340
+    eye = np.asfortranarray(np.eye(ld))
+    try:
+        ctx.basis_sync(0, 0)
+        for m in range(0, ld, 17):
+            ctx.basis_sync(m, 17, eye)                                    # identity blocks all the way: allowed
+        ctx.basis_sync(0, 0)
+        d = eye.copy(order="F")
+        d[3, 20] = 1e-3                                                   # a pending projection in the second block
+        for m in range(0, 306, 17):
+            ctx.basis_sync(m, 17, d)
+        with pytest.raises(capi.DlaError):
+            ctx.basis_sync(306, 17, d)                                    # 323 columns with something pending
+    finally:
+        ctx.basis_sync(0, 0)
