@@ -235,6 +235,26 @@ void orc_synth_matvec(const int* pn, const int* pm, const double* x, double* ax)
   free(t);
 }
 
+/* the product's sample metric (diaglib_amd/csrc/hip_engine.hip SynthKind 5, the operator the generalised multi-rank tests use):
+ * y = s(i) x + 0.1 W W^T x with s(i) = 1 + 0.5 / (1 + i mod 7), i the 1-based global row -- symmetric positive definite; the
+ * counterpart of the dense SPD metric the reference's harness builds for test_geneig (main.f90:403-526) */
+void orc_synth_metric(const int* pn, const int* pm, const double* x, double* bx)
+{
+  int n = *pn, m = *pm;
+  double* t = (double*)malloc(sizeof(double) * (size_t)g_rw * m);
+  orc_gemm_tn(n, g_rw, m, g_w, n, x, n, t, g_rw);   /* t = W^T x */
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < m; ++c)
+    for (int i = 0; i < n; ++i) {
+      unsigned long long gi = (unsigned long long)(g_row0 + i + 1);
+      double d = 1.0 + 0.5 / (1.0 + (double)(gi % 7ULL));
+      double s = 0.0;
+      for (int q = 0; q < g_rw; ++q) s += g_w[(size_t)q * n + i] * t[q + (size_t)c * g_rw];
+      bx[(size_t)c * n + i] = d * x[(size_t)c * n + i] + 0.1 * s;
+    }
+  free(t);
+}
+
 void orc_synth_precnd(const int* pn, const int* pm, const double* fac, const double* x, double* px)
 {
   int n = *pn, m = *pm;

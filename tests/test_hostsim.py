@@ -141,6 +141,31 @@ def test_two_ranks_gloo_equals_one_rank(sim, tmp_path, solver, guess):
         assert np.abs(v2[:, :t].T @ v2[:, :t] - np.eye(t)).max() < 1e-12
 
 
+def test_eight_ranks_gloo_at_the_cfg4_block_width_match_the_oracle(sim, oracle, tmp_path):
+    """BASELINE cfg 4's split (Davidson, 16 roots, n_max = 21, max_dav = 20) on EIGHT row shards over gloo -- eight shard offsets of
+    the generator and of the built-in operator, `shard_rows`' short last shard, blocks of two column tiles -- against the ORACLE on
+    one rank (eigenvalues to 1e-11 relative against the 1-rank reference result, iteration counts reported): the
+    8-rank path cannot run on hardware here, so its host logic and its reduction points run on the host engine."""
+    n, t, m = 20_000, 16, 21
+    spec = dict(n=n, n_targ=t, n_max=m, max_dav=20, tol=1e-9, solver="davidson", guess="unit", seed=3)
+    many = _run_world(tmp_path, spec, 8)
+    oracle.synth_setup(n, 0, n)
+    g = np.zeros((n, m), order="F")
+    g[np.arange(m), np.arange(m)] = 1.0
+    eo, vo, oko, tr = oracle.davidson(n, t, m, 200, 1e-9, 20, 0.0, oracle.fn("orc_synth_matvec"), oracle.fn("orc_synth_precnd"), g)
+    assert oko and all(bool(r["ok"]) for r in many)
+    assert all(np.array_equal(many[0]["eig"], r["eig"]) and int(r["iters"]) == int(many[0]["iters"]) and
+               int(r["cols"]) == int(many[0]["cols"]) for r in many)                    # identical decisions on all eight ranks
+    assert np.allclose(many[0]["eig"][:t], eo[:t], rtol=1e-11, atol=0)
+    assert abs(int(many[0]["iters"]) - tr.iters) <= max(1, tr.iters // 10), (int(many[0]["iters"]), tr.iters)
+    rows = [r["vec"].shape[0] for r in many]
+    assert sum(rows) == n and all(int(many[i + 1]["row0"]) == int(many[i]["row0"]) + rows[i] for i in range(7))
+    assert rows[-1] < rows[0] and all(x % 64 == 0 for x in rows[:-1])                   # (the short last shard)
+    v = np.vstack([r["vec"] for r in many]); sgn = np.sign((v * vo).sum(0))
+    assert np.abs(v * sgn - vo)[:, :t].max() < 1e-6
+    assert np.abs(v[:, :t].T @ v[:, :t] - np.eye(t)).max() < 1e-12
+
+
 PENDING_WORKER = r"""
 import os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised multi-rank runs on ONE GPU (2 .. 4 ranks sharing the device: peer-to-peer mailboxes or the reduction hook over
-gloo) against the single-rank run of the same problem: row counts that are no multiple of anything, block widths 2 .. 37,
+gloo) against the single-rank run of the same problem AND the oracle (oracle/pyoracle.py, one rank): row counts that are no multiple of anything, block widths 2 .. 37,
 Davidson / LOBPCG / generalised variants on the built-in operators.  Checked: every rank takes identical decisions (same
 eigenvalues to the bit, same iteration count), the result equals the single-rank result, the shards stitch together.
 
@@ -14,6 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import test_multirank_gpu as tm  # noqa: E402  (worker script and launcher of the test suite)
+from oracle.pyoracle import Oracle  # noqa: E402  (the checker: every multi-rank result is also held against the oracle's)
+
+ORACLE = Oracle()
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -44,8 +47,12 @@ for it in range(cases):
         v = np.vstack([r["vec"] for r in many]); v1 = one["vec"]
         sgn = np.sign((v1 * v).sum(0))
         res["vec"] = float(np.abs(v * sgn - v1)[:, :t].max())
+        eo, vo, oko, ito = tm.oracle_run(ORACLE, spec)
+        res["eig_vs_oracle"] = float(np.abs(many[0]["eig"][:t] / eo[:t] - 1.0).max())
+        res["iters_oracle"] = ito
         good = (res["all_ok"] and res["same_bits_on_all_ranks"] and res["eig_vs_one_rank"] < 1e-10 and res["vec"] < 1e-5 and
-                abs(res["iters"][0] - res["iters"][1]) <= max(1, res["iters"][1] // 5) and v.shape == v1.shape)
+                abs(res["iters"][0] - res["iters"][1]) <= max(1, res["iters"][1] // 5) and v.shape == v1.shape and
+                oko and res["eig_vs_oracle"] < 1e-10 and abs(res["iters"][0] - ito) <= max(2, ito // 5))
         print(("ok  " if good else "FAIL"), dict(spec, world=world), res, flush=True)
         bad += 0 if good else 1
 print(f"{cases} multi-rank cases, {bad} failures", flush=True)
