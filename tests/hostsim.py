@@ -7,8 +7,15 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "tests", "_build")
+# $DIAGLIB_HOSTSIM_SANITIZE=1 (tools/sanitize_cpu.sh): the same library with AddressSanitizer + UndefinedBehaviorSanitizer in every
+# C / C++ translation unit -- the product's host logic and small dense kernels (2 650 lines of hand-written LAPACK replacements and
+# pointer arithmetic) under a memory-error checker.  The caller preloads libasan / libubsan (python itself is not instrumented).
+SANITIZE = bool(os.environ.get("DIAGLIB_HOSTSIM_SANITIZE"))
+if SANITIZE:
+    BUILD = os.path.join(ROOT, "tests", "_build_asan")
 LIB = os.path.join(BUILD, "libdiaglib_hostsim.so")
 FLANG = "/opt/rocm/lib/llvm/bin/flang"
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g"] if SANITIZE else []
 
 
 def build() -> str:
@@ -32,15 +39,15 @@ def build() -> str:
     objs = []
     for s in srcs_cxx:
         o = os.path.join(BUILD, os.path.basename(s) + ".o")
-        run(["g++", "-O2", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-DSD_SINGLE_ISA", "-Wno-psabi", "-c", s, "-o", o]); objs.append(o)
+        run(["g++", "-O1" if SANITIZE else "-O2", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-DSD_SINGLE_ISA", "-Wno-psabi"] + SAN + ["-c", s, "-o", o]); objs.append(o)
     for s in srcs_c:
         o = os.path.join(BUILD, os.path.basename(s) + ".o")
-        run(["gcc", "-O3", "-march=x86-64-v3", "-fopenmp", "-fPIC", "-c", s, "-o", o]); objs.append(o)
+        run(["gcc", "-O1" if SANITIZE else "-O3", "-march=x86-64-v3", "-fopenmp", "-fPIC"] + SAN + ["-c", s, "-o", o]); objs.append(o)
     for s in srcs_f:
         o = os.path.join(BUILD, os.path.basename(s) + ".o")
         run([FLANG, "-O2", "-fPIC", "-c", s, "-o", o, "-module-dir", BUILD, "-I", BUILD]); objs.append(o)
     rt = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/*/libflang_rt.runtime.a")
     rt = rt or glob.glob(os.path.realpath("/opt/rocm") + "/lib/llvm/lib/clang/*/lib/*/libflang_rt.runtime.a")
-    run(["g++", "-shared", "-fPIC", "-fopenmp", "-o", LIB] + objs +
+    run(["g++", "-shared", "-fPIC", "-fopenmp"] + SAN + ["-o", LIB] + objs +
         ["-L" + os.path.dirname(rt[0]), "-lflang_rt.runtime", "-Wl,-Bsymbolic", "-lm"])
     return LIB

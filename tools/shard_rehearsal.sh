@@ -3,8 +3,8 @@
 # products travel through the one-shot peer-to-peer all-reduce (the transport of the real run).  What it shows: the
 # per-solve time of one shard including every cross-rank exchange -- the latency floor of the N-GPU run -- NOT its
 # bandwidth (the ranks share one HBM).   bash tools/shard_rehearsal.sh [ranks...]
-# (At most 6 ranks: the GPU pool's process guard ends a run with more than 6 processes on one card, so the 8 mailboxes of the
-#  driver's 8-GPU run cannot be rehearsed on one device here; 6 ranks leave the last shard short like 8 do.)
+# (At most 5 ranks: the GPU pool's process guard ends a run with more than 6 processes on one card -- the ranks and their launcher --
+#  so the 8 mailboxes of the driver's 8-GPU run cannot be rehearsed on one device here.)
 set -e
 mkdir -p gpurun_out
 for np in "${@:-2 4}"; do
