@@ -102,6 +102,13 @@ def _reference_buckets(text: str):
     return out or None
 
 
+def _reference_iterations(text: str):
+    """iterations of the reference's verbose table (format 1040 of diaglib.f90: `iter root eigenvalue rms max ok` rows): the largest
+    iteration number printed"""
+    its = [int(m.group(1)) for m in re.finditer(r"^\s+(\d+)\s+\d+\s+-?\d+\.\d{12}\s+\S+\s+\S+\s+[TF]\s*$", text, re.M)]
+    return max(its) if its else None
+
+
 def cpu_baseline(n_sample: int, n_targ: int, n_max: int, max_dav: int, tol: float, flops_per_row: float):
     """Reference (or port) on the host cores, bounded sample of the same workload."""
     from oracle.pyoracle import Oracle, Reference
@@ -110,8 +117,9 @@ def cpu_baseline(n_sample: int, n_targ: int, n_max: int, max_dav: int, tol: floa
     guess = np.zeros((n_sample, n_max), order="F")
     guess[np.arange(n_max), np.arange(n_max)] = 1.0
     mv, pc = o.fn("orc_synth_matvec"), o.fn("orc_synth_precnd")
-    kind, buckets = "port", None
+    kind, buckets, ref_iters = "port", None, None
     t0 = time.perf_counter()
+    o.synth_counters(reset=True)
     try:
         ref = Reference()
         kind = "reference"
@@ -122,12 +130,21 @@ def cpu_baseline(n_sample: int, n_targ: int, n_max: int, max_dav: int, tol: floa
             if hasattr(ref.lib, "ref_flush"):
                 ref.lib.ref_flush()                    # the table sits in the Fortran runtime's buffer of unit 6
         buckets = _reference_buckets(cap.text)
+        ref_iters = _reference_iterations(cap.text)
     except (OSError, FileNotFoundError):
+        o.synth_counters(reset=True)
         t0 = time.perf_counter()
-        _, _, ok, _ = o.davidson(n_sample, n_targ, n_max, 100, tol, max_dav, 0.0, mv, pc, guess)
+        _, _, ok, tr_ = o.davidson(n_sample, n_targ, n_max, 100, tol, max_dav, 0.0, mv, pc, guess)
         dt = time.perf_counter() - t0
+        ref_iters = tr_.iters
+    counters = o.synth_counters()
     flops = flops_per_row * n_sample
+    # what the CPU run itself did (the shared flop numerator is the GPU run's reference-schedule count per row: it is the CPU run's
+    # too when both took the same iterations over the same block widths -- checkable from these two numbers against config.iters /
+    # config.matvec_cols of the same line)
     res = {"value": flops / dt / 1e9, "unit": "GFLOP/s", "cores": CPU_THREADS, "host_cpus": HOST_CPUS, "kind": kind,
+           "iters": ref_iters, "matvec_cols": counters["matvec_cols"], "matvec_calls": counters["matvec_calls"],
+           "precnd_cols": counters["precnd_cols"],
            "seconds_whole_call": round(dt, 3),
            "sample": f"same Davidson-Liu solve (synthetic operator, {n_targ} roots, n_max={n_max}, tol={tol:g}) at "
                      f"n={n_sample} rows, whole call incl. the reference's allocation + zero-fill of its panels, "

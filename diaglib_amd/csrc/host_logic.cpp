@@ -67,11 +67,31 @@ thread_local DefaultCtxOwner g_default_owner;
 // built-in operator callbacks have the reference's context-free shape; they act on the calling thread's setup
 thread_local dla_ctx* g_synth_ctx = nullptr;
 thread_local dla_ctx* g_spmm_ctx = nullptr;
+// The sample operators have the reference's callback shape -- void, no status (README.md:34-35) -- so a failure inside one (used before
+// its setup, an engine error) is left here for the trampoline that called it: dla_call_matvec / dla_call_precnd / dla_call_lrprec
+// return it as their own status (the Fortran drivers then end the program the way they end it for every engine failure).  Nothing
+// in the library calls abort() once a context exists (round-5 review: the process holds the GPU).
+thread_local int g_cb_status = 0;
+thread_local std::string g_cb_msg;
+void callback_failed(int code, const std::string& msg)
+{
+  if (g_cb_status == 0) { g_cb_status = code; g_cb_msg = msg; }
+  std::fprintf(stderr, "diaglib_amd: %s\n", msg.c_str());
+}
 
 int fail(dla_ctx* c, int code, const std::string& msg)
 {
   if (c) c->err = msg;
   return code;
+}
+
+// status a sample-operator callback left behind (see g_cb_status); clears it
+int callback_status(dla_ctx* c)
+{
+  if (g_cb_status == 0) return DLA_OK;
+  const int code = g_cb_status;
+  g_cb_status = 0;
+  return fail(c, code, g_cb_msg);
 }
 
 int engfail(dla_ctx* c, int code)
@@ -1222,9 +1242,12 @@ int dla_call_matvec(dla_ctx* c, dla_matvec_fn fn, int n, int m, const double* x,
     int st = c->eng->callback_begin(order);
     if (st) return engfail(c, st);
     fn(&n, &m, x, ax);
+    if (int cbs = callback_status(c)) { (void)c->eng->callback_end(order); return cbs; }
     return engfail(c, c->eng->callback_end(order));
   }
-  return staged_callback(c, n, m, x, ax, [&](int mc, const double* hx, double* hy) { fn(&n, &mc, hx, hy); });
+  const int sts = staged_callback(c, n, m, x, ax, [&](int mc, const double* hx, double* hy) { fn(&n, &mc, hx, hy); });
+  if (int cbs = callback_status(c)) return cbs;
+  return sts;
 }
 
 // Expansion step of the Davidson / LOBPCG drivers (include/diaglib_amd.h).  The three operations form a dependent chain on
@@ -1728,9 +1751,12 @@ int dla_call_precnd(dla_ctx* c, dla_precnd_fn fn, int n, int m, double fac, cons
     int st = c->eng->callback_begin(order);
     if (st) return engfail(c, st);
     fn(&n, &m, &fac, x, px);
+    if (int cbs = callback_status(c)) { (void)c->eng->callback_end(order); return cbs; }
     return engfail(c, c->eng->callback_end(order));
   }
-  return staged_callback(c, n, m, x, px, [&](int mc, const double* hx, double* hy) { fn(&n, &mc, &fac, hx, hy); });
+  const int sts = staged_callback(c, n, m, x, px, [&](int mc, const double* hx, double* hy) { fn(&n, &mc, &fac, hx, hy); });
+  if (int cbs = callback_status(c)) return cbs;
+  return sts;
 }
 
 // linear-response preconditioner lrprec(n,m,fac,xp,xm,yp,ym) (reference diaglib.f90:1317, caller main.f90:257-281):
@@ -1745,6 +1771,7 @@ int dla_call_lrprec(dla_ctx* c, dla_lrprec_fn fn, int n, int m, double fac, cons
     int st = c->eng->callback_begin(order);
     if (st) return engfail(c, st);
     fn(&n, &m, &fac, xp, xm, yp, ym);
+    if (int cbs = callback_status(c)) { (void)c->eng->callback_end(order); return cbs; }
     return engfail(c, c->eng->callback_end(order));
   }
   const size_t bytes = sizeof(double) * (size_t)n * m;
@@ -1756,6 +1783,7 @@ int dla_call_lrprec(dla_ctx* c, dla_lrprec_fn fn, int n, int m, double fac, cons
   if (!st) st = c->eng->d2h(hx + (size_t)n * m, xm, bytes);
   if (st) return engfail(c, st);
   fn(&n, &m, &fac, hx, hx + (size_t)n * m, hy, hy + (size_t)n * m);
+  if (int cbs = callback_status(c)) return cbs;
   st = c->eng->h2d(yp, hy, bytes);
   if (!st) st = c->eng->h2d(ym, hy + (size_t)n * m, bytes);
   return engfail(c, st);
@@ -1782,23 +1810,23 @@ int dla_synth_setup(dla_ctx* c, long long n_global, long long row0, int n_local,
 void dla_synth_matvec(const int* n, const int* m, const double* x, double* ax)
 {
   dla_ctx* c = g_synth_ctx;
-  if (!c) { std::fprintf(stderr, "diaglib_amd: dla_synth_matvec before dla_synth_setup\n"); std::abort(); }
-  if (c->eng->synth_matvec(*n, *m, x, ax)) { std::fprintf(stderr, "diaglib_amd: synth_matvec failed: %s\n", c->eng->err.c_str()); std::abort(); }
+  if (!c) { callback_failed(DLA_ERR_ARG, "dla_synth_matvec before dla_synth_setup"); return; }
+  if (int st = c->eng->synth_matvec(*n, *m, x, ax)) callback_failed(st, "synth_matvec failed: " + c->eng->err);
 }
 
 void dla_synth_precnd(const int* n, const int* m, const double* fac, const double* x, double* px)
 {
   dla_ctx* c = g_synth_ctx;
-  if (!c) { std::fprintf(stderr, "diaglib_amd: dla_synth_precnd before dla_synth_setup\n"); std::abort(); }
-  if (c->eng->synth_precnd(*n, *m, *fac, x, px)) { std::fprintf(stderr, "diaglib_amd: synth_precnd failed: %s\n", c->eng->err.c_str()); std::abort(); }
+  if (!c) { callback_failed(DLA_ERR_ARG, "dla_synth_precnd before dla_synth_setup"); return; }
+  if (int st = c->eng->synth_precnd(*n, *m, *fac, x, px)) callback_failed(st, "synth_precnd failed: " + c->eng->err);
 }
 
 // sample operators of the linear-response / generalised drivers (hip_engine.hip SynthKind), reference callback shapes
 static void synth_kind(int kind, const char* what, const int* n, const int* m, const double* x, double* y)
 {
   dla_ctx* c = g_synth_ctx;
-  if (!c) { std::fprintf(stderr, "diaglib_amd: %s before dla_synth_setup\n", what); std::abort(); }
-  if (c->eng->synth_apply(kind, *n, *m, x, y)) { std::fprintf(stderr, "diaglib_amd: %s failed: %s\n", what, c->eng->err.c_str()); std::abort(); }
+  if (!c) { callback_failed(DLA_ERR_ARG, std::string(what) + " before dla_synth_setup"); return; }
+  if (int st = c->eng->synth_apply(kind, *n, *m, x, y)) callback_failed(st, std::string(what) + " failed: " + c->eng->err);
 }
 void dla_synth_apbmul(const int* n, const int* m, const double* x, double* y) { synth_kind(1, "dla_synth_apbmul", n, m, x, y); }
 void dla_synth_ambmul(const int* n, const int* m, const double* x, double* y) { synth_kind(2, "dla_synth_ambmul", n, m, x, y); }
@@ -1808,8 +1836,8 @@ void dla_synth_metric(const int* n, const int* m, const double* x, double* y) { 
 static void synth_lrp(int variant, const int* n, const int* m, const double* fac, const double* xp, const double* xm, double* yp, double* ym)
 {
   dla_ctx* c = g_synth_ctx;
-  if (!c) { std::fprintf(stderr, "diaglib_amd: dla_synth_lrprec before dla_synth_setup\n"); std::abort(); }
-  if (c->eng->synth_lrprec(variant, *n, *m, *fac, xp, xm, yp, ym)) { std::fprintf(stderr, "diaglib_amd: synth_lrprec failed: %s\n", c->eng->err.c_str()); std::abort(); }
+  if (!c) { callback_failed(DLA_ERR_ARG, "dla_synth_lrprec before dla_synth_setup"); return; }
+  if (int st = c->eng->synth_lrprec(variant, *n, *m, *fac, xp, xm, yp, ym)) callback_failed(st, "synth_lrprec failed: " + c->eng->err);
 }
 void dla_synth_lrprec1(const int* n, const int* m, const double* fac, const double* xp, const double* xm, double* yp, double* ym) { synth_lrp(1, n, m, fac, xp, xm, yp, ym); }
 void dla_synth_lrprec2(const int* n, const int* m, const double* fac, const double* xp, const double* xm, double* yp, double* ym) { synth_lrp(2, n, m, fac, xp, xm, yp, ym); }
@@ -1834,15 +1862,15 @@ int dla_spmm_setup_csr_sharded(dla_ctx* c, int n_local, long long row0, long lon
 void dla_spmm_matvec(const int* n, const int* m, const double* x, double* ax)
 {
   dla_ctx* c = g_spmm_ctx;
-  if (!c) { std::fprintf(stderr, "diaglib_amd: dla_spmm_matvec before dla_spmm_setup_csr\n"); std::abort(); }
-  if (c->eng->spmm_matvec(*n, *m, x, ax)) { std::fprintf(stderr, "diaglib_amd: spmm_matvec failed: %s\n", c->eng->err.c_str()); std::abort(); }
+  if (!c) { callback_failed(DLA_ERR_ARG, "dla_spmm_matvec before dla_spmm_setup_csr"); return; }
+  if (int st = c->eng->spmm_matvec(*n, *m, x, ax)) callback_failed(st, "spmm_matvec failed: " + c->eng->err);
 }
 
 void dla_spmm_precnd(const int* n, const int* m, const double* fac, const double* x, double* px)
 {
   dla_ctx* c = g_spmm_ctx;
-  if (!c) { std::fprintf(stderr, "diaglib_amd: dla_spmm_precnd before dla_spmm_setup_csr\n"); std::abort(); }
-  if (c->eng->spmm_precnd(*n, *m, *fac, x, px)) { std::fprintf(stderr, "diaglib_amd: spmm_precnd failed: %s\n", c->eng->err.c_str()); std::abort(); }
+  if (!c) { callback_failed(DLA_ERR_ARG, "dla_spmm_precnd before dla_spmm_setup_csr"); return; }
+  if (int st = c->eng->spmm_precnd(*n, *m, *fac, x, px)) callback_failed(st, "spmm_precnd failed: " + c->eng->err);
 }
 
 }  // extern "C"

@@ -216,12 +216,22 @@ void orc_synth_setup(long long n_global, long long row0, int n_local, int rank_w
   }
 }
 
+/* call counters of the synthetic operator: what a driver (the reference's, timed by bench.py's cpu_baseline leg) actually asked of
+ * its callbacks -- calls and block columns of matvec and precnd since the last reset */
+static long long g_cnt[4] = {0, 0, 0, 0};
+void orc_synth_counters(int reset, long long* out4)
+{
+  if (out4) for (int i = 0; i < 4; ++i) out4[i] = g_cnt[i];
+  if (reset) for (int i = 0; i < 4; ++i) g_cnt[i] = 0;
+}
+
 const double* orc_synth_w(void) { return g_w; }
 const double* orc_synth_diag(void) { return g_diag; }
 
 void orc_synth_matvec(const int* pn, const int* pm, const double* x, double* ax)
 {
   int n = *pn, m = *pm;
+  g_cnt[0] += 1; g_cnt[1] += m;
   double* t = (double*)malloc(sizeof(double) * (size_t)g_rw * m);
   orc_gemm_tn(n, g_rw, m, g_w, n, x, n, t, g_rw);   /* t = W^T x */
 #pragma omp parallel for schedule(static)
@@ -258,6 +268,7 @@ void orc_synth_metric(const int* pn, const int* pm, const double* x, double* bx)
 void orc_synth_precnd(const int* pn, const int* pm, const double* fac, const double* x, double* px)
 {
   int n = *pn, m = *pm;
+  g_cnt[2] += 1; g_cnt[3] += m;
 #pragma omp parallel for schedule(static)
   for (int c = 0; c < m; ++c)
     for (int i = 0; i < n; ++i) {

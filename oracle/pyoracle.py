@@ -188,6 +188,12 @@ class Oracle:
         self.lib.orc_synth_setup(n_global, row0, n_local, rank_w, sigma)
         self._synth = (n_local, rank_w)
 
+    def synth_counters(self, reset=False):
+        """calls / block columns the synthetic operator's matvec and precnd have seen since the last reset"""
+        out = (C.c_longlong * 4)()
+        self.lib.orc_synth_counters(int(reset), out)
+        return dict(matvec_calls=int(out[0]), matvec_cols=int(out[1]), precnd_calls=int(out[2]), precnd_cols=int(out[3]))
+
     def synth_w(self):
         n, r = self._synth
         return np.ctypeslib.as_array(self.lib.orc_synth_w(), (r, n)).T.copy(order="F")

@@ -21,6 +21,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    if os.environ.get("DIAGLIB_HOSTSIM_SANITIZE"):
+        # tools/sanitize_cpu.sh: every CPU test of the host-size kernels runs on the ASan + UBSan build (tests/hostsim.py), which
+        # exports the same C-ABI -- tests/test_host_dense.py then exercises the instrumented smalldense.cpp
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import hostsim
+        from diaglib_amd import capi
+        capi.load(hostsim.build())
 
 
 @pytest.fixture(scope="session")

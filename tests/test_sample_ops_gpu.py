@@ -193,3 +193,35 @@ def test_full_size_generalised_residuals(dev, solver):
             p_.free()
     finally:
         dev.trim()
+
+
+def test_a_sample_operator_used_before_its_setup_returns_an_error():
+    """Round-5 review: the sample-operator callbacks (reference callback shape: void, no status) used to abort() the process -- which
+    holds the GPU -- when they failed.  They now leave their failure to the trampoline that called them (dla_call_matvec /
+    dla_call_precnd), which returns it as its own status.  A fresh host thread has no operator set up (the setup belongs to the
+    calling thread); the process survives, the context stays usable."""
+    import threading
+    seen = {}
+
+    def work():
+        c = capi.Context()
+        try:
+            c.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+            x, y = c.panel(np.ones((64, 2), order="F")), c.panel(64, 2)
+            for name, call in (("matvec", lambda: c.synth_matvec(x, y)),
+                               ("spmm", lambda: c._chk(c.lib.dla_call_matvec(c.h, capi.fn_address("dla_spmm_matvec"), 64, 2, x.ptr, y.ptr)))):
+                try:
+                    call()
+                    seen[name] = "no error"
+                except capi.DlaError as e:
+                    seen[name] = str(e)
+            c.synth_setup(64, 0, 64)                 # ... and the same context works once the operator exists
+            c.synth_matvec(x, y)
+            seen["after"] = float(np.abs(y.download()).max())
+        finally:
+            c.destroy()
+
+    t = threading.Thread(target=work)
+    t.start(); t.join()
+    assert "before dla_synth_setup" in seen["matvec"] and "before dla_spmm_setup_csr" in seen["spmm"], seen
+    assert seen["after"] > 0.0

@@ -19,7 +19,7 @@ mkdir -p profiles/r06
   echo "# instrumented: diaglib_amd/csrc/host_logic.cpp, diaglib_amd/csrc/smalldense.cpp, oracle/hostsim_engine.cpp, oracle/oracle.c, oracle/oracle_ops.c"
   echo "# ASAN_OPTIONS=$ASAN_OPTIONS  UBSAN_OPTIONS=$UBSAN_OPTIONS"
 } > "$out"
-python -m pytest tests/test_hostsim.py tests/test_ortho_qr.py tests/test_lr.py tests/test_trace_text.py tests/test_spmm_sharded.py \
+python -m pytest tests/test_host_dense.py tests/test_hostsim.py tests/test_ortho_qr.py tests/test_lr.py tests/test_trace_text.py tests/test_spmm_sharded.py \
        -q -m "not gpu" -p no:cacheprovider "$@" 2>&1 | tee -a "$out"
 rc=${PIPESTATUS[0]}
 echo "# exit code $rc; sanitizer reports in the output above: $(grep -c 'ERROR: AddressSanitizer\|runtime error:' "$out")" >> "$out"
