@@ -109,6 +109,8 @@ struct BlockOps {
   // columns and is NOT the identity (a projection against the stored columns alone would leave |X_c^T X_c - I| of what it removes),
   // -1 = the copy does not describe them.
   virtual int basis_state(int /*m*/) const { return 0; }
+  // basis columns (block included) up to which the device-driven chain can project with the caller's D (0: not at all)
+  virtual int basis_capacity() const { return 0; }
   // the device-driven chain must not take the next calls: the host-driven loop runs (dla_expand_project mode 5 on a shape the device
   // cannot project exactly, mode 6)
   bool chain_off = false;

@@ -4292,12 +4292,16 @@ struct HipEngine : dla::Engine {
   // DMAT_LD -- what the exact projection of ortho_tail16 multiplies with.  Columns arrive in order, block by block.
   static const int DMAT_LD = T16_ZS_ROWS;
   double* d_dmat = nullptr;
-  std::vector<double> h_dmat;        // the same on the host (basis_dd)
-  int dmat_cols = 0;                 // columns described so far (-1: the basis has outgrown the buffer)
+  // the same on the host, column by column (column j: rows 0 .. j) -- what the host-driven loop multiplies with (basis_dd).  The host
+  // copy has no width limit: a basis that outgrows the device copy (DMAT_LD columns) goes on with blocks finished in memory by the
+  // host-driven loop, exactly, instead of being refused or -- before round 6 -- silently projected against unfinished columns
+  std::vector<std::vector<double>> h_dcols;
+  int dmat_cols = 0;                 // columns described so far
   bool dmat_nontrivial = false;      // some entry differs from the identity at all (exact comparison: a rounding-level pending factor
                                      // already switches the chains to the D D^T assembly -- two more k x k x m products per step --
                                      // because a threshold would make the projections inexact by that threshold)
   int basis_state(int m) const override { return m <= 0 ? 0 : dmat_cols != m ? -1 : dmat_nontrivial ? 1 : 0; }
+  int basis_capacity() const override { return DMAT_LD; }
   bool basis_exact_ok() const override { return !hook && !local_only && tune[6] != 3 && tune[6] != 5 && tune[6] != 14 && lds_limit > (size_t)128 * 1024; }   // (knob 6 = 14: A/B, mode 5 behaves like mode 4)
   int basis_dd(int m, int k, double* xu, int ld) override
   {
@@ -4308,14 +4312,14 @@ struct HipEngine : dla::Engine {
     for (int j = 0; j < k; ++j) {
       double* s = xu + (size_t)j * ld;
       for (int r = 0; r < m; ++r) {                      // y = D^T s: column r of D, rows 0 .. r
-        const double* dr = &h_dmat[(size_t)r * DMAT_LD];
+        const double* dr = h_dcols[r].data();
         double acc = 0.0;
         for (int i = 0; i <= r; ++i) acc += dr[i] * s[i];
         y[r] = acc;
       }
       for (int i = 0; i < m; ++i) s[i] = 0.0;
       for (int q = 0; q < m; ++q) {                      // s = D y
-        const double* dq = &h_dmat[(size_t)q * DMAT_LD];
+        const double* dq = h_dcols[q].data();
         const double yq = y[q];
         for (int i = 0; i <= q; ++i) s[i] += dq[i] * yq;
       }
@@ -4324,22 +4328,22 @@ struct HipEngine : dla::Engine {
   }
   int basis_sync(int m, int k, const double* dmat, int ld) override
   {
-    if (k <= 0) { dmat_cols = 0; dmat_nontrivial = false; return DLA_OK; }
-    if (dmat_cols < 0) return DLA_OK;
+    if (k <= 0) { dmat_cols = 0; dmat_nontrivial = false; h_dcols.clear(); return DLA_OK; }
     if (m != dmat_cols) { err = "basis_sync: the blocks of D arrive in order (" + std::to_string(dmat_cols) + " columns known, block starts at " + std::to_string(m) + ")"; return DLA_ERR_ARG; }
-    if (m + k > DMAT_LD) {
-      // beyond the copy's width: a basis whose blocks have all been finished in memory so far may go on that way (nothing to store:
-      // D = I), anything else is refused -- later projections could not be made exact and would silently lose orthogonality
-      // (round-5 advisor)
-      bool ident = !dmat_nontrivial;
-      for (int j = 0; j < k && ident; ++j)
-        for (int i = 0; i <= m + j; ++i)
-          if (dmat[(size_t)i + (size_t)(m + j) * ld] != (i == m + j ? 1.0 : 0.0)) { ident = false; break; }
-      if (ident) { dmat_cols = m + k; return DLA_OK; }
-      dmat_cols = -1;
-      err = "basis_sync: a basis with pending blocks cannot grow beyond " + std::to_string(DMAT_LD) + " columns (finish the blocks in memory: dla_expand_project mode 0 / 6)";
-      return DLA_ERR_ARG;
+    h_dcols.resize((size_t)m + k);
+    for (int j = 0; j < k; ++j) {
+      std::vector<double>& col = h_dcols[(size_t)m + j];
+      col.resize((size_t)m + j + 1);
+      for (int i = 0; i <= m + j; ++i) {
+        const double v = dmat[(size_t)i + (size_t)(m + j) * ld];
+        col[i] = v;
+        if (v != (i == m + j ? 1.0 : 0.0)) dmat_nontrivial = true;
+      }
     }
+    dmat_cols = m + k;
+    // the device copy takes the first DMAT_LD columns (what the exact projection of ortho_tail16 keeps in LDS); a block that reaches
+    // beyond them stays on the host only -- dla_expand_project sends such a basis through the host-driven loop (round-5 advisor)
+    if (m + k > DMAT_LD) return DLA_OK;
     bind();
     if (!d_dmat) {
       HIPCHK(hipMalloc((void**)&d_dmat, sizeof(double) * (size_t)DMAT_LD * DMAT_LD));
@@ -4351,15 +4355,7 @@ struct HipEngine : dla::Engine {
     const int stc = stage_slot(bytes, &h, &slot);
     if (stc) return stc;
     std::memset(h, 0, bytes);
-    if (h_dmat.empty()) h_dmat.assign((size_t)DMAT_LD * DMAT_LD, 0.0);
-    for (int j = 0; j < k; ++j)
-      for (int i = 0; i <= m + j; ++i) {
-        const double v = dmat[(size_t)i + (size_t)(m + j) * ld];
-        h[(size_t)j * DMAT_LD + i] = v;
-        h_dmat[(size_t)(m + j) * DMAT_LD + i] = v;
-        if (v != (i == m + j ? 1.0 : 0.0)) dmat_nontrivial = true;
-      }
-    dmat_cols = m + k;
+    for (int j = 0; j < k; ++j) std::memcpy(h + (size_t)j * DMAT_LD, h_dcols[(size_t)m + j].data(), sizeof(double) * (size_t)(m + j + 1));
     return stage_commit(slot, bytes, d_dmat + (size_t)m * DMAT_LD);
   }
 
@@ -4398,7 +4394,7 @@ struct HipEngine : dla::Engine {
     //  loop, which ends on the reference's growth test, must not take such a block)
     auto not_handled = [&]() {
       if (!(basis_exact && m > 0) || dmat_cols == m) return (int)DLA_OK;     // (the host-driven loop projects with D as well: basis_dd)
-      err = "ortho_chain: dla_expand_project mode 5 needs the caller's pending blocks (dla_basis_sync after every block; at most 320 basis columns)";
+      err = "ortho_chain: dla_expand_project mode 5 needs the caller's pending blocks (dla_basis_sync after every block of the basis)";
       return (int)DLA_ERR_ARG;
     };
     if (tune[6] == 3 || chain_off) return not_handled();                  // A/B / the caller's request: host-driven loop
@@ -4425,7 +4421,7 @@ struct HipEngine : dla::Engine {
     const bool rebuilt = drop_final && publish_pending && drop_final_tol <= 0.0;
     // (basis_exact: the caller keeps its pending blocks on the device (dla_basis_sync) and every projection of this chain is exact
     //  against the FINISHED basis -- a loose stored basis costs later chains nothing, so the schedule that ends soonest always)
-    if (basis_exact && vsx && (fold == 0 || dmat_cols != m)) return not_handled();
+    if (basis_exact && vsx && (fold == 0 || dmat_cols != m || (dmat_nontrivial && m > DMAT_LD))) return not_handled();
     const bool x3 = fold == 1 && bx == x && tune[6] != 12 && (x3_cooldown <= 0 || tune[6] == 13 || rebuilt || basis_exact);
     // wider blocks (LDS-loop tail): X^T U and U^T U in ONE sweep when [X | U] fits one pass of the Gram kernel (the plain
     // product with the contiguous panel [X | U] on the left: U follows X, bx == x) and the leading ortho_cd takes one step

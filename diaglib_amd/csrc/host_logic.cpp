@@ -1371,7 +1371,7 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
   // algebra well conditioned (max |S| < 0.05, Gram matrix factorable in one step) -- not by what later projections could absorb
   // (where the device cannot project with D -- wider blocks, a wider basis, an all-reduce hook -- the block is finished in memory,
   //  mode 0: nothing of it stays pending in a basis that later blocks are projected against)
-  const bool exact = mode == 5 && c->pending_blocks && c->eng->basis_exact_ok() && k <= 16 && m + k <= 320;
+  const bool exact = mode == 5 && c->pending_blocks && c->eng->basis_exact_ok() && k <= 16 && m + k <= c->eng->basis_capacity();
   if (mode == 5 || mode == 6) {
     // What the copy of the caller's D says about the m stored columns decides what a call that cannot be exact may do (round-5
     // advisor: the device's ability can change between two calls of one solve -- a refused LDS request lowers the engine's limit --
@@ -1385,7 +1385,7 @@ int dla_expand_project(dla_ctx* c, int mode, int n, int m, int k, double* basis,
     const int bs = c->eng->basis_state(m);
     if (bs < 0)
       return fail(c, DLA_ERR_ARG, "dla_expand_project: the engine's copy of the caller's pending blocks does not describe the columns in front of "
-                                  "this block (dla_basis_sync after every block; a basis with pending blocks holds at most 320 columns)");
+                                  "this block (dla_basis_sync after every block of the basis, identity ones included)");
     if (mode == 6 || (!exact && bs > 0)) {
       struct Flags { dla::Engine* e; explicit Flags(dla::Engine* e_) : e(e_) { e->basis_exact = true; e->chain_off = true; }
                      ~Flags() { e->basis_exact = false; e->chain_off = false; } } flags(c->eng);

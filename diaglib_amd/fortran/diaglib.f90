@@ -768,7 +768,10 @@ contains
       britz  = dev_panel(e%ctx, n, n_max, 'b_evec')
     end if
     allocate (h(s%ld,s%ld), y(s%ld,s%ld), theta(s%ld), dmat(s%ld,s%ld), hraw(s%ld,s%ld), pblk(s%ld,n_max))
-    exact_basis = (.not.with_metric) .and. n_max.le.16 .and. s%ld.le.320
+!   (the engine decides block by block what it can keep pending: blocks of up to 16 columns while the basis fits its copy of D --
+!    BASELINE cfg 4's n_max = 21 gets there once five roots are locked -- everything else is finished in memory, by the device chain
+!    while nothing is pending in front of the block and by the host-driven loop with D D^T otherwise)
+    exact_basis = .not.with_metric
     call reset_pending()
 !
 !   The reference zero-fills both n x lda panels (:1632-1633).  On the device no column is read before it has been
@@ -919,8 +922,9 @@ contains
 !           factor pending (the sweeps of :3543-3544 and :3327 are not run on it): the finished block is [X | U] p for the STORED
 !           columns; its columns of the projected matrix come back for the stored block and are corrected here, D^T h_raw D with
 !           the upper-triangular D that collects the pending blocks of the whole basis.
-!           mode 5 (blocks of up to 16 columns, up to 320 basis columns): the device holds D as well and projects with
-!           X (D D^T) X^T -- what may stay pending is then bounded by the conditioning of the k x k algebra only
+!           mode 5: the device holds D as well and projects with X (D D^T) X^T -- what may stay pending (blocks of up to 16
+!           columns, up to 320 basis columns) is then bounded by the conditioning of the k x k algebra only; shapes beyond that
+!           are finished in memory, exactly against panel*D
 !
             if (exact_basis) then
               if (synced.lt.s%cols) then
@@ -930,7 +934,7 @@ contains
               call chk(e%ctx, dla_expand_project(e%ctx, 5_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
                                                  h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
             else
-!             (wider blocks / a wider basis: the device cannot project with D -- the block is finished in memory, nothing pending)
+!             (with a metric: the block is finished in memory, nothing pending)
               call chk(e%ctx, dla_expand_project(e%ctx, 0_c_int, n, s%cols, s%act, basis, abasis, op, zero, &
                                                  h(1,s%head), s%ld), 'ortho_vs_x + matvec + projection')
             end if

@@ -286,8 +286,9 @@ int  dla_expand_project(dla_ctx* ctx, int mode, int n, int m, int k, double* bas
  * an engine whose LDS limit went down after a refused request -- which can happen between two calls of one solve) the block is
  * finished in memory and dla_pending_block answers [0 ; I]: by mode 0 when the copy of D says the m stored columns are finished
  * (D = I there), by the host-driven loop with every X^T U multiplied by D D^T when they are not -- never by a plain projection
- * against unfinished columns.  The call fails (DLA_ERR_ARG) when the copy does not describe the m columns in front of the block;
- * dla_basis_sync refuses a basis with pending blocks that grows beyond 320 columns.
+ * against unfinished columns.  The call fails (DLA_ERR_ARG) when the copy does not describe the m columns in front of the block.
+ * The engine's HOST copy of D has no width limit: a basis with pending blocks that grows beyond the 320 columns of the device copy
+ * goes on with blocks finished in memory by the host-driven loop (slower: one host wait per operation; exact).
  * mode 6 = the block is finished in memory against the finished basis X D whatever the device could do (host-driven loop with D D^T),
  * operator and projection on the result, nothing pending: the way out for a caller whose dla_basis_admit answered DLA_ERR_ORTHO (the
  * closing factor I - F^T F of the pending block was not positive definite) -- called on the same block, which is still what the
@@ -304,9 +305,10 @@ int  dla_pending_block(dla_ctx* ctx, int m, int k, double* p_host, int ldp, int*
  * dmat^T hraw dmat.  dla_basis_fold: c <- dmat(0:rows,0:rows) c. */
 int  dla_basis_admit(int m, int k, double* p_host, int ldp, int applied, double* hraw, double* dmat, double* h, int ld);
 int  dla_basis_fold(int rows, int ncol, const double* dmat, int ld, double* c, int ldc);
-/* Device copy of the caller's D for dla_expand_project mode 5: columns m .. m+k-1 of dmat (upper triangular, leading dimension ld;
- * rows 0 .. m+k-1 are read) follow the m columns sent so far -- blocks arrive in order, every block of the basis, identity ones
- * included; k <= 0 forgets everything (new solve, restart).  Asynchronous: the host array may be changed when the call returns. */
+/* The engine's copy of the caller's D for dla_expand_project mode 5 (on the device for the first 320 columns, on the host for all of
+ * them): columns m .. m+k-1 of dmat (upper triangular, leading dimension ld; rows 0 .. m+k-1 are read) follow the m columns sent so
+ * far -- blocks arrive in order, every block of the basis, identity ones included; k <= 0 forgets everything (new solve, restart).
+ * Asynchronous: the host array may be changed when the call returns. */
 int  dla_basis_sync(dla_ctx* ctx, int m, int k, const double* dmat, int ld);
 /* The expansion step with a metric B (gen_david_driver diaglib.f90:2170-2190, lobpcg_driver with gen_eig :523-529): on
  * basis = [X | U], bbasis = [BX | BU], abasis = [AX | AU]:  b_ortho_vs_x(X, BX, U) (:3576-3663),  BU = B U (the caller's bvec),

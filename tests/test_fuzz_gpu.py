@@ -24,6 +24,7 @@ SLICES = [
     ("fuzz_degenerate_drivers.py", ["21", "112"]),    # the drivers on operators with multiple / zero / all-equal eigenvalues: never ok with a wrong answer
     ("fuzz_pending_basis.py", ["60", "110"]),         # bases grown through dla_expand_project modes 4 / 5: (panel D) orthonormal, h exact
     ("fuzz_pending_basis.py", ["40", "111", "-1", "wide"]),   # ... blocks of 17 .. 40 columns (mode 4, host-driven loops beyond 223 columns)
+    ("fuzz_pending_basis.py", ["40", "112", "-1", "mixed"]),  # ... mode 5 with a width per block (1 .. 40): wide blocks behind pending narrow ones, bases beyond the device copy of D
 ]
 
 

@@ -297,21 +297,63 @@ def test_a_call_that_cannot_be_exact_still_projects_against_the_finished_basis(c
         ctx.set_shard(-1, 0)
 
 
-def test_a_basis_with_pending_blocks_is_refused_beyond_the_copy(ctx):
-    """dla_basis_sync past 320 columns: fine while every block so far was finished in memory (D = I: nothing to store), refused -- not
-    silently dropped -- once something is pending."""
-    ld = 340
-    eye = np.asfortranarray(np.eye(ld))
+def test_a_basis_with_pending_blocks_goes_on_beyond_the_device_copy(ctx, rng):
+    """The device copy of D holds 320 columns; the engine's host copy has no limit.  A basis with pending blocks that grows beyond
+    320 columns is neither refused nor -- the defect the round-5 advisor found -- projected against its unfinished stored columns: the
+    blocks past the copy are finished in memory by the host-driven loop with X^T U multiplied by D D^T.  22 blocks of 16 columns
+    (352): the first 19 through the device chains with pending parts, the last ones on the host."""
+    n, k, nb = 5000, 16, 22
     try:
-        ctx.basis_sync(0, 0)
-        for m in range(0, ld, 17):
-            ctx.basis_sync(m, 17, eye)                                    # identity blocks all the way: allowed
-        ctx.basis_sync(0, 0)
-        d = eye.copy(order="F")
-        d[3, 20] = 1e-3                                                   # a pending projection in the second block
-        for m in range(0, 306, 17):
-            ctx.basis_sync(m, 17, d)
-        with pytest.raises(capi.DlaError):
-            ctx.basis_sync(306, 17, d)                                    # 323 columns with something pending
+        ctx.set_shard(n, 0); ctx.synth_setup(n, 0, n); ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+        b, ab, dmat, h, n_pending = _grow(ctx, rng, n, k, nb, "random", True, mode=5)
+        assert n_pending >= 8 and np.array_equal(dmat[320:, 320:], np.eye(nb * k - 320))      # (nothing pending past the copy)
+        l = nb * k
+        v = b @ dmat
+        assert np.abs(v.T @ v - np.eye(l)).max() < 50 * EPS, (np.abs(v.T @ v - np.eye(l)).max(), n_pending)
+        href = v.T @ (ab @ dmat)
+        assert np.abs(np.triu(h - href)).max() < 1e-13 * np.abs(href).max()
     finally:
         ctx.basis_sync(0, 0)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)
+
+
+def test_blocks_of_one_and_two_column_tiles_in_one_basis(ctx, rng):
+    """What davidson_core produces at n_max = 21 (BASELINE cfg 4): blocks of 21 ... 17 columns while fewer than five roots are
+    locked -- finished in memory, D = I there -- then blocks of 16 and fewer columns that keep their closing passes pending, and (a C
+    caller may do that) a wide block behind them, which the host-driven loop finishes against panel*D."""
+    n = 6000
+    widths = [21, 21, 20, 18, 16, 12, 8, 8, 19]
+    mv = capi.fn_address("dla_synth_matvec")
+    try:
+        ctx.set_shard(n, 0); ctx.synth_setup(n, 0, n); ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+        ld = sum(widths)
+        x0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, widths[0])))[0])
+        basis = ctx.panel(np.asfortranarray(np.hstack([x0, np.zeros((n, ld - widths[0]))])))
+        abasis = ctx.panel(np.zeros((n, ld), order="F"))
+        k0 = widths[0]
+        ctx.synth_matvec(basis.col(0, k0), abasis.col(0, k0))
+        hraw = np.zeros((ld, ld), order="F"); dmat = np.asfortranarray(np.eye(ld)); h = np.zeros((ld, ld), order="F")
+        b = basis.download(); ab = abasis.download()
+        hraw[:k0, :k0] = b[:, :k0].T @ ab[:, :k0]; h[:k0, :k0] = hraw[:k0, :k0]
+        ctx.basis_sync(0, 0); ctx.basis_sync(0, k0, dmat)
+        m, pending = k0, []
+        for k in widths[1:]:
+            u = b[:, :m] @ rng.standard_normal((m, k)) + 0.3 * rng.standard_normal((n, k))
+            basis.col(m, k).upload(np.asfortranarray(u))
+            h4 = ctx.expand_project(5, basis, abasis, m, k, mv, 0.0)
+            p = ctx.pending_block(m, k)
+            pending.append(bool(np.any(p[:m] != 0.0) or not np.array_equal(p[m:], np.eye(k))))
+            h[:m + k, m:m + k] = h4
+            ctx.basis_admit(m, k, p, hraw, dmat, h, applied=ctx.pending_applied)
+            ctx.basis_sync(m, k, dmat)
+            b = basis.download(); m += k
+        assert not any(pending[:3]) and any(pending[3:7]) and not pending[7]      # wide: finished; narrow: pending; wide again: finished
+        v = b @ dmat
+        assert np.abs(v.T @ v - np.eye(ld)).max() < 50 * EPS, np.abs(v.T @ v - np.eye(ld)).max()
+        href = v.T @ (abasis.download() @ dmat)
+        assert np.abs(np.triu(h - href)).max() < 1e-13 * np.abs(href).max()
+    finally:
+        ctx.basis_sync(0, 0)
+        ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
+        ctx.set_shard(-1, 0)

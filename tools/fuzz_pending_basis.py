@@ -4,7 +4,12 @@ closing pass left to the caller's small matrices): random r
 schedule), block widths 1 .. 16, up to 320 columns, random / nearly dependent / inside-span(X) / tiny-norm blocks, every schedule
 knob.  Checked: (panel D)^T (panel D) = I to 100 eps and h = (panel D)^T A (panel D) to 1e-12.
 
-    python tools/fuzz_pending_basis.py [cases] [seed] [only this case]      (FUZZ_WIDE=1 or a fourth argument `wide`: blocks of 17 .. 40 columns, mode 4)"""
+    python tools/fuzz_pending_basis.py [cases] [seed] [only this case]      (FUZZ_WIDE=1 or a fourth argument `wide`: blocks of 17 .. 40 columns, mode 4;
+                                                                             a fourth argument `mixed`: mode 5 with a width of its own per block,
+                                                                             1 .. 40 columns -- wide blocks are finished in memory, by the device chain
+                                                                             while nothing is pending in front of them and by the host-driven loop with
+                                                                             D D^T otherwise (round-5 advisor), bases of up to 400 columns: beyond the
+                                                                             320 of the device copy of D the host-driven loop takes every block)"""
 import os
 import sys
 
@@ -29,25 +34,37 @@ for it in range(cases):
     mode = int(rng.choice([4, 5, 5]))
     if os.environ.get("FUZZ_WIDE") or (len(sys.argv) > 4 and sys.argv[4] == "wide"):             # blocks of two and three column tiles (the LDS-loop k x k step): mode 4 only
         k = int(rng.integers(17, 41)); nb = int(rng.integers(3, 11)); mode = 4
-    n = int(rng.integers(max(600, 3 * nb * k), 9000))
+    mixed = len(sys.argv) > 4 and sys.argv[4] == "mixed"
+    widths = [k] * nb
+    if mixed:
+        mode = 5
+        nb = int(rng.integers(3, 14))
+        widths = [int(rng.choice([rng.integers(1, 17), rng.integers(1, 17), rng.integers(17, 41)])) for _ in range(nb)]
+        while sum(widths) > 400:
+            widths.pop()
+        nb = len(widths); k = max(widths)
+    n = int(rng.integers(max(600, 3 * sum(widths)), 9000))
     knob = int(rng.choice([0, 0, 12, 13, 15, 16]))
     spec = dict(n=n, k=k, nb=nb, mode=mode, knob=knob)
+    if mixed:
+        spec["widths"] = widths
     try:
         ctx.set_shard(n, 0); ctx.synth_setup(n, 0, n); ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
         ctx.set_option(100 + 6, knob)
-        ld = nb * k
-        x0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, k)))[0])
-        basis = ctx.panel(np.asfortranarray(np.hstack([x0, np.zeros((n, ld - k))])))
+        ld = sum(widths)
+        k0 = widths[0]
+        x0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, k0)))[0])
+        basis = ctx.panel(np.asfortranarray(np.hstack([x0, np.zeros((n, ld - k0))])))
         abasis = ctx.panel(np.zeros((n, ld), order="F"))
-        ctx.synth_matvec(basis.col(0, k), abasis.col(0, k))
+        ctx.synth_matvec(basis.col(0, k0), abasis.col(0, k0))
         hraw = np.zeros((ld, ld), order="F"); dmat = np.asfortranarray(np.eye(ld)); h = np.zeros((ld, ld), order="F")
         b = basis.download(); ab = abasis.download()
-        hraw[:k, :k] = b[:, :k].T @ ab[:, :k]; h[:k, :k] = hraw[:k, :k]
+        hraw[:k0, :k0] = b[:, :k0].T @ ab[:, :k0]; h[:k0, :k0] = hraw[:k0, :k0]
         if mode == 5:
-            ctx.basis_sync(0, 0); ctx.basis_sync(0, k, dmat)
+            ctx.basis_sync(0, 0); ctx.basis_sync(0, k0, dmat)
         kinds = []
         for blk in range(1, nb):
-            m = blk * k
+            m = sum(widths[:blk]); k = widths[blk]
             kind = str(rng.choice(["random", "random", "inside", "dependent", "tiny", "scaled"]))
             kinds.append(kind)
             u = b[:, :m] @ rng.standard_normal((m, k)) + 0.3 * rng.standard_normal((n, k))
