@@ -55,6 +55,9 @@ template <int V, int NT> __device__ __forceinline__ typename VecOf<V>::type ploa
 // may_alias types so that type-based alias analysis cannot reorder them against each other
 typedef double __attribute__((may_alias)) lds_f64;
 typedef v2d __attribute__((may_alias)) lds_v2f64;
+// LDS arrays handed to device functions: address-space-3 pointers (a generic pointer makes every access a flat load)
+typedef __attribute__((address_space(3))) double as3_f64;
+typedef __attribute__((address_space(3))) int as3_i32;
 __device__ __forceinline__ void lds_store2(double* p, v2d v) { *(lds_v2f64*)p = v; }
 __device__ __forceinline__ void lds_store1(double* p, double v) { *(lds_f64*)p = v; }
 __device__ __forceinline__ double lds_load1(const double* p) { return *(const lds_f64*)p; }
@@ -942,44 +945,50 @@ struct RitzArgs {
 // that the plain Ritz step keeps its code (the same tests as run-time branches cost the one-tile kernel 37 %)
 // SCHED (A/B, tune knob 0 = 7 / 8, wide blocks only): 1 = __builtin_amdgcn_iglp_opt(0) in the pipelined loop, 2 = an explicit
 // sched_group_barrier pipeline (four MFMAs, then one coefficient read of a later column step / one panel load of the next stage)
-template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int QT = 0, bool XP = false, int SCHED = 0>
-__global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
+// The sweep of one wave over its row tiles for the column tiles Q0 .. Q0 + KT - 1 of a coefficient block of KTOT tiles (ritz_kernel:
+// Q0 = 0, KT = KTOT, four waves per block; ritz_pair_kernel: two groups of four waves, each with a part of the tiles).  csall: the LDS
+// copy of the whole block, [KTOT][l4][16]; wave: 0 .. 3 inside the group; s_nrm: the group's norm accumulators (KT >= 4 only).
+// Ends with the wave's column sums / maxima in sred ([4][16 KTOT][2]) -- the caller synchronises around it.
+// what a sweep needs of RitzArgs, by value (a reference to the kernel's argument block -- which holds two 48-entry arrays that are
+// indexed at run time -- made the compiler keep a copy of it: 20 ... 90 registers more per kernel)
+struct RitzPanels {
+  const double* v; const double* av; double* evec; double* r; double* avy; double* p2; double* ap2;
+  long long n; int l, l4, k, k2;
+};
+__device__ __forceinline__ RitzPanels ritz_panels(const RitzArgs& a) { return RitzPanels{a.v, a.av, a.evec, a.r, a.avy, a.p2, a.ap2, a.n, a.l, a.l4, a.k, a.k2}; }
+template <int KT, int VEC, int NT, int PIPE, int QT, bool XP, int SCHED, int KTOT, int Q0, bool NRM_LDS>
+__device__ __forceinline__ void ritz_sweep(const RitzPanels a, as3_f64* csall, const int wave, const as3_f64* s_theta, const as3_i32* s_active,
+                                           as3_f64* s_nrm, as3_f64* sred_all, const int blocks_x)
 {
+  // (the LDS arrays come in as address-space-3 pointers: as generic pointers the compiler turned their accesses into flat loads
+  //  with 64-bit addresses -- 20 ... 90 registers more per kernel, spills in the five-tile one)
   constexpr int RG = 16 * VEC;             // rows per wave tile (one row group)
-  extern __shared__ __attribute__((aligned(16))) double cs[];  // [KT][l4][16], later reduction scratch
+  as3_f64* cs = csall + (size_t)Q0 * a.l4 * 16;
   typedef typename VecOf<VEC>::type vec_t;
   const long long n = a.n;
   const int l = a.l, l4 = a.l4;
   constexpr int KF = QT > 0 ? KT - 1 : KT;   // full tiles; the last tile has 4*QT live columns (see mfma_quarter)
-  for (int idx = threadIdx.x; idx < KF * l4 * 16; idx += 256) cs[idx] = a.cpk[idx];
-  if constexpr (QT > 0) {                    // ... and keeps only its 8 leading columns in LDS, [l4][8] (see gemm_kernel)
-    for (int idx = threadIdx.x; idx < l4 * 8; idx += 256) cs[KF * l4 * 16 + idx] = a.cpk[KF * l4 * 16 + (idx >> 3) * 16 + (idx & 7)];
-  }
-  __shared__ double s_theta[48];
-  __shared__ int s_active[48];
-  if (threadIdx.x < 48) { s_theta[threadIdx.x] = a.theta[threadIdx.x]; s_active[threadIdx.x] = a.active[threadIdx.x]; }
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int J0 = 16 * Q0;                // first column of this group's tiles
+  const int lane = threadIdx.x & 63;
   const int i = lane & 15, g = lane >> 4;
   const int i4 = lane & 3;
   const long long ntiles = (n + RG - 1) / RG;
   const int nsteps = l4 / 4;
 
-  constexpr int KR = KT < 3 ? KT : 3;     // tiles that can hold residual columns (m <= 48); further tiles: extra products only
-  constexpr bool TH_LDS = KT >= 4;
-  double th[KR][4];
-  int act[KR][4];
-  double ssq[KR][4], smx[KR][4];
-  // (four and five tiles: the norm accumulators live in LDS, one slot per lane -- 48 registers less in a kernel whose
-  //  accumulators the compiler otherwise shuffles between VGPRs and AGPRs in every stage)
-  __shared__ double s_nrm[TH_LDS ? 4 * 48 * 16 * 2 : 2];
-  double* my_nrm = s_nrm + (TH_LDS ? (size_t)wave * 48 * 16 * 2 + i * 2 : 0);      // [col j][lane i][2], this wave
+  // tiles of this group that can hold residual columns (m <= 48: tiles 0 .. 2 of the block); further tiles: extra products only
+  constexpr int KR0 = (3 - Q0) < 0 ? 0 : (3 - Q0);
+  constexpr int KR = KT < KR0 ? KT : KR0;
+  constexpr int KRA = KR > 0 ? KR : 1;    // (array extents)
+  constexpr bool TH_LDS = NRM_LDS;        // the norm accumulators (and theta / active) live in LDS, one slot per lane
+  double th[KRA][4];
+  int act[KRA][4];
+  double ssq[KRA][4], smx[KRA][4];
+  as3_f64* my_nrm = s_nrm + (TH_LDS ? (size_t)wave * 48 * 16 * 2 + i * 2 : 0);      // [col j][lane i][2], this wave
 #pragma unroll
   for (int q = 0; q < KR; ++q)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int j = 16 * q + g + 4 * reg;
+      const int j = J0 + 16 * q + g + 4 * reg;
       th[q][reg] = s_theta[j];
       act[q][reg] = s_active[j];
       ssq[q][reg] = 0.0;
@@ -987,7 +996,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
       if constexpr (TH_LDS) { my_nrm[(size_t)j * 32 + 0] = 0.0; my_nrm[(size_t)j * 32 + 1] = 0.0; }
     }
 
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)blocks_x * 4) {
     long long row = tile * RG + VEC * i;
     const bool rok = row < n;
     if (!rok) row = 0;
@@ -1134,7 +1143,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
       for (int q = 0; q < KT; ++q)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const int j = 16 * q + g + 4 * reg;
+          const int j = J0 + 16 * q + g + 4 * reg;
           if (j >= a.k + (XP ? a.k2 : 0)) continue;
           const double e0 = avv(0, q, reg), e1 = avv(VEC - 1, q, reg);
           double r0 = aavv(0, q, reg), r1 = aavv(VEC - 1, q, reg);
@@ -1145,8 +1154,9 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
               continue;
             }
           }
-          constexpr int KRm = KR - 1;
-          const int qr = q < KR ? q : KRm;  // (j < k <= 48 implies q < 3; the clamp only keeps the unrolled indices in range)
+          constexpr int KRm = KRA - 1;
+          const int qr = q < KR ? q : KRm;  // (j < k <= 48 implies tile < 3; the clamp only keeps the unrolled indices in range)
+          if constexpr (KR == 0) continue;  // (a group without residual columns: everything it holds is an extra product)
           if (a.avy) pstore<VEC, NT>(a.avy + (size_t)j * (size_t)n + row, vmake<VEC>(r0, r1));
           // (the four- and five-tile kernels sit at the register limit: they read theta / active from LDS per tile)
           const double thv = TH_LDS ? s_theta[j] : th[qr][reg];
@@ -1155,7 +1165,7 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
             r0 = r0 - thv * e0;            // daxpy(-eig), reference diaglib.f90:1729
             if constexpr (TH_LDS) {
               // (same order of additions as the register accumulators of the narrower kernels: same bits)
-              double* slot = my_nrm + (size_t)j * 32;
+              as3_f64* slot = my_nrm + (size_t)j * 32;
               double sq = slot[0], mx = slot[1];
               sq += r0 * r0; mx = fmax(mx, fabs(r0));
               if constexpr (VEC == 2) { r1 = r1 - thv * e1; sq += r1 * r1; mx = fmax(mx, fabs(r1)); }
@@ -1178,36 +1188,98 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
   }
   // reduce over the 16 lanes that share g (xor-shuffles stay inside 16-lane groups), then over waves
   __syncthreads();   // everyone is done with cs as the copy of Y
-  double* sred = cs; // [4 waves][16*KT][2]
+  as3_f64* sred = sred_all; // [4 waves][16*KTOT][2]
 #pragma unroll
   for (int q = 0; q < KR; ++q)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       double s = ssq[q][reg], m = smx[q][reg];
-      if constexpr (TH_LDS) { const int j = 16 * q + g + 4 * reg; s = my_nrm[(size_t)j * 32 + 0]; m = my_nrm[(size_t)j * 32 + 1]; }
+      if constexpr (TH_LDS) { const int j = J0 + 16 * q + g + 4 * reg; s = my_nrm[(size_t)j * 32 + 0]; m = my_nrm[(size_t)j * 32 + 1]; }
 #pragma unroll
       for (int off = 1; off < 16; off <<= 1) {
         s += __shfl_xor(s, off, 64);
         m = fmax(m, __shfl_xor(m, off, 64));
       }
       if (i == 0) {
-        const int j = 16 * q + g + 4 * reg;
-        sred[(wave * 16 * KT + j) * 2 + 0] = s;
-        sred[(wave * 16 * KT + j) * 2 + 1] = m;
+        const int j = J0 + 16 * q + g + 4 * reg;
+        sred[(wave * 16 * KTOT + j) * 2 + 0] = s;
+        sred[(wave * 16 * KTOT + j) * 2 + 1] = m;
       }
     }
-  __syncthreads();
-  if (threadIdx.x < 16 * KT) {
+}
+
+// block partials of the column sums / maxima: the four waves that hold column j, in wave order (columns beyond the residual tiles: zero)
+template <int KTOT>
+__device__ __forceinline__ void ritz_partials_out(const RitzArgs& a, const as3_f64* sred)
+{
+  if (threadIdx.x < 16 * KTOT) {
     const int j = threadIdx.x;
+    constexpr int KRT = KTOT < 3 ? KTOT : 3;
     double s = 0.0, m = 0.0;
-    for (int w = 0; w < 4 && j < 16 * KR; ++w) {
-      s += sred[(w * 16 * KT + j) * 2 + 0];
-      m = fmax(m, sred[(w * 16 * KT + j) * 2 + 1]);
+    for (int w = 0; w < 4 && j < 16 * KRT; ++w) {
+      s += sred[(w * 16 * KTOT + j) * 2 + 0];
+      m = fmax(m, sred[(w * 16 * KTOT + j) * 2 + 1]);
     }
-    a.red[((size_t)blockIdx.x * 16 * KT + j) * 2 + 0] = s;
-    a.red[((size_t)blockIdx.x * 16 * KT + j) * 2 + 1] = m;
+    a.red[((size_t)blockIdx.x * 16 * KTOT + j) * 2 + 0] = s;
+    a.red[((size_t)blockIdx.x * 16 * KTOT + j) * 2 + 1] = m;
   }
 }
+
+template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int QT = 0, bool XP = false, int SCHED = 0>
+__global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) double cs[];  // [KT][l4][16], later reduction scratch
+  const int l4 = a.l4;
+  constexpr int KF = QT > 0 ? KT - 1 : KT;   // full tiles; the last tile has 4*QT live columns (see mfma_quarter)
+  for (int idx = threadIdx.x; idx < KF * l4 * 16; idx += 256) cs[idx] = a.cpk[idx];
+  if constexpr (QT > 0) {                    // ... and keeps only its 8 leading columns in LDS, [l4][8] (see gemm_kernel)
+    for (int idx = threadIdx.x; idx < l4 * 8; idx += 256) cs[KF * l4 * 16 + idx] = a.cpk[KF * l4 * 16 + (idx >> 3) * 16 + (idx & 7)];
+  }
+  __shared__ double s_theta[48];
+  __shared__ int s_active[48];
+  // (four and five tiles: the norm accumulators live in LDS, one slot per lane -- 48 registers less in a kernel whose
+  //  accumulators the compiler otherwise shuffles between VGPRs and AGPRs in every stage)
+  __shared__ double s_nrm[KT >= 4 ? 4 * 48 * 16 * 2 : 2];
+  if (threadIdx.x < 48) { s_theta[threadIdx.x] = a.theta[threadIdx.x]; s_active[threadIdx.x] = a.active[threadIdx.x]; }
+  __syncthreads();
+  ritz_sweep<KT, VEC, NT, PIPE, QT, XP, SCHED, KT, 0, (KT >= 4)>(ritz_panels(a), (as3_f64*)cs, (int)(threadIdx.x >> 6), (const as3_f64*)s_theta, (const as3_i32*)s_active,
+                                                                 (as3_f64*)s_nrm, (as3_f64*)cs, (int)gridDim.x);
+  __syncthreads();
+  ritz_partials_out<KT>(a, (const as3_f64*)cs);
+}
+
+// Two waves per SIMD for the wide sweeps (round-5 review, item 5): the one-wave-per-SIMD kernels of four and five column tiles keep
+// neither HBM nor the matrix cores busy -- a wave that waits for its loads issues no MFMAs (rocprofv3: MfmaUtil 62-65 %,
+// SQ_WAIT_INST_ANY 64 % of the wave cycles).  Here a block has EIGHT waves in two groups; both groups walk the same row tiles, group 0
+// forms the column tiles 0 .. KA - 1 and group 1 the tiles KA .. KA + KB - 1, each from its own loads of the rows (the second read of
+// a line is served by the caches; no LDS staging, no barrier inside the sweep).  Half the accumulators per wave, so two waves fit a
+// SIMD's registers.  Same contraction order per output element as ritz_kernel: bit-identical results.
+// MEASURED AND REJECTED (profiles/r06/ritz_pair_ab.txt, n = 1e7, 111 basis columns): 37 + 37 outputs 8.29 ms (pipeline depth 2 / 2; 8.9 with
+// 3 / 2, 10.3 without a pipeline) against 7.7-8.0 ms for the one-wave kernel; 30 + 30 outputs 8.85 against 6.9 ms -- every row is
+// fetched by two waves, and the second fetch is not free: it doubles the load instructions and the L2 -> CU traffic of a sweep
+// that already moves 4 TB/s.  Built only with -DDLA_AB_VARIANTS (tune knob 0 = 12 .. 15), for tools/ritz_pair_ab.py.
+#ifdef DLA_AB_VARIANTS
+template <int KA, int KB, int VEC, bool XP, int PA = (KA >= 3 ? 3 : KA >= 2 ? 2 : 0), int PB = (KB >= 3 ? 3 : KB >= 2 ? 2 : 0)>
+__global__ __launch_bounds__(512) void ritz_pair_kernel(RitzArgs a)
+{
+  constexpr int KTOT = KA + KB;
+  extern __shared__ __attribute__((aligned(16))) double cs[];  // [KTOT][l4][16], later reduction scratch
+  const int l4 = a.l4;
+  for (int idx = threadIdx.x; idx < KTOT * l4 * 16; idx += 512) cs[idx] = a.cpk[idx];
+  __shared__ double s_theta[48];
+  __shared__ int s_active[48];
+  __shared__ double s_nrm[4 * 48 * 16 * 2];      // group 0 holds every residual column (tiles 0 .. 2 when KA = 3; KA = 2: tile 2 is group 1's)
+  if (threadIdx.x < 48) { s_theta[threadIdx.x] = a.theta[threadIdx.x]; s_active[threadIdx.x] = a.active[threadIdx.x]; }
+  __syncthreads();
+  // (the reduction scratch of the two groups must not overlap the coefficient copy the other group may still read: both groups
+  //  synchronise inside ritz_sweep before they write it)
+  const int wv = (int)(threadIdx.x >> 6);
+  if (wv < 4) ritz_sweep<KA, VEC, 3, PA, 0, XP, 0, KTOT, 0, true>(ritz_panels(a), (as3_f64*)cs, wv, (const as3_f64*)s_theta, (const as3_i32*)s_active, (as3_f64*)s_nrm, (as3_f64*)cs, (int)gridDim.x);
+  else        ritz_sweep<KB, VEC, 3, PB, 0, XP, 0, KTOT, KA, false>(ritz_panels(a), (as3_f64*)cs, wv - 4, (const as3_f64*)s_theta, (const as3_i32*)s_active, (as3_f64*)s_nrm, (as3_f64*)cs, (int)gridDim.x);
+  __syncthreads();
+  ritz_partials_out<KTOT>(a, (const as3_f64*)cs);
+}
+#endif
 
 // The same sweep with TWO coefficient blocks: e = V Y1 (stored when a.evec is given), r = AV Y2 - theta e for the active columns,
 // sum r^2 and max |r| -- the residual blocks of the linear-response drivers (reference diaglib.f90:872-889, 1337-1353:
@@ -5428,11 +5500,35 @@ struct HipEngine : dla::Engine {
 #else
       const int sched = 0; (void)t0;
 #endif
+      // (tune knob 0 = 12: A/B, the wide Ritz + P sweeps with two wave groups per block -- ritz_pair_kernel, see there)
+#ifdef DLA_AB_VARIANTS
+      const bool pair = k2 > 0 && qt == 0 && kt >= 4 && vec2 && tune[0] >= 12 && tune[0] <= 15;
+#else
+      const bool pair = false;
+#endif
+      const int pdepth = tune[0] == 12 ? -1 : 15 - tune[0];      // pipeline depth of both groups: the sweep's own default, 2, 1, 0
+      if (pair) std::snprintf(kn, sizeof kn, "ritz_pair_kernel<%d, %d, 2, true, %d, %d>", kt == 5 ? 3 : 2, 2, pdepth < 0 ? (kt == 5 ? 3 : 2) : pdepth, pdepth < 0 ? 2 : pdepth);
+      else
       std::snprintf(kn, sizeof kn, "ritz_kernel<%d, %d, 3, %d, %d, %s, %d>", kt, vec2 ? 2 : 1, kt >= 3 ? 3 : kt >= 2 ? 2 : 0, qt, k2 > 0 ? "true" : "false", sched);
       // (flops: the two Ritz products and, with extra columns, the two panel products they replace)
       Scope s(this, DLA_OP_RITZ, 8.0 * n * (2.0 * l + ((avy ? 2.0 : 1.0) + (evec ? 1.0 : 0.0)) * m + 2.0 * k2),
               4.0 * (double)n * l * (m + k2) + 5.0 * (double)n * nact, kn);
 #define RZ(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds, ritz_static_lds(kt))) return DLA_ERR_RUNTIME; DLA_LAUNCH(kfn, dim3(blocks), dim3(256), lds, st, a); } while (0)
+#define RZP(K) do { auto kfn = K; if (!raise_lds((const void*)kfn, lds, ritz_static_lds(4))) return DLA_ERR_RUNTIME; DLA_LAUNCH(kfn, dim3(blocks), dim3(512), lds, st, a); } while (0)
+#ifdef DLA_AB_VARIANTS
+      if (pair) {
+        if (kt == 5) {
+          if (pdepth < 0) RZP((ritz_pair_kernel<3, 2, 2, true>));
+          else if (pdepth == 2) RZP((ritz_pair_kernel<3, 2, 2, true, 2, 2>));
+          else if (pdepth == 1) RZP((ritz_pair_kernel<3, 2, 2, true, 1, 1>));
+          else RZP((ritz_pair_kernel<3, 2, 2, true, 0, 0>));
+        } else {
+          if (pdepth < 0 || pdepth == 2) RZP((ritz_pair_kernel<2, 2, 2, true>));
+          else if (pdepth == 1) RZP((ritz_pair_kernel<2, 2, 2, true, 1, 1>));
+          else RZP((ritz_pair_kernel<2, 2, 2, true, 0, 0>));
+        }
+      } else
+#endif
       if (k2 > 0) {
         // [Y | C2]: vec2 guaranteed by the caller (ritz_residual_p)
         if (qt == 1) { if (kt == 2) RZ((ritz_kernel<2, 2, 3, 2, 1, true>)); else RZ((ritz_kernel<3, 2, 3, 3, 1, true>)); }
@@ -5476,6 +5572,7 @@ struct HipEngine : dla::Engine {
         else RZ((ritz_kernel<3, 1>));
       }
 #undef RZ
+#undef RZP
     }
     {
       Scope s2(this, DLA_OP_RITZ, 0.0, 0.0, "ritz_reduce_kernel");
