@@ -949,6 +949,277 @@ struct RitzArgs {
 // Q0 = 0, KT = KTOT, four waves per block; ritz_pair_kernel: two groups of four waves, each with a part of the tiles).  csall: the LDS
 // copy of the whole block, [KTOT][l4][16]; wave: 0 .. 3 inside the group; s_nrm: the group's norm accumulators (KT >= 4 only).
 // Ends with the wave's column sums / maxima in sred ([4][16 KTOT][2]) -- the caller synchronises around it.
+template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int QT = 0, bool XP = false, int SCHED = 0>
+__global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
+{
+  constexpr int RG = 16 * VEC;             // rows per wave tile (one row group)
+  extern __shared__ __attribute__((aligned(16))) double cs[];  // [KT][l4][16], later reduction scratch
+  typedef typename VecOf<VEC>::type vec_t;
+  const long long n = a.n;
+  const int l = a.l, l4 = a.l4;
+  constexpr int KF = QT > 0 ? KT - 1 : KT;   // full tiles; the last tile has 4*QT live columns (see mfma_quarter)
+  for (int idx = threadIdx.x; idx < KF * l4 * 16; idx += 256) cs[idx] = a.cpk[idx];
+  if constexpr (QT > 0) {                    // ... and keeps only its 8 leading columns in LDS, [l4][8] (see gemm_kernel)
+    for (int idx = threadIdx.x; idx < l4 * 8; idx += 256) cs[KF * l4 * 16 + idx] = a.cpk[KF * l4 * 16 + (idx >> 3) * 16 + (idx & 7)];
+  }
+  __shared__ double s_theta[48];
+  __shared__ int s_active[48];
+  if (threadIdx.x < 48) { s_theta[threadIdx.x] = a.theta[threadIdx.x]; s_active[threadIdx.x] = a.active[threadIdx.x]; }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int i4 = lane & 3;
+  const long long ntiles = (n + RG - 1) / RG;
+  const int nsteps = l4 / 4;
+
+  constexpr int KR = KT < 3 ? KT : 3;     // tiles that can hold residual columns (m <= 48); further tiles: extra products only
+  constexpr bool TH_LDS = KT >= 4;
+  double th[KR][4];
+  int act[KR][4];
+  double ssq[KR][4], smx[KR][4];
+  // (four and five tiles: the norm accumulators live in LDS, one slot per lane -- 48 registers less in a kernel whose
+  //  accumulators the compiler otherwise shuffles between VGPRs and AGPRs in every stage)
+  __shared__ double s_nrm[TH_LDS ? 4 * 48 * 16 * 2 : 2];
+  double* my_nrm = s_nrm + (TH_LDS ? (size_t)wave * 48 * 16 * 2 + i * 2 : 0);      // [col j][lane i][2], this wave
+#pragma unroll
+  for (int q = 0; q < KR; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = 16 * q + g + 4 * reg;
+      th[q][reg] = s_theta[j];
+      act[q][reg] = s_active[j];
+      ssq[q][reg] = 0.0;
+      smx[q][reg] = 0.0;
+      if constexpr (TH_LDS) { my_nrm[(size_t)j * 32 + 0] = 0.0; my_nrm[(size_t)j * 32 + 1] = 0.0; }
+    }
+
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    long long row = tile * RG + VEC * i;
+    const bool rok = row < n;
+    if (!rok) row = 0;
+    v4d av[VEC][KT], aav[VEC][KT];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+      for (int q = 0; q < KT; ++q) { av[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; aav[e][q] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+    double avq[VEC][QT > 0 ? QT : 1], aavq[VEC][QT > 0 ? QT : 1];   // quarter tiles: scalars of their own (see gemm_kernel)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+      for (int qq = 0; qq < (QT > 0 ? QT : 1); ++qq) { avq[e][qq] = 0.0; aavq[e][qq] = 0.0; }
+    auto avv = [&](int e, int q, int reg) -> double {
+      if (QT > 0 && q == KF) return reg < QT ? avq[e][reg < QT ? reg : 0] : 0.0;
+      return av[e][q][reg];
+    };
+    auto aavv = [&](int e, int q, int reg) -> double {
+      if (QT > 0 && q == KF) return reg < QT ? aavq[e][reg < QT ? reg : 0] : 0.0;
+      return aav[e][q][reg];
+    };
+    int cs4 = 0;
+    if constexpr (PIPE > 0) {
+      // two-stage register pipeline over column steps (see gemm_kernel)
+      const int nfull4 = l / 4;
+      auto load_stage = [&](int c0, vec_t (&xs)[PIPE], vec_t (&ys)[PIPE]) {
+#pragma unroll
+        for (int u4 = 0; u4 < PIPE; ++u4) {
+          const size_t off = (size_t)(4 * (c0 + u4) + g) * (size_t)n + row;
+          xs[u4] = pload<VEC, NT>(a.v + off);
+          ys[u4] = pload<VEC, NT>(a.av + off);
+        }
+      };
+      auto mfma_stage = [&](int c0, const vec_t (&xs)[PIPE], const vec_t (&ys)[PIPE]) {
+#pragma unroll
+        for (int u4 = 0; u4 < PIPE; ++u4) {
+          double cfu[KT];
+#pragma unroll
+          for (int q = 0; q < KF; ++q) cfu[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * (c0 + u4) + g) * 16 + i];
+          double cfq[QT > 0 ? QT : 1];
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) cfq[qq] = cs[(size_t)KF * l4 * 16 + (size_t)(4 * (c0 + u4) + g) * 8 + 4 * qq + i4];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+            for (int q = 0; q < KF; ++q) {
+              av[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(xs[u4], e), av[e][q], 0, 0, 0);
+              aav[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cfu[q], vget<VEC>(ys[u4], e), aav[e][q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int qq = 0; qq < QT; ++qq) {
+              avq[e][qq] = mfma_quarter(cfq[qq], vget<VEC>(xs[u4], e), avq[e][qq]);
+              aavq[e][qq] = mfma_quarter(cfq[qq], vget<VEC>(ys[u4], e), aavq[e][qq]);
+            }
+          }
+        }
+      };
+      if (PIPE <= nfull4) {
+        vec_t xa[PIPE], ya[PIPE];
+        load_stage(0, xa, ya);
+        if constexpr (SCHED == 5) {
+          // two stages per trip with the register sets changing roles: no copies, and a stage's loads are first read a whole
+          // stage of MFMAs after their issue
+          vec_t xc[PIPE], yc[PIPE];
+          for (; cs4 + 3 * PIPE <= nfull4; cs4 += 2 * PIPE) {
+            load_stage(cs4 + PIPE, xc, yc);
+            mfma_stage(cs4, xa, ya);
+            load_stage(cs4 + 2 * PIPE, xa, ya);
+            mfma_stage(cs4 + PIPE, xc, yc);
+          }
+        }
+        for (; cs4 + 2 * PIPE <= nfull4; cs4 += PIPE) {
+          vec_t xb[PIPE], yb[PIPE];
+          load_stage(cs4 + PIPE, xb, yb);
+          mfma_stage(cs4, xa, ya);
+#pragma unroll
+          for (int u4 = 0; u4 < PIPE; ++u4) { xa[u4] = xb[u4]; ya[u4] = yb[u4]; }
+          if constexpr (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
+          if constexpr (SCHED == 3) __builtin_amdgcn_iglp_opt(1);
+          if constexpr (SCHED == 4) {
+            // per column step: the coefficient reads of the NEXT step behind the first MFMAs, the panel loads of the next stage
+            // spread over the second half
+            __builtin_amdgcn_sched_group_barrier(0x100, KT, 0);
+#pragma unroll
+            for (int u4 = 0; u4 < PIPE; ++u4) {
+#pragma unroll
+              for (int q = 0; q < KT; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (u4 + 1 < PIPE) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+#pragma unroll
+              for (int q = 0; q < KT; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * VEC - 2, 0);
+                if (q < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+              }
+            }
+          }
+          if constexpr (SCHED == 2) {
+            constexpr int NG = PIPE * VEC * KT / 2;        // groups of four MFMAs
+            constexpr int ND = PIPE * KT, NV = 2 * PIPE;   // coefficient reads, panel loads of the next stage
+            __builtin_amdgcn_sched_group_barrier(0x100, KT, 0);
+#pragma unroll
+            for (int sg = 0; sg < NG; ++sg) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+              if (sg < ND - KT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              if ((sg & 1) == 0 && sg / 2 < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+          }
+        }
+        mfma_stage(cs4, xa, ya);
+        cs4 += PIPE;
+      }
+    }
+    for (; cs4 < nsteps; ++cs4) {
+      int col = 4 * cs4 + g;
+      const bool cok = col < l;
+      col = cok ? col : l - 1;
+      vec_t xv = pload<VEC, NT>(a.v + (size_t)col * (size_t)n + row);
+      vec_t yv = pload<VEC, NT>(a.av + (size_t)col * (size_t)n + row);
+      xv = cok ? xv : vzero<VEC>();
+      yv = cok ? yv : vzero<VEC>();
+      double cf[KT];
+#pragma unroll
+      for (int q = 0; q < KF; ++q) cf[q] = cs[(size_t)q * l4 * 16 + (size_t)(4 * cs4 + g) * 16 + i];
+      double cfq[QT > 0 ? QT : 1];
+#pragma unroll
+      for (int qq = 0; qq < QT; ++qq) cfq[qq] = cs[(size_t)KF * l4 * 16 + (size_t)(4 * cs4 + g) * 8 + 4 * qq + i4];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+        for (int q = 0; q < KF; ++q) {
+          av[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[q], vget<VEC>(xv, e), av[e][q], 0, 0, 0);
+          aav[e][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[q], vget<VEC>(yv, e), aav[e][q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) {
+          avq[e][qq] = mfma_quarter(cfq[qq], vget<VEC>(xv, e), avq[e][qq]);
+          aavq[e][qq] = mfma_quarter(cfq[qq], vget<VEC>(yv, e), aavq[e][qq]);
+        }
+      }
+    }
+    if (rok) {
+#pragma unroll
+      for (int q = 0; q < KT; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int j = 16 * q + g + 4 * reg;
+          if (j >= a.k + (XP ? a.k2 : 0)) continue;
+          const double e0 = avv(0, q, reg), e1 = avv(VEC - 1, q, reg);
+          double r0 = aavv(0, q, reg), r1 = aavv(VEC - 1, q, reg);
+          if constexpr (XP) {
+            if (j >= a.k) {                // a column of the extra block: two plain products
+              pstore<VEC, NT>(a.p2 + (size_t)(j - a.k) * (size_t)n + row, vmake<VEC>(e0, e1));
+              pstore<VEC, NT>(a.ap2 + (size_t)(j - a.k) * (size_t)n + row, vmake<VEC>(r0, r1));
+              continue;
+            }
+          }
+          constexpr int KRm = KR - 1;
+          const int qr = q < KR ? q : KRm;  // (j < k <= 48 implies q < 3; the clamp only keeps the unrolled indices in range)
+          if (a.avy) pstore<VEC, NT>(a.avy + (size_t)j * (size_t)n + row, vmake<VEC>(r0, r1));
+          // (the four- and five-tile kernels sit at the register limit: they read theta / active from LDS per tile)
+          const double thv = TH_LDS ? s_theta[j] : th[qr][reg];
+          const int actv = TH_LDS ? s_active[j] : act[qr][reg];
+          if (actv) {
+            r0 = r0 - thv * e0;            // daxpy(-eig), reference diaglib.f90:1729
+            if constexpr (TH_LDS) {
+              // (same order of additions as the register accumulators of the narrower kernels: same bits)
+              double* slot = my_nrm + (size_t)j * 32;
+              double sq = slot[0], mx = slot[1];
+              sq += r0 * r0; mx = fmax(mx, fabs(r0));
+              if constexpr (VEC == 2) { r1 = r1 - thv * e1; sq += r1 * r1; mx = fmax(mx, fabs(r1)); }
+              slot[0] = sq;
+              slot[1] = mx;
+            } else {
+              ssq[qr][reg] += r0 * r0;
+              smx[qr][reg] = fmax(smx[qr][reg], fabs(r0));
+              if constexpr (VEC == 2) {
+                r1 = r1 - thv * e1;
+                ssq[qr][reg] += r1 * r1;
+                smx[qr][reg] = fmax(smx[qr][reg], fabs(r1));
+              }
+            }
+          }
+          if (a.evec) pstore<VEC, NT>(a.evec + (size_t)j * (size_t)n + row, vmake<VEC>(e0, e1));     // (optional: Ritz vectors nobody reads are not written)
+          pstore<VEC, NT>(a.r + (size_t)j * (size_t)n + row, vmake<VEC>(r0, r1));
+        }
+    }
+  }
+  // reduce over the 16 lanes that share g (xor-shuffles stay inside 16-lane groups), then over waves
+  __syncthreads();   // everyone is done with cs as the copy of Y
+  double* sred = cs; // [4 waves][16*KT][2]
+#pragma unroll
+  for (int q = 0; q < KR; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      double s = ssq[q][reg], m = smx[q][reg];
+      if constexpr (TH_LDS) { const int j = 16 * q + g + 4 * reg; s = my_nrm[(size_t)j * 32 + 0]; m = my_nrm[(size_t)j * 32 + 1]; }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        s += __shfl_xor(s, off, 64);
+        m = fmax(m, __shfl_xor(m, off, 64));
+      }
+      if (i == 0) {
+        const int j = 16 * q + g + 4 * reg;
+        sred[(wave * 16 * KT + j) * 2 + 0] = s;
+        sred[(wave * 16 * KT + j) * 2 + 1] = m;
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x < 16 * KT) {
+    const int j = threadIdx.x;
+    double s = 0.0, m = 0.0;
+    for (int w = 0; w < 4 && j < 16 * KR; ++w) {
+      s += sred[(w * 16 * KT + j) * 2 + 0];
+      m = fmax(m, sred[(w * 16 * KT + j) * 2 + 1]);
+    }
+    a.red[((size_t)blockIdx.x * 16 * KT + j) * 2 + 0] = s;
+    a.red[((size_t)blockIdx.x * 16 * KT + j) * 2 + 1] = m;
+  }
+}
+
+#ifdef DLA_AB_VARIANTS
+// ---- the same sweep as a device function over a RANGE of column tiles, for ritz_pair_kernel below (A/B builds only: the shipped
+// ritz_kernel above keeps its own text -- wrapping it around this function cost the one-tile kernel 4 % on the benchmark although
+// the register counts came out equal, profiles/r06/ritz_pair_ab.txt)
 // what a sweep needs of RitzArgs, by value (a reference to the kernel's argument block -- which holds two 48-entry arrays that are
 // indexed at run time -- made the compiler keep a copy of it: 20 ... 90 registers more per kernel)
 struct RitzPanels {
@@ -1225,29 +1496,6 @@ __device__ __forceinline__ void ritz_partials_out(const RitzArgs& a, const as3_f
   }
 }
 
-template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int QT = 0, bool XP = false, int SCHED = 0>
-__global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
-{
-  extern __shared__ __attribute__((aligned(16))) double cs[];  // [KT][l4][16], later reduction scratch
-  const int l4 = a.l4;
-  constexpr int KF = QT > 0 ? KT - 1 : KT;   // full tiles; the last tile has 4*QT live columns (see mfma_quarter)
-  for (int idx = threadIdx.x; idx < KF * l4 * 16; idx += 256) cs[idx] = a.cpk[idx];
-  if constexpr (QT > 0) {                    // ... and keeps only its 8 leading columns in LDS, [l4][8] (see gemm_kernel)
-    for (int idx = threadIdx.x; idx < l4 * 8; idx += 256) cs[KF * l4 * 16 + idx] = a.cpk[KF * l4 * 16 + (idx >> 3) * 16 + (idx & 7)];
-  }
-  __shared__ double s_theta[48];
-  __shared__ int s_active[48];
-  // (four and five tiles: the norm accumulators live in LDS, one slot per lane -- 48 registers less in a kernel whose
-  //  accumulators the compiler otherwise shuffles between VGPRs and AGPRs in every stage)
-  __shared__ double s_nrm[KT >= 4 ? 4 * 48 * 16 * 2 : 2];
-  if (threadIdx.x < 48) { s_theta[threadIdx.x] = a.theta[threadIdx.x]; s_active[threadIdx.x] = a.active[threadIdx.x]; }
-  __syncthreads();
-  ritz_sweep<KT, VEC, NT, PIPE, QT, XP, SCHED, KT, 0, (KT >= 4)>(ritz_panels(a), (as3_f64*)cs, (int)(threadIdx.x >> 6), (const as3_f64*)s_theta, (const as3_i32*)s_active,
-                                                                 (as3_f64*)s_nrm, (as3_f64*)cs, (int)gridDim.x);
-  __syncthreads();
-  ritz_partials_out<KT>(a, (const as3_f64*)cs);
-}
-
 // Two waves per SIMD for the wide sweeps (round-5 review, item 5): the one-wave-per-SIMD kernels of four and five column tiles keep
 // neither HBM nor the matrix cores busy -- a wave that waits for its loads issues no MFMAs (rocprofv3: MfmaUtil 62-65 %,
 // SQ_WAIT_INST_ANY 64 % of the wave cycles).  Here a block has EIGHT waves in two groups; both groups walk the same row tiles, group 0
@@ -1258,7 +1506,6 @@ __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 // 3 / 2, 10.3 without a pipeline) against 7.7-8.0 ms for the one-wave kernel; 30 + 30 outputs 8.85 against 6.9 ms -- every row is
 // fetched by two waves, and the second fetch is not free: it doubles the load instructions and the L2 -> CU traffic of a sweep
 // that already moves 4 TB/s.  Built only with -DDLA_AB_VARIANTS (tune knob 0 = 12 .. 15), for tools/ritz_pair_ab.py.
-#ifdef DLA_AB_VARIANTS
 template <int KA, int KB, int VEC, bool XP, int PA = (KA >= 3 ? 3 : KA >= 2 ? 2 : 0), int PB = (KB >= 3 ? 3 : KB >= 2 ? 2 : 0)>
 __global__ __launch_bounds__(512) void ritz_pair_kernel(RitzArgs a)
 {
@@ -1279,7 +1526,7 @@ __global__ __launch_bounds__(512) void ritz_pair_kernel(RitzArgs a)
   __syncthreads();
   ritz_partials_out<KTOT>(a, (const as3_f64*)cs);
 }
-#endif
+#endif  // DLA_AB_VARIANTS
 
 // The same sweep with TWO coefficient blocks: e = V Y1 (stored when a.evec is given), r = AV Y2 - theta e for the active columns,
 // sum r^2 and max |r| -- the residual blocks of the linear-response drivers (reference diaglib.f90:872-889, 1337-1353:
