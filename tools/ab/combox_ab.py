@@ -4,7 +4,7 @@ width, for several blocks-per-pass settings (tune knob 4) -- interleaved, one pr
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 from diaglib_amd import capi  # noqa: E402
