@@ -34,11 +34,17 @@ cp $P/bench_lobpcg_cfg5shape_1gpu.json $P/bench_davidson_cfg4shape_1gpu.json $P/
 echo "extra done"
 fi
 if [[ $PART == *B* ]]; then
-bash tools/shard_rehearsal.sh 1 2 4 > $OUT/shard_rehearsal_2e6.txt 2>&1
+bash tools/shard_rehearsal.sh 1 2 4 5 > $OUT/shard_rehearsal_2e6.txt 2>&1
 python3 tools/lr_gen_bench.py > $OUT/bench_lr_gen_2e6.jsonl 2> $OUT/lr_gen.err
 DIAGLIB_AMD_HOSTTIME=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --n 250000 --steps 20 --warmup 3 --no-cpu-baseline --no-random-leg > $OUT/hosttime_250k_rows.txt 2>&1
 DIAGLIB_AMD_CHAIN_DEBUG=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-random-leg 2>&1 | grep -A4 "chain k=13 m=39" | tail -5 | cut -c1-260 > $OUT/chain_timing_k13_m39.txt
 python3 tools/host_mode_probe.py 2>&1 | tail -8 > $OUT/host_mode_probe.txt
+# Davidson at n_max = 21 (cfg 4 shape): blocks of up to 16 columns keep their closing passes pending (r06) / everything finished in memory
+for r in 1 2 3; do
+  DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --roots 16 --steps 10 --warmup 3 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('davidson n=2e6 16 roots n_max=21, pending blocks on :', d['ms_per_step'], 'ms,', d['iters'], 'iterations')"
+  DIAGLIB_AMD_NO_PENDING=1 DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --roots 16 --steps 10 --warmup 3 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('davidson n=2e6 16 roots n_max=21, pending blocks off:', d['ms_per_step'], 'ms,', d['iters'], 'iterations')"
+done > $OUT/davidson_cfg4_pending_ab.txt 2>&1 || true
+for nn in 50000 250000; do DIAGLIB_BENCH_NOPROFILE=1 python3 bench.py --n $nn --steps 30 --warmup 3 --no-cpu-baseline --no-random-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('shard of $nn rows:', d['ms_per_step'], 'ms per solve,', d['iters'], 'iterations,', d['host_syncs'] // d['steps'], 'host waits')"; done > $OUT/shard_floor.txt 2>&1 || true
 # drop-in mode: time inside the caller's routine / waiting for downloads / waiting for small results against the chunk count
 for c in 1 2 4 8; do
   echo "== DLA_OPT_STAGE_CHUNKS = $c (two solves; api lines = totals over both)" >> $OUT/host_mode_chunks.txt

@@ -19,7 +19,7 @@ python3 bench.py --solver davidson --n 2000000 --roots 16 --steps 5 --warmup 1 -
 python3 bench.py --solver lobpcg --steps 5 --warmup 1 --no-cpu-baseline --no-random-leg > $OUT/bench_lobpcg_cfg3.json 2> $OUT/cfg3.err
 echo "cfg4 bench done"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt250 -o run -- python3 bench.py --n 250000 --steps 4 --warmup 2 --no-cpu-baseline --no-random-leg > $OUT/kt250.log 2>&1
-python3 tools/kt_gaps.py $OUT/kt250/run_kernel_trace.csv 3 > $OUT/kernel_trace_one_solve_250k_rows.txt
+python3 tools/kt_gaps.py $OUT/kt250/run_kernel_trace.csv 3 --timeline > $OUT/kernel_trace_one_solve_250k_rows.txt
 rm -rf $OUT/kt250
 python3 bench.py --n 250000 --steps 10 --warmup 3 --no-cpu-baseline --no-random-leg > $OUT/bench_250k_rows.json 2>/dev/null
 echo "250k done"
