@@ -90,7 +90,7 @@ def test_drivers_vs_reference_results(ctx, oracle, gold, name):
     if name == "gdav_n600_rand":
         # This run restarts once (iteration 20).  The UNMODIFIED reference zeroes bspace at the restart
         # (diaglib.f90:2196-2200) and then "converges" with ok=.true. to eigenvalues ~1e-15 --
-        # the fixture records that.  Our drivers keep the kept block's B*x (DESIGN.md section 4) and must
+        # the fixture records that.  Our drivers keep the kept block's B*x (DESIGN.md section 5) and must
         # return the true generalised eigenvalues instead.
         import scipy.linalg as sla
         assert np.abs(gold[name + "_eig"][:t]).max() < 1e-10

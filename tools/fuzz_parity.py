@@ -124,7 +124,7 @@ for it in range(cases):
     res = dict(ok=(ok, oko, okr), d_oracle=float(np.abs(e[:t] - eo[:t]).max() / scale), d_ref=float(np.abs(e[:t] - er[:t]).max() / scale),
                iters=(info["iters"], tr.iters))
     # unit guesses: the history is robust to rounding; random guesses and tolerances near the rounding floor of max|r| (1e-11 on
-    # these spectra: DESIGN 11.7) end a few sweeps earlier or later with the last bits of the small eigensolver
+    # these spectra: docs/HISTORY.md 11.7) end a few sweeps earlier or later with the last bits of the small eigensolver
     slack = 1 if (guess == "unit" and tol >= 1e-10) else max(3, tr.iters // 8)
     if "lobpcg" in solver and slack == 1:
         # LOBPCG's 3m x 3m Rayleigh-Ritz problem has clusters whose eigenvectors the partial solver here and the oracle's solver

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised bases grown block by block through dla_expand_project modes 4 / 5 (the Davidson drivers' expansion step with the
-closing pass left to the caller's small matrices): random row counts (odd ones take the sweep-per-update
+closing pass left to the caller's small matrices; docs/HISTORY.md 14.1 / 14.1b): random row counts (odd ones take the sweep-per-update
 schedule), block widths 1 .. 16, up to 320 columns, random / nearly dependent / inside-span(X) / tiny-norm blocks, every schedule
 knob.  Checked: (panel D)^T (panel D) = I to 100 eps and h = (panel D)^T A (panel D) to 1e-12.
 

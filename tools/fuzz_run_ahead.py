@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run-ahead of the expansion step (dla_expand_project / dla_expand_project_metric) on and off: the same Davidson / LOBPCG
+"""Run-ahead of the expansion step (dla_expand_project / dla_expand_project_metric, DESIGN 4, docs/HISTORY.md 11.3) on and off: the same Davidson / LOBPCG
 solves (standard and generalised) on the device-resident benchmark operators must give the SAME BITS either way -- eigenvalues, eigenvectors, iteration and operator
 column counts -- because the run-ahead changes when the host learns the orthogonalisation's outcome, not one kernel's input.
     python tools/fuzz_run_ahead.py [cases] [seed]"""
