@@ -1,4 +1,4 @@
-// tools/rr_device.hip -- EXPERIMENT (not part of the library): Rayleigh-Ritz on the device, the lowest p
+// tools/rr_device.hip -- EXPERIMENT (not part of the library, see DESIGN.md 11, docs/HISTORY.md 13.4): Rayleigh-Ritz on the device, the lowest p
 // eigenpairs of the projected matrix by one workgroup.  Built and timed by tools/rr_probe.hip.
 //
 // The reference solves the projected problem with LAPACK's dsyev on the host (diaglib.f90:1708) and uses the first n_max

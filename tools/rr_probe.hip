@@ -1,4 +1,4 @@
-// tools/rr_probe.hip -- EXPERIMENT: a device Rayleigh-Ritz kernel (tools/rr_device.hip) against the host solver
+// tools/rr_probe.hip -- EXPERIMENT (docs/HISTORY.md 13.4): a device Rayleigh-Ritz kernel (tools/rr_device.hip) against the host solver
 // (dla_syev_lowest of the built library): eigenvalues, residuals, orthonormality, and the time per call.
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/rr_probe.hip -Ldiaglib_amd/lib -ldiaglib_amd -Wl,-rpath,$PWD/diaglib_amd/lib -o /tmp/rr_probe && /tmp/rr_probe 20
 #include <hip/hip_runtime.h>
