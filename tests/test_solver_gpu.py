@@ -712,3 +712,29 @@ def test_short_lived_threads_release_their_contexts():
     free1, _ = torch.cuda.mem_get_info()
     assert not errs, errs
     assert free0 - free1 < 256 << 20, (free0 - free1) / 2 ** 20      # 30 leaked contexts would hold ~7 GB
+
+
+@pytest.mark.parametrize("solver,n,t,m,max_dav,tol,seed", [("davidson", 2000, 4, 8, 20, 1e-8, 5), ("lobpcg", 2000, 4, 8, 20, 1e-8, 5),
+                                                          ("davidson", 1000, 10, 15, 20, 1e-8, 7), ("davidson", 600, 4, 8, 10, 1e-8, 9),
+                                                          ("lobpcg", 3000, 16, 21, 20, 1e-8, 11), ("davidson", 3000, 16, 21, 10, 1e-9, 13),
+                                                          ("lobpcg", 2500, 32, 37, 20, 1e-8, 15), ("davidson", 2500, 32, 37, 10, 1e-8, 17)])
+def test_seeded_random_guess_histories_match_the_oracle(ctx, oracle, solver, n, t, m, max_dav, tol, seed):
+    """Round-5 review: with random guesses the tests above allow 10-15 % in the iteration count (one historic LOBPCG case moves
+    between 43 and 51 with the last bits of the Gram sums), which would hide a real regression of that size.  On these eight seeded
+    uniform guesses -- the reference's dense test matrix, block widths 8 ... 37, restarts at max_dav = 10, both drivers -- the HIP path
+    takes EXACTLY the oracle's iteration counts (profiles/r06/iteration_counts.txt: 30 / 30, 30 / 30, 17 / 17, 23 / 23, 35 / 35, 39 / 39,
+    23 / 23, 24 / 24; matvec columns equal in seven cases, 236 against 239 in the first); the test holds it to one iteration and 2 %
+    of the columns, an order of magnitude tighter than the statistical bound."""
+    oracle.dense_setup(n)
+    mv, pc = oracle.fn("orc_dense_matvec"), oracle.fn("orc_dense_precnd")
+    g = np.asfortranarray(np.random.default_rng(seed).random((n, m)) - 0.5)
+    if solver == "davidson":
+        e, _, ok, info = ctx.davidson_driver(n, t, m, 400, tol, max_dav, 0.0, mv, pc, g.copy(order="F"))
+        eo, _, oko, tr = oracle.davidson(n, t, m, 400, tol, max_dav, 0.0, mv, pc, g)
+    else:
+        e, _, ok, info = ctx.lobpcg_driver(n, t, m, 400, tol, 0.0, mv, pc, g.copy(order="F"))
+        eo, _, oko, tr = oracle.lobpcg(n, t, m, 400, tol, 0.0, mv, pc, g)
+    assert ok and oko
+    assert abs(info["iters"] - tr.iters) <= 1, (info, tr.iters)
+    assert abs(info["matvec_cols"] - tr.matvec_cols) <= 2 + tr.matvec_cols // 50, (info, tr.matvec_cols)
+    assert np.allclose(e[:t], eo[:t], rtol=1e-8, atol=0)          # (tol 1e-8 ... 1e-9 in the residual: eigenvalues to its square)
