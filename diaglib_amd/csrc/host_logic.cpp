@@ -1298,6 +1298,14 @@ static int close_pending_block(int m, int k, double* p, int ldp, const double* d
   for (int j = 0; j < k; ++j)
     for (int i = 0; i < m; ++i) emax = std::max(emax, std::fabs(p[(size_t)i + (size_t)j * ldp]));
   if (emax == 0.0) return DLA_OK;
+  // TEST hook ($DIAGLIB_AMD_FAIL_CLOSE = n: the n-th closing pass of the calling thread reports a factor that is not positive
+  // definite): nothing bounds |D| |T| where a chain ended, so the failure exists in principle and its recovery -- the block is finished
+  // in memory instead, dla_expand_project mode 6 / the repeat inside mode 3 -- must be exercised (tests/test_pending_basis_gpu.py)
+  {
+    static thread_local long n_close = 0;
+    const char* fc = std::getenv("DIAGLIB_AMD_FAIL_CLOSE");
+    if (fc != nullptr && ++n_close == std::atol(fc)) return DLA_ERR_ORTHO;
+  }
   // (D = I + N: the products with N matter only when |N| |E'| m reaches rounding level in E -- skip them otherwise)
   double nmax = 0.0;
   if (dmat)

@@ -284,38 +284,6 @@ def test_ritz_sweep_with_extra_products(ctx, rng, n, l, m, k2):
         assert np.all(np.abs(gp[:, 1:k2 + 1] - v @ c2[:l]) <= bound)
 
 
-@pytest.mark.parametrize("knob", [12, 13, 14, 15])
-@pytest.mark.parametrize("n,l,m,k2", [(2000, 111, 37, 37), (4110, 111, 37, 30), (64, 111, 37, 37), (2000, 130, 30, 30), (3000, 100, 48, 16), (2000, 63, 21, 21)])
-def test_ritz_sweep_with_two_wave_groups(ctx, rng, knob, n, l, m, k2):
-    """The wide Ritz + P sweeps with two wave groups per block (ritz_pair_kernel, tune knob 0 = 12 .. 15: round-5 review, item 5):
-    each group forms part of the column tiles from its own loads of the rows -- the same contraction order per output element as
-    the one-group kernel, so every output and the norms are bit-identical to it (four and five column tiles; three tiles stay
-    with the one-group kernel whatever the knob says)."""
-    v = np.asfortranarray(rng.standard_normal((n, l))); av = np.asfortranarray(rng.standard_normal((n, l)))
-    y = np.asfortranarray(rng.standard_normal((l, m))); c2 = np.asfortranarray(rng.standard_normal((l, k2)))
-    eig = rng.standard_normal(m)
-    skip = np.zeros(m, np.int32); skip[m // 3] = 1
-    pv, pav = ctx.panel(v), ctx.panel(av)
-    outs = []
-    try:
-        names = []
-        for kb in (0, knob):
-            ctx.set_option(100 + 0, kb)
-            ctx.reset_stats()
-            pe, pr, pa, pp, pap = ctx.panel(n, m), ctx.panel(n, m), ctx.panel(n, m), ctx.panel(n, k2), ctx.panel(n, k2)
-            rn = ctx.ritz_residual_p(pv, pav, y, eig, m, skip, pe, pr, pa, c2, pp, pap)
-            outs.append((rn, pe.download(), pr.download(), pa.download(), pp.download(), pap.download()))
-            if kb:
-                names = list(ctx.kernel_stats())
-    finally:
-        ctx.set_option(100 + 0, 0)
-    if (m + k2 + 15) // 16 >= 4 and not any(nm.startswith("ritz_pair_kernel") for nm in names):
-        pytest.skip("built without -DDLA_AB_VARIANTS: the two-group kernels were measured slower (profiles/r06/ritz_pair_ab.txt) and are not shipped")
-    for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a, b)
-    assert np.all(np.abs(outs[1][4] - v @ c2) <= 64 * EPS * (np.abs(v) @ np.abs(c2)) + 1e-300)
-
-
 @pytest.mark.parametrize("n,l,m", [(4096, 40, 8), (3001, 77, 13), (2048, 160, 8), (2500, 64, 21), (1024, 30, 52)])
 def test_ritz_sweep_with_two_coefficient_blocks(ctx, rng, n, l, m):
     """dla_ritz_residual2: e = V y1, r = AV y2 - theta e and the norms of r in one sweep (the residual blocks of the linear-response

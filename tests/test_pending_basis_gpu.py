@@ -357,3 +357,53 @@ def test_blocks_of_one_and_two_column_tiles_in_one_basis(ctx, rng):
         ctx.basis_sync(0, 0)
         ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 0)
         ctx.set_shard(-1, 0)
+
+
+RECOVERY_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from diaglib_amd import capi
+from oracle.pyoracle import Oracle
+ctx, o = capi.Context(), Oracle()
+n, t, m = 60000, 8, 13
+ctx.set_option(capi.OPT_CALLBACKS_ON_DEVICE, 1)
+ctx.synth_setup(n, 0, n); o.synth_setup(n, 0, n)
+g = np.zeros((n, m), order="F"); g[np.arange(m), np.arange(m)] = 1.0
+mv, pc = capi.fn_address("dla_synth_matvec"), capi.fn_address("dla_synth_precnd")
+solver = sys.argv[1]
+if solver == "davidson":
+    e, v, ok, info = ctx.davidson_driver(n, t, m, 200, 1e-10, 20, 0.0, mv, pc, g.copy(order="F"))
+    eo, vo, oko, tr = o.davidson(n, t, m, 200, 1e-10, 20, 0.0, o.fn("orc_synth_matvec"), o.fn("orc_synth_precnd"), g)
+else:
+    e, v, ok, info = ctx.lobpcg_driver(n, t, m, 200, 1e-10, 0.0, mv, pc, g.copy(order="F"))
+    eo, vo, oko, tr = o.lobpcg(n, t, m, 200, 1e-10, 0.0, o.fn("orc_synth_matvec"), o.fn("orc_synth_precnd"), g)
+assert ok and oko
+assert np.allclose(e[:t], eo[:t], rtol=1e-11, atol=0), (e[:t], eo[:t])
+assert abs(info["iters"] - tr.iters) <= 1, (info, tr.iters)
+assert np.abs(v[:, :t].T @ v[:, :t] - np.eye(t)).max() < 1e-12
+print("RECOVERED", info["iters"], tr.iters, "waits", ctx.stats()["host_syncs"], flush=True)
+"""
+
+
+@pytest.mark.parametrize("solver,nth", [("davidson", 2), ("davidson", 4), ("lobpcg", 3)])
+def test_a_closing_pass_that_fails_is_recovered_by_finishing_the_block_in_memory(tmp_path, solver, nth):
+    """Round-5 advisor (low): the pending criterion bounds S, nothing bounds |D| |T|, so the closing factor I - F^T F of a pending block
+    may fail to factor -- before r06 the Fortran driver answered that with `error stop`.  The failure is forced here
+    ($DIAGLIB_AMD_FAIL_CLOSE = n: the n-th closing pass reports it; a child process, because the counter belongs to the thread):
+    the Davidson driver finishes the block in memory through dla_expand_project mode 6 (host-driven loop against panel*D), LOBPCG's
+    mode 3 repeats the expansion without anything pending -- same eigenvalues and iteration count as the oracle either way."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(RECOVERY_WORKER.format(root=root))
+    waits = []
+    for env_n in (None, str(nth)):
+        env = dict(os.environ)
+        env.pop("DIAGLIB_AMD_FAIL_CLOSE", None)
+        if env_n:
+            env["DIAGLIB_AMD_FAIL_CLOSE"] = env_n
+        p = subprocess.run([sys.executable, str(script), solver], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0 and "RECOVERED" in p.stdout, (env_n, p.stdout[-1500:], p.stderr[-3000:])
+        waits.append(int(p.stdout.split("waits")[1].split()[0]))
+    assert waits[1] > waits[0], waits          # (the recovery did run: the repeated orthogonalisation waits for the host)

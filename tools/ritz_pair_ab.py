@@ -23,6 +23,18 @@ for l, m, k2 in ((111, 37, 37), (111, 30, 30)):
     y = np.asfortranarray(rng.standard_normal((l, m))); c2 = np.asfortranarray(rng.standard_normal((l, k2)))
     eig = rng.standard_normal(m); skip = np.zeros(m, np.int32)
     pe, pr, pa, pp, pap = ctx.panel(n, m), ctx.panel(n, m), ctx.panel(n, m), ctx.panel(n, k2), ctx.panel(n, k2)
+    # the two-group kernels must give the one-group kernel's bits (same contraction order per output element)
+    outs = {}
+    for knob in (0, 12, 13, 14, 15):
+        ctx.set_option(100 + 0, knob); ctx.reset_stats()
+        rn = ctx.ritz_residual_p(pv, pav, y, eig, m, skip, pe, pr, pa, c2, pp, pap)
+        names = [nm for nm in ctx.kernel_stats() if nm.startswith("ritz") and "reduce" not in nm]
+        if knob and not any(nm.startswith("ritz_pair_kernel") for nm in names):
+            raise SystemExit("this library was built without -DDLA_AB_VARIANTS: the two-group kernels are not in it")
+        outs[knob] = (rn.copy(), pr.col(0, 1).download(), pp.col(k2 - 1, 1).download(), pap.col(0, 1).download())
+    for knob in (12, 13, 14, 15):
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[knob])), f"knob {knob}: results differ from the one-group kernel"
+    print(f"l={l} m={m}+{k2}: all four two-group variants bit-identical to the one-group kernel (norms, first / last columns of r, P, AP)", flush=True)
     res = {}
     for r in range(rounds):
         for knob in (0, 12, 13, 14, 15):
