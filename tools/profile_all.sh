@@ -29,7 +29,7 @@ cp gpurun_out/profile_${TAG}c5/pmc_traffic.txt $OUT/pmc_traffic_cfg5shape.txt
 cp gpurun_out/profile_${TAG}c5/pmc_traffic.json $OUT/pmc_traffic_cfg5shape.json
 echo "cfg5 counters done"
 bash tools/profile_extra.sh $TAG > $OUT/profile_extra.log 2>&1
-cp $P/bench_lobpcg_cfg5shape_1gpu.json $P/bench_davidson_cfg4shape_1gpu.json $P/bench_lobpcg_cfg3.json $P/bench_250k_rows.json \
+cp $P/bench_lobpcg_cfg5shape_1gpu.json $P/bench_davidson_cfg4shape_1gpu.json $P/bench_lobpcg_cfg3.json $P/bench_250k_rows.json $P/bench_davidson_cfg2_500k_rows.json \
    $P/kernel_stats_lobpcg_cfg5shape.csv $P/kernel_trace_one_solve_250k_rows.txt $OUT/
 echo "extra done"
 fi

@@ -22,4 +22,6 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT/kt250 -o run -- python3 ben
 python3 tools/kt_gaps.py $OUT/kt250/run_kernel_trace.csv 3 --timeline > $OUT/kernel_trace_one_solve_250k_rows.txt
 rm -rf $OUT/kt250
 python3 bench.py --n 250000 --steps 10 --warmup 3 --no-cpu-baseline --no-random-leg > $OUT/bench_250k_rows.json 2>/dev/null
+# BASELINE configs[1]: n = 5e5, 8 roots, Davidson, one GPU
+python3 bench.py --n 500000 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_davidson_cfg2_500k_rows.json 2>/dev/null
 echo "250k done"
