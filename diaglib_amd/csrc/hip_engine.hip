@@ -945,10 +945,6 @@ struct RitzArgs {
 // that the plain Ritz step keeps its code (the same tests as run-time branches cost the one-tile kernel 37 %)
 // SCHED (A/B, tune knob 0 = 7 / 8, wide blocks only): 1 = __builtin_amdgcn_iglp_opt(0) in the pipelined loop, 2 = an explicit
 // sched_group_barrier pipeline (four MFMAs, then one coefficient read of a later column step / one panel load of the next stage)
-// The sweep of one wave over its row tiles for the column tiles Q0 .. Q0 + KT - 1 of a coefficient block of KTOT tiles (ritz_kernel:
-// Q0 = 0, KT = KTOT, four waves per block; ritz_pair_kernel: two groups of four waves, each with a part of the tiles).  csall: the LDS
-// copy of the whole block, [KTOT][l4][16]; wave: 0 .. 3 inside the group; s_nrm: the group's norm accumulators (KT >= 4 only).
-// Ends with the wave's column sums / maxima in sred ([4][16 KTOT][2]) -- the caller synchronises around it.
 template <int KT, int VEC, int NT = 3, int PIPE = (KT >= 3 ? 3 : KT >= 2 ? 2 : 0), int QT = 0, bool XP = false, int SCHED = 0>
 __global__ __launch_bounds__(256) void ritz_kernel(RitzArgs a)
 {
@@ -1227,6 +1223,10 @@ struct RitzPanels {
   long long n; int l, l4, k, k2;
 };
 __device__ __forceinline__ RitzPanels ritz_panels(const RitzArgs& a) { return RitzPanels{a.v, a.av, a.evec, a.r, a.avy, a.p2, a.ap2, a.n, a.l, a.l4, a.k, a.k2}; }
+// The sweep of one wave over its row tiles for the column tiles Q0 .. Q0 + KT - 1 of a coefficient block of KTOT tiles (Q0 = 0, KT = KTOT: the
+// whole block, as ritz_kernel does it; ritz_pair_kernel: two groups of four waves, each with a part of the tiles).  csall: the LDS
+// copy of the whole block, [KTOT][l4][16]; wave: 0 .. 3 inside the group; s_nrm: the group's norm accumulators (KT >= 4 only).
+// Ends with the wave's column sums / maxima in sred ([4][16 KTOT][2]) -- the caller synchronises around it.
 template <int KT, int VEC, int NT, int PIPE, int QT, bool XP, int SCHED, int KTOT, int Q0, bool NRM_LDS>
 __device__ __forceinline__ void ritz_sweep(const RitzPanels a, as3_f64* csall, const int wave, const as3_f64* s_theta, const as3_i32* s_active,
                                            as3_f64* s_nrm, as3_f64* sred_all, const int blocks_x)
