@@ -55,7 +55,7 @@ template <int V, int NT> __device__ __forceinline__ typename VecOf<V>::type ploa
 // may_alias types so that type-based alias analysis cannot reorder them against each other
 typedef double __attribute__((may_alias)) lds_f64;
 typedef v2d __attribute__((may_alias)) lds_v2f64;
-// LDS arrays handed to device functions: address-space-3 pointers (a generic pointer makes every access a flat load)
+// LDS arrays handed to device functions: address-space-3 pointers (a generic pointer may turn every access into a flat load)
 typedef __attribute__((address_space(3))) double as3_f64;
 typedef __attribute__((address_space(3))) int as3_i32;
 __device__ __forceinline__ void lds_store2(double* p, v2d v) { *(lds_v2f64*)p = v; }
@@ -1231,8 +1231,8 @@ template <int KT, int VEC, int NT, int PIPE, int QT, bool XP, int SCHED, int KTO
 __device__ __forceinline__ void ritz_sweep(const RitzPanels a, as3_f64* csall, const int wave, const as3_f64* s_theta, const as3_i32* s_active,
                                            as3_f64* s_nrm, as3_f64* sred_all, const int blocks_x)
 {
-  // (the LDS arrays come in as address-space-3 pointers: as generic pointers the compiler turned their accesses into flat loads
-  //  with 64-bit addresses -- 20 ... 90 registers more per kernel, spills in the five-tile one)
+  // (the LDS arrays come in as address-space-3 pointers, so that their accesses stay ds_read / ds_write whatever the inliner proves;
+  //  the 20 ... 90 extra registers of this function's first version came from the argument block by reference, see RitzPanels)
   constexpr int RG = 16 * VEC;             // rows per wave tile (one row group)
   as3_f64* cs = csall + (size_t)Q0 * a.l4 * 16;
   typedef typename VecOf<VEC>::type vec_t;
