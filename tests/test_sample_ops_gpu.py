@@ -225,3 +225,21 @@ def test_a_sample_operator_used_before_its_setup_returns_an_error():
     t.start(); t.join()
     assert "before dla_synth_setup" in seen["matvec"] and "before dla_spmm_setup_csr" in seen["spmm"], seen
     assert seen["after"] > 0.0
+
+
+def test_the_oracles_restatement_of_the_sample_metric_equals_the_device_operator(dev, oracle, rng):
+    """The multi-rank parity tests run the generalised drivers with dla_synth_metric on the device and orc_synth_metric in the oracle
+    (oracle/oracle_ops.c, r06): the two must be the same operator, entry by entry (same generator, same order of additions per row up
+    to the 4-term sum)."""
+    import ctypes as C
+    n, m = 5000, 7
+    dev.synth_setup(n, 0, n); oracle.synth_setup(n, 0, n)
+    x = np.asfortranarray(rng.standard_normal((n, m)))
+    y_dev = _apply(dev, "dla_synth_metric", x)
+    y_orc = np.zeros((n, m), order="F")
+    nn, mm = C.c_int(n), C.c_int(m)
+    oracle.lib.orc_synth_metric(C.byref(nn), C.byref(mm), x.ctypes.data_as(C.POINTER(C.c_double)), y_orc.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.abs(y_dev - y_orc).max() <= 8 * np.finfo(float).eps * np.abs(y_orc).max()
+    # ... and the metric is symmetric positive definite: x^T B x > 0, x^T B y = y^T B x
+    g = x.T @ y_dev
+    assert np.abs(g - g.T).max() < 1e-10 * np.abs(g).max() and np.all(np.linalg.eigvalsh(0.5 * (g + g.T)) > 0)
