@@ -166,6 +166,26 @@ def test_eight_ranks_gloo_at_the_cfg4_block_width_match_the_oracle(sim, oracle, 
     assert np.abs(v[:, :t].T @ v[:, :t] - np.eye(t)).max() < 1e-12
 
 
+def test_eight_ranks_gloo_at_the_cfg5_block_width_match_the_oracle(sim, oracle, tmp_path):
+    """BASELINE cfg 5's split (LOBPCG, 32 roots, n_max = 37: blocks of three column tiles, the P-block products, get_coeffs
+    replicated on every rank) on EIGHT row shards over gloo against the ORACLE on one rank -- eigenvalues to 1e-11, iteration count,
+    identical decisions on all ranks."""
+    n, t, m = 24_000, 32, 37
+    spec = dict(n=n, n_targ=t, n_max=m, max_dav=20, tol=1e-9, solver="lobpcg", guess="unit", seed=3)
+    many = _run_world(tmp_path, spec, 8)
+    oracle.synth_setup(n, 0, n)
+    g = np.zeros((n, m), order="F")
+    g[np.arange(m), np.arange(m)] = 1.0
+    eo, vo, oko, tr = oracle.lobpcg(n, t, m, 200, 1e-9, 0.0, oracle.fn("orc_synth_matvec"), oracle.fn("orc_synth_precnd"), g)
+    assert oko and all(bool(r["ok"]) for r in many)
+    assert all(np.array_equal(many[0]["eig"], r["eig"]) and int(r["iters"]) == int(many[0]["iters"]) for r in many)
+    assert np.allclose(many[0]["eig"][:t], eo[:t], rtol=1e-11, atol=0)
+    assert abs(int(many[0]["iters"]) - tr.iters) <= max(1, tr.iters // 10), (int(many[0]["iters"]), tr.iters)
+    v = np.vstack([r["vec"] for r in many]); sgn = np.sign((v * vo).sum(0))
+    assert v.shape == vo.shape and np.abs(v * sgn - vo)[:, :t].max() < 1e-6
+    assert np.abs(v[:, :t].T @ v[:, :t] - np.eye(t)).max() < 1e-12
+
+
 PENDING_WORKER = r"""
 import os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
