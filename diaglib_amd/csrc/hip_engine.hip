@@ -4397,6 +4397,13 @@ struct HipEngine : dla::Engine {
     return DLA_OK;
   }
 
+  // groups of the reduction's first level: one per 32 block partials, at most 32 (the second level adds them in one pass of 32 loads).
+  // (tune knob 7 = 22 / 23: A/B, one group per 16 / 64 partials -- measured r06, see DESIGN "Measured and rejected")
+  int reduce_groups(int nblk) const
+  {
+    const int per = tune[7] == 22 ? 16 : tune[7] == 23 ? 64 : 32;
+    return std::max(1, std::min(32, (nblk + per - 1) / per));
+  }
   void launch_reduce(GramReduceArgs& ra, dim3 grid)
   {
     exchange_fused = false;
@@ -4572,7 +4579,7 @@ struct HipEngine : dla::Engine {
     double* cdst = self ? d_small : d_xug;
     {
       Scope s2(this, DLA_OP_GRAM, 0.0, 0.0, "gram_reduce_kernel");
-      const int groups = std::max(1, std::min(32, (blocks + 31) / 32));
+      const int groups = reduce_groups(blocks);
       const size_t need2 = sizeof(double) * (size_t)n_out * groups * 256;
       if (need2 > lvl2_bytes) {
         HIPCHK(hipStreamSynchronize(st));
@@ -5218,7 +5225,7 @@ struct HipEngine : dla::Engine {
     }
     {
       Scope s2(this, cls, 0.0, 0.0, "gram_reduce_kernel");
-      const int groups = std::max(1, std::min(32, (blocks_per_pass + 31) / 32));
+      const int groups = reduce_groups(blocks_per_pass);
       const size_t need2 = sizeof(double) * (size_t)passes * slots * groups * 256;
       if (need2 > lvl2_bytes) {
         HIPCHK(hipStreamSynchronize(st));
@@ -5305,7 +5312,7 @@ struct HipEngine : dla::Engine {
     int stc = ensure_small(sizeof(double) * (size_t)k * k);
     if (stc) return stc;
     const int kt = (k + 15) / 16;
-    const int groups = std::max(1, std::min(32, (fused_blocks + 31) / 32));
+    const int groups = reduce_groups(fused_blocks);
     const size_t need2 = sizeof(double) * (size_t)kt * kt * groups * 256;
     if (need2 > lvl2_bytes) {
       HIPCHK(hipStreamSynchronize(st));
