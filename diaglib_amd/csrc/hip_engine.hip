@@ -4754,6 +4754,8 @@ struct HipEngine : dla::Engine {
     const int ktw = (k + 15) / 16;
     const bool wide_gramx = fold == 0 && vsx && vec2 && bx == x && tune[6] != 7 && tune[6] != 8 && ktw >= 2 && ktw <= 3 &&
                             (m + k + 15) / 16 <= (ktw == 2 ? 8 : 7) && lds_limit > (size_t)128 * 1024;
+    // ([X | U] in TWO passes of that sweep -- the 18-column block behind 125 basis columns of the cfg 4 shape would then take
+    //  `6 4 2 8 4 5` instead of `1 3 4 2 2 3 4 5` -- measured r06: 32.23-32.27 against 32.24-32.38 ms per solve, no gain; not built in)
     // ... and inside the loop the triangular update is stored together with X^T U and U^T U of what it stores (OP_XW, the sweep the
     // one-tile schedule closes with) while X^T U fits one pass beside the block's tiles: 5 sweeps per call instead of 6
     // (two-tile blocks: measured r04 at n = 1e7, m = 64, k = 32: 1777 us against 937 + 1010 for the two sweeps it replaces; the
